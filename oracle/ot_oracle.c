@@ -1,0 +1,296 @@
+/*
+ * ot_oracle.c — CPU restatement of the IKNP OT-extension expansion, the AES-CTR column
+ * PRG, MITCCRH and the COT pad processing (oracle, test infrastructure).
+ *
+ *   ot/iknp.go:622-645   newPrg / prg / prgLabels (AES-128-CTR, zero IV, stateful stream)
+ *   ot/iknp.go:468-511   IKNPReceiver.receive
+ *   ot/iknp.go:197-226   IKNPSender.send
+ *   ot/iknp.go:647-683   createLabels (bit-matrix transpose)
+ *   ot/mitccrh.go:61-128 MITCCRH
+ *   ot/cot.go:136-235    COT.Send / COT.Receive pad handling
+ *   ot/mul128_generic.go, ot/mul128_ref.go, ot/gf128.go
+ *
+ * CTR mode restates Go's crypto/cipher.NewCTR (SP 800-38A §6.5 with the whole 16-byte
+ * block as a big-endian counter, starting from the IV = 0).
+ */
+#include "oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- PRG: iknp.go:622-645 ---------------------------------------------- */
+
+void orc_prg_init(orc_prg *p, orc_label key) { /* newPrg :622-630 */
+    uint8_t kb[16];
+    orc_label_get_data(&key, kb);
+    orc_aes_init(&p->aes, kb, 16);
+    memset(p->ctr, 0, 16);
+    p->used = 16;
+}
+
+static void prg_refill(orc_prg *p) {
+    orc_aes_encrypt(&p->aes, p->ctr, p->ks);
+    for (int i = 15; i >= 0; i--) /* 128-bit big-endian increment */
+        if (++p->ctr[i]) break;
+    p->used = 0;
+}
+
+void orc_prg_bytes(orc_prg *p, uint8_t *buf, size_t n) { /* prg :632-637 */
+    for (size_t i = 0; i < n; i++) {
+        if (p->used == 16) prg_refill(p);
+        buf[i] = p->ks[p->used++];
+    }
+}
+
+void orc_prg_labels(orc_prg *p, orc_label *labels, size_t n) { /* prgLabels :639-645 */
+    uint8_t buf[16];
+    for (size_t i = 0; i < n; i++) {
+        orc_prg_bytes(p, buf, 16);
+        orc_label_set_data(&labels[i], buf);
+    }
+}
+
+/* ---- createLabels: iknp.go:647-683 -------------------------------------- */
+
+void orc_create_labels(orc_label *l, size_t nl, const uint8_t *buf, int w) {
+    size_t end = (size_t)w * 8;
+    if (end > nl) end = nl;
+    for (int row = 0; row < w; row++) {
+        orc_label out[8];
+        memset(out, 0, sizeof out);
+        for (int j = 0; j < 128; j++) {
+            uint8_t b = buf[j * w + row];
+            uint64_t mask = (uint64_t)1 << (j & 63);
+            for (int bit = 0; bit < 8; bit++) {
+                if ((b >> bit) & 1) {
+                    if (j < 64) out[bit].d0 |= mask;
+                    else out[bit].d1 |= mask;
+                }
+            }
+        }
+        size_t base = (size_t)row * 8;
+        for (int bit = 0; bit < 8; bit++) {
+            size_t i = base + (size_t)bit;
+            if (i >= end) return;
+            l[i] = out[bit];
+        }
+    }
+}
+
+/* ---- IKNP receiver / sender --------------------------------------------- */
+
+void orc_iknp_receiver_init(orc_iknp_receiver *r, const orc_wire base[ORC_IKNP_K]) { /* :347-356 */
+    for (int i = 0; i < ORC_IKNP_K; i++) {
+        orc_prg_init(&r->g0[i], base[i].l0);
+        orc_prg_init(&r->g1[i], base[i].l1);
+    }
+}
+
+void orc_iknp_sender_init(orc_iknp_sender *s, orc_label delta, const orc_label k0[ORC_IKNP_K]) { /* :117-122 */
+    s->delta = delta;
+    for (int i = 0; i < ORC_IKNP_K; i++) orc_prg_init(&s->g0[i], k0[i]);
+}
+
+size_t orc_iknp_receive(orc_iknp_receiver *r, const uint8_t *b, size_t n, uint8_t *u_out, orc_label *result) {
+    /* :472-477 pack the choice bits LSB first */
+    size_t blen = (n + 7) / 8;
+    uint8_t *bbuf = calloc(blen ? blen : 1, 1);
+    for (size_t i = 0; i < n; i++)
+        if (b[i]) bbuf[i / 8] |= (uint8_t)(1u << (i % 8));
+
+    uint8_t *chunk = malloc(ORC_IKNP_CHUNK), *out = malloc(ORC_IKNP_CHUNK);
+    uint8_t tmp[ORC_IKNP_CHUNK / ORC_IKNP_K];
+    size_t written = 0;
+    const size_t chunk_rows = (ORC_IKNP_CHUNK / ORC_IKNP_K) * 8;
+    for (size_t ofs = 0; ofs < n;) { /* :482-505 */
+        size_t rows = chunk_rows;
+        if (rows > n - ofs) rows = n - ofs;
+        size_t byte_rows = (rows + 7) / 8;
+        for (int i = 0; i < ORC_IKNP_K; i++) {
+            orc_prg_bytes(&r->g0[i], chunk + (size_t)i * byte_rows, byte_rows);
+            orc_prg_bytes(&r->g1[i], tmp, byte_rows);
+            for (size_t k = 0; k < byte_rows; k++) {
+                tmp[k] ^= chunk[(size_t)i * byte_rows + k];
+                if (ofs / 8 + k < blen) tmp[k] ^= bbuf[ofs / 8 + k]; /* xor() truncates to the shorter slice */
+            }
+            memcpy(out + (size_t)i * byte_rows, tmp, byte_rows);
+        }
+        memcpy(u_out + written, out, byte_rows * ORC_IKNP_K); /* SendData(out[:byteRows*128]) :499 */
+        written += byte_rows * ORC_IKNP_K;
+        orc_create_labels(result + ofs, n - ofs, chunk, (int)byte_rows);
+        ofs += rows;
+    }
+    free(bbuf);
+    free(chunk);
+    free(out);
+    return written;
+}
+
+size_t orc_iknp_send(orc_iknp_sender *s, const uint8_t *u_in, size_t n, orc_label *result) {
+    uint8_t *t = malloc(ORC_IKNP_CHUNK);
+    size_t consumed = 0;
+    const size_t chunk_rows = (ORC_IKNP_CHUNK / ORC_IKNP_K) * 8;
+    for (size_t ofs = 0; ofs < n;) { /* :202-223; the chunk length is what the receiver sent */
+        size_t rows = chunk_rows;
+        if (rows > n - ofs) rows = n - ofs;
+        size_t byte_rows = (rows + 7) / 8;
+        const uint8_t *chunk = u_in + consumed;
+        for (int i = 0; i < ORC_IKNP_K; i++) {
+            orc_prg_bytes(&s->g0[i], t + (size_t)i * byte_rows, byte_rows);
+            if (orc_label_bit(&s->delta, i) == 1)
+                for (size_t k = 0; k < byte_rows; k++) t[(size_t)i * byte_rows + k] ^= chunk[(size_t)i * byte_rows + k];
+        }
+        consumed += byte_rows * ORC_IKNP_K;
+        orc_create_labels(result + ofs, n - ofs, t, (int)byte_rows);
+        ofs += byte_rows * 8;
+    }
+    free(t);
+    return consumed;
+}
+
+/* ---- MITCCRH: mitccrh.go:50-128 ------------------------------------------ */
+
+void orc_mitccrh_init(orc_mitccrh *m, orc_label seed, int batch_size) { /* :61-68 */
+    m->batch_size = batch_size;
+    m->start = seed;
+    m->gid = 0;
+    m->key_used = batch_size; /* force renew on first use */
+}
+
+static void mitccrh_renew(orc_mitccrh *m) { /* :70-89 */
+    for (int i = 0; i < m->batch_size; i++) {
+        orc_label key = {m->gid, 0};
+        m->gid++;
+        key.d0 ^= m->start.d0;
+        key.d1 ^= m->start.d1;
+        uint8_t kb[16];
+        orc_label_get_data(&key, kb);
+        orc_aes_init(&m->ciphers[i], kb, 16);
+    }
+    m->key_used = 0;
+}
+
+void orc_mitccrh_hash(orc_mitccrh *m, orc_label *blks, int k, int h) { /* :93-128 */
+    if (m->key_used == m->batch_size) mitccrh_renew(m);
+    for (int i = 0; i < k; i++) {
+        const orc_aes *c = &m->ciphers[m->key_used + i];
+        for (int j = 0; j < h; j++) {
+            int idx = i * h + j;
+            uint8_t tmp[16];
+            orc_label t;
+            orc_label_get_data(&blks[idx], tmp);
+            orc_aes_encrypt(c, tmp, tmp);
+            orc_label_set_data(&t, tmp);
+            blks[idx].d0 ^= t.d0;
+            blks[idx].d1 ^= t.d1;
+        }
+    }
+    m->key_used += k;
+}
+
+/* ---- COT pads: cot.go:136-235 -------------------------------------------- */
+
+void orc_cot_send_pads(orc_label seed, orc_label delta, const orc_label *data, const orc_wire *wires, size_t n,
+                       orc_label *out) {
+    orc_mitccrh m;
+    orc_mitccrh_init(&m, seed, 8);
+    orc_label pad[16];
+    memset(pad, 0, sizeof pad);
+    size_t w = 0;
+    for (size_t i = 0; i < n; i += 8) { /* cot.go:160-181 */
+        size_t end = i + 8;
+        if (end > n) end = n;
+        for (size_t j = i; j < end; j++) {
+            pad[2 * (j - i)] = data[j];
+            pad[2 * (j - i) + 1] = data[j];
+            pad[2 * (j - i) + 1].d0 ^= delta.d0;
+            pad[2 * (j - i) + 1].d1 ^= delta.d1;
+        }
+        orc_mitccrh_hash(&m, pad, 8, 2);
+        for (size_t j = i; j < end; j++) {
+            pad[2 * (j - i)].d0 ^= wires[j].l0.d0;
+            pad[2 * (j - i)].d1 ^= wires[j].l0.d1;
+            pad[2 * (j - i) + 1].d0 ^= wires[j].l1.d0;
+            pad[2 * (j - i) + 1].d1 ^= wires[j].l1.d1;
+        }
+        for (size_t j = 0; j < 2 * (end - i); j++) out[w++] = pad[j];
+    }
+}
+
+void orc_cot_receive_unpad(orc_label seed, const uint8_t *flags, const orc_label *sent, orc_label *result, size_t n) {
+    orc_mitccrh m;
+    orc_mitccrh_init(&m, seed, 8);
+    orc_label pad[8];
+    memset(pad, 0, sizeof pad);
+    for (size_t i = 0; i < n; i += 8) { /* cot.go:203-232 */
+        size_t end = 8;
+        if (end > n - i) end = n - i;
+        for (size_t j = 0; j < end; j++) pad[j] = result[i + j]; /* copy(pad, result[i:]) */
+        orc_mitccrh_hash(&m, pad, 8, 1);
+        for (size_t j = 0; j < end; j++) {
+            orc_label res0 = sent[2 * (i + j)], res1 = sent[2 * (i + j) + 1];
+            result[i + j] = flags[i + j] ? res1 : res0;
+            result[i + j].d0 ^= pad[j].d0;
+            result[i + j].d1 ^= pad[j].d1;
+        }
+    }
+}
+
+/* ---- GF(2^128): mul128_generic.go:9-46, mul128_ref.go:9-36, gf128.go:14-27 */
+
+static void clmul64(uint64_t a, uint64_t b, uint64_t *lo, uint64_t *hi) {
+    uint64_t l = 0, h = 0;
+    for (int i = 0; i < 64; i++) {
+        if ((b >> i) & 1) {
+            if (i == 0) l ^= a;
+            else {
+                l ^= a << i;
+                h ^= a >> (64 - i);
+            }
+        }
+    }
+    *lo = l;
+    *hi = h;
+}
+
+void orc_mul128(orc_label a, orc_label b, orc_label *lo, orc_label *hi) {
+    uint64_t p00l, p00h, p01l, p01h, p10l, p10h, p11l, p11h;
+    clmul64(a.d0, b.d0, &p00l, &p00h);
+    clmul64(a.d0, b.d1, &p01l, &p01h);
+    clmul64(a.d1, b.d0, &p10l, &p10h);
+    clmul64(a.d1, b.d1, &p11l, &p11h);
+    uint64_t midl = p01l ^ p10l, midh = p01h ^ p10h;
+    lo->d0 = p00l;
+    lo->d1 = p00h ^ midl;
+    hi->d0 = midh ^ p11l;
+    hi->d1 = p11h;
+}
+
+void orc_mul128_ref(orc_label a, orc_label b, orc_label *lo, orc_label *hi) {
+    uint8_t r[256];
+    memset(r, 0, sizeof r);
+    for (int i = 0; i < 128; i++) {
+        if (!orc_label_bit(&a, i)) continue;
+        for (int j = 0; j < 128; j++)
+            if (orc_label_bit(&b, j)) r[i + j] ^= 1;
+    }
+    lo->d0 = lo->d1 = hi->d0 = hi->d1 = 0;
+    for (int i = 0; i < 64; i++) {
+        lo->d0 |= (uint64_t)r[i] << i;
+        lo->d1 |= (uint64_t)r[64 + i] << i;
+        hi->d0 |= (uint64_t)r[128 + i] << i;
+        hi->d1 |= (uint64_t)r[192 + i] << i;
+    }
+}
+
+void orc_inner_product(const orc_label *a, const orc_label *b, size_t n, orc_label *r1, orc_label *r2) {
+    r1->d0 = r1->d1 = r2->d0 = r2->d1 = 0;
+    for (size_t i = 0; i < n; i++) {
+        orc_label lo, hi;
+        orc_mul128(a[i], b[i], &lo, &hi);
+        r1->d0 ^= lo.d0;
+        r1->d1 ^= lo.d1;
+        r2->d0 ^= hi.d0;
+        r2->d1 ^= hi.d1;
+    }
+}

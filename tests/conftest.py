@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def aes_circ():
+    from mpc_amd.circuit import parse_file
+    return parse_file(os.path.join(GOLDEN, "aes_128.gcf"))
+
+
+@pytest.fixture(scope="session")
+def sha_circ():
+    from mpc_amd.circuit import parse_file
+    return parse_file(os.path.join(GOLDEN, "sha256xor.gcf"))
+
+
+@pytest.fixture(scope="session")
+def add64_circ():
+    from mpc_amd.circuit import parse_file
+    return parse_file(os.path.join(GOLDEN, "add64.gcf"))
