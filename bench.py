@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — AND-gates/s (garble+eval) of the AES-128 circuit batch on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic instances that are already
+resident in HBM: Circuit.Garble for `batch` instances, hand-over of the evaluator's input labels,
+Circuit.Eval, and BitFromLabel decoding (+ the RCCL gather of the decoded outputs when N > 1).
+Workload at N=1: BASELINE.json configs[1] — aes_128 (36 663 gates, 6 400 AND) x 1 024 instances,
+32-byte garbling key (AES-256, as circuit.Garbler uses).  N > 1: the same per-GPU batch on every
+rank (weak scaling, independent instances, no data-path collective except the output gather).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per gate per side (SURVEY.md §8d / DESIGN.md): 16-byte labels, L1 never stored
+ALG_BYTES = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+
+def alg_bytes_per_instance(info):
+    return (info.n_xor * ALG_BYTES["xor"] + info.n_xnor * ALG_BYTES["xnor"] + info.n_and * ALG_BYTES["and"] +
+            info.n_inv * ALG_BYTES["inv"] + info.n_or * ALG_BYTES["or"])
+
+
+def cpu_baseline(circ, key, seconds=12.0):
+    """The oracle (CPU restatement of the reference's serial Garble/Eval loops, AES-NI) timed on the
+    host cores: one instance per thread-iteration, all cores.  Reported, never the target."""
+    import oracle
+
+    threads = os.cpu_count() or 1
+    probe = 40 * threads
+    dt = oracle.bench_garble_eval(circ.Gates, circ.NumWires, circ.num_inputs, circ.num_outputs, key, probe, threads)
+    reps = max(probe, int(probe * seconds / max(dt, 1e-3)))
+    dt = oracle.bench_garble_eval(circ.Gates, circ.NumWires, circ.num_inputs, circ.num_outputs, key, reps, threads)
+    ands = circ.stats()["AND"]
+    out = {
+        "value": reps * ands / dt,
+        "unit": "AND-gates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d instances of %s garble+eval, oracle C loop (AES-NI=%s), %d threads, %.1f s" % (
+            reps, circ.name or "circuit", oracle.using_aesni(), threads, dt),
+        "published_reference": "155.1 ns/AND garble-only = 6.45 M AND/s, Go, i5-8257U 1 thread (benchmarks.md:726)",
+    }
+    ref = os.path.join(ROOT, "oracle", "_ref", "aesni_bench")
+    if os.path.exists(ref):
+        try:
+            import subprocess
+            txt = subprocess.run([ref], capture_output=True, text=True, timeout=60).stdout
+            for ln in txt.splitlines():
+                if ln.startswith("AES-NI+C"):
+                    out["reference_aesni_c_ns_per_encrypt"] = float(ln.split()[-2])
+        except Exception:
+            pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--circuit", default=os.path.join(ROOT, "tests", "golden", "aes_128.gcf"))
+    ap.add_argument("--key-bytes", type=int, default=32, choices=[16, 24, 32])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--schedule", type=int, default=1)
+    ap.add_argument("--check", action="store_true", help="verify decoded outputs against plaintext evaluation")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus, file=sys.stderr)
+            sys.exit(2)
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from mpc_amd import engine, parse_file
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    circ = parse_file(args.circuit)
+    circ.name = os.path.splitext(os.path.basename(args.circuit))[0]
+    key = bytes(range(args.key_bytes))
+    ctx = engine.Context(local_rank)
+    dc = engine.DeviceCircuit(ctx, circ)
+    info = dc.info
+    batch = args.batch
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    for b in (gb, ev):
+        b.set_graph(not args.no_graph)
+        b.set_schedule(args.schedule)
+
+    # synthetic inputs, resident in HBM before the timed region
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    d_rnd = torch.randint(0, 256, (batch, circ.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
+    d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
+    d_out = torch.zeros((batch, circ.num_outputs), dtype=torch.uint8, device="cuda")
+    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_all = torch.zeros((world, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") if world > 1 else None
+
+    def step():
+        gb.garble(key, d_rnd.data_ptr())
+        ev.select_inputs(gb, d_bits.data_ptr())
+        ev.eval(key, gb)
+        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        if world > 1:
+            ctx.sync()  # hand the engine stream's result to torch's stream
+            dist.all_gather_into_tensor(d_all, d_out)  # RCCL over xGMI: the only collective
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    g_ms, e_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event times of the passes, recorded on the engine's own stream (gc_batch_last_ms)
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-pass device times (events on the engine stream) from a few extra, untimed-by-wall steps
+    for _ in range(min(5, max(1, args.steps))):
+        gb.garble(key, d_rnd.data_ptr())
+        g_ms.append(gb.last_ms)
+        ev.select_inputs(gb, d_bits.data_ptr())
+        ev.eval(key, gb)
+        e_ms.append(ev.last_ms)
+    ctx.sync()
+    mismatches = int(d_mis.cpu()[0])
+
+    ok = mismatches == 0
+    if args.check:
+        import oracle  # checker only
+        bits = d_bits.cpu().numpy()
+        out = d_out.cpu().numpy()
+        for i in range(0, batch, max(1, batch // 16)):
+            plain = oracle.compute(circ.Gates, circ.NumWires, circ.num_inputs, bits[i])
+            ok = ok and bool((plain[circ.NumWires - circ.num_outputs:] == out[i]).all())
+
+    n_and = info.n_and
+    total_and = n_and * batch * world * args.steps
+    value = total_and / elapsed
+    algb = alg_bytes_per_instance(info)
+    g_avg = float(np.mean(g_ms))
+    e_avg = float(np.mean(e_ms))
+    launches = gb.last_launches
+    # dominant kernel: k_garble_level (one launch per level).  Algorithmic bytes per launch =
+    # garble bytes per instance x batch / launches; average launch duration = pass time / launches
+    achieved = algb * batch / (g_avg * 1e-3) / 1e9
+    res = {
+        "metric": "AND-gates/sec (garble+eval), AES-128 circuit batch",
+        "value": value,
+        "unit": "AND-gates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 (AES T-table / 128-bit label XOR, integer)",
+        "data": "synthetic (uniform random label streams and input bits, resident in HBM)",
+        "config": {
+            "workload": "%s.circ %d gates / %d AND, batch=%d instances per GPU, %d-byte garbling key" % (
+                circ.name, info.ngates, n_and, batch, args.key_bytes),
+            "instances_per_gpu": batch,
+            "levels": int(info.nlevels),
+            "launches_per_garble": int(launches),
+            "graph": not args.no_graph,
+            "outputs_ok": ok,
+        },
+        "garble_ms": g_avg,
+        "eval_ms": e_avg,
+        "and_gates_per_s_garble_only": n_and * batch / (g_avg * 1e-3),
+        "and_gates_per_s_eval_only": n_and * batch / (e_avg * 1e-3),
+        "hbm_alg_GBs_garble_plus_eval": 2 * algb * batch / ((g_avg + e_avg) * 1e-3) / 1e9,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_garble_level",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "alg_bytes_per_launch": algb * batch / max(launches, 1),
+            "avg_launch_us": g_avg * 1e3 / max(launches, 1),
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(circ, key)
+        print(json.dumps(res))
+    gb.close()
+    ev.close()
+    dc.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,229 @@
+/*
+ * gcengine.h — C ABI of the MI355X garbled-circuit engine (libgcengine.so).
+ *
+ * This is the drop-in boundary for the hot path of markkurossi/mpc.  The reference is pure
+ * Go and has no FFI layer; each entry point below names the exported Go function whose BODY
+ * it replaces (the cgo stub a maintainer adds is shown in INTEGRATION.md and go/).
+ * Plain C: pointers + sizes only, no callbacks, every function re-entrant.  All pointers
+ * are caller-owned and only used for the duration of the call unless stated otherwise.
+ *
+ * Memory layouts are Go's in-memory structs, so Go slices cross cgo without copies:
+ *   gc_label == ot.Label   {D0,D1 uint64}            ot/label.go:28-31
+ *   gc_wire  == ot.Wire    {L0,L1 Label}             ot/label.go:18-21
+ *   gc_gate  == circuit.Gate (20 bytes)              circuit/circuit.go:260-266
+ */
+#ifndef GCENGINE_H
+#define GCENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gc_label { uint64_t d0, d1; } gc_label;
+typedef struct gc_wire { gc_label l0, l1; } gc_wire;
+typedef struct gc_gate {
+    uint32_t in0, in1, out;
+    uint8_t op; /* circuit.Operation: XOR=0 XNOR=1 AND=2 OR=3 INV=4 (circuit.go:25-34) */
+    uint8_t pad_[3];
+    uint32_t level;
+} gc_gate;
+
+enum {
+    GC_XOR = 0, GC_XNOR = 1, GC_AND = 2, GC_OR = 3, GC_INV = 4
+};
+
+/* status codes; the Go shim maps them to the reference's error values */
+enum {
+    GC_OK = 0,
+    GC_E_KEYSIZE = -1, /* aes.NewCipher: "crypto/aes: invalid key size" (garble.go:260, eval.go:20) */
+    GC_E_RAND = -2,    /* random stream shorter than R + inputs (io.Reader error, garble.go:253,272) */
+    GC_E_GATE = -3,    /* "invalid gate type" / "invalid operation" (garble.go:326, eval.go:43) */
+    GC_E_ROWS = -4,    /* "corrupted circuit": table shorter than the gates need (eval.go:54-56,86-89) */
+    GC_E_ARG = -5,     /* NULL / size mismatch */
+    GC_E_HIP = -6,     /* HIP runtime failure (no device, launch error); see gc_last_error() */
+    GC_E_NOMEM = -7,   /* device or host allocation failed */
+    GC_E_WIRE = -8     /* gate reads a wire that no input/gate has written, or wire id >= nwires */
+};
+
+const char *gc_strerror(int status);
+/* thread-local detail of the last GC_E_HIP / GC_E_NOMEM on this thread ("" if none) */
+const char *gc_last_error(void);
+/* ABI version of this header (checked by the bindings) */
+#define GC_ABI_VERSION 1
+int gc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Circuit plan — host-only "compile" of a gate list (no GPU needed).
+ * Replaces nothing in the reference; it is the levelised re-encoding the device needs
+ * (reference analogue: Circuit.AssignLevels, circuit/circuit.go:206-254, TargetYao).
+ * Gates are renamed to single-assignment slots, bucketed by dependency level, and given the
+ * tweak / table-row prefix sums of the reference's serial loop (garble.go:357-359,419-420,
+ * 451-452 and :199-211) so that level-parallel execution is bit-identical to it.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_plan gc_plan;
+
+typedef struct gc_plan_info {
+    uint32_t ngates, nwires, ninputs, noutputs;
+    uint32_t nlevels;   /* == Stats[NumLevels] of AssignLevels(TargetYao) */
+    uint32_t max_width; /* == Stats[MaxWidth] */
+    uint32_t slab_rows; /* table labels per instance: AND 2, OR 3, INV 1 */
+    uint32_t n_xor, n_xnor, n_and, n_or, n_inv;
+    uint32_t nslots;    /* device wire slots = ninputs + ngates */
+    uint32_t n_steps;   /* kernel launches per garble (fused schedule) */
+} gc_plan_info;
+
+gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                        uint32_t noutputs, int *status);
+void gc_plan_free(gc_plan *);
+int gc_plan_get_info(const gc_plan *, gc_plan_info *out);
+/* introspection used by the parity tests (arrays sized by the caller):
+ *  level_of_gate[ngates]  reference gate.Level for every gate (original order)
+ *  tweak_of_gate[ngates]  value of `id` when the serial loop reaches the gate
+ *  row_of_gate[ngates+1]  first slab row of the gate (== Garbled.Gates[i] offset into the slab)
+ *  slot_of_gate[ngates]   device wire slot written by the gate
+ * any pointer may be NULL */
+int gc_plan_describe(const gc_plan *, uint32_t *level_of_gate, uint32_t *tweak_of_gate,
+                     uint32_t *row_of_gate, uint32_t *slot_of_gate);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context + circuit
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_ctx gc_ctx;   /* one HIP device + one stream; create one per goroutine/thread for concurrency */
+typedef struct gc_circ gc_circ; /* a plan uploaded to a device; immutable, shareable between threads */
+
+int gc_device_count(void);
+gc_ctx *gc_ctx_create(int device, int *status);
+void gc_ctx_destroy(gc_ctx *);
+int gc_ctx_sync(gc_ctx *);
+/* the ctx's HIP stream as an opaque pointer (hipStream_t) for callers that enqueue their own work */
+void *gc_ctx_stream(gc_ctx *);
+
+gc_circ *gc_circ_load(gc_ctx *, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+                      uint32_t ninputs, uint32_t noutputs, int *status);
+void gc_circ_free(gc_circ *);
+const gc_plan *gc_circ_plan(const gc_circ *);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-buffer API — bodies of the reference's per-call entry points, plus a batch dimension
+ * (instance-major: instance i's data follows instance i-1's).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Replaces (c *Circuit) Garble(rand io.Reader, key []byte) (*Garbled, error)   circuit/garble.go:248
+ *  key/keylen  16, 24 or 32 bytes
+ *  rnd         per instance the bytes the io.Reader would deliver, in consumption order:
+ *              R (16 B; S bit is forced on, garble.go:258) then one L0 per input wire
+ *              (garble.go:271-278): stride 16*(1+ninputs); rndlen >= batch*stride or GC_E_RAND
+ *  r_out       [batch]                    Garbled.R
+ *  wires_out   [batch][nwires] or NULL    Garbled.Wires (both labels, original wire ids)
+ *  io_out      [batch][ninputs+noutputs] or NULL: Wires[0:ninputs] then Wires[nwires-noutputs:]
+ *              — the only ranges the reference's callers read (garbler.go:87,132,153)
+ *  slab_out    [batch][slab_rows]         the dense table slab, gate order (Garbled.Gates[i] =
+ *              slab[row_of_gate[i] : row_of_gate[i+1]])                                     */
+int gc_garble(gc_circ *, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen,
+              uint32_t batch, gc_label *r_out, gc_wire *wires_out, gc_wire *io_out, gc_label *slab_out);
+
+/* Replaces (c *Circuit) Eval(key []byte, wires []ot.Label, garbled [][]ot.Label) error   circuit/eval.go:17
+ *  wires_inout [batch][nwires] or NULL: inputs pre-filled at [0,ninputs); all wires written in place
+ *  inputs      [batch][ninputs]  used when wires_inout is NULL
+ *  slab        [batch][slab_rows], slab_rows_given must equal the plan's slab_rows (else GC_E_ROWS)
+ *  out_labels  [batch][noutputs] or NULL: wires[nwires-noutputs:]                              */
+int gc_eval(gc_circ *, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
+            const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,
+ * additive to the reference API) calls; also what bench.py times.  All d_* arguments are
+ * DEVICE pointers; calls enqueue on the ctx stream and return without waiting.
+ * Device layouts are wire-major / instance-minor so that a wavefront reads 64 consecutive
+ * instances of one wire as one 1 KiB coalesced access:
+ *   wire labels  uint4 [nslots][bstride]     tables  uint4 [slab_rows][bstride]
+ * where bstride = batch rounded up to 64.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_batch gc_batch;
+
+gc_batch *gc_batch_create(gc_circ *, uint32_t batch, int *status);
+void gc_batch_free(gc_batch *);
+uint32_t gc_batch_stride(const gc_batch *);
+/* schedule: 0 = one launch per dependency level (the reference's AssignLevels order),
+ *           1 = fused schedule (default).  Results are bit-identical. */
+int gc_batch_set_schedule(gc_batch *, int schedule);
+/* use a captured hipGraph for the per-level launches (default on) */
+int gc_batch_set_graph(gc_batch *, int on);
+
+/* garble all instances: d_rnd = [batch][1+ninputs][16] bytes (same stream as gc_garble) */
+int gc_batch_garble(gc_batch *, const uint8_t *key, size_t keylen, const void *d_rnd);
+/* evaluator inputs: active label of input wire w of instance i = L0 ^ bit*R, picked on the
+ * device from the garbler's state (stands in for "send own labels + OT", garbler.go:85-132);
+ * d_bits = u8 [batch][ninputs] */
+int gc_batch_select_inputs(gc_batch *evaluator, const gc_batch *garbler, const void *d_bits);
+/* evaluator inputs from explicit labels, d_labels = gc_label [batch][ninputs] */
+int gc_batch_set_inputs(gc_batch *evaluator, const void *d_labels);
+/* evaluate with the tables of `tables` (device layout [slab_rows][bstride]); may be the
+ * garbler's batch itself */
+int gc_batch_eval(gc_batch *evaluator, const uint8_t *key, size_t keylen, const gc_batch *tables);
+/* BitFromLabel (circuit/helpers.go:18-28) for every output wire: d_bits_out = u8 [batch][noutputs];
+ * *d_mismatch (u32, device) counts labels that match neither L0 nor L1 */
+int gc_batch_decode(const gc_batch *garbler, const gc_batch *evaluator, void *d_bits_out, void *d_mismatch);
+
+/* read-backs (synchronous; host pointers) */
+int gc_batch_read_r(gc_batch *, gc_label *r_out);                     /* [batch] */
+int gc_batch_read_slab(gc_batch *, gc_label *slab_out);               /* [batch][slab_rows] (reference order) */
+int gc_batch_read_wires(gc_batch *, gc_wire *wires_out);              /* garbler: [batch][nwires] */
+int gc_batch_read_labels(gc_batch *, gc_label *labels_out);           /* evaluator: [batch][nwires] */
+int gc_batch_read_outputs(gc_batch *, gc_label *out);                 /* [batch][noutputs] active/L0 labels */
+int gc_batch_write_slab(gc_batch *, const gc_label *slab);            /* host [batch][slab_rows] -> device layout */
+/* raw device pointers (for RCCL gathers / the caller's own kernels) */
+void *gc_batch_dev_wires(gc_batch *);
+void *gc_batch_dev_slab(gc_batch *);
+void *gc_batch_dev_r(gc_batch *);
+/* output-wire labels gathered into a dense device buffer gc_label [noutputs][bstride] */
+int gc_batch_gather_outputs(gc_batch *, void *d_out);
+
+/* timing of the most recent garble / eval on this batch, measured with HIP events recorded on
+ * the ctx stream around the level launches (ms); negative if none */
+float gc_batch_last_ms(gc_batch *);
+/* kernel launches issued by the most recent garble / eval */
+uint32_t gc_batch_last_launches(gc_batch *);
+
+/* ------------------------------------------------------------------------------------------
+ * IKNP OT extension + MITCCRH (ot/iknp.go, ot/mitccrh.go, ot/cot.go)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_iknp gc_iknp;
+
+/* Receiver state after the base OTs: replaces the tail of NewIKNPReceiver (iknp.go:347-356):
+ * base[128] are the (L0,L1) pairs sent through the base OT; column PRGs g0/g1 are keyed by them */
+gc_iknp *gc_iknp_receiver_create(gc_ctx *, const gc_wire *base, int *status);
+/* Sender state: replaces the tail of NewIKNPSender (iknp.go:104-122): delta and the 128 labels
+ * k0[i] received from the base OT with choice bits delta.Bit(i) */
+gc_iknp *gc_iknp_sender_create(gc_ctx *, const gc_label *delta, const gc_label *k0, int *status);
+void gc_iknp_free(gc_iknp *);
+
+/* bytes of u-matrix data exchanged for n OTs (sum of the chunk lengths of iknp.go:482-505) */
+size_t gc_iknp_u_bytes(size_t n);
+/* Replaces the body of (*IKNPReceiver).receive(b, result)   ot/iknp.go:468-511
+ *  choice  bool per OT (n bytes, non-zero = true)
+ *  u_out   the chunks the Go loop would SendData, concatenated (gc_iknp_u_bytes(n) bytes); the
+ *          shim frames them as ≤8 KiB messages exactly like iknp.go:499
+ *  labels_out [n]                                                                         */
+int gc_iknp_receive(gc_iknp *, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out);
+/* Replaces the body of (*IKNPSender).send(n)   ot/iknp.go:197-226 (u_in = the received chunks, concatenated) */
+int gc_iknp_send(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out);
+
+/* Replaces (*MITCCRH).Hash over a whole COT/ROT run (mitccrh.go:93-128 as driven by cot.go:160-171,
+ * 203-211): OT j (key index gid0+j, key = BE(Label{D0:gid,D1:0} ^ seed)) hashes its h consecutive
+ * blocks in place: blk ^= AES_key(blk).  blks = [n][h] */
+int gc_mitccrh_hash(gc_ctx *, const gc_label *seed, uint64_t gid0, gc_label *blks, size_t n, uint32_t h);
+/* Replaces the pad loop of COT.Send (cot.go:155-182): out[2n] = the labels sent on the wire */
+int gc_cot_send_pads(gc_ctx *, const gc_label *seed, const gc_label *delta, const gc_label *data,
+                     const gc_wire *wires, size_t n, gc_label *out);
+/* Replaces the unpad loop of COT.Receive (cot.go:200-232): result[n] in = IKNP output, out = chosen labels */
+int gc_cot_receive_unpad(gc_ctx *, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
+                         gc_label *result, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCENGINE_H */

@@ -1,0 +1,134 @@
+// aes_device.h — CDNA4 device-side AES (T-table in LDS) and 128-bit label helpers.
+//
+// A label is kept exactly as Go lays out ot.Label{D0,D1 uint64} in memory (little-endian
+// limbs), loaded as one uint4:  x = D0 low32, y = D0 high32, z = D1 low32, w = D1 high32.
+// The AES input block is BE(D0)||BE(D1) (ot/label.go:105-108), i.e. the four big-endian
+// state columns are  s0 = y, s1 = x, s2 = w, s3 = z  — no byte swaps anywhere on the device.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gc {
+
+// LDS image of the round tables: Te0..Te3, 256 words each.
+constexpr int kTeWords = 4 * 256;
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t v, uint32_t n) { return __builtin_amdgcn_alignbit(v, v, n); }
+
+// Cooperative table load (blockDim.x must be a multiple of 256 or at least cover 256 entries
+// through the stride loop).  g_te0 is the 1 KiB Te0 table in global memory (L2-resident).
+__device__ __forceinline__ void load_te_tables(uint32_t *te, const uint32_t *__restrict__ g_te0) {
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        uint32_t t = g_te0[i];
+        te[i] = t;
+        te[256 + i] = rotr32(t, 8);
+        te[512 + i] = rotr32(t, 16);
+        te[768 + i] = rotr32(t, 24);
+    }
+}
+
+// N independent blocks through NR rounds in lock-step (N-way ILP hides the LDS latency).
+// s[k][0..3] are the big-endian columns; rk are big-endian round-key words (wave-uniform ->
+// scalar loads).
+template <int NR, int N>
+__device__ __forceinline__ void aes_encrypt_n(uint32_t (&s)[N][4], const uint32_t *__restrict__ rk,
+                                              const uint32_t *te) {
+    const uint32_t *te0 = te, *te1 = te + 256, *te2 = te + 512, *te3 = te + 768;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        s[k][0] ^= rk[0];
+        s[k][1] ^= rk[1];
+        s[k][2] ^= rk[2];
+        s[k][3] ^= rk[3];
+    }
+#pragma unroll
+    for (int r = 1; r < NR; r++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+            s[k][0] = te0[a0 >> 24] ^ te1[(a1 >> 16) & 0xff] ^ te2[(a2 >> 8) & 0xff] ^ te3[a3 & 0xff] ^ rk[4 * r + 0];
+            s[k][1] = te0[a1 >> 24] ^ te1[(a2 >> 16) & 0xff] ^ te2[(a3 >> 8) & 0xff] ^ te3[a0 & 0xff] ^ rk[4 * r + 1];
+            s[k][2] = te0[a2 >> 24] ^ te1[(a3 >> 16) & 0xff] ^ te2[(a0 >> 8) & 0xff] ^ te3[a1 & 0xff] ^ rk[4 * r + 2];
+            s[k][3] = te0[a3 >> 24] ^ te1[(a0 >> 16) & 0xff] ^ te2[(a1 >> 8) & 0xff] ^ te3[a2 & 0xff] ^ rk[4 * r + 3];
+        }
+    }
+    // final round: SubBytes + ShiftRows only; S[x] sits in Te2's top byte, Te3's byte 2,
+    // Te0's byte 1 and Te1's low byte
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+        s[k][0] = (te2[a0 >> 24] & 0xff000000u) ^ (te3[(a1 >> 16) & 0xff] & 0x00ff0000u) ^
+                  (te0[(a2 >> 8) & 0xff] & 0x0000ff00u) ^ (te1[a3 & 0xff] & 0x000000ffu) ^ rk[4 * NR + 0];
+        s[k][1] = (te2[a1 >> 24] & 0xff000000u) ^ (te3[(a2 >> 16) & 0xff] & 0x00ff0000u) ^
+                  (te0[(a3 >> 8) & 0xff] & 0x0000ff00u) ^ (te1[a0 & 0xff] & 0x000000ffu) ^ rk[4 * NR + 1];
+        s[k][2] = (te2[a2 >> 24] & 0xff000000u) ^ (te3[(a3 >> 16) & 0xff] & 0x00ff0000u) ^
+                  (te0[(a0 >> 8) & 0xff] & 0x0000ff00u) ^ (te1[a1 & 0xff] & 0x000000ffu) ^ rk[4 * NR + 2];
+        s[k][3] = (te2[a3 >> 24] & 0xff000000u) ^ (te3[(a0 >> 16) & 0xff] & 0x00ff0000u) ^
+                  (te0[(a1 >> 8) & 0xff] & 0x0000ff00u) ^ (te1[a2 & 0xff] & 0x000000ffu) ^ rk[4 * NR + 3];
+    }
+}
+
+// ---- label arithmetic (ot/label.go) on the uint4 form --------------------------------------
+
+__device__ __forceinline__ uint4 lxor(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
+__device__ __forceinline__ uint4 land(uint4 a, uint32_t m) { return make_uint4(a.x & m, a.y & m, a.z & m, a.w & m); }
+// Label.S(): MSB of D0 (label.go:65-67)
+__device__ __forceinline__ bool lbit_s(uint4 a) { return (a.y >> 31) != 0; }
+// all-ones mask if S is set
+__device__ __forceinline__ uint32_t smask(uint4 a) { return (uint32_t)((int32_t)a.y >> 31); }
+__device__ __forceinline__ bool leq(uint4 a, uint4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+
+// K = (x << sh) as big-endian columns; sh = 1 (Mul2, label.go:79-83) or 2 (Mul4, :86-90)
+template <int SH>
+__device__ __forceinline__ void label_shl_cols(uint4 v, uint32_t (&k)[4]) {
+    // columns: s0 = D0 hi (y), s1 = D0 lo (x), s2 = D1 hi (w), s3 = D1 lo (z)
+    k[0] = __builtin_amdgcn_alignbit(v.y, v.x, 32 - SH);
+    k[1] = __builtin_amdgcn_alignbit(v.x, v.w, 32 - SH);
+    k[2] = __builtin_amdgcn_alignbit(v.w, v.z, 32 - SH);
+    k[3] = v.z << SH;
+}
+
+__device__ __forceinline__ uint4 cols_to_label(const uint32_t (&s)[4]) { return make_uint4(s[1], s[0], s[3], s[2]); }
+
+// Hash inputs of encryptHalf (circuit/garble.go:104-136): K = 2x ^ i, i in the low 32 bits of D1
+__device__ __forceinline__ void make_k_half(uint4 x, uint32_t tweak, uint32_t (&k)[4]) {
+    label_shl_cols<1>(x, k);
+    k[3] ^= tweak;
+}
+// makeK (circuit/garble.go:74-83): K = 2a ^ 4b ^ t
+__device__ __forceinline__ void make_k(uint4 a, uint4 b, uint32_t tweak, uint32_t (&k)[4]) {
+    uint32_t kb[4];
+    label_shl_cols<1>(a, k);
+    label_shl_cols<2>(b, kb);
+    k[0] ^= kb[0];
+    k[1] ^= kb[1];
+    k[2] ^= kb[2];
+    k[3] ^= kb[3] ^ tweak;
+}
+
+// N hashes pi(K) ^ K in lock-step; k[][] in: hash inputs, out: hash values (as labels)
+template <int NR, int N>
+__device__ __forceinline__ void hash_n(uint32_t (&k)[N][4], uint4 (&out)[N], const uint32_t *__restrict__ rk,
+                                       const uint32_t *te) {
+    uint32_t s[N][4];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i][0] = k[i][0];
+        s[i][1] = k[i][1];
+        s[i][2] = k[i][2];
+        s[i][3] = k[i][3];
+    }
+    aes_encrypt_n<NR, N>(s, rk, te);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i][0] ^= k[i][0];
+        s[i][1] ^= k[i][1];
+        s[i][2] ^= k[i][2];
+        s[i][3] ^= k[i][3];
+        out[i] = cols_to_label(s[i]);
+    }
+}
+
+}  // namespace gc

@@ -1,0 +1,588 @@
+// engine.cpp — C ABI of libgcengine.so: contexts, circuits, batches, host-buffer entry points.
+// (HIP host code; kernels are in gc_kernels.hip / ot_kernels.hip.)
+#include "engine.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace gc {
+
+thread_local char tls_error[512] = "";
+
+void set_error(const char *what, hipError_t e) {
+    std::snprintf(tls_error, sizeof tls_error, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+}  // namespace gc
+
+using namespace gc;
+
+extern "C" {
+
+const char *gc_strerror(int status) {
+    switch (status) {
+    case GC_OK: return "ok";
+    case GC_E_KEYSIZE: return "crypto/aes: invalid key size";
+    case GC_E_RAND: return "random stream too short";
+    case GC_E_GATE: return "invalid gate type";
+    case GC_E_ROWS: return "corrupted circuit: garbled table size";
+    case GC_E_ARG: return "invalid argument";
+    case GC_E_HIP: return "HIP runtime error";
+    case GC_E_NOMEM: return "out of memory";
+    case GC_E_WIRE: return "gate input wire not set";
+    default: return "unknown status";
+    }
+}
+
+const char *gc_last_error(void) { return tls_error; }
+int gc_abi_version(void) { return GC_ABI_VERSION; }
+
+int gc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- context ---------------------------------------------------------------------------------
+
+gc_ctx *gc_ctx_create(int device, int *status) {
+    int rc = GC_OK;
+    gc_ctx *c = new (std::nothrow) gc_ctx;
+    if (!c) rc = GC_E_NOMEM;
+    if (rc == GC_OK) {
+        c->device = device;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_te0, 256 * sizeof(uint32_t));
+        if (e == hipSuccess)
+            e = hipMemcpy(c->d_te0, aes_tables().te0, 256 * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("gc_ctx_create", e);
+            rc = GC_E_HIP;
+        }
+    }
+    if (rc != GC_OK && c) {
+        gc_ctx_destroy(c);
+        c = nullptr;
+    }
+    if (status) *status = rc;
+    return c;
+}
+
+void gc_ctx_destroy(gc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->d_te0) (void)hipFree(c->d_te0);
+    delete c;
+}
+
+int gc_ctx_sync(gc_ctx *c) {
+    if (!c) return GC_E_ARG;
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipStreamSynchronize(c->stream));
+    return GC_OK;
+}
+
+void *gc_ctx_stream(gc_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---- circuit ---------------------------------------------------------------------------------
+
+gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                      uint32_t noutputs, int *status) {
+    int rc = GC_OK;
+    gc_circ *c = nullptr;
+    if (!ctx) rc = GC_E_ARG;
+    if (rc == GC_OK) {
+        c = new (std::nothrow) gc_circ;
+        if (!c) rc = GC_E_NOMEM;
+    }
+    if (rc == GC_OK) {
+        c->ctx = ctx;
+        rc = build_plan(gates, ngates, nwires, ninputs, noutputs, &c->plan.p);
+    }
+    if (rc == GC_OK) {
+        const Plan &p = c->plan.p;
+        hipError_t e = hipSetDevice(ctx->device);
+        auto up = [&](void **dptr, const void *src, size_t bytes) {
+            if (e != hipSuccess) return;
+            e = hipMalloc(dptr, bytes ? bytes : 16);
+            if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+        };
+        up((void **)&c->d_descs, p.descs.data(), p.descs.size() * sizeof(GateDesc));
+        up((void **)&c->d_out_slots, p.out_slots.data(), p.out_slots.size() * sizeof(uint32_t));
+        up((void **)&c->d_slot_of_wire, p.slot_of_wire.data(), p.slot_of_wire.size() * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            set_error("gc_circ_load", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        }
+    }
+    if (rc != GC_OK && c) {
+        gc_circ_free(c);
+        c = nullptr;
+    }
+    if (status) *status = rc;
+    return c;
+}
+
+void gc_circ_free(gc_circ *c) {
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    for (gc_batch *b : c->pool) gc_batch_free(b);
+    c->pool.clear();
+    if (c->d_descs) (void)hipFree(c->d_descs);
+    if (c->d_out_slots) (void)hipFree(c->d_out_slots);
+    if (c->d_slot_of_wire) (void)hipFree(c->d_slot_of_wire);
+    delete c;
+}
+
+const gc_plan *gc_circ_plan(const gc_circ *c) { return c ? &c->plan : nullptr; }
+
+// ---- batch -----------------------------------------------------------------------------------
+
+gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) {
+    int rc = GC_OK;
+    gc_batch *b = nullptr;
+    if (!circ || batch == 0) rc = GC_E_ARG;
+    if (rc == GC_OK) {
+        b = new (std::nothrow) gc_batch;
+        if (!b) rc = GC_E_NOMEM;
+    }
+    if (rc == GC_OK) {
+        b->circ = circ;
+        b->g = make_geom(batch);
+        const Plan &p = circ->plan.p;
+        hipError_t e = hipSetDevice(circ->ctx->device);
+        size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
+        size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_T, tbytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_R, (size_t)b->g.bstride * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_rk, 60 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_R, 0, (size_t)b->g.bstride * sizeof(uint4), circ->ctx->stream);
+        if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+        if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+        if (e != hipSuccess) {
+            set_error("gc_batch_create", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        }
+    }
+    if (rc != GC_OK && b) {
+        gc_batch_free(b);
+        b = nullptr;
+    }
+    if (status) *status = rc;
+    return b;
+}
+
+static void drop_graphs(gc_batch *b) {
+    for (auto &ge : b->graphs) {
+        if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+    }
+    b->graphs.clear();
+}
+
+void gc_batch_free(gc_batch *b) {
+    if (!b) return;
+    if (b->circ && b->circ->ctx) {
+        (void)hipSetDevice(b->circ->ctx->device);
+        (void)hipStreamSynchronize(b->circ->ctx->stream);
+    }
+    drop_graphs(b);
+    if (b->d_W) (void)hipFree(b->d_W);
+    if (b->d_T) (void)hipFree(b->d_T);
+    if (b->d_R) (void)hipFree(b->d_R);
+    if (b->d_rk) (void)hipFree(b->d_rk);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+uint32_t gc_batch_stride(const gc_batch *b) { return b ? b->g.bstride : 0; }
+
+int gc_batch_set_schedule(gc_batch *b, int schedule) {
+    if (!b || schedule < 0 || schedule > 1) return GC_E_ARG;
+    b->schedule = schedule;
+    return GC_OK;
+}
+
+int gc_batch_set_graph(gc_batch *b, int on) {
+    if (!b) return GC_E_ARG;
+    b->use_graph = on != 0;
+    return GC_OK;
+}
+
+static int set_key(gc_batch *b, const uint8_t *key, size_t keylen) {
+    AesKey k;
+    if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
+    if (b->rounds == k.rounds && std::memcmp(b->rk_host, k.w, sizeof k.w) == 0) return GC_OK;
+    std::memcpy(b->rk_host, k.w, sizeof k.w);
+    b->rounds = k.rounds;
+    // pageable source: the runtime stages it before returning, so rk_host may change afterwards
+    GC_HIP(hipMemcpyAsync(b->d_rk, b->rk_host, sizeof k.w, hipMemcpyHostToDevice, b->circ->ctx->stream));
+    return GC_OK;
+}
+
+// enqueue the level launches of one garble (eval == false) or eval pass
+static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s) {
+    const Plan &p = b->circ->plan.p;
+    LevelArgs a{};
+    a.W = b->d_W;
+    a.R = b->d_R;
+    a.T = const_cast<uint4 *>(T);
+    a.rk = b->d_rk;
+    a.te0 = b->circ->ctx->d_te0;
+    a.rounds = b->rounds;
+    for (const Step &st : p.levels) {
+        a.descs = b->circ->d_descs + st.first;
+        a.count = st.count;
+        a.nonfree = st.nonfree;
+        a.out_slot0 = p.info.ninputs + st.first;
+        if (eval) launch_eval_level(a, b->g, s);
+        else launch_garble_level(a, b->g, s);
+    }
+}
+
+static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
+    hipStream_t s = b->circ->ctx->stream;
+    const Plan &p = b->circ->plan.p;
+    b->last_launches = (uint32_t)p.levels.size();
+    if (!b->use_graph || p.levels.size() < 2) {
+        enqueue_levels(b, eval, T, s);
+        GC_HIP(hipGetLastError());
+        return GC_OK;
+    }
+    // one captured graph per (pass, rounds, table pointer, schedule)
+    for (auto &ge : b->graphs) {
+        if (ge.eval == eval && ge.rounds == b->rounds && ge.T == T && ge.schedule == b->schedule) {
+            GC_HIP(hipGraphLaunch(ge.exec, s));
+            return GC_OK;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e == hipSuccess) {
+        enqueue_levels(b, eval, T, s);
+        e = hipStreamEndCapture(s, &graph);
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        // capture unsupported in this environment: fall back to direct launches (same kernels)
+        (void)hipGetLastError();
+        b->use_graph = false;
+        enqueue_levels(b, eval, T, s);
+        GC_HIP(hipGetLastError());
+        return GC_OK;
+    }
+    b->graphs.push_back({eval, b->rounds, b->schedule, T, exec});
+    GC_HIP(hipGraphLaunch(exec, s));
+    return GC_OK;
+}
+
+int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *d_rnd) {
+    if (!b || !d_rnd) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = set_key(b, key, keylen);
+    if (rc != GC_OK) return rc;
+    const Plan &p = b->circ->plan.p;
+    GC_HIP(hipEventRecord(b->ev0, ctx->stream));
+    launch_init_garble((const uint4 *)d_rnd, p.info.ninputs, b->d_W, b->d_R, b->g, ctx->stream);
+    rc = run_levels(b, false, b->d_T);
+    if (rc != GC_OK) return rc;
+    b->last_launches += 1;
+    GC_HIP(hipEventRecord(b->ev1, ctx->stream));
+    b->timed = true;
+    return GC_OK;
+}
+
+int gc_batch_select_inputs(gc_batch *ev, const gc_batch *gb, const void *d_bits) {
+    if (!ev || !gb || !d_bits || ev->circ != gb->circ || ev->g.batch != gb->g.batch) return GC_E_ARG;
+    gc_ctx *ctx = ev->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_select_inputs(ev->d_W, gb->d_W, gb->d_R, (const uint8_t *)d_bits, ev->circ->plan.p.info.ninputs, ev->g,
+                         ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_batch_set_inputs(gc_batch *ev, const void *d_labels) {
+    if (!ev || !d_labels) return GC_E_ARG;
+    gc_ctx *ctx = ev->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    uint32_t nin = ev->circ->plan.p.info.ninputs;
+    launch_scatter((const uint4 *)d_labels, nin, nin, nullptr, 0, ev->d_W, ev->g, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batch *tables) {
+    if (!ev || !tables || tables->circ != ev->circ || tables->g.bstride != ev->g.bstride) return GC_E_ARG;
+    gc_ctx *ctx = ev->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = set_key(ev, key, keylen);
+    if (rc != GC_OK) return rc;
+    GC_HIP(hipEventRecord(ev->ev0, ctx->stream));
+    rc = run_levels(ev, true, tables->d_T);
+    if (rc != GC_OK) return rc;
+    GC_HIP(hipEventRecord(ev->ev1, ctx->stream));
+    ev->timed = true;
+    return GC_OK;
+}
+
+int gc_batch_decode(const gc_batch *gb, const gc_batch *ev, void *d_bits_out, void *d_mismatch) {
+    if (!gb || !ev || !d_bits_out || gb->circ != ev->circ || gb->g.batch != ev->g.batch) return GC_E_ARG;
+    gc_ctx *ctx = gb->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_decode(gb->d_W, gb->d_R, ev->d_W, gb->circ->d_out_slots, gb->circ->plan.p.info.noutputs,
+                  (uint8_t *)d_bits_out, (uint32_t *)d_mismatch, gb->g, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+// ---- read-backs --------------------------------------------------------------------------------
+
+namespace {
+
+// temp device buffer freed on scope exit
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+}  // namespace
+
+int gc_batch_read_r(gc_batch *b, gc_label *r_out) {
+    if (!b || !r_out) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipMemcpyAsync(r_out, b->d_R, (size_t)b->g.batch * sizeof(gc_label), hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+}
+
+static int read_gather(gc_batch *b, const uint4 *src, const uint32_t *slots, uint32_t slot0, uint32_t n, int mode,
+                       void *host_out) {
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t elems = (size_t)n * (mode ? 2 : 1);
+    // bounded staging: move at most ~256 MiB per pass
+    const size_t per_inst = elems * sizeof(uint4);
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)256 << 20) / per_inst));
+    chunk = (chunk + 31u) & ~31u;
+    DevBuf tmp;
+    GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
+    for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
+        BatchGeom g = b->g;
+        g.batch = std::min(chunk, b->g.batch - i0);
+        launch_gather(src + i0, slots, slot0, n, b->d_R + i0, mode, (uint4 *)tmp.p, elems, g, ctx->stream);
+        GC_HIP(hipGetLastError());
+        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, tmp.p, (size_t)g.batch * per_inst,
+                              hipMemcpyDeviceToHost, ctx->stream));
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GC_OK;
+}
+
+int gc_batch_read_slab(gc_batch *b, gc_label *slab_out) {
+    if (!b || !slab_out) return GC_E_ARG;
+    return read_gather(b, b->d_T, nullptr, 0, b->circ->plan.p.info.slab_rows, 0, slab_out);
+}
+
+int gc_batch_read_wires(gc_batch *b, gc_wire *wires_out) {
+    if (!b || !wires_out) return GC_E_ARG;
+    return read_gather(b, b->d_W, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 1, wires_out);
+}
+
+int gc_batch_read_labels(gc_batch *b, gc_label *labels_out) {
+    if (!b || !labels_out) return GC_E_ARG;
+    return read_gather(b, b->d_W, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 0, labels_out);
+}
+
+int gc_batch_read_outputs(gc_batch *b, gc_label *out) {
+    if (!b || !out) return GC_E_ARG;
+    return read_gather(b, b->d_W, b->circ->d_out_slots, 0, b->circ->plan.p.info.noutputs, 0, out);
+}
+
+static int write_scatter(gc_batch *b, const void *host_src, size_t src_stride_elems, size_t col0, uint32_t n,
+                         const uint32_t *slots, uint32_t slot0, uint4 *dst) {
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t per_inst = (size_t)n * sizeof(uint4);
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)256 << 20) / per_inst));
+    chunk = (chunk + 31u) & ~31u;
+    DevBuf tmp;
+    GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
+    for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
+        BatchGeom g = b->g;
+        g.batch = std::min(chunk, b->g.batch - i0);
+        const uint8_t *src = (const uint8_t *)host_src + ((size_t)i0 * src_stride_elems + col0) * sizeof(uint4);
+        GC_HIP(hipMemcpy2DAsync(tmp.p, per_inst, src, src_stride_elems * sizeof(uint4), per_inst, g.batch,
+                                hipMemcpyHostToDevice, ctx->stream));
+        launch_scatter((const uint4 *)tmp.p, n, n, slots, slot0, dst + i0, g, ctx->stream);
+        GC_HIP(hipGetLastError());
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GC_OK;
+}
+
+int gc_batch_write_slab(gc_batch *b, const gc_label *slab) {
+    if (!b || !slab) return GC_E_ARG;
+    uint32_t rows = b->circ->plan.p.info.slab_rows;
+    return write_scatter(b, slab, rows, 0, rows, nullptr, 0, b->d_T);
+}
+
+void *gc_batch_dev_wires(gc_batch *b) { return b ? b->d_W : nullptr; }
+void *gc_batch_dev_slab(gc_batch *b) { return b ? b->d_T : nullptr; }
+void *gc_batch_dev_r(gc_batch *b) { return b ? b->d_R : nullptr; }
+
+int gc_batch_gather_outputs(gc_batch *b, void *d_out) {
+    if (!b || !d_out) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_gather_rows(b->d_W, b->circ->d_out_slots, b->circ->plan.p.info.noutputs, (uint4 *)d_out, b->g,
+                       ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+float gc_batch_last_ms(gc_batch *b) {
+    if (!b || !b->timed) return -1.0f;
+    if (hipSetDevice(b->circ->ctx->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+uint32_t gc_batch_last_launches(gc_batch *b) { return b ? b->last_launches : 0; }
+
+// ---- host-buffer API -------------------------------------------------------------------------
+
+static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);
+        for (size_t i = 0; i < c->pool.size(); i++) {
+            if (c->pool[i]->g.batch == batch) {
+                gc_batch *b = c->pool[i];
+                c->pool.erase(c->pool.begin() + (long)i);
+                return b;
+            }
+        }
+    }
+    return gc_batch_create(c, batch, rc);
+}
+
+static void pool_put(gc_circ *c, gc_batch *b) {
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    if (c->pool.size() < 4) {
+        c->pool.push_back(b);
+        return;
+    }
+    gc_batch_free(b);
+}
+
+int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen, uint32_t batch,
+              gc_label *r_out, gc_wire *wires_out, gc_wire *io_out, gc_label *slab_out) {
+    if (!c || !rnd || batch == 0) return GC_E_ARG;
+    const Plan &p = c->plan.p;
+    // error order of the reference: R is read first (garble.go:253), then aes.NewCipher (:260),
+    // then the input labels (:271-278)
+    if (rndlen < 16) return GC_E_RAND;
+    AesKey k;
+    if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
+    const size_t stride = 16 * ((size_t)p.info.ninputs + 1);
+    if (rndlen < stride * batch) return GC_E_RAND;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, batch, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    // one HIP stream per ctx: serialise host-buffer calls that share the ctx
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        DevBuf d_rnd;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = d_rnd.alloc(stride * batch);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rnd.p, rnd, stride * batch, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_garble", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            break;
+        }
+        rc = gc_batch_garble(b, key, keylen, d_rnd.p);
+        if (rc != GC_OK) break;
+        if (r_out && (rc = gc_batch_read_r(b, r_out)) != GC_OK) break;
+        if (slab_out && (rc = gc_batch_read_slab(b, slab_out)) != GC_OK) break;
+        if (wires_out && (rc = gc_batch_read_wires(b, wires_out)) != GC_OK) break;
+        if (io_out) {
+            // Wires[0:ninputs] then Wires[nwires-noutputs:]
+            const uint32_t nio = p.info.ninputs + p.info.noutputs;
+            // gather the two ranges separately into a strided host buffer
+            std::vector<gc_wire> in((size_t)batch * p.info.ninputs), out((size_t)batch * p.info.noutputs);
+            rc = read_gather(b, b->d_W, nullptr, 0, p.info.ninputs, 1, in.data());
+            if (rc != GC_OK) break;
+            rc = read_gather(b, b->d_W, c->d_out_slots, 0, p.info.noutputs, 1, out.data());
+            if (rc != GC_OK) break;
+            for (uint32_t i = 0; i < batch; i++) {
+                std::copy(in.begin() + (size_t)i * p.info.ninputs, in.begin() + (size_t)(i + 1) * p.info.ninputs,
+                          io_out + (size_t)i * nio);
+                std::copy(out.begin() + (size_t)i * p.info.noutputs, out.begin() + (size_t)(i + 1) * p.info.noutputs,
+                          io_out + (size_t)i * nio + p.info.ninputs);
+            }
+        }
+        hipError_t es = hipStreamSynchronize(ctx->stream);
+        if (es != hipSuccess) {
+            set_error("gc_garble", es);
+            rc = GC_E_HIP;
+        }
+    } while (0);
+    pool_put(c, b);
+    return rc;
+}
+
+int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
+            const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels) {
+    if (!c || batch == 0 || (!wires_inout && !inputs)) return GC_E_ARG;
+    const Plan &p = c->plan.p;
+    AesKey k;
+    if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
+    if (slab_rows_given != p.info.slab_rows || (!slab && p.info.slab_rows)) return GC_E_ROWS;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, batch, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        if (p.info.slab_rows && (rc = gc_batch_write_slab(b, slab)) != GC_OK) break;
+        if (wires_inout)
+            rc = write_scatter(b, wires_inout, p.info.nwires, 0, p.info.ninputs, nullptr, 0, b->d_W);
+        else
+            rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W);
+        if (rc != GC_OK) break;
+        rc = gc_batch_eval(b, key, keylen, b);
+        if (rc != GC_OK) break;
+        if (wires_inout && (rc = gc_batch_read_labels(b, wires_inout)) != GC_OK) break;
+        if (out_labels && (rc = gc_batch_read_outputs(b, out_labels)) != GC_OK) break;
+        hipError_t es = hipStreamSynchronize(ctx->stream);
+        if (es != hipSuccess) {
+            set_error("gc_eval", es);
+            rc = GC_E_HIP;
+        }
+    } while (0);
+    pool_put(c, b);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// engine.h — internal structs behind the opaque C-ABI handles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+#include "../../include/gcengine.h"
+#include "aes_host.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace gc {
+extern thread_local char tls_error[512];
+void set_error(const char *what, hipError_t e);
+}  // namespace gc
+
+#define GC_HIP(expr)                                                   \
+    do {                                                               \
+        hipError_t e__ = (expr);                                       \
+        if (e__ != hipSuccess) {                                       \
+            gc::set_error(#expr, e__);                                 \
+            return e__ == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP; \
+        }                                                              \
+    } while (0)
+
+struct gc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *d_te0 = nullptr;  // Te0 (1 KiB), L2-resident source of the LDS tables
+    std::mutex mu;              // serialises host-buffer calls sharing this ctx's stream
+};
+
+struct gc_circ {
+    gc_ctx *ctx = nullptr;
+    gc_plan plan;
+    gc::GateDesc *d_descs = nullptr;
+    uint32_t *d_out_slots = nullptr;
+    uint32_t *d_slot_of_wire = nullptr;
+    std::mutex pool_mu;
+    std::vector<gc_batch *> pool;  // idle batches reused by gc_garble / gc_eval (cf. garble.go:195-225)
+};
+
+struct gc_graph_entry {
+    bool eval;
+    int rounds;
+    int schedule;
+    const uint4 *T;
+    hipGraphExec_t exec;
+};
+
+struct gc_batch {
+    gc_circ *circ = nullptr;
+    gc::BatchGeom g{};
+    uint4 *d_W = nullptr;  // wire labels [nslots][bstride]: L0 (garbler) or active label (evaluator)
+    uint4 *d_T = nullptr;  // garbled tables [slab_rows][bstride]
+    uint4 *d_R = nullptr;  // [bstride]
+    uint32_t *d_rk = nullptr;
+    uint32_t rk_host[60] = {0};
+    int rounds = 0;
+    int schedule = 1;
+    bool use_graph = true;
+    std::vector<gc_graph_entry> graphs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint32_t last_launches = 0;
+};

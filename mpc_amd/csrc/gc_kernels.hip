@@ -1,0 +1,435 @@
+// gc_kernels.hip — CDNA4 (gfx950) kernels for Circuit.Garble / Circuit.Eval.
+//
+// Mapping: one thread = one gate of one instance.  Lanes of a wavefront run along the
+// INSTANCE axis, so every label access of a wave is 64 consecutive uint4 = one 1 KiB
+// coalesced transaction, the gate descriptor is wave-uniform (scalar loads, no divergence)
+// and the AES round keys live in SGPRs.  The four T-tables sit in LDS (4 KiB per block).
+// Arithmetic restated from circuit/garble.go:311-482 (garbleInto) and circuit/eval.go:28-112.
+#include "aes_device.h"
+#include "kernels.h"
+
+namespace gc {
+
+BatchGeom make_geom(uint32_t batch) {
+    BatchGeom g{};
+    g.batch = batch;
+    g.bstride = (batch + 63u) & ~63u;
+    if (g.bstride == 0) g.bstride = 64;
+    if (batch >= 256) {
+        g.lg = 8;
+        g.yblocks = (batch + 255) / 256;
+    } else {
+        uint32_t lg = 0;
+        while ((1u << lg) < batch) lg++;
+        g.lg = lg;
+        g.yblocks = 1;
+    }
+    return g;
+}
+
+struct ThreadPos {
+    uint32_t gate, inst;
+};
+
+// gate / instance of this thread; when the instance tile covers whole waves (lg >= 6) the gate
+// index is made provably wave-uniform so that the descriptor comes in through scalar loads.
+template <bool UNIFORM>
+__device__ __forceinline__ ThreadPos thread_pos(uint32_t lg) {
+    ThreadPos p;
+    uint32_t gl = threadIdx.x >> lg;
+    if (UNIFORM) gl = __builtin_amdgcn_readfirstlane(gl);
+    p.gate = blockIdx.x * (256u >> lg) + gl;
+    p.inst = blockIdx.y * 256u + (threadIdx.x & ((1u << lg) - 1u));
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// Garble one step (a set of mutually independent gates) for all instances.
+// ------------------------------------------------------------------------------------------
+template <int NR, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_garble_level(const GateDesc *__restrict__ descs, uint32_t count,
+                                                      uint32_t nonfree, uint32_t out_slot0, uint32_t batch,
+                                                      uint32_t bstride, uint32_t lg, uint4 *__restrict__ W,
+                                                      const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
+                                                      const uint32_t *__restrict__ rk,
+                                                      const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeWords];
+    const bool need_tables = blockIdx.x * (256u >> lg) < nonfree;  // block-uniform
+    if (need_tables) {
+        load_te_tables(te, g_te0);
+        __syncthreads();
+    }
+    const ThreadPos tp = thread_pos<UNIFORM>(lg);
+    if (tp.gate >= count || tp.inst >= batch) return;
+    const GateDesc d = descs[tp.gate];
+    const uint32_t op = d.row_op >> kOpShift;
+    const size_t i = tp.inst;
+    const uint4 R = Rv[i];
+    const uint4 a0 = W[(size_t)d.in0 * bstride + i];
+    uint4 *out = W + (size_t)(out_slot0 + tp.gate) * bstride + i;
+
+    if (op == GC_XOR) {  // garble.go:331-340
+        *out = lxor(a0, W[(size_t)d.in1 * bstride + i]);
+        return;
+    }
+    if (op == GC_XNOR) {  // garble.go:342-351: L0 = a0^b0^R
+        *out = lxor(lxor(a0, W[(size_t)d.in1 * bstride + i]), R);
+        return;
+    }
+    uint4 *row = T + (size_t)(d.row_op & kRowMask) * bstride + i;
+    if (op == GC_AND) {  // garble.go:353-395
+        const uint4 b0 = W[(size_t)d.in1 * bstride + i];
+        const uint4 a1 = lxor(a0, R), b1 = lxor(b0, R);
+        uint32_t k[4][4];
+        make_k_half(a0, d.tweak, k[0]);
+        make_k_half(a1, d.tweak, k[1]);
+        make_k_half(b0, d.tweak + 1, k[2]);
+        make_k_half(b1, d.tweak + 1, k[3]);
+        uint4 h[4];
+        hash_n<NR, 4>(k, h, rk, te);
+        const uint32_t pa = smask(a0), pb = smask(b0);
+        // first half gate: TG = H(a0)^H(a1)^(pb?R:0); WG0 = H(a0)^(pa?TG:0)
+        uint4 tg = lxor(lxor(h[0], h[1]), land(R, pb));
+        uint4 wg0 = lxor(h[0], land(tg, pa));
+        // second half gate: TE = H(b0)^H(b1)^a0; WE0 = H(b0)^(pb?TE^a0:0)
+        uint4 te_ = lxor(lxor(h[2], h[3]), a0);
+        uint4 we0 = lxor(h[2], land(lxor(te_, a0), pb));
+        *out = lxor(wg0, we0);
+        row[0] = tg;
+        row[bstride] = te_;
+        return;
+    }
+    if (op == GC_INV) {  // garble.go:446-474; enc(a,0,0,id) == H(a,id)
+        const uint4 a1 = lxor(a0, R);
+        uint32_t k[2][4];
+        make_k_half(a0, d.tweak, k[0]);
+        make_k_half(a1, d.tweak, k[1]);
+        uint4 e[2];
+        hash_n<NR, 2>(k, e, rk, te);
+        // table[S(a0)] = E0, table[S(a1)] = E1; row 0 is folded into the output labels:
+        // S(a0)==0: L0 = E0^R (L1 = E0);  S(a0)==1: L0 = E1 (L1 = E1^R);  row[1] = E0^E1^R
+        const bool s = lbit_s(a0);
+        *out = s ? e[1] : lxor(e[0], R);
+        row[0] = lxor(lxor(e[0], e[1]), R);
+        return;
+    }
+    // GC_OR: garble.go:412-444
+    {
+        const uint4 b0 = W[(size_t)d.in1 * bstride + i];
+        const uint4 a1 = lxor(a0, R), b1 = lxor(b0, R);
+        uint32_t k[4][4];
+        make_k(a0, b0, d.tweak, k[0]);
+        make_k(a0, b1, d.tweak, k[1]);
+        make_k(a1, b0, d.tweak, k[2]);
+        make_k(a1, b1, d.tweak, k[3]);
+        uint4 e[4];  // e[2u+v] = enc(a_u, b_v, 0, id)
+        hash_n<NR, 4>(k, e, rk, te);
+        const uint32_t pa = lbit_s(a0) ? 1u : 0u, pb = lbit_s(b0) ? 1u : 0u;
+        const uint32_t l0 = 2u * pa + pb;  // idx(a0,b0)
+        // table[2s+t] = e[2(s^pa) + (t^pb)]
+        // (mask selects keep everything in registers — no dynamically indexed arrays)
+        const uint32_t m0 = l0 == 0 ? ~0u : 0u, m1 = l0 == 1 ? ~0u : 0u, m2 = l0 == 2 ? ~0u : 0u,
+                       m3 = l0 == 3 ? ~0u : 0u;
+        auto pick = [&](uint32_t ma, uint32_t mb, uint32_t mc, uint32_t md) {
+            // e[q ^ l0] for the q whose (q^l0) pattern is given by the masks of l0
+            return lxor(lxor(land(e[0], ma), land(e[1], mb)), lxor(land(e[2], mc), land(e[3], md)));
+        };
+        const uint4 t0 = pick(m0, m1, m2, m3);  // q=0: src = l0
+        const uint4 t1 = pick(m1, m0, m3, m2);  // q=1: src = l0^1
+        const uint4 t2 = pick(m2, m3, m0, m1);  // q=2: src = l0^2
+        const uint4 t3 = pick(m3, m2, m1, m0);  // q=3: src = l0^3
+        // c.L0 = c.L1 = table[0]; the label of the (a0,b0) row gets no R when l0 == 0
+        const uint4 c0 = lxor(t0, land(R, ~m0));
+        const uint4 c1 = lxor(t0, land(R, m0));
+        // table[i] ^= (i == l0) ? c.L0 : c.L1, rows 1..3 are emitted
+        row[0] = lxor(t1, lxor(land(c0, m1), land(c1, ~m1)));
+        row[bstride] = lxor(t2, lxor(land(c0, m2), land(c1, ~m2)));
+        row[2 * (size_t)bstride] = lxor(t3, lxor(land(c0, m3), land(c1, ~m3)));
+        *out = c0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Evaluate one step for all instances (circuit/eval.go:28-112).
+// ------------------------------------------------------------------------------------------
+template <int NR, bool UNIFORM>
+__global__ __launch_bounds__(256) void k_eval_level(const GateDesc *__restrict__ descs, uint32_t count,
+                                                    uint32_t nonfree, uint32_t out_slot0, uint32_t batch,
+                                                    uint32_t bstride, uint32_t lg, uint4 *__restrict__ W,
+                                                    const uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
+                                                    const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeWords];
+    const bool need_tables = blockIdx.x * (256u >> lg) < nonfree;
+    if (need_tables) {
+        load_te_tables(te, g_te0);
+        __syncthreads();
+    }
+    const ThreadPos tp = thread_pos<UNIFORM>(lg);
+    if (tp.gate >= count || tp.inst >= batch) return;
+    const GateDesc d = descs[tp.gate];
+    const uint32_t op = d.row_op >> kOpShift;
+    const size_t i = tp.inst;
+    const uint4 a = W[(size_t)d.in0 * bstride + i];
+    uint4 *out = W + (size_t)(out_slot0 + tp.gate) * bstride + i;
+
+    if (op == GC_XOR || op == GC_XNOR) {  // eval.go:49-51
+        *out = lxor(a, W[(size_t)d.in1 * bstride + i]);
+        return;
+    }
+    const uint4 *row = T + (size_t)(d.row_op & kRowMask) * bstride + i;
+    if (op == GC_AND) {  // eval.go:53-78
+        const uint4 b = W[(size_t)d.in1 * bstride + i];
+        const uint4 tg = row[0], te_ = row[bstride];
+        uint32_t k[2][4];
+        make_k_half(a, d.tweak, k[0]);
+        make_k_half(b, d.tweak + 1, k[1]);
+        uint4 h[2];
+        hash_n<NR, 2>(k, h, rk, te);
+        uint4 wg = lxor(h[0], land(tg, smask(a)));
+        uint4 we = lxor(h[1], land(lxor(te_, a), smask(b)));
+        *out = lxor(wg, we);
+        return;
+    }
+    if (op == GC_INV) {  // eval.go:96-109: c = S(a) ? row[0] : 0; out = c ^ pi(K) ^ K
+        uint32_t k[1][4];
+        make_k_half(a, d.tweak, k[0]);
+        uint4 h[1];
+        hash_n<NR, 1>(k, h, rk, te);
+        *out = lxor(h[0], land(row[0], smask(a)));
+        return;
+    }
+    {  // GC_OR: eval.go:80-94
+        const uint4 b = W[(size_t)d.in1 * bstride + i];
+        const uint32_t index = (lbit_s(a) ? 2u : 0u) | (lbit_s(b) ? 1u : 0u);
+        uint4 c = make_uint4(0, 0, 0, 0);
+        if (index > 0) c = row[(size_t)(index - 1) * bstride];
+        uint32_t k[1][4];
+        make_k(a, b, d.tweak, k[0]);
+        uint4 h[1];
+        hash_n<NR, 1>(k, h, rk, te);
+        *out = lxor(h[0], c);
+    }
+}
+
+#define GC_DISPATCH_LEVEL(KERNEL, ...)                                                                     \
+    do {                                                                                                   \
+        dim3 grid((a.count + (256u >> g.lg) - 1) / (256u >> g.lg), g.yblocks), block(256);                 \
+        const bool uni = g.lg >= 6;                                                                        \
+        switch (a.rounds) {                                                                                \
+        case 10:                                                                                           \
+            if (uni) hipLaunchKernelGGL((KERNEL<10, true>), grid, block, 0, s, __VA_ARGS__);               \
+            else hipLaunchKernelGGL((KERNEL<10, false>), grid, block, 0, s, __VA_ARGS__);                  \
+            break;                                                                                         \
+        case 12:                                                                                           \
+            if (uni) hipLaunchKernelGGL((KERNEL<12, true>), grid, block, 0, s, __VA_ARGS__);               \
+            else hipLaunchKernelGGL((KERNEL<12, false>), grid, block, 0, s, __VA_ARGS__);                  \
+            break;                                                                                         \
+        default:                                                                                           \
+            if (uni) hipLaunchKernelGGL((KERNEL<14, true>), grid, block, 0, s, __VA_ARGS__);               \
+            else hipLaunchKernelGGL((KERNEL<14, false>), grid, block, 0, s, __VA_ARGS__);                  \
+            break;                                                                                         \
+        }                                                                                                  \
+    } while (0)
+
+void launch_garble_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s) {
+    if (a.count == 0) return;
+    GC_DISPATCH_LEVEL(k_garble_level, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W, a.R,
+                      a.T, a.rk, a.te0);
+}
+
+void launch_eval_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s) {
+    if (a.count == 0) return;
+    GC_DISPATCH_LEVEL(k_eval_level, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W,
+                      (const uint4 *)a.T, a.rk, a.te0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout movers: [instance][n] (host / reference order) <-> [slot][instance] (device order).
+// 32x32 tiles of 16-byte elements through LDS; both the global read and the global write are
+// coalesced along their fast axis.
+// ------------------------------------------------------------------------------------------
+constexpr int TILE = 32;
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+// ot.Label.SetData on 16 big-endian bytes loaded as a uint4 of little-endian words:
+// D0 = BE(bytes 0..7): D0.hi = bswap(word0), D0.lo = bswap(word1); likewise D1.
+__device__ __forceinline__ uint4 label_from_be(uint4 raw) {
+    return make_uint4(bswap32(raw.y), bswap32(raw.x), bswap32(raw.w), bswap32(raw.z));
+}
+
+// rnd [batch][1+ninputs] -> R [inst], W[w][inst]   (garble.go:253-258, 271-278)
+__global__ __launch_bounds__(256) void k_init_garble(const uint4 *__restrict__ rnd, uint32_t ninputs,
+                                                     uint4 *__restrict__ W, uint4 *__restrict__ Rv, uint32_t batch,
+                                                     uint32_t bstride) {
+    __shared__ uint4 tile[TILE][TILE + 1];
+    const uint32_t n = ninputs + 1;
+    const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t i = i0 + r, j = j0 + tx;
+        if (i < batch && j < n) tile[r][tx] = label_from_be(rnd[(size_t)i * n + j]);
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t j = j0 + r, i = i0 + tx;
+        if (i < batch && j < n) {
+            uint4 v = tile[tx][r];
+            if (j == 0) {
+                v.y |= 0x80000000u;  // R.SetS(true)
+                Rv[i] = v;
+            } else {
+                W[(size_t)(j - 1) * bstride + i] = v;
+            }
+        }
+    }
+}
+
+void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s) {
+    dim3 grid((ninputs + 1 + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_init_garble, grid, dim3(256), 0, s, rnd, ninputs, W, R, g.batch, g.bstride);
+}
+
+// dst[inst][j] = W[slot(j)][inst]            (mode 0, one label per element)
+// dst[inst][j] = {L0, L0 ^ R[inst]}          (mode 1, ot.Wire per element)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ W, const uint32_t *__restrict__ slots,
+                                                uint32_t slot0, uint32_t n, const uint4 *__restrict__ Rv,
+                                                uint4 *__restrict__ dst, size_t dst_stride, uint32_t batch,
+                                                uint32_t bstride) {
+    __shared__ uint4 tile[TILE][TILE + 1];
+    const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t j = j0 + r, i = i0 + tx;
+        if (j < n && i < batch) {
+            uint32_t slot = slots ? slots[j] : slot0 + j;
+            tile[r][tx] = slot == 0xffffffffu ? make_uint4(0, 0, 0, 0) : W[(size_t)slot * bstride + i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t i = i0 + r, j = j0 + tx;
+        if (j < n && i < batch) {
+            uint4 v = tile[tx][r];
+            if (MODE == 0) {
+                dst[(size_t)i * dst_stride + j] = v;
+            } else {
+                uint4 *o = dst + (size_t)i * dst_stride + 2 * (size_t)j;
+                o[0] = v;
+                o[1] = lxor(v, Rv[i]);
+            }
+        }
+    }
+}
+
+void launch_gather(const uint4 *W, const uint32_t *slots, uint32_t slot0, uint32_t n, const uint4 *R, int mode,
+                   uint4 *dst, size_t dst_stride_elems, const BatchGeom &g, hipStream_t s) {
+    if (n == 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_gather<0>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, g.batch,
+                           g.bstride);
+    else
+        hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, g.batch,
+                           g.bstride);
+}
+
+// W[slot(j)][inst] = src[inst][j]
+__global__ __launch_bounds__(256) void k_scatter(const uint4 *__restrict__ src, size_t src_stride, uint32_t n,
+                                                 const uint32_t *__restrict__ slots, uint32_t slot0,
+                                                 uint4 *__restrict__ W, uint32_t batch, uint32_t bstride) {
+    __shared__ uint4 tile[TILE][TILE + 1];
+    const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t i = i0 + r, j = j0 + tx;
+        if (j < n && i < batch) tile[r][tx] = src[(size_t)i * src_stride + j];
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < TILE; r += 8) {
+        uint32_t j = j0 + r, i = i0 + tx;
+        if (j < n && i < batch) {
+            uint32_t slot = slots ? slots[j] : slot0 + j;
+            if (slot != 0xffffffffu) W[(size_t)slot * bstride + i] = tile[tx][r];
+        }
+    }
+}
+
+void launch_scatter(const uint4 *src, size_t src_stride_elems, uint32_t n, const uint32_t *slots, uint32_t slot0,
+                    uint4 *W, const BatchGeom &g, hipStream_t s) {
+    if (n == 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, s, src, src_stride_elems, n, slots, slot0, W, g.batch,
+                       g.bstride);
+}
+
+// evaluator's active input labels: L0 ^ (bit ? R : 0)   (LabelForBit, circuit/helpers.go:10-15)
+__global__ __launch_bounds__(256) void k_select_inputs(uint4 *__restrict__ We, const uint4 *__restrict__ Wg,
+                                                       const uint4 *__restrict__ Rv,
+                                                       const uint8_t *__restrict__ bits, uint32_t ninputs,
+                                                       uint32_t batch, uint32_t bstride) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= batch) return;
+    const uint4 R = Rv[i];
+    for (uint32_t w = blockIdx.y; w < ninputs; w += gridDim.y) {
+        const uint32_t m = bits[(size_t)i * ninputs + w] ? 0xffffffffu : 0u;
+        We[(size_t)w * bstride + i] = lxor(Wg[(size_t)w * bstride + i], land(R, m));
+    }
+}
+
+void launch_select_inputs(uint4 *We, const uint4 *Wg, const uint4 *R, const uint8_t *bits, uint32_t ninputs,
+                          const BatchGeom &g, hipStream_t s) {
+    if (ninputs == 0) return;
+    dim3 grid((g.batch + 255) / 256, ninputs < 65535u ? ninputs : 65535u);
+    hipLaunchKernelGGL(k_select_inputs, grid, dim3(256), 0, s, We, Wg, R, bits, ninputs, g.batch, g.bstride);
+}
+
+// BitFromLabel (circuit/helpers.go:18-28) over all output wires
+__global__ __launch_bounds__(256) void k_decode(const uint4 *__restrict__ Wg, const uint4 *__restrict__ Rv,
+                                                const uint4 *__restrict__ We,
+                                                const uint32_t *__restrict__ out_slots, uint32_t noutputs,
+                                                uint8_t *__restrict__ bits_out, uint32_t *__restrict__ mismatch,
+                                                uint32_t batch, uint32_t bstride) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= batch) return;
+    const uint4 R = Rv[i];
+    for (uint32_t j = blockIdx.y; j < noutputs; j += gridDim.y) {
+        const size_t at = (size_t)out_slots[j] * bstride + i;
+        const uint4 l0 = Wg[at], lab = We[at];
+        uint8_t bit = 0;
+        if (leq(lab, l0)) bit = 0;
+        else if (leq(lab, lxor(l0, R))) bit = 1;
+        else {
+            bit = 0xff;
+            if (mismatch) atomicAdd(mismatch, 1u);
+        }
+        bits_out[(size_t)i * noutputs + j] = bit;
+    }
+}
+
+void launch_decode(const uint4 *Wg, const uint4 *R, const uint4 *We, const uint32_t *out_slots, uint32_t noutputs,
+                   uint8_t *bits_out, uint32_t *mismatch, const BatchGeom &g, hipStream_t s) {
+    if (noutputs == 0) return;
+    dim3 grid((g.batch + 255) / 256, noutputs < 65535u ? noutputs : 65535u);
+    hipLaunchKernelGGL(k_decode, grid, dim3(256), 0, s, Wg, R, We, out_slots, noutputs, bits_out, mismatch, g.batch,
+                       g.bstride);
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const uint4 *__restrict__ W, const uint32_t *__restrict__ slots,
+                                                     uint32_t n, uint4 *__restrict__ dst, uint32_t batch,
+                                                     uint32_t bstride) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= bstride) return;
+    for (uint32_t j = blockIdx.y; j < n; j += gridDim.y)
+        dst[(size_t)j * bstride + i] = i < batch ? W[(size_t)slots[j] * bstride + i] : make_uint4(0, 0, 0, 0);
+}
+
+void launch_gather_rows(const uint4 *W, const uint32_t *slots, uint32_t n, uint4 *dst, const BatchGeom &g,
+                        hipStream_t s) {
+    if (n == 0) return;
+    dim3 grid((g.bstride + 255) / 256, n < 65535u ? n : 65535u);
+    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, s, W, slots, n, dst, g.batch, g.bstride);
+}
+
+}  // namespace gc

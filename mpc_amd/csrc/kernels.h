@@ -1,0 +1,73 @@
+// kernels.h — launch wrappers of the HIP kernels (implemented in gc_kernels.hip / ot_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace gc {
+
+// Geometry of one instance batch on the device.
+struct BatchGeom {
+    uint32_t batch;    // instances
+    uint32_t bstride;  // row stride of every [x][instance] array (batch rounded up to 64)
+    uint32_t lg;       // log2 of the per-block instance tile (<= 8); 256>>lg gates share a block
+    uint32_t yblocks;  // instance blocks of 256 (1 when batch <= 256)
+};
+BatchGeom make_geom(uint32_t batch);
+
+struct LevelArgs {
+    const GateDesc *descs;  // device, already offset to the step
+    uint32_t count, nonfree, out_slot0;
+    uint4 *W;               // wire labels [nslots][bstride]
+    const uint4 *R;         // garbler: [bstride]
+    uint4 *T;               // tables [slab_rows][bstride]
+    const uint32_t *rk;     // device round keys (big-endian words)
+    const uint32_t *te0;    // device Te0
+    int rounds;
+};
+
+void launch_garble_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s);
+void launch_eval_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s);
+
+// rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
+void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);
+
+// generic [instance][n] <-> [slot][instance] movers (16-byte elements, LDS-tiled transpose).
+// slots == nullptr means slot j = slot0 + j.
+// mode: 0 = labels, 1 = wires {L0, L0^R} (gather only)
+void launch_gather(const uint4 *W, const uint32_t *slots, uint32_t slot0, uint32_t n, const uint4 *R, int mode,
+                   uint4 *dst, size_t dst_stride_elems, const BatchGeom &g, hipStream_t s);
+void launch_scatter(const uint4 *src, size_t src_stride_elems, uint32_t n, const uint32_t *slots, uint32_t slot0,
+                    uint4 *W, const BatchGeom &g, hipStream_t s);
+
+void launch_select_inputs(uint4 *We, const uint4 *Wg, const uint4 *R, const uint8_t *bits, uint32_t ninputs,
+                          const BatchGeom &g, hipStream_t s);
+void launch_decode(const uint4 *Wg, const uint4 *R, const uint4 *We, const uint32_t *out_slots, uint32_t noutputs,
+                   uint8_t *bits_out, uint32_t *mismatch, const BatchGeom &g, hipStream_t s);
+// dst [n][bstride] <- W[slots[j]][*]
+void launch_gather_rows(const uint4 *W, const uint32_t *slots, uint32_t n, uint4 *dst, const BatchGeom &g,
+                        hipStream_t s);
+
+// ---- OT kernels (ot_kernels.hip) -------------------------------------------------------------
+// Column AES-128-CTR PRG of IKNP.  rk0/rk1: [128][44] expanded column keys (big-endian words);
+// pos0: bytes every column stream has already produced; n OTs -> chunks of 512.
+//   recv: tbuf = PRG(g0), u_out = PRG(g0)^PRG(g1)^choice bytes (bbuf packed LSB first)
+//   send: tbuf = PRG(g0) ^ (delta.Bit(col) ? u_in : 0)
+void launch_iknp_prg(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64_t pos0, size_t n,
+                     const uint8_t *bbuf, const uint8_t *u_in, uint4 delta, uint8_t *tbuf, uint8_t *u_out,
+                     const uint32_t *te0, hipStream_t s);
+// createLabels over all chunks of tbuf
+void launch_iknp_transpose(const uint8_t *tbuf, size_t n, uint4 *labels, hipStream_t s);
+void launch_pack_bits(const uint8_t *b, size_t n, uint8_t *out, hipStream_t s);
+// blk[j*h + t] ^= AES_{key(gid0+j)}(blk[j*h+t])
+void launch_mitccrh(uint4 seed, uint64_t gid0, uint4 *blks, size_t n, uint32_t h, const uint32_t *te0,
+                    hipStream_t s);
+void launch_cot_send(uint4 seed, uint4 delta, const uint4 *data, const uint4 *wires /*[n][2]*/, size_t n, uint4 *out,
+                     const uint32_t *te0, hipStream_t s);
+void launch_cot_recv(uint4 seed, const uint8_t *flags, const uint4 *sent, uint4 *result, size_t n,
+                     const uint32_t *te0, hipStream_t s);
+
+}  // namespace gc

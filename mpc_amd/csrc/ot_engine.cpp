@@ -1,0 +1,226 @@
+// ot_engine.cpp — C ABI for the IKNP OT extension, MITCCRH and the COT pad loops.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+using namespace gc;
+
+struct gc_iknp {
+    gc_ctx *ctx = nullptr;
+    bool receiver = false;
+    uint32_t *d_rk0 = nullptr, *d_rk1 = nullptr;  // [128][44]
+    uint64_t pos = 0;                             // bytes drawn so far from every column stream
+    uint4 delta{};
+};
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+inline uint4 to_u4(const gc_label &l) {
+    return make_uint4((uint32_t)l.d0, (uint32_t)(l.d0 >> 32), (uint32_t)l.d1, (uint32_t)(l.d1 >> 32));
+}
+
+// newPrg (iknp.go:622-630): AES-128 key = BE(label)
+void expand_label_key(const gc_label &l, uint32_t *out44) {
+    uint8_t kb[16];
+    for (int i = 0; i < 8; i++) {
+        kb[i] = (uint8_t)(l.d0 >> (56 - 8 * i));
+        kb[8 + i] = (uint8_t)(l.d1 >> (56 - 8 * i));
+    }
+    AesKey k;
+    aes_expand_key(kb, 16, &k);
+    std::memcpy(out44, k.w, 44 * sizeof(uint32_t));
+}
+
+int upload_keys(gc_ctx *ctx, const std::vector<uint32_t> &host, uint32_t **dptr) {
+    GC_HIP(hipMalloc((void **)dptr, host.size() * sizeof(uint32_t)));
+    GC_HIP(hipMemcpy(*dptr, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    (void)ctx;
+    return GC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+gc_iknp *gc_iknp_receiver_create(gc_ctx *ctx, const gc_wire *base, int *status) {
+    int rc = (ctx && base) ? GC_OK : GC_E_ARG;
+    gc_iknp *k = nullptr;
+    if (rc == GC_OK && !(k = new (std::nothrow) gc_iknp)) rc = GC_E_NOMEM;
+    if (rc == GC_OK) {
+        k->ctx = ctx;
+        k->receiver = true;
+        std::vector<uint32_t> r0(128 * 44), r1(128 * 44);
+        for (int i = 0; i < 128; i++) {
+            expand_label_key(base[i].l0, &r0[44 * i]);
+            expand_label_key(base[i].l1, &r1[44 * i]);
+        }
+        if (hipSetDevice(ctx->device) != hipSuccess) rc = GC_E_HIP;
+        if (rc == GC_OK) rc = upload_keys(ctx, r0, &k->d_rk0);
+        if (rc == GC_OK) rc = upload_keys(ctx, r1, &k->d_rk1);
+    }
+    if (rc != GC_OK && k) {
+        gc_iknp_free(k);
+        k = nullptr;
+    }
+    if (status) *status = rc;
+    return k;
+}
+
+gc_iknp *gc_iknp_sender_create(gc_ctx *ctx, const gc_label *delta, const gc_label *k0, int *status) {
+    int rc = (ctx && delta && k0) ? GC_OK : GC_E_ARG;
+    gc_iknp *k = nullptr;
+    if (rc == GC_OK && !(k = new (std::nothrow) gc_iknp)) rc = GC_E_NOMEM;
+    if (rc == GC_OK) {
+        k->ctx = ctx;
+        k->receiver = false;
+        k->delta = to_u4(*delta);
+        std::vector<uint32_t> r0(128 * 44);
+        for (int i = 0; i < 128; i++) expand_label_key(k0[i], &r0[44 * i]);
+        if (hipSetDevice(ctx->device) != hipSuccess) rc = GC_E_HIP;
+        if (rc == GC_OK) rc = upload_keys(ctx, r0, &k->d_rk0);
+    }
+    if (rc != GC_OK && k) {
+        gc_iknp_free(k);
+        k = nullptr;
+    }
+    if (status) *status = rc;
+    return k;
+}
+
+void gc_iknp_free(gc_iknp *k) {
+    if (!k) return;
+    if (k->ctx) (void)hipSetDevice(k->ctx->device);
+    if (k->d_rk0) (void)hipFree(k->d_rk0);
+    if (k->d_rk1) (void)hipFree(k->d_rk1);
+    delete k;
+}
+
+size_t gc_iknp_u_bytes(size_t n) {
+    // full chunks: 512 rows = 64 byte-rows x 128 columns; the last chunk has ceil(rows/8) byte-rows
+    size_t full = n / 512, rem = n % 512;
+    return full * 8192 + ((rem + 7) / 8) * 128;
+}
+
+static size_t stream_advance(size_t n) { return (n / 512) * 64 + ((n % 512) + 7) / 8; }
+
+int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out) {
+    if (!k || !k->receiver || (n && (!choice || !u_out || !labels_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = k->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t chunks = (n + 511) / 512, ub = gc_iknp_u_bytes(n);
+    DevBuf d_choice, d_bits, d_t, d_u, d_lab;
+    GC_HIP(d_choice.alloc(n));
+    GC_HIP(d_bits.alloc(chunks * 64 + 16));
+    GC_HIP(d_t.alloc(chunks * 8192));
+    GC_HIP(d_u.alloc(chunks * 8192));
+    GC_HIP(d_lab.alloc(n * sizeof(uint4)));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipMemcpyAsync(d_choice.p, choice, n, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemsetAsync(d_bits.p, 0, chunks * 64 + 16, s));
+    launch_pack_bits((const uint8_t *)d_choice.p, n, (uint8_t *)d_bits.p, s);
+    launch_iknp_prg(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_bits.p, nullptr, k->delta,
+                    (uint8_t *)d_t.p, (uint8_t *)d_u.p, ctx->d_te0, s);
+    launch_iknp_transpose((const uint8_t *)d_t.p, n, (uint4 *)d_lab.p, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(u_out, d_u.p, ub, hipMemcpyDeviceToHost, s));
+    GC_HIP(hipMemcpyAsync(labels_out, d_lab.p, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    GC_HIP(hipStreamSynchronize(s));
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out) {
+    if (!k || k->receiver || (n && (!u_in || !labels_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    if (u_len != gc_iknp_u_bytes(n)) return GC_E_ARG;  // "invalid chunk size" (iknp.go:207-209)
+    gc_ctx *ctx = k->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t chunks = (n + 511) / 512;
+    DevBuf d_t, d_u, d_lab;
+    GC_HIP(d_t.alloc(chunks * 8192));
+    GC_HIP(d_u.alloc(chunks * 8192));
+    GC_HIP(d_lab.alloc(n * sizeof(uint4)));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipMemcpyAsync(d_u.p, u_in, u_len, hipMemcpyHostToDevice, s));
+    launch_iknp_prg(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u.p, k->delta, (uint8_t *)d_t.p,
+                    nullptr, ctx->d_te0, s);
+    launch_iknp_transpose((const uint8_t *)d_t.p, n, (uint4 *)d_lab.p, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(labels_out, d_lab.p, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
+    GC_HIP(hipStreamSynchronize(s));
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+int gc_mitccrh_hash(gc_ctx *ctx, const gc_label *seed, uint64_t gid0, gc_label *blks, size_t n, uint32_t h) {
+    if (!ctx || !seed || (n && !blks)) return GC_E_ARG;
+    if (n == 0 || h == 0) return GC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    DevBuf d;
+    const size_t bytes = n * h * sizeof(uint4);
+    GC_HIP(d.alloc(bytes));
+    GC_HIP(hipMemcpyAsync(d.p, blks, bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_mitccrh(to_u4(*seed), gid0, (uint4 *)d.p, n, h, ctx->d_te0, ctx->stream);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(blks, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+}
+
+int gc_cot_send_pads(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, const gc_label *data,
+                     const gc_wire *wires, size_t n, gc_label *out) {
+    if (!ctx || !seed || !delta || (n && (!data || !wires || !out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    DevBuf d_data, d_w, d_out;
+    GC_HIP(d_data.alloc(n * 16));
+    GC_HIP(d_w.alloc(n * 32));
+    GC_HIP(d_out.alloc(n * 32));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipMemcpyAsync(d_data.p, data, n * 16, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemcpyAsync(d_w.p, wires, n * 32, hipMemcpyHostToDevice, s));
+    launch_cot_send(to_u4(*seed), to_u4(*delta), (const uint4 *)d_data.p, (const uint4 *)d_w.p, n, (uint4 *)d_out.p,
+                    ctx->d_te0, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(out, d_out.p, n * 32, hipMemcpyDeviceToHost, s));
+    GC_HIP(hipStreamSynchronize(s));
+    return GC_OK;
+}
+
+int gc_cot_receive_unpad(gc_ctx *ctx, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
+                         gc_label *result, size_t n) {
+    if (!ctx || !seed || (n && (!flags || !sent || !result))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    DevBuf d_f, d_s, d_r;
+    GC_HIP(d_f.alloc(n));
+    GC_HIP(d_s.alloc(n * 32));
+    GC_HIP(d_r.alloc(n * 16));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipMemcpyAsync(d_f.p, flags, n, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemcpyAsync(d_s.p, sent, n * 32, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemcpyAsync(d_r.p, result, n * 16, hipMemcpyHostToDevice, s));
+    launch_cot_recv(to_u4(*seed), (const uint8_t *)d_f.p, (const uint4 *)d_s.p, (uint4 *)d_r.p, n, ctx->d_te0, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(result, d_r.p, n * 16, hipMemcpyDeviceToHost, s));
+    GC_HIP(hipStreamSynchronize(s));
+    return GC_OK;
+}
+
+}  // extern "C"

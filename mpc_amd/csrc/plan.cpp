@@ -1,0 +1,157 @@
+// plan.cpp — build the levelised plan (host only; see plan.h).
+#include "plan.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace gc {
+
+static inline int op_class(uint8_t op) {
+    // execution order inside a level: table-producing gates first so that the blocks that need
+    // the AES tables are contiguous; XOR/XNOR (free) last
+    switch (op) {
+    case GC_AND: return 0;
+    case GC_OR: return 1;
+    case GC_INV: return 2;
+    default: return 3;
+    }
+}
+
+int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+               Plan *out) {
+    if ((!gates && ngates) || !out) return GC_E_ARG;
+    if (ninputs > nwires || noutputs > nwires) return GC_E_ARG;
+    if ((uint64_t)ninputs + ngates >= 0xffffffffull) return GC_E_ARG;
+    Plan &p = *out;
+    p = Plan{};
+    p.info.ngates = ngates;
+    p.info.nwires = nwires;
+    p.info.ninputs = ninputs;
+    p.info.noutputs = noutputs;
+    p.info.nslots = ninputs + ngates;
+
+    const uint32_t NONE = 0xffffffffu;
+    p.level_of_gate.resize(ngates);
+    p.tweak_of_gate.resize(ngates);
+    p.row_of_gate.resize((size_t)ngates + 1);
+    p.slot_of_gate.resize(ngates);
+    p.slot_of_wire.assign(nwires, NONE);
+    for (uint32_t w = 0; w < ninputs; w++) p.slot_of_wire[w] = w;
+
+    // pass 1 (original order): levels, tweaks, rows, resolve reads to the producing gate.
+    // A gate's slot is only known after sorting, so reads are first recorded as
+    // "input wire w" (< ninputs) or "gate g" (ninputs + g).
+    std::vector<uint32_t> wire_level(nwires, 0);
+    std::vector<uint32_t> src0(ngates), src1(ngates);
+    std::vector<uint32_t> cur(nwires, NONE);  // producer id of the wire's current value
+    for (uint32_t w = 0; w < ninputs; w++) cur[w] = w;
+    uint32_t id = 0, row = 0, max_level = 0;
+    for (uint32_t g = 0; g < ngates; g++) {
+        const gc_gate &G = gates[g];
+        if (G.op > GC_INV) return GC_E_GATE;
+        const bool unary = (G.op == GC_INV);
+        if (G.in0 >= nwires || G.out >= nwires || (!unary && G.in1 >= nwires)) return GC_E_WIRE;
+        if (cur[G.in0] == NONE || (!unary && cur[G.in1] == NONE)) return GC_E_WIRE;
+        uint32_t level = wire_level[G.in0];
+        if (!unary) level = std::max(level, wire_level[G.in1]);
+        p.level_of_gate[g] = level;
+        src0[g] = cur[G.in0];
+        src1[g] = unary ? cur[G.in0] : cur[G.in1];
+        p.tweak_of_gate[g] = id;
+        p.row_of_gate[g] = row;
+        switch (G.op) {
+        case GC_AND: id += 2; row += 2; p.info.n_and++; break;
+        case GC_OR: id += 1; row += 3; p.info.n_or++; break;
+        case GC_INV: id += 1; row += 1; p.info.n_inv++; break;
+        case GC_XOR: p.info.n_xor++; break;
+        default: p.info.n_xnor++; break;
+        }
+        if (row > kRowMask) return GC_E_ARG;
+        wire_level[G.out] = level + 1;
+        max_level = std::max(max_level, level + 1);
+        cur[G.out] = ninputs + g;
+    }
+    p.row_of_gate[ngates] = row;
+    p.info.slab_rows = row;
+    p.info.nlevels = max_level;
+
+    // pass 2: stable sort by (level, class)
+    std::vector<uint32_t> order(ngates);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (p.level_of_gate[a] != p.level_of_gate[b]) return p.level_of_gate[a] < p.level_of_gate[b];
+        return op_class(gates[a].op) < op_class(gates[b].op);
+    });
+    for (uint32_t k = 0; k < ngates; k++) p.slot_of_gate[order[k]] = ninputs + k;
+    auto slot_of_src = [&](uint32_t s) { return s < ninputs ? s : p.slot_of_gate[s - ninputs]; };
+
+    p.descs.resize(ngates);
+    p.gate_of_desc = order;
+    uint32_t width = 0;
+    for (uint32_t k = 0; k < ngates;) {
+        uint32_t lvl = p.level_of_gate[order[k]];
+        Step st{k, 0, 0};
+        while (k < ngates && p.level_of_gate[order[k]] == lvl) {
+            uint32_t g = order[k];
+            GateDesc &d = p.descs[k];
+            d.in0 = slot_of_src(src0[g]);
+            d.in1 = slot_of_src(src1[g]);
+            d.tweak = p.tweak_of_gate[g];
+            d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
+            if (op_class(gates[g].op) != 3) st.nonfree++;
+            st.count++;
+            k++;
+        }
+        width = std::max(width, st.count);
+        p.levels.push_back(st);
+    }
+    p.info.max_width = width;
+    p.info.n_steps = (uint32_t)p.levels.size();
+
+    for (uint32_t w = ninputs; w < nwires; w++)
+        if (cur[w] != NONE) p.slot_of_wire[w] = slot_of_src(cur[w]);
+    p.out_slots.resize(noutputs);
+    for (uint32_t j = 0; j < noutputs; j++) {
+        uint32_t s = p.slot_of_wire[nwires - noutputs + j];
+        if (s == NONE) return GC_E_WIRE;
+        p.out_slots[j] = s;
+    }
+    return GC_OK;
+}
+
+}  // namespace gc
+
+extern "C" {
+
+gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                        uint32_t noutputs, int *status) {
+    gc_plan *pl = new (std::nothrow) gc_plan;
+    int rc = pl ? gc::build_plan(gates, ngates, nwires, ninputs, noutputs, &pl->p) : GC_E_NOMEM;
+    if (rc != GC_OK) {
+        delete pl;
+        pl = nullptr;
+    }
+    if (status) *status = rc;
+    return pl;
+}
+
+void gc_plan_free(gc_plan *pl) { delete pl; }
+
+int gc_plan_get_info(const gc_plan *pl, gc_plan_info *out) {
+    if (!pl || !out) return GC_E_ARG;
+    *out = pl->p.info;
+    return GC_OK;
+}
+
+int gc_plan_describe(const gc_plan *pl, uint32_t *level_of_gate, uint32_t *tweak_of_gate, uint32_t *row_of_gate,
+                     uint32_t *slot_of_gate) {
+    if (!pl) return GC_E_ARG;
+    const gc::Plan &p = pl->p;
+    if (level_of_gate) std::copy(p.level_of_gate.begin(), p.level_of_gate.end(), level_of_gate);
+    if (tweak_of_gate) std::copy(p.tweak_of_gate.begin(), p.tweak_of_gate.end(), tweak_of_gate);
+    if (row_of_gate) std::copy(p.row_of_gate.begin(), p.row_of_gate.end(), row_of_gate);
+    if (slot_of_gate) std::copy(p.slot_of_gate.begin(), p.slot_of_gate.end(), slot_of_gate);
+    return GC_OK;
+}
+
+}  // extern "C"

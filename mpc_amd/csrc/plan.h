@@ -1,0 +1,59 @@
+// plan.h — host-side levelised re-encoding of a circuit (no HIP types here).
+//
+// The reference executes gates serially (circuit/garble.go:285-299, circuit/eval.go:28-112) and
+// derives two running counters from that order: the hash tweak `id` (AND +2, OR/INV +1:
+// garble.go:357-359,419-420,451-452) and the slab offset (AND 2, OR 3, INV 1: garble.go:199-211,
+// 296-298).  The plan freezes both per gate, renames wires to single-assignment slots and buckets
+// gates by dependency level (== Circuit.AssignLevels(TargetYao), circuit.go:206-254), so that a
+// level can run as one data-parallel launch and still produce the serial loop's exact bytes.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/gcengine.h"
+
+namespace gc {
+
+// One gate as the kernels see it (16 bytes, one s_load_dwordx4 when wave-uniform).
+struct GateDesc {
+    uint32_t in0;     // wire slot of input 0
+    uint32_t in1;     // wire slot of input 1 (== in0 for INV)
+    uint32_t tweak;   // reference `id` at this gate
+    uint32_t row_op;  // first slab row | op << 29
+};
+static_assert(sizeof(GateDesc) == 16, "GateDesc must be 16 bytes");
+
+constexpr uint32_t kOpShift = 29;
+constexpr uint32_t kRowMask = (1u << kOpShift) - 1;
+
+// A launch unit: descs [first, first+count) are mutually independent; the first `nonfree`
+// of them (AND, OR, INV — sorted to the front) need the AES tables.
+struct Step {
+    uint32_t first;
+    uint32_t count;
+    uint32_t nonfree;
+};
+
+struct Plan {
+    gc_plan_info info{};
+    // original gate order
+    std::vector<uint32_t> level_of_gate, tweak_of_gate, row_of_gate /* ngates+1 */, slot_of_gate;
+    // execution order: desc k writes slot ninputs + k
+    std::vector<GateDesc> descs;
+    std::vector<uint32_t> gate_of_desc;
+    std::vector<Step> levels;  // schedule 0: one step per dependency level
+    // wire id -> slot holding its final value (inputs: identity); 0xffffffff if never written
+    std::vector<uint32_t> slot_of_wire;
+    std::vector<uint32_t> out_slots;  // slots of wires [nwires-noutputs, nwires)
+};
+
+// returns GC_OK or GC_E_GATE / GC_E_WIRE / GC_E_ARG
+int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+               Plan *out);
+
+}  // namespace gc
+
+struct gc_plan {
+    gc::Plan p;
+};

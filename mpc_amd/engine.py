@@ -1,0 +1,412 @@
+"""ctypes binding of the C ABI (include/gcengine.h -> mpc_amd/csrc/libgcengine.so).
+
+This is the same boundary the Go shim binds through cgo; the tests and bench.py
+drive the product exclusively through it.  There is no CPU fallback: if the HIP library is
+missing or no GPU is present, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .circuit import GATE, LABEL, WIRE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgcengine.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "gcengine.h")
+
+GC_OK, GC_E_KEYSIZE, GC_E_RAND, GC_E_GATE, GC_E_ROWS, GC_E_ARG, GC_E_HIP, GC_E_NOMEM, GC_E_WIRE = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8)
+
+
+class EngineError(RuntimeError):
+    """Carries the C-ABI status; str() follows the reference's error text where one exists."""
+
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().gc_strerror(code).decode() if _lib is not None else "status %d" % code
+        detail = lib().gc_last_error().decode() if _lib is not None and code in (GC_E_HIP, GC_E_NOMEM) else ""
+        super().__init__("%s%s%s" % (what + ": " if what else "", msg, " [" + detail + "]" if detail else ""))
+
+
+def build(force=False):
+    """Compile libgcengine.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-s", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.check_call(cmd + ["clean"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "ngates", "nwires", "ninputs", "noutputs", "nlevels", "max_width", "slab_rows", "n_xor", "n_xnor", "n_and",
+        "n_or", "n_inv", "nslots", "n_steps")]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is the product; there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, sz, i32 = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
+    ip = C.POINTER(C.c_int)
+    sigs = {
+        "gc_strerror": (C.c_char_p, [i32]),
+        "gc_last_error": (C.c_char_p, []),
+        "gc_abi_version": (i32, []),
+        "gc_plan_create": (vp, [vp, u32, u32, u32, u32, ip]),
+        "gc_plan_free": (None, [vp]),
+        "gc_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
+        "gc_plan_describe": (i32, [vp, vp, vp, vp, vp]),
+        "gc_device_count": (i32, []),
+        "gc_ctx_create": (vp, [i32, ip]),
+        "gc_ctx_destroy": (None, [vp]),
+        "gc_ctx_sync": (i32, [vp]),
+        "gc_ctx_stream": (vp, [vp]),
+        "gc_circ_load": (vp, [vp, vp, u32, u32, u32, u32, ip]),
+        "gc_circ_free": (None, [vp]),
+        "gc_circ_plan": (vp, [vp]),
+        "gc_garble": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, vp]),
+        "gc_eval": (i32, [vp, vp, sz, u32, vp, vp, vp, sz, vp]),
+        "gc_batch_create": (vp, [vp, u32, ip]),
+        "gc_batch_free": (None, [vp]),
+        "gc_batch_stride": (u32, [vp]),
+        "gc_batch_set_schedule": (i32, [vp, i32]),
+        "gc_batch_set_graph": (i32, [vp, i32]),
+        "gc_batch_garble": (i32, [vp, vp, sz, vp]),
+        "gc_batch_select_inputs": (i32, [vp, vp, vp]),
+        "gc_batch_set_inputs": (i32, [vp, vp]),
+        "gc_batch_eval": (i32, [vp, vp, sz, vp]),
+        "gc_batch_decode": (i32, [vp, vp, vp, vp]),
+        "gc_batch_read_r": (i32, [vp, vp]),
+        "gc_batch_read_slab": (i32, [vp, vp]),
+        "gc_batch_read_wires": (i32, [vp, vp]),
+        "gc_batch_read_labels": (i32, [vp, vp]),
+        "gc_batch_read_outputs": (i32, [vp, vp]),
+        "gc_batch_write_slab": (i32, [vp, vp]),
+        "gc_batch_dev_wires": (vp, [vp]),
+        "gc_batch_dev_slab": (vp, [vp]),
+        "gc_batch_dev_r": (vp, [vp]),
+        "gc_batch_gather_outputs": (i32, [vp, vp]),
+        "gc_batch_last_ms": (C.c_float, [vp]),
+        "gc_batch_last_launches": (u32, [vp]),
+        "gc_iknp_receiver_create": (vp, [vp, vp, ip]),
+        "gc_iknp_sender_create": (vp, [vp, vp, vp, ip]),
+        "gc_iknp_free": (None, [vp]),
+        "gc_iknp_u_bytes": (sz, [sz]),
+        "gc_iknp_receive": (i32, [vp, vp, sz, vp, vp]),
+        "gc_iknp_send": (i32, [vp, vp, sz, sz, vp]),
+        "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
+        "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
+        "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
+    }
+    for name, (res, args) in sigs.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    if L.gc_abi_version() != 1:
+        raise ImportError("libgcengine.so ABI %d != 1" % L.gc_abi_version())
+    return L
+
+
+def _p(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def _check(rc, what):
+    if rc != GC_OK:
+        raise EngineError(rc, what)
+
+
+def device_count():
+    return lib().gc_device_count()
+
+
+# ---- plan (host only) ---------------------------------------------------------------------
+
+
+class Plan:
+    """Levelised plan of a circuit; needs no GPU (gc_plan_*)."""
+
+    def __init__(self, gates, nwires, ninputs, noutputs):
+        L = lib()
+        g = np.ascontiguousarray(gates, dtype=GATE)
+        st = C.c_int(0)
+        self.h = L.gc_plan_create(_p(g), len(g), nwires, ninputs, noutputs, C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_plan_create")
+        self.info = PlanInfo()
+        _check(L.gc_plan_get_info(self.h, C.byref(self.info)), "gc_plan_get_info")
+        n = len(g)
+        self.level_of_gate = np.zeros(n, np.uint32)
+        self.tweak_of_gate = np.zeros(n, np.uint32)
+        self.row_of_gate = np.zeros(n + 1, np.uint32)
+        self.slot_of_gate = np.zeros(n, np.uint32)
+        _check(L.gc_plan_describe(self.h, _p(self.level_of_gate), _p(self.tweak_of_gate), _p(self.row_of_gate),
+                                  _p(self.slot_of_gate)), "gc_plan_describe")
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.gc_plan_free(self.h)
+            self.h = None
+
+
+# ---- device objects -----------------------------------------------------------------------
+
+
+class Context:
+    def __init__(self, device=0):
+        st = C.c_int(0)
+        self.h = lib().gc_ctx_create(device, C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_ctx_create(%d)" % device)
+        self.device = device
+
+    def sync(self):
+        _check(lib().gc_ctx_sync(self.h), "gc_ctx_sync")
+
+    @property
+    def stream(self):
+        return lib().gc_ctx_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().gc_ctx_destroy(self.h)
+            self.h = None
+
+
+class DeviceCircuit:
+    """gc_circ: a circuit.Circuit uploaded to one device."""
+
+    def __init__(self, ctx, circuit):
+        self.ctx = ctx
+        self.c = circuit
+        st = C.c_int(0)
+        g = np.ascontiguousarray(circuit.Gates, dtype=GATE)
+        self.h = lib().gc_circ_load(ctx.h, _p(g), len(g), circuit.NumWires, circuit.num_inputs, circuit.num_outputs,
+                                    C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_circ_load")
+        self.info = PlanInfo()
+        _check(lib().gc_plan_get_info(lib().gc_circ_plan(self.h), C.byref(self.info)), "gc_plan_get_info")
+
+    # -- host-buffer API: Circuit.Garble / Circuit.Eval with a batch dimension --
+
+    def garble(self, key, rnd, batch=1, want_wires=False, want_io=True):
+        """gc_garble.  Returns dict(R[batch], slab[batch,rows], wires[batch,nwires]?, io[batch,nin+nout]?)."""
+        k, r = _u8(key), _u8(rnd)
+        R = np.zeros(batch, LABEL)
+        slab = np.zeros((batch, max(self.info.slab_rows, 1)), LABEL)
+        wires = np.zeros((batch, self.c.NumWires), WIRE) if want_wires else None
+        io = np.zeros((batch, self.c.num_inputs + self.c.num_outputs), WIRE) if want_io else None
+        rc = lib().gc_garble(self.h, _p(k), len(k), _p(r), len(r), batch, _p(R), _p(wires), _p(io), _p(slab))
+        _check(rc, "gc_garble")
+        out = {"R": R, "slab": slab[:, : self.info.slab_rows]}
+        if want_wires:
+            out["wires"] = wires
+        if want_io:
+            out["io"] = io
+        return out
+
+    def eval(self, key, slab, wires=None, inputs=None, batch=1, slab_rows=None):
+        """gc_eval.  wires: LABEL [batch,nwires] (in place) or inputs: LABEL [batch,ninputs].
+        Returns output labels [batch,noutputs]."""
+        k = _u8(key)
+        slab = np.ascontiguousarray(slab, dtype=LABEL)
+        rows = slab.size // batch if slab_rows is None else slab_rows
+        out = np.zeros((batch, max(self.c.num_outputs, 1)), LABEL)
+        if wires is not None:
+            assert wires.dtype == LABEL and wires.flags.c_contiguous and wires.size == batch * self.c.NumWires
+        if inputs is not None:
+            inputs = np.ascontiguousarray(inputs, dtype=LABEL)
+        rc = lib().gc_eval(self.h, _p(k), len(k), batch, _p(wires), _p(inputs), _p(slab) if slab.size else None,
+                           rows, _p(out))
+        _check(rc, "gc_eval")
+        return out[:, : self.c.num_outputs]
+
+    def close(self):
+        if self.h:
+            lib().gc_circ_free(self.h)
+            self.h = None
+
+
+class Batch:
+    """gc_batch: device-resident state of `batch` instances (garbler or evaluator role)."""
+
+    def __init__(self, dcirc, batch):
+        self.dc = dcirc
+        self.batch = batch
+        st = C.c_int(0)
+        self.h = lib().gc_batch_create(dcirc.h, batch, C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_batch_create")
+        self.stride = lib().gc_batch_stride(self.h)
+
+    def set_graph(self, on):
+        _check(lib().gc_batch_set_graph(self.h, 1 if on else 0), "gc_batch_set_graph")
+
+    def set_schedule(self, s):
+        _check(lib().gc_batch_set_schedule(self.h, s), "gc_batch_set_schedule")
+
+    def garble(self, key, d_rnd):
+        k = _u8(key)
+        _check(lib().gc_batch_garble(self.h, _p(k), len(k), C.c_void_p(d_rnd)), "gc_batch_garble")
+
+    def select_inputs(self, garbler, d_bits):
+        _check(lib().gc_batch_select_inputs(self.h, garbler.h, C.c_void_p(d_bits)), "gc_batch_select_inputs")
+
+    def set_inputs(self, d_labels):
+        _check(lib().gc_batch_set_inputs(self.h, C.c_void_p(d_labels)), "gc_batch_set_inputs")
+
+    def eval(self, key, tables):
+        k = _u8(key)
+        _check(lib().gc_batch_eval(self.h, _p(k), len(k), tables.h), "gc_batch_eval")
+
+    def decode(self, evaluator, d_bits_out, d_mismatch):
+        _check(lib().gc_batch_decode(self.h, evaluator.h, C.c_void_p(d_bits_out), C.c_void_p(d_mismatch)),
+               "gc_batch_decode")
+
+    def read_r(self):
+        out = np.zeros(self.batch, LABEL)
+        _check(lib().gc_batch_read_r(self.h, _p(out)), "gc_batch_read_r")
+        return out
+
+    def read_slab(self):
+        out = np.zeros((self.batch, max(self.dc.info.slab_rows, 1)), LABEL)
+        _check(lib().gc_batch_read_slab(self.h, _p(out)), "gc_batch_read_slab")
+        return out[:, : self.dc.info.slab_rows]
+
+    def read_wires(self):
+        out = np.zeros((self.batch, self.dc.c.NumWires), WIRE)
+        _check(lib().gc_batch_read_wires(self.h, _p(out)), "gc_batch_read_wires")
+        return out
+
+    def read_labels(self):
+        out = np.zeros((self.batch, self.dc.c.NumWires), LABEL)
+        _check(lib().gc_batch_read_labels(self.h, _p(out)), "gc_batch_read_labels")
+        return out
+
+    def read_outputs(self):
+        out = np.zeros((self.batch, max(self.dc.c.num_outputs, 1)), LABEL)
+        _check(lib().gc_batch_read_outputs(self.h, _p(out)), "gc_batch_read_outputs")
+        return out[:, : self.dc.c.num_outputs]
+
+    def write_slab(self, slab):
+        s = np.ascontiguousarray(slab, dtype=LABEL)
+        assert s.size == self.batch * self.dc.info.slab_rows
+        _check(lib().gc_batch_write_slab(self.h, _p(s)), "gc_batch_write_slab")
+
+    def gather_outputs(self, d_out):
+        _check(lib().gc_batch_gather_outputs(self.h, C.c_void_p(d_out)), "gc_batch_gather_outputs")
+
+    @property
+    def last_ms(self):
+        return float(lib().gc_batch_last_ms(self.h))
+
+    @property
+    def last_launches(self):
+        return int(lib().gc_batch_last_launches(self.h))
+
+    def close(self):
+        if self.h:
+            lib().gc_batch_free(self.h)
+            self.h = None
+
+
+# ---- OT -------------------------------------------------------------------------------------
+
+
+def _lab1(x):
+    a = np.zeros(1, LABEL)
+    a[0] = (int(x[0]), int(x[1])) if isinstance(x, (tuple, list)) else (int(x["d0"]), int(x["d1"]))
+    return a
+
+
+class IKNPReceiver:
+    """tail of NewIKNPReceiver + receive() (ot/iknp.go:347-356, 468-511)"""
+
+    def __init__(self, ctx, base_wires):
+        bw = np.ascontiguousarray(base_wires, dtype=WIRE)
+        assert len(bw) == 128
+        st = C.c_int(0)
+        self.h = lib().gc_iknp_receiver_create(ctx.h, _p(bw), C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_iknp_receiver_create")
+
+    def receive(self, b):
+        bb = np.ascontiguousarray(b, dtype=np.uint8)
+        n = len(bb)
+        u = np.zeros(max(lib().gc_iknp_u_bytes(n), 1), np.uint8)
+        res = np.zeros(max(n, 1), LABEL)
+        _check(lib().gc_iknp_receive(self.h, _p(bb), n, _p(u), _p(res)), "gc_iknp_receive")
+        return u[: lib().gc_iknp_u_bytes(n)].tobytes(), res[:n]
+
+    def close(self):
+        if self.h:
+            lib().gc_iknp_free(self.h)
+            self.h = None
+
+
+class IKNPSender:
+    """tail of NewIKNPSender + send() (ot/iknp.go:104-122, 197-226)"""
+
+    def __init__(self, ctx, delta, k0):
+        k = np.ascontiguousarray(k0, dtype=LABEL)
+        assert len(k) == 128
+        d = _lab1(delta)
+        st = C.c_int(0)
+        self.h = lib().gc_iknp_sender_create(ctx.h, _p(d), _p(k), C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_iknp_sender_create")
+
+    def send(self, u, n):
+        ub = np.frombuffer(bytes(u), np.uint8) if len(u) else np.zeros(1, np.uint8)
+        res = np.zeros(max(n, 1), LABEL)
+        _check(lib().gc_iknp_send(self.h, _p(ub), len(u), n, _p(res)), "gc_iknp_send")
+        return res[:n]
+
+    def close(self):
+        if self.h:
+            lib().gc_iknp_free(self.h)
+            self.h = None
+
+
+def mitccrh_hash(ctx, seed, gid0, blks, h):
+    b = np.ascontiguousarray(blks, dtype=LABEL).copy()
+    assert len(b) % h == 0
+    s = _lab1(seed)
+    _check(lib().gc_mitccrh_hash(ctx.h, _p(s), gid0, _p(b), len(b) // h, h), "gc_mitccrh_hash")
+    return b
+
+
+def cot_send_pads(ctx, seed, delta, data, wires):
+    d = np.ascontiguousarray(data, dtype=LABEL)
+    w = np.ascontiguousarray(wires, dtype=WIRE)
+    out = np.zeros(max(2 * len(d), 1), LABEL)
+    _check(lib().gc_cot_send_pads(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), _p(d), _p(w), len(d), _p(out)),
+           "gc_cot_send_pads")
+    return out[: 2 * len(d)]
+
+
+def cot_receive_unpad(ctx, seed, flags, sent, result):
+    f = np.ascontiguousarray(flags, dtype=np.uint8)
+    s = np.ascontiguousarray(sent, dtype=LABEL)
+    r = np.ascontiguousarray(result, dtype=LABEL).copy()
+    _check(lib().gc_cot_receive_unpad(ctx.h, _p(_lab1(seed)), _p(f), _p(s), _p(r), len(f)), "gc_cot_receive_unpad")
+    return r

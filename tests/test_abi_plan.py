@@ -1,0 +1,113 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol
+include/gcengine.h declares, and the host-only plan (levelisation + tweak/row prefix sums)
+agrees with the oracle's serial restatement of the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from mpc_amd import engine
+from mpc_amd.circuit import GATE, Circuit, and_chain, comparator64, synthetic_levelised
+
+
+def declared_functions():
+    src = open(engine.HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = engine.lib()
+    names = declared_functions()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(L, n), "libgcengine.so does not export %s" % n
+    assert L.gc_abi_version() == 1
+    assert L.gc_strerror(engine.GC_E_KEYSIZE).decode() == "crypto/aes: invalid key size"
+
+
+def test_struct_sizes_match_go_layouts():
+    # circuit_test.go:14-19: unsafe.Sizeof(Gate) == 20; Label 16, Wire 32
+    assert engine.GATE.itemsize == 20 and engine.LABEL.itemsize == 16 and engine.WIRE.itemsize == 32
+
+
+def plan_of(c):
+    return engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs)
+
+
+def test_plan_matches_assign_levels(aes_circ, sha_circ):
+    for c, want in ((aes_circ, (308, 192)), (sha_circ, None)):
+        p = plan_of(c)
+        g, nl, mw = oracle.assign_levels(c.Gates, c.NumWires)
+        assert (p.info.nlevels, p.info.max_width) == (nl, mw)
+        if want:
+            assert (nl, mw) == want
+        assert (p.level_of_gate == g["level"]).all()
+        assert p.info.slab_rows == c.slab_rows()
+
+
+def test_plan_tweaks_and_rows_follow_the_serial_loop():
+    c = synthetic_levelised(9, 33, 0.3, seed=11, ninputs=24, or_frac=0.1, inv_frac=0.15, xnor_frac=0.1)
+    p = plan_of(c)
+    # serial counters of garble.go:357-359,419-420,451-452 and :199-211
+    idv, row = 0, 0
+    for i, g in enumerate(c.Gates):
+        assert p.tweak_of_gate[i] == idv and p.row_of_gate[i] == row
+        op = g["op"]
+        idv += {0: 0, 1: 0, 2: 2, 3: 1, 4: 1}[int(op)]
+        row += {0: 0, 1: 0, 2: 2, 3: 3, 4: 1}[int(op)]
+    assert p.row_of_gate[-1] == row == c.slab_rows()
+    # rows also equal the oracle's gate offsets
+    gr = oracle.garble(c.Gates, c.NumWires, c.num_inputs, bytes(16), bytes(16 * (c.num_inputs + 1)))
+    assert (gr["gate_off"] == p.row_of_gate).all()
+    # slots: a permutation of [ninputs, ninputs+ngates), level-monotone
+    assert sorted(p.slot_of_gate.tolist()) == list(range(c.num_inputs, c.num_inputs + c.NumGates))
+    order = np.argsort(p.slot_of_gate)
+    assert (np.diff(p.level_of_gate[order].astype(np.int64)) >= 0).all()
+
+
+def test_plan_rejects_bad_circuits():
+    g = np.zeros(1, GATE)
+    g[0] = (0, 1, 2, 9, 0)
+    with pytest.raises(engine.EngineError) as e:
+        engine.Plan(g, 3, 2, 1)
+    assert e.value.code == engine.GC_E_GATE
+    g[0] = (0, 2, 2, 0, 0)  # reads wire 2 before anything wrote it ("input %d of gate %d not set")
+    with pytest.raises(engine.EngineError) as e:
+        engine.Plan(g, 3, 2, 1)
+    assert e.value.code == engine.GC_E_WIRE
+    g[0] = (0, 1, 5, 0, 0)  # wire id out of range
+    with pytest.raises(engine.EngineError) as e:
+        engine.Plan(g, 3, 2, 1)
+    assert e.value.code == engine.GC_E_WIRE
+
+
+def test_plan_handles_wire_reuse():
+    # the parsers do not enforce single assignment (parser.go:38-44): a re-written wire must read its
+    # latest value in gate order.  w2 = w0^w1 ; w2 = w2 & w0 ; w3 = w2 ^ w1
+    g = np.zeros(3, GATE)
+    g[0] = (0, 1, 2, 0, 0)
+    g[1] = (2, 0, 2, 2, 0)
+    g[2] = (2, 1, 3, 0, 0)
+    p = engine.Plan(g, 4, 2, 1)
+    assert p.info.nlevels == 3 and p.level_of_gate.tolist() == [0, 1, 2]
+    assert len(set(p.slot_of_gate.tolist())) == 3
+
+
+def test_and_chain_and_comparator_plans():
+    c = and_chain(50)
+    p = plan_of(c)
+    assert (p.info.nlevels, p.info.max_width, p.info.slab_rows) == (50, 1, 100)
+    c = comparator64()
+    p = plan_of(c)
+    assert p.info.n_or == 63 and p.info.n_inv == 127 and p.info.n_and == 127
+
+
+def test_no_gpu_means_loud_failure():
+    if engine.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(engine.EngineError) as e:
+        engine.Context(0)
+    assert e.value.code == engine.GC_E_HIP

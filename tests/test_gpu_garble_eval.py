@@ -1,0 +1,276 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, driven through the C ABI,
+must be bit-identical to the CPU oracle / the committed golden digests.
+
+Mirrors the reference's own checks: garble -> eval -> decoded outputs equal the plaintext result
+(compiler/arithmetic_test.go:102-151, sha2pc/sha2pc_test.go:15-71), error behaviour of
+Circuit.Garble / Circuit.Eval, and the edge cases (batch sizes that are not wave multiples,
+all gate types, width-1 chains, wire reuse)."""
+import hashlib
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from mpc_amd import engine
+from mpc_amd.circuit import GATE, LABEL, Circuit, and_chain, comparator64, synthetic_levelised
+from tests.util import bits_lsb, bits_to_bytes_little, bytes_to_bits_little, drbg, int_from_bits
+
+pytestmark = pytest.mark.gpu
+
+KEY256 = bytes(range(32))
+KEY128 = b"0123456789abcdef"  # circuit/garble_bench_test.go:35
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def rnd_for(c, seed, batch):
+    return drbg(seed, 16 * (c.num_inputs + 1) * batch)
+
+
+def oracle_instance(c, key, rnd, i):
+    stride = 16 * (c.num_inputs + 1)
+    return oracle.garble(c.Gates, c.NumWires, c.num_inputs, key, rnd[i * stride:(i + 1) * stride])
+
+
+def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True):
+    """host-buffer API vs oracle, every instance, every byte"""
+    dc = engine.DeviceCircuit(ctx, c)
+    rnd = rnd_for(c, seed, batch)
+    g = dc.garble(key, rnd, batch=batch, want_wires=check_all_wires, want_io=True)
+    bits = (np.frombuffer(drbg(seed + "/bits", c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
+    wires = np.zeros((batch, c.NumWires), LABEL)
+    refs = []
+    nin, nout = c.num_inputs, c.num_outputs
+    for i in range(batch):
+        ref = oracle_instance(c, key, rnd, i)
+        refs.append(ref)
+        assert g["R"][i] == ref["R"], "R of instance %d" % i
+        assert (g["slab"][i] == ref["slab"]).all(), "slab of instance %d" % i
+        if check_all_wires:
+            assert (g["wires"][i] == ref["wires"]).all(), "wires of instance %d" % i
+        assert (g["io"][i][:nin] == ref["wires"][:nin]).all()
+        assert (g["io"][i][nin:] == ref["wires"][c.NumWires - nout:]).all()
+        wires[i, :nin] = np.where(bits[i].astype(bool), ref["wires"]["l1"][:nin], ref["wires"]["l0"][:nin])
+    inputs = wires[:, :nin].copy()
+    out = dc.eval(key, g["slab"], wires=wires, batch=batch)
+    for i in range(batch):
+        w = np.zeros(c.NumWires, LABEL)
+        w[:nin] = inputs[i]
+        oracle.eval_(c.Gates, c.NumWires, key, w, refs[i]["slab"])
+        assert (wires[i] == w).all(), "evaluated wires of instance %d" % i
+        assert (out[i] == w[c.NumWires - nout:]).all()
+        plain = oracle.compute(c.Gates, c.NumWires, nin, bits[i])
+        for j in range(nout):  # BitFromLabel
+            wi = c.NumWires - nout + j
+            want = refs[i]["wires"][wi]["l1"] if plain[wi] else refs[i]["wires"][wi]["l0"]
+            assert out[i][j] == want
+    # inputs-only entry (the evaluator normally holds just its input labels)
+    out2 = dc.eval(key, g["slab"], inputs=inputs, batch=batch)
+    assert (out2 == out).all()
+    dc.close()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 5, 33, 64, 65, 100, 255, 256, 257, 300])
+def test_all_gate_types_ragged_batches(ctx, batch):
+    c = synthetic_levelised(10, 48, 0.3, seed=5, ninputs=40, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1)
+    check_garble_eval(ctx, c, KEY256, batch, "ragged%d" % batch)
+
+
+@pytest.mark.parametrize("key", [KEY128, bytes(range(7, 31)), KEY256], ids=["aes128", "aes192", "aes256"])
+def test_key_sizes(ctx, key):
+    c = synthetic_levelised(6, 70, 0.4, seed=9, ninputs=32, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1)
+    check_garble_eval(ctx, c, key, 70, "keys%d" % len(key))
+
+
+def test_and_chain_width_one(ctx):
+    # buildANDChain (garble_bench_test.go:19-33): depth n, width 1 — one launch per gate
+    check_garble_eval(ctx, and_chain(300), KEY128, 17, "chain")
+
+
+def test_comparator64_millionaire(ctx):
+    c = comparator64()
+    check_garble_eval(ctx, c, KEY256, 9, "cmp")
+    dc = engine.DeviceCircuit(ctx, c)
+    for a, b in ((750000, 800000), (900000, 800000)):  # README.md:57-108
+        rnd = rnd_for(c, "mill", 1)
+        g = dc.garble(KEY256, rnd, batch=1)
+        bits = np.concatenate([bits_lsb(a, 64), bits_lsb(b, 64)]).astype(bool)
+        inp = np.where(bits, g["io"][0]["l1"][:128], g["io"][0]["l0"][:128])
+        out = dc.eval(KEY256, g["slab"], inputs=inp[None, :], batch=1)
+        ow = g["io"][0][128]
+        assert out[0][0] == (ow["l1"] if a > b else ow["l0"])
+    dc.close()
+
+
+def test_wire_reuse(ctx):
+    g = np.zeros(3, GATE)
+    g[0] = (0, 1, 2, 0, 0)
+    g[1] = (2, 0, 2, 2, 0)
+    g[2] = (2, 1, 3, 0, 0)
+    check_garble_eval(ctx, Circuit(4, [1, 1], [1], g), KEY256, 7, "reuse")
+
+
+def test_add64(ctx, add64_circ):
+    check_garble_eval(ctx, add64_circ, KEY256, 40, "add64")
+
+
+def test_aes128_circuit_batch(ctx, aes_circ):
+    check_garble_eval(ctx, aes_circ, KEY256, 6, "aes", check_all_wires=True)
+
+
+def test_sha256xor_reference_digest(ctx, sha_circ):
+    # sha2pc/sha2pc_test.go:124: a[i]=i, b[i]=32-i -> 4b2f7457...; instance 1 random
+    c = sha_circ
+    dc = engine.DeviceCircuit(ctx, c)
+    assert dc.info.slab_rows == 42914  # sha2pc/params.go:26
+    batch = 2
+    key = drbg("shakey", 32)
+    g = dc.garble(key, rnd_for(c, "sha", batch), batch=batch)
+    a = [bytes(range(32)), drbg("a1", 32)]
+    b = [bytes(32 - i for i in range(32)), drbg("b1", 32)]
+    inputs = np.zeros((batch, 512), LABEL)
+    for i in range(batch):
+        bits = np.concatenate([bytes_to_bits_little(a[i]), bytes_to_bits_little(b[i])]).astype(bool)
+        inputs[i] = np.where(bits, g["io"][i]["l1"][:512], g["io"][i]["l0"][:512])
+    out = dc.eval(key, g["slab"], inputs=inputs, batch=batch)
+    for i in range(batch):
+        ow = g["io"][i][512:]
+        bits = []
+        for j in range(256):
+            assert out[i][j] == ow[j]["l0"] or out[i][j] == ow[j]["l1"]
+            bits.append(1 if out[i][j] == ow[j]["l1"] else 0)
+        want = hashlib.sha256(bytes(x ^ y for x, y in zip(a[i], b[i]))).hexdigest()
+        assert bits_to_bytes_little(bits).hex() == want
+        if i == 0:
+            assert want == "4b2f74579fc7c778745121996f604371a326dc5174f9851706032626668abf2e"
+    dc.close()
+
+
+def test_golden_digests(ctx, golden_dir):
+    """committed fixtures (tests/golden/garble_golden.json, made by make_golden.py with the oracle)"""
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(golden_dir, "garble_golden.json")))
+    for name, c in mk.circuits().items():
+        dc = engine.DeviceCircuit(ctx, c)
+        n = mk.COUNTS[name]
+        for kn, kh in gold["keys"].items():
+            key = bytes.fromhex(kh)
+            streams = [mk.instance_streams(name, c, i) for i in range(n)]
+            rnd = b"".join(s[0] for s in streams)
+            g = dc.garble(key, rnd, batch=n)
+            nin, nout = c.num_inputs, c.num_outputs
+            wires = np.zeros((n, c.NumWires), LABEL)
+            for i in range(n):
+                h = hashlib.sha256()
+                h.update(g["R"][i:i + 1].tobytes())
+                h.update(np.ascontiguousarray(g["slab"][i]).tobytes())
+                h.update(np.ascontiguousarray(g["io"][i]["l0"][nin:]).tobytes())
+                assert h.hexdigest() == gold["circuits"][name][kn][i]["garble"], (name, kn, i)
+                wires[i, :nin] = np.where(streams[i][1].astype(bool), g["io"][i]["l1"][:nin], g["io"][i]["l0"][:nin])
+            dc.eval(key, g["slab"], wires=wires, batch=n)
+            for i in range(n):
+                assert hashlib.sha256(wires[i].tobytes()).hexdigest() == gold["circuits"][name][kn][i]["eval"]
+        dc.close()
+
+
+def test_error_behaviour(ctx, add64_circ):
+    c = add64_circ
+    dc = engine.DeviceCircuit(ctx, c)
+    rnd = rnd_for(c, "err", 1)
+    for klen in (0, 15, 17, 33):  # aes.NewCipher (garble.go:260)
+        with pytest.raises(engine.EngineError) as e:
+            dc.garble(bytes(klen), rnd)
+        assert e.value.code == engine.GC_E_KEYSIZE
+        assert "invalid key size" in str(e.value)
+    with pytest.raises(engine.EngineError) as e:  # io.Reader runs dry (garble.go:272)
+        dc.garble(KEY256, rnd[:-1])
+    assert e.value.code == engine.GC_E_RAND
+    with pytest.raises(engine.EngineError) as e:  # R is read before the cipher is built (garble.go:253-260)
+        dc.garble(bytes(5), rnd[:8])
+    assert e.value.code == engine.GC_E_RAND
+    g = dc.garble(KEY256, rnd)
+    inp = g["io"][0]["l0"][: c.num_inputs][None, :]
+    with pytest.raises(engine.EngineError) as e:  # corrupted circuit: rows missing (eval.go:54-56)
+        dc.eval(KEY256, np.ascontiguousarray(g["slab"][:, :-1]), inputs=inp, batch=1)
+    assert e.value.code == engine.GC_E_ROWS
+    with pytest.raises(engine.EngineError) as e:
+        dc.eval(bytes(3), g["slab"], inputs=inp, batch=1)
+    assert e.value.code == engine.GC_E_KEYSIZE
+    dc.close()
+    bad = np.zeros(1, GATE)
+    bad[0] = (0, 1, 2, 6, 0)
+    with pytest.raises(engine.EngineError) as e:  # "invalid gate type" (garble.go:326)
+        engine.DeviceCircuit(ctx, Circuit(3, [1, 1], [1], bad))
+    assert e.value.code == engine.GC_E_GATE
+
+
+def test_graph_and_direct_launch_agree(ctx):
+    import torch
+    c = synthetic_levelised(12, 64, 0.25, seed=21, ninputs=64, inv_frac=0.05)
+    dc = engine.DeviceCircuit(ctx, c)
+    batch = 128
+    rnd = rnd_for(c, "graph", batch)
+    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    slabs = []
+    for graph in (True, False, True):
+        b = engine.Batch(dc, batch)
+        b.set_graph(graph)
+        b.garble(KEY256, d_rnd.data_ptr())
+        b.garble(KEY256, d_rnd.data_ptr())  # second call replays the captured graph
+        slabs.append(b.read_slab().copy())
+        assert b.last_ms > 0 and b.last_launches == dc.info.n_steps + 1
+        b.close()
+    assert (slabs[0] == slabs[1]).all() and (slabs[0] == slabs[2]).all()
+    ref = oracle_instance(c, KEY256, rnd, 77)
+    assert (slabs[0][77] == ref["slab"]).all()
+    dc.close()
+
+
+def test_device_resident_pipeline_full_size(ctx, aes_circ):
+    """BASELINE config 2 shape: AES-128 circuit x 1024 instances, device-resident API.
+    Size-independent property: decoded outputs == AES-128(key, pt) for every instance; plus byte
+    parity with the oracle on sampled instances."""
+    import torch
+    c = aes_circ
+    batch = 1024
+    dc = engine.DeviceCircuit(ctx, c)
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    rnd = rnd_for(c, "full", batch)
+    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    keys = [drbg("k%d" % i, 16) for i in range(batch)]
+    pts = [drbg("p%d" % i, 16) for i in range(batch)]
+    bits = np.zeros((batch, 256), np.uint8)
+    for i in range(batch):
+        bits[i, :128] = bits_lsb(int.from_bytes(keys[i], "big"), 128)
+        bits[i, 128:] = bits_lsb(int.from_bytes(pts[i], "big"), 128)
+    d_bits = torch.from_numpy(bits).cuda()
+    d_out = torch.zeros((batch, 128), dtype=torch.uint8, device="cuda")
+    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gb.garble(KEY256, d_rnd.data_ptr())
+    ev.select_inputs(gb, d_bits.data_ptr())
+    ev.eval(KEY256, gb)
+    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    ctx.sync()
+    assert int(d_mis.cpu()[0]) == 0
+    out = d_out.cpu().numpy()
+    for i in range(batch):
+        ct = int_from_bits(out[i]).to_bytes(16, "big")
+        assert ct == oracle.aes_encrypt(keys[i], pts[i]), "instance %d" % i
+    slab = gb.read_slab()
+    R = gb.read_r()
+    for i in (0, 1, 63, 64, 511, 1023):
+        ref = oracle_instance(c, KEY256, rnd, i)
+        assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all()
+    assert gb.last_ms > 0 and ev.last_ms > 0
+    gb.close(); ev.close(); dc.close()
