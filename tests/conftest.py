@@ -9,6 +9,14 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# torch bundles its own ROCm runtime (libamdhip64.so.7, same soname as /opt/rocm's).  Whichever copy
+# is loaded first serves the whole process, so load torch's before libgcengine.so pulls in the
+# system one — otherwise a later `import torch` finds "No HIP GPUs".  (bench.py does the same.)
+try:  # pragma: no cover - torch is optional for the CPU suite
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
