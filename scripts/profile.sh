@@ -10,11 +10,11 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/bench_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/bench_kt.log 2>&1
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/kt -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > '$OUT'/kernel_trace_head.csv' _ {} \;
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_r -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_r.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_w -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_r -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_r.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_w -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_w.log 2>&1
 python $REPO/scripts/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1
 rm -rf $OUT/kt/*/*.db $OUT/pmc_r/*/*.db $OUT/pmc_w/*/*.db 2>/dev/null
 du -sh $OUT; ls $OUT
