@@ -105,6 +105,9 @@ gc_circ *gc_circ_load(gc_ctx *, const gc_gate *gates, uint32_t ngates, uint32_t 
                       uint32_t ninputs, uint32_t noutputs, int *status);
 void gc_circ_free(gc_circ *);
 const gc_plan *gc_circ_plan(const gc_circ *);
+/* execution schedule used by gc_garble / gc_eval on this circuit (see gc_batch_set_schedule):
+ * 0 = one launch per dependency level, 1 = fused single launch (default).  Bit-identical results. */
+int gc_circ_set_schedule(gc_circ *, int schedule);
 
 /* ------------------------------------------------------------------------------------------
  * Host-buffer API — bodies of the reference's per-call entry points, plus a batch dimension
@@ -147,8 +150,11 @@ typedef struct gc_batch gc_batch;
 gc_batch *gc_batch_create(gc_circ *, uint32_t batch, int *status);
 void gc_batch_free(gc_batch *);
 uint32_t gc_batch_stride(const gc_batch *);
-/* schedule: 0 = one launch per dependency level (the reference's AssignLevels order),
- *           1 = fused schedule (default).  Results are bit-identical. */
+/* schedule: 0 = one launch per dependency level (the reference's AssignLevels order), labels laid
+ *               out [wire][instance];
+ *           1 = fused (default): ONE launch per pass, every workgroup owns a tile of instances and
+ *               walks all levels with workgroup barriers; labels laid out [tile][wire][instance].
+ * Results are bit-identical.  Changing the schedule re-allocates the batch's device arrays. */
 int gc_batch_set_schedule(gc_batch *, int schedule);
 /* use a captured hipGraph for the per-level launches (default on) */
 int gc_batch_set_graph(gc_batch *, int on);

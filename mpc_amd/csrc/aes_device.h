@@ -70,6 +70,68 @@ __device__ __forceinline__ void aes_encrypt_n(uint32_t (&s)[N][4], const uint32_
     }
 }
 
+// ---- bank-conflict-free variant ------------------------------------------------------------------
+// One table (Te0) replicated 32x in LDS: entry x of copy c lives at word x*32 + c, so lane l always
+// reads bank (l mod 32) — no two lanes of a 32-lane LDS group ever collide, whatever the indices
+// (ds_read_b32: 2 LDS cycles per wave instruction instead of ~7 with random conflicts).
+// Te1..Te3 are byte rotations of Te0 (one v_alignbit each).  32 KiB per workgroup.
+constexpr int kTeReplWords = 256 * 32;
+
+__device__ __forceinline__ void load_te_replicated(uint32_t *te, const uint32_t *__restrict__ g_te0) {
+    // thread t writes copies (t & 31) of entries (t >> 5), (t >> 5) + blockDim/32, ...
+    const uint32_t c = threadIdx.x & 31;
+    for (uint32_t x = threadIdx.x >> 5; x < 256; x += blockDim.x >> 5) te[x * 32 + c] = g_te0[x];
+}
+
+// byte offset of this lane's copy inside an entry row
+__device__ __forceinline__ uint32_t te_lane_off() { return (threadIdx.x & 31u) * 4u; }
+
+__device__ __forceinline__ uint32_t te_at(const uint32_t *te, uint32_t x, uint32_t lane_off) {
+    return *(const uint32_t *)((const char *)te + (x << 7) + lane_off);
+}
+
+template <int NR, int N>
+__device__ __forceinline__ void aes_encrypt_repl(uint32_t (&s)[N][4], const uint32_t *__restrict__ rk,
+                                                 const uint32_t *te, uint32_t lo) {
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        s[k][0] ^= rk[0];
+        s[k][1] ^= rk[1];
+        s[k][2] ^= rk[2];
+        s[k][3] ^= rk[3];
+    }
+#pragma unroll
+    for (int r = 1; r < NR; r++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+#define GC_COL(b0, b1, b2, b3)                                                                               \
+    (te_at(te, (b0) >> 24, lo) ^ rotr32(te_at(te, ((b1) >> 16) & 0xff, lo), 8) ^                          \
+     rotr32(te_at(te, ((b2) >> 8) & 0xff, lo), 16) ^ rotr32(te_at(te, (b3)&0xff, lo), 24))
+            s[k][0] = GC_COL(a0, a1, a2, a3) ^ rk[4 * r + 0];
+            s[k][1] = GC_COL(a1, a2, a3, a0) ^ rk[4 * r + 1];
+            s[k][2] = GC_COL(a2, a3, a0, a1) ^ rk[4 * r + 2];
+            s[k][3] = GC_COL(a3, a0, a1, a2) ^ rk[4 * r + 3];
+#undef GC_COL
+        }
+    }
+    // final round: S[x] is byte 1 (and byte 2) of Te0[x]
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+#define GC_SB(v) ((te_at(te, (v), lo) >> 8) & 0xffu)
+#define GC_LAST(b0, b1, b2, b3)                                                                          \
+    ((GC_SB((b0) >> 24) << 24) | (GC_SB(((b1) >> 16) & 0xff) << 16) | (GC_SB(((b2) >> 8) & 0xff) << 8) | \
+     GC_SB((b3)&0xff))
+        s[k][0] = GC_LAST(a0, a1, a2, a3) ^ rk[4 * NR + 0];
+        s[k][1] = GC_LAST(a1, a2, a3, a0) ^ rk[4 * NR + 1];
+        s[k][2] = GC_LAST(a2, a3, a0, a1) ^ rk[4 * NR + 2];
+        s[k][3] = GC_LAST(a3, a0, a1, a2) ^ rk[4 * NR + 3];
+#undef GC_LAST
+#undef GC_SB
+    }
+}
+
 // ---- label arithmetic (ot/label.go) on the uint4 form --------------------------------------
 
 __device__ __forceinline__ uint4 lxor(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
@@ -121,6 +183,29 @@ __device__ __forceinline__ void hash_n(uint32_t (&k)[N][4], uint4 (&out)[N], con
         s[i][3] = k[i][3];
     }
     aes_encrypt_n<NR, N>(s, rk, te);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i][0] ^= k[i][0];
+        s[i][1] ^= k[i][1];
+        s[i][2] ^= k[i][2];
+        s[i][3] ^= k[i][3];
+        out[i] = cols_to_label(s[i]);
+    }
+}
+
+// same as hash_n but through the conflict-free replicated table
+template <int NR, int N>
+__device__ __forceinline__ void hash_repl(uint32_t (&k)[N][4], uint4 (&out)[N], const uint32_t *__restrict__ rk,
+                                          const uint32_t *te, uint32_t lo) {
+    uint32_t s[N][4];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i][0] = k[i][0];
+        s[i][1] = k[i][1];
+        s[i][2] = k[i][2];
+        s[i][3] = k[i][3];
+    }
+    aes_encrypt_repl<NR, N>(s, rk, te, lo);
 #pragma unroll
     for (int i = 0; i < N; i++) {
         s[i][0] ^= k[i][0];

@@ -117,6 +117,7 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_descs, p.descs.data(), p.descs.size() * sizeof(GateDesc));
         up((void **)&c->d_out_slots, p.out_slots.data(), p.out_slots.size() * sizeof(uint32_t));
         up((void **)&c->d_slot_of_wire, p.slot_of_wire.data(), p.slot_of_wire.size() * sizeof(uint32_t));
+        up((void **)&c->d_steps, p.levels.data(), p.levels.size() * sizeof(Step));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -138,12 +139,43 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_descs) (void)hipFree(c->d_descs);
     if (c->d_out_slots) (void)hipFree(c->d_out_slots);
     if (c->d_slot_of_wire) (void)hipFree(c->d_slot_of_wire);
+    if (c->d_steps) (void)hipFree(c->d_steps);
     delete c;
 }
 
 const gc_plan *gc_circ_plan(const gc_circ *c) { return c ? &c->plan : nullptr; }
 
+int gc_circ_set_schedule(gc_circ *c, int schedule) {
+    if (!c || schedule < 0 || schedule > 1) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    c->schedule = schedule;
+    return GC_OK;
+}
+
 // ---- batch -----------------------------------------------------------------------------------
+
+static void drop_graphs(gc_batch *b);
+
+static void free_buffers(gc_batch *b) {
+    if (b->d_W) (void)hipFree(b->d_W);
+    if (b->d_T) (void)hipFree(b->d_T);
+    if (b->d_R) (void)hipFree(b->d_R);
+    b->d_W = b->d_T = b->d_R = nullptr;
+}
+
+// (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
+static hipError_t alloc_buffers(gc_batch *b) {
+    const Plan &p = b->circ->plan.p;
+    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows);
+    const size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
+    const size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
+    hipError_t e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_T, tbytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_R, (size_t)b->g.bstride * sizeof(uint4));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(b->d_R, 0, (size_t)b->g.bstride * sizeof(uint4), b->circ->ctx->stream);
+    return e;
+}
 
 gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) {
     int rc = GC_OK;
@@ -155,16 +187,10 @@ gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) {
     }
     if (rc == GC_OK) {
         b->circ = circ;
-        b->g = make_geom(batch);
-        const Plan &p = circ->plan.p;
+        b->g.batch = batch;
         hipError_t e = hipSetDevice(circ->ctx->device);
-        size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
-        size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
-        if (e == hipSuccess) e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
-        if (e == hipSuccess) e = hipMalloc((void **)&b->d_T, tbytes);
-        if (e == hipSuccess) e = hipMalloc((void **)&b->d_R, (size_t)b->g.bstride * sizeof(uint4));
+        if (e == hipSuccess) e = alloc_buffers(b);
         if (e == hipSuccess) e = hipMalloc((void **)&b->d_rk, 60 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemsetAsync(b->d_R, 0, (size_t)b->g.bstride * sizeof(uint4), circ->ctx->stream);
         if (e == hipSuccess) e = hipEventCreate(&b->ev0);
         if (e == hipSuccess) e = hipEventCreate(&b->ev1);
         if (e != hipSuccess) {
@@ -194,9 +220,7 @@ void gc_batch_free(gc_batch *b) {
         (void)hipStreamSynchronize(b->circ->ctx->stream);
     }
     drop_graphs(b);
-    if (b->d_W) (void)hipFree(b->d_W);
-    if (b->d_T) (void)hipFree(b->d_T);
-    if (b->d_R) (void)hipFree(b->d_R);
+    free_buffers(b);
     if (b->d_rk) (void)hipFree(b->d_rk);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -207,7 +231,15 @@ uint32_t gc_batch_stride(const gc_batch *b) { return b ? b->g.bstride : 0; }
 
 int gc_batch_set_schedule(gc_batch *b, int schedule) {
     if (!b || schedule < 0 || schedule > 1) return GC_E_ARG;
+    if (schedule == b->schedule) return GC_OK;
+    // the schedule fixes the HBM layout: start over with fresh arrays (contents are per-pass anyway)
+    GC_HIP(hipSetDevice(b->circ->ctx->device));
+    GC_HIP(hipStreamSynchronize(b->circ->ctx->stream));
+    drop_graphs(b);
+    free_buffers(b);
     b->schedule = schedule;
+    b->timed = false;
+    GC_HIP(alloc_buffers(b));
     return GC_OK;
 }
 
@@ -251,6 +283,24 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
 static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
+    if (b->schedule == 1) {  // fused: one launch walks every level
+        FusedArgs a{};
+        a.descs = b->circ->d_descs;
+        a.steps = b->circ->d_steps;
+        a.nsteps = (uint32_t)p.levels.size();
+        a.ninputs = p.info.ninputs;
+        a.W = b->d_W;
+        a.R = b->d_R;
+        a.T = const_cast<uint4 *>(T);
+        a.rk = b->d_rk;
+        a.te0 = b->circ->ctx->d_te0;
+        a.rounds = b->rounds;
+        if (eval) launch_eval_fused(a, b->g, s);
+        else launch_garble_fused(a, b->g, s);
+        GC_HIP(hipGetLastError());
+        b->last_launches = a.nsteps ? 1 : 0;
+        return GC_OK;
+    }
     b->last_launches = (uint32_t)p.levels.size();
     if (!b->use_graph || p.levels.size() < 2) {
         enqueue_levels(b, eval, T, s);
@@ -304,7 +354,9 @@ int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *
 }
 
 int gc_batch_select_inputs(gc_batch *ev, const gc_batch *gb, const void *d_bits) {
-    if (!ev || !gb || !d_bits || ev->circ != gb->circ || ev->g.batch != gb->g.batch) return GC_E_ARG;
+    if (!ev || !gb || !d_bits || ev->circ != gb->circ || ev->g.batch != gb->g.batch ||
+        ev->schedule != gb->schedule)
+        return GC_E_ARG;
     gc_ctx *ctx = ev->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     launch_select_inputs(ev->d_W, gb->d_W, gb->d_R, (const uint8_t *)d_bits, ev->circ->plan.p.info.ninputs, ev->g,
@@ -318,13 +370,15 @@ int gc_batch_set_inputs(gc_batch *ev, const void *d_labels) {
     gc_ctx *ctx = ev->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     uint32_t nin = ev->circ->plan.p.info.ninputs;
-    launch_scatter((const uint4 *)d_labels, nin, nin, nullptr, 0, ev->d_W, ev->g, ctx->stream);
+    launch_scatter((const uint4 *)d_labels, nin, nin, nullptr, 0, ev->d_W, ev->g.lw, 0, ev->g.batch, ctx->stream);
     GC_HIP(hipGetLastError());
     return GC_OK;
 }
 
 int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batch *tables) {
-    if (!ev || !tables || tables->circ != ev->circ || tables->g.bstride != ev->g.bstride) return GC_E_ARG;
+    if (!ev || !tables || tables->circ != ev->circ || tables->g.bstride != ev->g.bstride ||
+        tables->schedule != ev->schedule)
+        return GC_E_ARG;
     gc_ctx *ctx = ev->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     int rc = set_key(ev, key, keylen);
@@ -338,7 +392,9 @@ int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batc
 }
 
 int gc_batch_decode(const gc_batch *gb, const gc_batch *ev, void *d_bits_out, void *d_mismatch) {
-    if (!gb || !ev || !d_bits_out || gb->circ != ev->circ || gb->g.batch != ev->g.batch) return GC_E_ARG;
+    if (!gb || !ev || !d_bits_out || gb->circ != ev->circ || gb->g.batch != ev->g.batch ||
+        gb->schedule != ev->schedule)
+        return GC_E_ARG;
     gc_ctx *ctx = gb->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     launch_decode(gb->d_W, gb->d_R, ev->d_W, gb->circ->d_out_slots, gb->circ->plan.p.info.noutputs,
@@ -371,8 +427,8 @@ int gc_batch_read_r(gc_batch *b, gc_label *r_out) {
     return GC_OK;
 }
 
-static int read_gather(gc_batch *b, const uint4 *src, const uint32_t *slots, uint32_t slot0, uint32_t n, int mode,
-                       void *host_out) {
+static int read_gather(gc_batch *b, const uint4 *src, const Layout &lay, const uint32_t *slots, uint32_t slot0,
+                       uint32_t n, int mode, void *host_out) {
     if (n == 0) return GC_OK;
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
@@ -384,11 +440,10 @@ static int read_gather(gc_batch *b, const uint4 *src, const uint32_t *slots, uin
     DevBuf tmp;
     GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
     for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
-        BatchGeom g = b->g;
-        g.batch = std::min(chunk, b->g.batch - i0);
-        launch_gather(src + i0, slots, slot0, n, b->d_R + i0, mode, (uint4 *)tmp.p, elems, g, ctx->stream);
+        const uint32_t cnt = std::min(chunk, b->g.batch - i0);
+        launch_gather(src, lay, i0, slots, slot0, n, b->d_R, mode, (uint4 *)tmp.p, elems, cnt, ctx->stream);
         GC_HIP(hipGetLastError());
-        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, tmp.p, (size_t)g.batch * per_inst,
+        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, tmp.p, (size_t)cnt * per_inst,
                               hipMemcpyDeviceToHost, ctx->stream));
         GC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -397,26 +452,26 @@ static int read_gather(gc_batch *b, const uint4 *src, const uint32_t *slots, uin
 
 int gc_batch_read_slab(gc_batch *b, gc_label *slab_out) {
     if (!b || !slab_out) return GC_E_ARG;
-    return read_gather(b, b->d_T, nullptr, 0, b->circ->plan.p.info.slab_rows, 0, slab_out);
+    return read_gather(b, b->d_T, b->g.lt, nullptr, 0, b->circ->plan.p.info.slab_rows, 0, slab_out);
 }
 
 int gc_batch_read_wires(gc_batch *b, gc_wire *wires_out) {
     if (!b || !wires_out) return GC_E_ARG;
-    return read_gather(b, b->d_W, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 1, wires_out);
+    return read_gather(b, b->d_W, b->g.lw, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 1, wires_out);
 }
 
 int gc_batch_read_labels(gc_batch *b, gc_label *labels_out) {
     if (!b || !labels_out) return GC_E_ARG;
-    return read_gather(b, b->d_W, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 0, labels_out);
+    return read_gather(b, b->d_W, b->g.lw, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 0, labels_out);
 }
 
 int gc_batch_read_outputs(gc_batch *b, gc_label *out) {
     if (!b || !out) return GC_E_ARG;
-    return read_gather(b, b->d_W, b->circ->d_out_slots, 0, b->circ->plan.p.info.noutputs, 0, out);
+    return read_gather(b, b->d_W, b->g.lw, b->circ->d_out_slots, 0, b->circ->plan.p.info.noutputs, 0, out);
 }
 
 static int write_scatter(gc_batch *b, const void *host_src, size_t src_stride_elems, size_t col0, uint32_t n,
-                         const uint32_t *slots, uint32_t slot0, uint4 *dst) {
+                         const uint32_t *slots, uint32_t slot0, uint4 *dst, const Layout &lay) {
     if (n == 0) return GC_OK;
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
@@ -426,12 +481,11 @@ static int write_scatter(gc_batch *b, const void *host_src, size_t src_stride_el
     DevBuf tmp;
     GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
     for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
-        BatchGeom g = b->g;
-        g.batch = std::min(chunk, b->g.batch - i0);
+        const uint32_t cnt = std::min(chunk, b->g.batch - i0);
         const uint8_t *src = (const uint8_t *)host_src + ((size_t)i0 * src_stride_elems + col0) * sizeof(uint4);
-        GC_HIP(hipMemcpy2DAsync(tmp.p, per_inst, src, src_stride_elems * sizeof(uint4), per_inst, g.batch,
+        GC_HIP(hipMemcpy2DAsync(tmp.p, per_inst, src, src_stride_elems * sizeof(uint4), per_inst, cnt,
                                 hipMemcpyHostToDevice, ctx->stream));
-        launch_scatter((const uint4 *)tmp.p, n, n, slots, slot0, dst + i0, g, ctx->stream);
+        launch_scatter((const uint4 *)tmp.p, n, n, slots, slot0, dst, lay, i0, cnt, ctx->stream);
         GC_HIP(hipGetLastError());
         GC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -441,7 +495,7 @@ static int write_scatter(gc_batch *b, const void *host_src, size_t src_stride_el
 int gc_batch_write_slab(gc_batch *b, const gc_label *slab) {
     if (!b || !slab) return GC_E_ARG;
     uint32_t rows = b->circ->plan.p.info.slab_rows;
-    return write_scatter(b, slab, rows, 0, rows, nullptr, 0, b->d_T);
+    return write_scatter(b, slab, rows, 0, rows, nullptr, 0, b->d_T, b->g.lt);
 }
 
 void *gc_batch_dev_wires(gc_batch *b) { return b ? b->d_W : nullptr; }
@@ -472,17 +526,28 @@ uint32_t gc_batch_last_launches(gc_batch *b) { return b ? b->last_launches : 0; 
 // ---- host-buffer API -------------------------------------------------------------------------
 
 static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
+    int schedule;
     {
         std::lock_guard<std::mutex> lk(c->pool_mu);
+        schedule = c->schedule;
         for (size_t i = 0; i < c->pool.size(); i++) {
-            if (c->pool[i]->g.batch == batch) {
+            if (c->pool[i]->g.batch == batch && c->pool[i]->schedule == schedule) {
                 gc_batch *b = c->pool[i];
                 c->pool.erase(c->pool.begin() + (long)i);
                 return b;
             }
         }
     }
-    return gc_batch_create(c, batch, rc);
+    gc_batch *b = gc_batch_create(c, batch, rc);
+    if (b && b->schedule != schedule) {
+        int r2 = gc_batch_set_schedule(b, schedule);
+        if (r2 != GC_OK) {
+            gc_batch_free(b);
+            if (rc) *rc = r2;
+            return nullptr;
+        }
+    }
+    return b;
 }
 
 static void pool_put(gc_circ *c, gc_batch *b) {
@@ -531,9 +596,9 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
             const uint32_t nio = p.info.ninputs + p.info.noutputs;
             // gather the two ranges separately into a strided host buffer
             std::vector<gc_wire> in((size_t)batch * p.info.ninputs), out((size_t)batch * p.info.noutputs);
-            rc = read_gather(b, b->d_W, nullptr, 0, p.info.ninputs, 1, in.data());
+            rc = read_gather(b, b->d_W, b->g.lw, nullptr, 0, p.info.ninputs, 1, in.data());
             if (rc != GC_OK) break;
-            rc = read_gather(b, b->d_W, c->d_out_slots, 0, p.info.noutputs, 1, out.data());
+            rc = read_gather(b, b->d_W, b->g.lw, c->d_out_slots, 0, p.info.noutputs, 1, out.data());
             if (rc != GC_OK) break;
             for (uint32_t i = 0; i < batch; i++) {
                 std::copy(in.begin() + (size_t)i * p.info.ninputs, in.begin() + (size_t)(i + 1) * p.info.ninputs,
@@ -567,9 +632,9 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
     do {
         if (p.info.slab_rows && (rc = gc_batch_write_slab(b, slab)) != GC_OK) break;
         if (wires_inout)
-            rc = write_scatter(b, wires_inout, p.info.nwires, 0, p.info.ninputs, nullptr, 0, b->d_W);
+            rc = write_scatter(b, wires_inout, p.info.nwires, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         else
-            rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W);
+            rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         if (rc != GC_OK) break;
         rc = gc_batch_eval(b, key, keylen, b);
         if (rc != GC_OK) break;

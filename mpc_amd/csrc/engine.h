@@ -39,6 +39,8 @@ struct gc_circ {
     gc::GateDesc *d_descs = nullptr;
     uint32_t *d_out_slots = nullptr;
     uint32_t *d_slot_of_wire = nullptr;
+    gc::Step *d_steps = nullptr;
+    int schedule = 1;  // default schedule of pooled batches
     std::mutex pool_mu;
     std::vector<gc_batch *> pool;  // idle batches reused by gc_garble / gc_eval (cf. garble.go:195-225)
 };

@@ -10,11 +10,9 @@
 
 namespace gc {
 
-BatchGeom make_geom(uint32_t batch) {
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows) {
     BatchGeom g{};
     g.batch = batch;
-    g.bstride = (batch + 63u) & ~63u;
-    if (g.bstride == 0) g.bstride = 64;
     if (batch >= 256) {
         g.lg = 8;
         g.yblocks = (batch + 255) / 256;
@@ -23,6 +21,23 @@ BatchGeom make_geom(uint32_t batch) {
         while ((1u << lg) < batch) lg++;
         g.lg = lg;
         g.yblocks = 1;
+    }
+    if (schedule == 0) {
+        g.bstride = (batch + 63u) & ~63u;
+        g.ti_log2 = 31;
+        g.ntiles = 1;
+        g.lw = Layout{31, 0x7fffffffu, g.bstride, 0};
+        g.lt = Layout{31, 0x7fffffffu, g.bstride, 0};
+    } else {
+        // instances per workgroup tile: aim at >= 256 workgroups (one per CU), at most 64 lanes wide
+        uint32_t t = 0;
+        while (t < 6 && (batch >> (t + 1)) >= 256) t++;
+        g.ti_log2 = t;
+        const uint32_t ti = 1u << t;
+        g.ntiles = (batch + ti - 1) / ti;
+        g.bstride = g.ntiles * ti;
+        g.lw = Layout{t, ti - 1, ti, (size_t)nslots * ti};
+        g.lt = Layout{t, ti - 1, ti, (size_t)(slab_rows ? slab_rows : 1) * ti};
     }
     return g;
 }
@@ -261,7 +276,7 @@ __device__ __forceinline__ uint4 label_from_be(uint4 raw) {
 // rnd [batch][1+ninputs] -> R [inst], W[w][inst]   (garble.go:253-258, 271-278)
 __global__ __launch_bounds__(256) void k_init_garble(const uint4 *__restrict__ rnd, uint32_t ninputs,
                                                      uint4 *__restrict__ W, uint4 *__restrict__ Rv, uint32_t batch,
-                                                     uint32_t bstride) {
+                                                     Layout lay) {
     __shared__ uint4 tile[TILE][TILE + 1];
     const uint32_t n = ninputs + 1;
     const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(256) void k_init_garble(const uint4 *__restrict__ r
                 v.y |= 0x80000000u;  // R.SetS(true)
                 Rv[i] = v;
             } else {
-                W[(size_t)(j - 1) * bstride + i] = v;
+                W[lay.at(j - 1, i)] = v;
             }
         }
     }
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256) void k_init_garble(const uint4 *__restrict__ r
 
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s) {
     dim3 grid((ninputs + 1 + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
-    hipLaunchKernelGGL(k_init_garble, grid, dim3(256), 0, s, rnd, ninputs, W, R, g.batch, g.bstride);
+    hipLaunchKernelGGL(k_init_garble, grid, dim3(256), 0, s, rnd, ninputs, W, R, g.batch, g.lw);
 }
 
 // dst[inst][j] = W[slot(j)][inst]            (mode 0, one label per element)
@@ -296,7 +311,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ W, const uint32_t *__restrict__ slots,
                                                 uint32_t slot0, uint32_t n, const uint4 *__restrict__ Rv,
                                                 uint4 *__restrict__ dst, size_t dst_stride, uint32_t batch,
-                                                uint32_t bstride) {
+                                                Layout lay, uint32_t inst0) {
     __shared__ uint4 tile[TILE][TILE + 1];
     const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
     const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ W, con
         uint32_t j = j0 + r, i = i0 + tx;
         if (j < n && i < batch) {
             uint32_t slot = slots ? slots[j] : slot0 + j;
-            tile[r][tx] = slot == 0xffffffffu ? make_uint4(0, 0, 0, 0) : W[(size_t)slot * bstride + i];
+            tile[r][tx] = slot == 0xffffffffu ? make_uint4(0, 0, 0, 0) : W[lay.at(slot, inst0 + i)];
         }
     }
     __syncthreads();
@@ -317,28 +332,30 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ W, con
             } else {
                 uint4 *o = dst + (size_t)i * dst_stride + 2 * (size_t)j;
                 o[0] = v;
-                o[1] = lxor(v, Rv[i]);
+                o[1] = lxor(v, Rv[inst0 + i]);
             }
         }
     }
 }
 
-void launch_gather(const uint4 *W, const uint32_t *slots, uint32_t slot0, uint32_t n, const uint4 *R, int mode,
-                   uint4 *dst, size_t dst_stride_elems, const BatchGeom &g, hipStream_t s) {
-    if (n == 0) return;
-    dim3 grid((n + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
+void launch_gather(const uint4 *W, const Layout &lay, uint32_t inst0, const uint32_t *slots, uint32_t slot0,
+                   uint32_t n, const uint4 *R, int mode, uint4 *dst, size_t dst_stride_elems, uint32_t count,
+                   hipStream_t s) {
+    if (n == 0 || count == 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (count + TILE - 1) / TILE);
     if (mode == 0)
-        hipLaunchKernelGGL(k_gather<0>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, g.batch,
-                           g.bstride);
+        hipLaunchKernelGGL(k_gather<0>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, count, lay,
+                           inst0);
     else
-        hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, g.batch,
-                           g.bstride);
+        hipLaunchKernelGGL(k_gather<1>, grid, dim3(256), 0, s, W, slots, slot0, n, R, dst, dst_stride_elems, count, lay,
+                           inst0);
 }
 
 // W[slot(j)][inst] = src[inst][j]
 __global__ __launch_bounds__(256) void k_scatter(const uint4 *__restrict__ src, size_t src_stride, uint32_t n,
                                                  const uint32_t *__restrict__ slots, uint32_t slot0,
-                                                 uint4 *__restrict__ W, uint32_t batch, uint32_t bstride) {
+                                                 uint4 *__restrict__ W, uint32_t batch, Layout lay,
+                                                 uint32_t inst0) {
     __shared__ uint4 tile[TILE][TILE + 1];
     const uint32_t j0 = blockIdx.x * TILE, i0 = blockIdx.y * TILE;
     const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -351,30 +368,29 @@ __global__ __launch_bounds__(256) void k_scatter(const uint4 *__restrict__ src, 
         uint32_t j = j0 + r, i = i0 + tx;
         if (j < n && i < batch) {
             uint32_t slot = slots ? slots[j] : slot0 + j;
-            if (slot != 0xffffffffu) W[(size_t)slot * bstride + i] = tile[tx][r];
+            if (slot != 0xffffffffu) W[lay.at(slot, inst0 + i)] = tile[tx][r];
         }
     }
 }
 
 void launch_scatter(const uint4 *src, size_t src_stride_elems, uint32_t n, const uint32_t *slots, uint32_t slot0,
-                    uint4 *W, const BatchGeom &g, hipStream_t s) {
-    if (n == 0) return;
-    dim3 grid((n + TILE - 1) / TILE, (g.batch + TILE - 1) / TILE);
-    hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, s, src, src_stride_elems, n, slots, slot0, W, g.batch,
-                       g.bstride);
+                    uint4 *W, const Layout &lay, uint32_t inst0, uint32_t count, hipStream_t s) {
+    if (n == 0 || count == 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (count + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_scatter, grid, dim3(256), 0, s, src, src_stride_elems, n, slots, slot0, W, count, lay, inst0);
 }
 
 // evaluator's active input labels: L0 ^ (bit ? R : 0)   (LabelForBit, circuit/helpers.go:10-15)
 __global__ __launch_bounds__(256) void k_select_inputs(uint4 *__restrict__ We, const uint4 *__restrict__ Wg,
                                                        const uint4 *__restrict__ Rv,
                                                        const uint8_t *__restrict__ bits, uint32_t ninputs,
-                                                       uint32_t batch, uint32_t bstride) {
+                                                       uint32_t batch, Layout lay) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= batch) return;
     const uint4 R = Rv[i];
     for (uint32_t w = blockIdx.y; w < ninputs; w += gridDim.y) {
         const uint32_t m = bits[(size_t)i * ninputs + w] ? 0xffffffffu : 0u;
-        We[(size_t)w * bstride + i] = lxor(Wg[(size_t)w * bstride + i], land(R, m));
+        We[lay.at(w, i)] = lxor(Wg[lay.at(w, i)], land(R, m));
     }
 }
 
@@ -382,7 +398,7 @@ void launch_select_inputs(uint4 *We, const uint4 *Wg, const uint4 *R, const uint
                           const BatchGeom &g, hipStream_t s) {
     if (ninputs == 0) return;
     dim3 grid((g.batch + 255) / 256, ninputs < 65535u ? ninputs : 65535u);
-    hipLaunchKernelGGL(k_select_inputs, grid, dim3(256), 0, s, We, Wg, R, bits, ninputs, g.batch, g.bstride);
+    hipLaunchKernelGGL(k_select_inputs, grid, dim3(256), 0, s, We, Wg, R, bits, ninputs, g.batch, g.lw);
 }
 
 // BitFromLabel (circuit/helpers.go:18-28) over all output wires
@@ -390,12 +406,12 @@ __global__ __launch_bounds__(256) void k_decode(const uint4 *__restrict__ Wg, co
                                                 const uint4 *__restrict__ We,
                                                 const uint32_t *__restrict__ out_slots, uint32_t noutputs,
                                                 uint8_t *__restrict__ bits_out, uint32_t *__restrict__ mismatch,
-                                                uint32_t batch, uint32_t bstride) {
+                                                uint32_t batch, Layout lay) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= batch) return;
     const uint4 R = Rv[i];
     for (uint32_t j = blockIdx.y; j < noutputs; j += gridDim.y) {
-        const size_t at = (size_t)out_slots[j] * bstride + i;
+        const size_t at = lay.at(out_slots[j], i);
         const uint4 l0 = Wg[at], lab = We[at];
         uint8_t bit = 0;
         if (leq(lab, l0)) bit = 0;
@@ -413,23 +429,23 @@ void launch_decode(const uint4 *Wg, const uint4 *R, const uint4 *We, const uint3
     if (noutputs == 0) return;
     dim3 grid((g.batch + 255) / 256, noutputs < 65535u ? noutputs : 65535u);
     hipLaunchKernelGGL(k_decode, grid, dim3(256), 0, s, Wg, R, We, out_slots, noutputs, bits_out, mismatch, g.batch,
-                       g.bstride);
+                       g.lw);
 }
 
 __global__ __launch_bounds__(256) void k_gather_rows(const uint4 *__restrict__ W, const uint32_t *__restrict__ slots,
                                                      uint32_t n, uint4 *__restrict__ dst, uint32_t batch,
-                                                     uint32_t bstride) {
+                                                     uint32_t bstride, Layout lay) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= bstride) return;
     for (uint32_t j = blockIdx.y; j < n; j += gridDim.y)
-        dst[(size_t)j * bstride + i] = i < batch ? W[(size_t)slots[j] * bstride + i] : make_uint4(0, 0, 0, 0);
+        dst[(size_t)j * bstride + i] = i < batch ? W[lay.at(slots[j], i)] : make_uint4(0, 0, 0, 0);
 }
 
 void launch_gather_rows(const uint4 *W, const uint32_t *slots, uint32_t n, uint4 *dst, const BatchGeom &g,
                         hipStream_t s) {
     if (n == 0) return;
     dim3 grid((g.bstride + 255) / 256, n < 65535u ? n : 65535u);
-    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, s, W, slots, n, dst, g.batch, g.bstride);
+    hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, s, W, slots, n, dst, g.batch, g.bstride, g.lw);
 }
 
 }  // namespace gc

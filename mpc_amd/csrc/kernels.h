@@ -9,21 +9,45 @@
 
 namespace gc {
 
+// Placement of a [row][instance] array of 16-byte labels in HBM.
+//   level layout  (schedule 0): row-major, one row = bstride instances  -> a wave reads 64 consecutive
+//                               instances of one wire = 1 KiB coalesced
+//   tiled layout  (schedule 1): instances are grouped in tiles of TI = 1<<ti_log2; one tile's rows are
+//                               contiguous ([tile][row][TI]) so that the workgroup owning the tile
+//                               keeps its whole working set in one L2-friendly region
+struct Layout {
+    uint32_t ti_log2;    // 31 for the level layout (a single tile)
+    uint32_t ti_mask;    // (1 << ti_log2) - 1
+    size_t row_stride;   // elements between consecutive rows
+    size_t tile_stride;  // elements between consecutive tiles (0 for the level layout)
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    size_t at(size_t row, uint32_t inst) const {
+        return (size_t)(inst >> ti_log2) * tile_stride + row * row_stride + (inst & ti_mask);
+    }
+};
+
 // Geometry of one instance batch on the device.
 struct BatchGeom {
     uint32_t batch;    // instances
-    uint32_t bstride;  // row stride of every [x][instance] array (batch rounded up to 64)
-    uint32_t lg;       // log2 of the per-block instance tile (<= 8); 256>>lg gates share a block
-    uint32_t yblocks;  // instance blocks of 256 (1 when batch <= 256)
+    uint32_t bstride;  // instances allocated (batch rounded up to 64 / to the tile size)
+    uint32_t lg;       // level kernels: log2 of the per-block instance tile (<= 8)
+    uint32_t yblocks;  // level kernels: instance blocks of 256 (1 when batch <= 256)
+    uint32_t ti_log2;  // fused kernels: log2 of the instances per workgroup tile
+    uint32_t ntiles;
+    Layout lw;         // wire labels  [nslots][...]
+    Layout lt;         // table rows   [slab_rows][...]
 };
-BatchGeom make_geom(uint32_t batch);
+// schedule 0 = level layout, 1 = tiled layout
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows);
 
 struct LevelArgs {
     const GateDesc *descs;  // device, already offset to the step
     uint32_t count, nonfree, out_slot0;
-    uint4 *W;               // wire labels [nslots][bstride]
+    uint4 *W;               // wire labels
     const uint4 *R;         // garbler: [bstride]
-    uint4 *T;               // tables [slab_rows][bstride]
+    uint4 *T;               // tables
     const uint32_t *rk;     // device round keys (big-endian words)
     const uint32_t *te0;    // device Te0
     int rounds;
@@ -32,16 +56,33 @@ struct LevelArgs {
 void launch_garble_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s);
 void launch_eval_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s);
 
+// Fused schedule: ONE launch walks all levels; a workgroup owns a tile of instances and
+// synchronises its own waves between levels (no inter-workgroup dependency at all).
+struct FusedArgs {
+    const GateDesc *descs;
+    const Step *steps;  // device copy of Plan::levels
+    uint32_t nsteps, ninputs;
+    uint4 *W;
+    const uint4 *R;
+    uint4 *T;
+    const uint32_t *rk;
+    const uint32_t *te0;
+    int rounds;
+};
+void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
+void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
+
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);
 
-// generic [instance][n] <-> [slot][instance] movers (16-byte elements, LDS-tiled transpose).
-// slots == nullptr means slot j = slot0 + j.
+// generic [instance][n] <-> [row][instance] movers (16-byte elements, LDS-tiled transpose).
+// slots == nullptr means row j = slot0 + j.  lay = placement of the device array.
 // mode: 0 = labels, 1 = wires {L0, L0^R} (gather only)
-void launch_gather(const uint4 *W, const uint32_t *slots, uint32_t slot0, uint32_t n, const uint4 *R, int mode,
-                   uint4 *dst, size_t dst_stride_elems, const BatchGeom &g, hipStream_t s);
+void launch_gather(const uint4 *W, const Layout &lay, uint32_t inst0, const uint32_t *slots, uint32_t slot0,
+                   uint32_t n, const uint4 *R, int mode, uint4 *dst, size_t dst_stride_elems, uint32_t count,
+                   hipStream_t s);
 void launch_scatter(const uint4 *src, size_t src_stride_elems, uint32_t n, const uint32_t *slots, uint32_t slot0,
-                    uint4 *W, const BatchGeom &g, hipStream_t s);
+                    uint4 *W, const Layout &lay, uint32_t inst0, uint32_t count, hipStream_t s);
 
 void launch_select_inputs(uint4 *We, const uint4 *Wg, const uint4 *R, const uint8_t *bits, uint32_t ninputs,
                           const BatchGeom &g, hipStream_t s);

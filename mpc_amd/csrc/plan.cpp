@@ -90,7 +90,7 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
     uint32_t width = 0;
     for (uint32_t k = 0; k < ngates;) {
         uint32_t lvl = p.level_of_gate[order[k]];
-        Step st{k, 0, 0};
+        Step st{k, 0, 0, 0, 0, 0};
         while (k < ngates && p.level_of_gate[order[k]] == lvl) {
             uint32_t g = order[k];
             GateDesc &d = p.descs[k];
@@ -99,6 +99,9 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
             d.tweak = p.tweak_of_gate[g];
             d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
             if (op_class(gates[g].op) != 3) st.nonfree++;
+            if (gates[g].op == GC_AND) st.n_and++;
+            else if (gates[g].op == GC_OR) st.n_or++;
+            else if (gates[g].op == GC_INV) st.n_inv++;
             st.count++;
             k++;
         }

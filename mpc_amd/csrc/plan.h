@@ -33,6 +33,7 @@ struct Step {
     uint32_t first;
     uint32_t count;
     uint32_t nonfree;
+    uint32_t n_and, n_or, n_inv;  // sorted in this order at the front; nonfree = n_and + n_or + n_inv
 };
 
 struct Plan {

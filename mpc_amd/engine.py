@@ -75,6 +75,7 @@ def lib():
         "gc_circ_load": (vp, [vp, vp, u32, u32, u32, u32, ip]),
         "gc_circ_free": (None, [vp]),
         "gc_circ_plan": (vp, [vp]),
+        "gc_circ_set_schedule": (i32, [vp, i32]),
         "gc_garble": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, vp]),
         "gc_eval": (i32, [vp, vp, sz, u32, vp, vp, vp, sz, vp]),
         "gc_batch_create": (vp, [vp, u32, ip]),
@@ -194,7 +195,7 @@ class Context:
 class DeviceCircuit:
     """gc_circ: a circuit.Circuit uploaded to one device."""
 
-    def __init__(self, ctx, circuit):
+    def __init__(self, ctx, circuit, schedule=None):
         self.ctx = ctx
         self.c = circuit
         st = C.c_int(0)
@@ -205,6 +206,11 @@ class DeviceCircuit:
             raise EngineError(st.value, "gc_circ_load")
         self.info = PlanInfo()
         _check(lib().gc_plan_get_info(lib().gc_circ_plan(self.h), C.byref(self.info)), "gc_plan_get_info")
+        if schedule is not None:
+            self.set_schedule(schedule)
+
+    def set_schedule(self, schedule):
+        _check(lib().gc_circ_set_schedule(self.h, schedule), "gc_circ_set_schedule")
 
     # -- host-buffer API: Circuit.Garble / Circuit.Eval with a batch dimension --
 

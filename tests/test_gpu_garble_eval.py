@@ -40,9 +40,12 @@ def oracle_instance(c, key, rnd, i):
     return oracle.garble(c.Gates, c.NumWires, c.num_inputs, key, rnd[i * stride:(i + 1) * stride])
 
 
-def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True):
+SCHEDULES = [0, 1]  # 0 = one launch per level, 1 = fused single launch (gcengine.h)
+
+
+def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True, schedule=1):
     """host-buffer API vs oracle, every instance, every byte"""
-    dc = engine.DeviceCircuit(ctx, c)
+    dc = engine.DeviceCircuit(ctx, c, schedule=schedule)
     rnd = rnd_for(c, seed, batch)
     g = dc.garble(key, rnd, batch=batch, want_wires=check_all_wires, want_io=True)
     bits = (np.frombuffer(drbg(seed + "/bits", c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
@@ -78,26 +81,38 @@ def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True):
     dc.close()
 
 
-@pytest.mark.parametrize("batch", [1, 2, 3, 5, 33, 64, 65, 100, 255, 256, 257, 300])
-def test_all_gate_types_ragged_batches(ctx, batch):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+@pytest.mark.parametrize("batch", [1, 2, 3, 5, 33, 64, 65, 100, 255, 256, 257, 300, 513, 1030])
+def test_all_gate_types_ragged_batches(ctx, batch, schedule):
     c = synthetic_levelised(10, 48, 0.3, seed=5, ninputs=40, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1)
-    check_garble_eval(ctx, c, KEY256, batch, "ragged%d" % batch)
+    check_garble_eval(ctx, c, KEY256, batch, "ragged%d" % batch, schedule=schedule)
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_wide_levels(ctx, schedule):
+    # levels wider than one 1024-thread workgroup pass, every tile size of the fused schedule
+    c = synthetic_levelised(4, 700, 0.4, seed=13, ninputs=64, or_frac=0.05, inv_frac=0.1, xnor_frac=0.05)
+    for batch in (3, 520, 2100):
+        check_garble_eval(ctx, c, KEY128, batch, "wide%d" % batch, check_all_wires=(batch < 1000), schedule=schedule)
+
+
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("key", [KEY128, bytes(range(7, 31)), KEY256], ids=["aes128", "aes192", "aes256"])
-def test_key_sizes(ctx, key):
+def test_key_sizes(ctx, key, schedule):
     c = synthetic_levelised(6, 70, 0.4, seed=9, ninputs=32, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1)
-    check_garble_eval(ctx, c, key, 70, "keys%d" % len(key))
+    check_garble_eval(ctx, c, key, 70, "keys%d" % len(key), schedule=schedule)
 
 
-def test_and_chain_width_one(ctx):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_and_chain_width_one(ctx, schedule):
     # buildANDChain (garble_bench_test.go:19-33): depth n, width 1 — one launch per gate
-    check_garble_eval(ctx, and_chain(300), KEY128, 17, "chain")
+    check_garble_eval(ctx, and_chain(300), KEY128, 17, "chain", schedule=schedule)
 
 
 def test_comparator64_millionaire(ctx):
     c = comparator64()
-    check_garble_eval(ctx, c, KEY256, 9, "cmp")
+    for schedule in SCHEDULES:
+        check_garble_eval(ctx, c, KEY256, 9, "cmp", schedule=schedule)
     dc = engine.DeviceCircuit(ctx, c)
     for a, b in ((750000, 800000), (900000, 800000)):  # README.md:57-108
         rnd = rnd_for(c, "mill", 1)
@@ -115,15 +130,18 @@ def test_wire_reuse(ctx):
     g[0] = (0, 1, 2, 0, 0)
     g[1] = (2, 0, 2, 2, 0)
     g[2] = (2, 1, 3, 0, 0)
-    check_garble_eval(ctx, Circuit(4, [1, 1], [1], g), KEY256, 7, "reuse")
+    for schedule in SCHEDULES:
+        check_garble_eval(ctx, Circuit(4, [1, 1], [1], g), KEY256, 7, "reuse", schedule=schedule)
 
 
-def test_add64(ctx, add64_circ):
-    check_garble_eval(ctx, add64_circ, KEY256, 40, "add64")
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_add64(ctx, add64_circ, schedule):
+    check_garble_eval(ctx, add64_circ, KEY256, 40, "add64", schedule=schedule)
 
 
-def test_aes128_circuit_batch(ctx, aes_circ):
-    check_garble_eval(ctx, aes_circ, KEY256, 6, "aes", check_all_wires=True)
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_aes128_circuit_batch(ctx, aes_circ, schedule):
+    check_garble_eval(ctx, aes_circ, KEY256, 6, "aes", check_all_wires=True, schedule=schedule)
 
 
 def test_sha256xor_reference_digest(ctx, sha_circ):
@@ -161,26 +179,27 @@ def test_golden_digests(ctx, golden_dir):
     spec.loader.exec_module(mk)
     gold = json.load(open(os.path.join(golden_dir, "garble_golden.json")))
     for name, c in mk.circuits().items():
-        dc = engine.DeviceCircuit(ctx, c)
-        n = mk.COUNTS[name]
-        for kn, kh in gold["keys"].items():
-            key = bytes.fromhex(kh)
-            streams = [mk.instance_streams(name, c, i) for i in range(n)]
-            rnd = b"".join(s[0] for s in streams)
-            g = dc.garble(key, rnd, batch=n)
-            nin, nout = c.num_inputs, c.num_outputs
-            wires = np.zeros((n, c.NumWires), LABEL)
-            for i in range(n):
-                h = hashlib.sha256()
-                h.update(g["R"][i:i + 1].tobytes())
-                h.update(np.ascontiguousarray(g["slab"][i]).tobytes())
-                h.update(np.ascontiguousarray(g["io"][i]["l0"][nin:]).tobytes())
-                assert h.hexdigest() == gold["circuits"][name][kn][i]["garble"], (name, kn, i)
-                wires[i, :nin] = np.where(streams[i][1].astype(bool), g["io"][i]["l1"][:nin], g["io"][i]["l0"][:nin])
-            dc.eval(key, g["slab"], wires=wires, batch=n)
-            for i in range(n):
-                assert hashlib.sha256(wires[i].tobytes()).hexdigest() == gold["circuits"][name][kn][i]["eval"]
-        dc.close()
+        for schedule in SCHEDULES:
+          dc = engine.DeviceCircuit(ctx, c, schedule=schedule)
+          n = mk.COUNTS[name]
+          for kn, kh in gold["keys"].items():
+              key = bytes.fromhex(kh)
+              streams = [mk.instance_streams(name, c, i) for i in range(n)]
+              rnd = b"".join(s[0] for s in streams)
+              g = dc.garble(key, rnd, batch=n)
+              nin, nout = c.num_inputs, c.num_outputs
+              wires = np.zeros((n, c.NumWires), LABEL)
+              for i in range(n):
+                  h = hashlib.sha256()
+                  h.update(g["R"][i:i + 1].tobytes())
+                  h.update(np.ascontiguousarray(g["slab"][i]).tobytes())
+                  h.update(np.ascontiguousarray(g["io"][i]["l0"][nin:]).tobytes())
+                  assert h.hexdigest() == gold["circuits"][name][kn][i]["garble"], (name, kn, i)
+                  wires[i, :nin] = np.where(streams[i][1].astype(bool), g["io"][i]["l1"][:nin], g["io"][i]["l0"][:nin])
+              dc.eval(key, g["slab"], wires=wires, batch=n)
+              for i in range(n):
+                  assert hashlib.sha256(wires[i].tobytes()).hexdigest() == gold["circuits"][name][kn][i]["eval"]
+          dc.close()
 
 
 def test_error_behaviour(ctx, add64_circ):
@@ -224,6 +243,7 @@ def test_graph_and_direct_launch_agree(ctx):
     slabs = []
     for graph in (True, False, True):
         b = engine.Batch(dc, batch)
+        b.set_schedule(0)
         b.set_graph(graph)
         b.garble(KEY256, d_rnd.data_ptr())
         b.garble(KEY256, d_rnd.data_ptr())  # second call replays the captured graph
@@ -236,7 +256,8 @@ def test_graph_and_direct_launch_agree(ctx):
     dc.close()
 
 
-def test_device_resident_pipeline_full_size(ctx, aes_circ):
+@pytest.mark.parametrize("schedule", SCHEDULES)
+def test_device_resident_pipeline_full_size(ctx, aes_circ, schedule):
     """BASELINE config 2 shape: AES-128 circuit x 1024 instances, device-resident API.
     Size-independent property: decoded outputs == AES-128(key, pt) for every instance; plus byte
     parity with the oracle on sampled instances."""
@@ -245,6 +266,8 @@ def test_device_resident_pipeline_full_size(ctx, aes_circ):
     batch = 1024
     dc = engine.DeviceCircuit(ctx, c)
     gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    gb.set_schedule(schedule)
+    ev.set_schedule(schedule)
     rnd = rnd_for(c, "full", batch)
     d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
     keys = [drbg("k%d" % i, 16) for i in range(batch)]
