@@ -193,6 +193,11 @@ int gc_batch_gather_outputs(gc_batch *, void *d_out);
 float gc_batch_last_ms(gc_batch *);
 /* kernel launches issued by the most recent garble / eval */
 uint32_t gc_batch_last_launches(gc_batch *);
+/* developer aid: s_memtime breakdown of the fused kernels.  enable != 0 switches the instrumented
+ * build of the kernel on for subsequent passes; out8 (may be NULL) receives, averaged over
+ * workgroups, cycles of wave 0 in {descriptor fetch, label loads, hash+stores, barrier wait} followed
+ * by the same four for the last wave, from the most recent instrumented pass. */
+int gc_batch_debug_profile(gc_batch *, int enable, uint64_t *out8);
 
 /* ------------------------------------------------------------------------------------------
  * IKNP OT extension + MITCCRH (ot/iknp.go, ot/mitccrh.go, ot/cot.go)

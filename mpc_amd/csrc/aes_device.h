@@ -132,6 +132,94 @@ __device__ __forceinline__ void aes_encrypt_repl(uint32_t (&s)[N][4], const uint
     }
 }
 
+// ---- perm-addressed dual table (the production AES of the fused kernels) ---------------------------
+// LDS row x (256 bytes) = 32 copies of Te0[x] (bytes 0..127) followed by 32 copies of
+// Te2[x] = rotr16(Te0[x]) (bytes 128..255); 64 KiB in all.  Lane l always reads copy (l mod 32), so
+// bank = l mod 32 for every index: conflict-free by construction.  Because the index byte x sits
+// byte-aligned at address bits [15:8], the whole LDS address is assembled by ONE v_perm_b32
+// (state byte -> address byte 1, lane offset -> address byte 0) instead of a bfe + shift-or pair,
+// and Te1/Te3 = rotr8(Te0/Te2) cost one v_alignbit per COLUMN:
+//     col = Te0[b3(a0)] ^ Te2[b1(a2)] ^ rotr8(Te0[b2(a1)] ^ Te2[b0(a3)]) ^ rk
+// -> 9 VALU + 4 ds_read_b32 per column (36 + 16 per round) versus ~70 + 16 for the classic form.
+constexpr int kTeDualBytes = 256 * 256;
+
+__device__ __forceinline__ void load_te_dual(uint32_t *te, const uint32_t *__restrict__ g_te0) {
+    const uint32_t c = threadIdx.x & 31;
+    for (uint32_t x = threadIdx.x >> 5; x < 256; x += blockDim.x >> 5) {
+        const uint32_t t = g_te0[x];
+        te[x * 64 + c] = t;
+        te[x * 64 + 32 + c] = rotr32(t, 16);
+    }
+}
+
+// v_perm selectors: result byte1 = byte k of the state word (S0 -> selector 4+k), byte0 = lane offset
+// (S1 byte 0), upper bytes zero (0x0c)
+#define GC_PERM_SEL(k) (0x0c0c0000u | ((4u + (k)) << 8))
+
+__device__ __forceinline__ uint32_t te_dual(const uint32_t *te, uint32_t word, uint32_t sel, uint32_t lane_off) {
+    const uint32_t addr = __builtin_amdgcn_perm(word, lane_off, sel);
+    return *(const uint32_t *)((const char *)te + addr);
+}
+
+// rk: NR+1 round keys as big-endian words, expected in SGPRs (see load_round_keys)
+template <int NR, int N>
+__device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint32_t (&rk)[4 * (NR + 1)],
+                                                 const uint32_t *te, uint32_t lo0) {
+    const uint32_t lo2 = lo0 + 128u;
+    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        s[k][0] ^= rk[0];
+        s[k][1] ^= rk[1];
+        s[k][2] ^= rk[2];
+        s[k][3] ^= rk[3];
+    }
+#pragma unroll
+    for (int r = 1; r < NR; r++) {
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+#define GC_COL(c0, c1, c2, c3, key)                                                                   \
+    ((te_dual(te, c0, sel3, lo0) ^ te_dual(te, c2, sel1, lo2)) ^                                      \
+     rotr32(te_dual(te, c1, sel2, lo0) ^ te_dual(te, c3, sel0, lo2), 8) ^ (key))
+            s[k][0] = GC_COL(a0, a1, a2, a3, rk[4 * r + 0]);
+            s[k][1] = GC_COL(a1, a2, a3, a0, rk[4 * r + 1]);
+            s[k][2] = GC_COL(a2, a3, a0, a1, rk[4 * r + 2]);
+            s[k][3] = GC_COL(a3, a0, a1, a2, rk[4 * r + 3]);
+#undef GC_COL
+        }
+    }
+    // final round (no MixColumns): S[x] is bytes 2,1 of Te0[x] and bytes 3,0 of Te2[x]
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
+#define GC_LAST(c0, c1, c2, c3, key)                                                                       \
+    (((te_dual(te, c0, sel3, lo2) & 0xff000000u) | (te_dual(te, c1, sel2, lo0) & 0x00ff0000u) |           \
+      (te_dual(te, c2, sel1, lo0) & 0x0000ff00u) | (te_dual(te, c3, sel0, lo2) & 0x000000ffu)) ^ (key))
+        s[k][0] = GC_LAST(a0, a1, a2, a3, rk[4 * NR + 0]);
+        s[k][1] = GC_LAST(a1, a2, a3, a0, rk[4 * NR + 1]);
+        s[k][2] = GC_LAST(a2, a3, a0, a1, rk[4 * NR + 2]);
+        s[k][3] = GC_LAST(a3, a0, a1, a2, rk[4 * NR + 3]);
+#undef GC_LAST
+    }
+}
+
+// round keys -> scalar registers (the pointer is uniform; readfirstlane pins the values in SGPRs)
+template <int NR>
+__device__ __forceinline__ void load_round_keys(uint32_t (&rk)[4 * (NR + 1)], const uint32_t *__restrict__ g_rk) {
+#pragma unroll
+    for (int i = 0; i < 4 * (NR + 1); i++) rk[i] = __builtin_amdgcn_readfirstlane(g_rk[i]);
+}
+
+template <int NR>
+__device__ __forceinline__ uint4 hash_dual(const uint32_t (&k)[4], const uint32_t (&rk)[4 * (NR + 1)],
+                                           const uint32_t *te, uint32_t lo0) {
+    uint32_t s[1][4] = {{k[0], k[1], k[2], k[3]}};
+    aes_encrypt_dual<NR, 1>(s, rk, te, lo0);
+    uint32_t o[4] = {s[0][0] ^ k[0], s[0][1] ^ k[1], s[0][2] ^ k[2], s[0][3] ^ k[3]};
+    return make_uint4(o[1], o[0], o[3], o[2]);
+}
+
 // ---- label arithmetic (ot/label.go) on the uint4 form --------------------------------------
 
 __device__ __forceinline__ uint4 lxor(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }

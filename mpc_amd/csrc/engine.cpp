@@ -161,6 +161,8 @@ static void free_buffers(gc_batch *b) {
     if (b->d_T) (void)hipFree(b->d_T);
     if (b->d_R) (void)hipFree(b->d_R);
     b->d_W = b->d_T = b->d_R = nullptr;
+    if (b->d_prof) (void)hipFree(b->d_prof);
+    b->d_prof = nullptr;
 }
 
 // (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
@@ -295,6 +297,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
         a.rk = b->d_rk;
         a.te0 = b->circ->ctx->d_te0;
         a.rounds = b->rounds;
+        a.prof = b->d_prof;
         if (eval) launch_eval_fused(a, b->g, s);
         else launch_garble_fused(a, b->g, s);
         GC_HIP(hipGetLastError());
@@ -509,6 +512,31 @@ int gc_batch_gather_outputs(gc_batch *b, void *d_out) {
     launch_gather_rows(b->d_W, b->circ->d_out_slots, b->circ->plan.p.info.noutputs, (uint4 *)d_out, b->g,
                        ctx->stream);
     GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
+    if (!b) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)b->g.ntiles * 8;
+    if (out8 && b->d_prof) {  // average over workgroups
+        std::vector<uint64_t> h(n);
+        GC_HIP(hipMemcpy(h.data(), b->d_prof, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 8; k++) {
+            unsigned __int128 acc = 0;
+            for (uint32_t t = 0; t < b->g.ntiles; t++) acc += h[(size_t)t * 8 + k];
+            out8[k] = (uint64_t)(acc / b->g.ntiles);
+        }
+    }
+    if (enable && !b->d_prof) {
+        GC_HIP(hipMalloc((void **)&b->d_prof, n * sizeof(uint64_t)));
+        GC_HIP(hipMemset(b->d_prof, 0, n * sizeof(uint64_t)));
+    } else if (!enable && b->d_prof) {
+        (void)hipFree(b->d_prof);
+        b->d_prof = nullptr;
+    }
     return GC_OK;
 }
 

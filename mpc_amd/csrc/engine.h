@@ -60,6 +60,7 @@ struct gc_batch {
     uint4 *d_T = nullptr;  // garbled tables [slab_rows][bstride]
     uint4 *d_R = nullptr;  // [bstride]
     uint32_t *d_rk = nullptr;
+    uint64_t *d_prof = nullptr;  // debug cycle breakdown of the fused kernels (gc_batch_debug_profile)
     uint32_t rk_host[60] = {0};
     int rounds = 0;
     int schedule = 1;

@@ -40,68 +40,102 @@ __device__ __forceinline__ uint4 dpp128(uint4 v) {
     return make_uint4(dpp32<CTRL>(v.x), dpp32<CTRL>(v.y), dpp32<CTRL>(v.z), dpp32<CTRL>(v.w));
 }
 
-template <int NR>
-__device__ __forceinline__ uint4 hash1(const uint32_t (&k)[4], const uint32_t *__restrict__ rk, const uint32_t *te,
-                                       uint32_t lo) {
-    uint32_t kk[1][4] = {{k[0], k[1], k[2], k[3]}};
-    uint4 h[1];
-    hash_repl<NR, 1>(kk, h, rk, te, lo);
-    return h[0];
+// lane -> (kind, gate, instance, sub-lane) inside one level
+struct LanePos {
+    int kind;
+    uint32_t g, inst, q;
+};
+
+// QA / QO / QI: lanes per AND / OR / INV gate-instance (garble 4/4/2, eval 2/1/1 -> log2 2/2/1, 1/0/0)
+template <int LQA, int LQO, int LQI>
+__device__ __forceinline__ LanePos classify(const Step &st, uint32_t t, uint32_t ti_log2, uint32_t tim) {
+    LanePos p{0, 0, 0, 0};
+    const uint32_t e_and = (st.n_and << ti_log2) << LQA;
+    const uint32_t e_or = e_and + ((st.n_or << ti_log2) << LQO);
+    const uint32_t e_inv = e_or + ((st.n_inv << ti_log2) << LQI);
+    const uint32_t e_all = e_inv + ((st.count - st.nonfree) << ti_log2);
+    if (t < e_and) {
+        p.kind = 1;
+        p.g = t >> (ti_log2 + LQA);
+        p.inst = (t >> LQA) & tim;
+        p.q = t & ((1u << LQA) - 1);
+    } else if (t < e_or) {
+        const uint32_t u = t - e_and;
+        p.kind = 2;
+        p.g = st.n_and + (u >> (ti_log2 + LQO));
+        p.inst = (u >> LQO) & tim;
+        p.q = u & ((1u << LQO) - 1);
+    } else if (t < e_inv) {
+        const uint32_t u = t - e_or;
+        p.kind = 3;
+        p.g = st.n_and + st.n_or + (u >> (ti_log2 + LQI));
+        p.inst = (u >> LQI) & tim;
+        p.q = u & ((1u << LQI) - 1);
+    } else if (t < e_all) {
+        const uint32_t u = t - e_inv;
+        p.kind = 4;
+        p.g = st.nonfree + (u >> ti_log2);
+        p.inst = u & tim;
+    }
+    return p;
 }
 
-enum LaneKind { K_NONE = 0, K_AND, K_OR, K_INV, K_FREE };
+template <int LQA, int LQO, int LQI>
+__device__ __forceinline__ uint32_t level_lanes(const Step &st, uint32_t ti_log2) {
+    return ((st.n_and << ti_log2) << LQA) + ((st.n_or << ti_log2) << LQO) + ((st.n_inv << ti_log2) << LQI) +
+           ((st.count - st.nonfree) << ti_log2);
+}
 
-template <int NR>
+enum LaneKind { K_NONE = 0, K_AND = 1, K_OR = 2, K_INV = 3, K_FREE = 4 };
+
+// PROF: per-workgroup s_memtime breakdown (debug builds of the launch only, gc_batch_debug_profile):
+//   prof[wg*8 + {0,1,2,3}] = cycles wave 0 spent in {descriptor fetch, label loads, hash+combine+stores,
+//   barrier wait}; +4..7 the same for the last wave
+#define GC_PROF_MARK(slot)                                             \
+    if constexpr (PROF) {                                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    \
+        const uint64_t now__ = __builtin_amdgcn_s_memtime();           \
+        pacc[slot] += now__ - plast;                                   \
+        plast = now__;                                                 \
+    }
+
+template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *__restrict__ descs,
                                                                 const Step *__restrict__ steps, uint32_t nsteps,
                                                                 uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
                                                                 size_t t_tile, uint4 *__restrict__ W,
                                                                 const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
                                                                 const uint32_t *__restrict__ rk,
-                                                                const uint32_t *__restrict__ g_te0) {
-    __shared__ uint32_t te[kTeReplWords];
-    load_te_replicated(te, g_te0);
+                                                                const uint32_t *__restrict__ g_te0,
+                                                                uint64_t *__restrict__ prof) {
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    load_te_dual(te, g_te0);
+    uint32_t rkr[4 * (NR + 1)];
+    load_round_keys<NR>(rkr, rk);
     __syncthreads();
     const uint32_t lo = te_lane_off();
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
     uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
     uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
     const uint4 *Rt = Rv + (size_t)blockIdx.x * TI;
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
+    // software pipeline: the descriptor of this thread's first lane of the NEXT level is fetched
+    // before the barrier of the current one (it does not depend on anything the level computes)
+    Step st_next = steps[0];
+    LanePos lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
+    GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
     for (uint32_t lv = 0; lv < nsteps; lv++) {
-        const Step st = steps[lv];
-        const uint32_t l_and = (st.n_and << ti_log2) << 2, l_or = (st.n_or << ti_log2) << 2,
-                       l_inv = (st.n_inv << ti_log2) << 1, l_free = (st.count - st.nonfree) << ti_log2;
-        const uint32_t e_and = l_and, e_or = e_and + l_or, e_inv = e_or + l_inv, e_all = e_inv + l_free;
+        const Step st = st_next;
+        const uint32_t e_all = level_lanes<2, 2, 1>(st, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += kFusedThreads) {
-            const uint32_t t = t0 + threadIdx.x;
-            int kind = K_NONE;
-            uint32_t g = 0, inst = 0, q = 0;
-            if (t < e_and) {
-                kind = K_AND;
-                g = t >> (ti_log2 + 2);
-                inst = (t >> 2) & tim;
-                q = t & 3;
-            } else if (t < e_or) {
-                const uint32_t u = t - e_and;
-                kind = K_OR;
-                g = st.n_and + (u >> (ti_log2 + 2));
-                inst = (u >> 2) & tim;
-                q = u & 3;
-            } else if (t < e_inv) {
-                const uint32_t u = t - e_or;
-                kind = K_INV;
-                g = st.n_and + st.n_or + (u >> (ti_log2 + 1));
-                inst = (u >> 1) & tim;
-                q = u & 1;
-            } else if (t < e_all) {
-                const uint32_t u = t - e_inv;
-                kind = K_FREE;
-                g = st.nonfree + (u >> ti_log2);
-                inst = u & tim;
-            }
+            const LanePos lp = t0 == 0 ? lp_next : classify<2, 2, 1>(st, t0 + threadIdx.x, ti_log2, tim);
+            const int kind = lp.kind;
+            const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
             if (kind == K_NONE) continue;
-            const GateDesc d = descs[st.first + g];
+            const GateDesc d = t0 == 0 ? d_next : descs[st.first + g];
+            GC_PROF_MARK(0)
             const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
             const uint4 va = Wt[((size_t)d.in0 << ti_log2) + inst];
             if (kind == K_FREE) {
@@ -126,7 +160,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
                 const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
                 make_k_half(x, d.tweak + (second ? 1u : 0u), k);
             }
-            const uint4 h = hash1<NR>(k, rk, te, lo);
+            GC_PROF_MARK(1)
+            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
             uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
 
             if (kind == K_AND) {  // garble.go:353-395
@@ -171,58 +206,55 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
                 else row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
             }
         }
+        if (lv + 1 < nsteps) {  // prefetch the next level's step + this thread's first descriptor
+            st_next = steps[lv + 1];
+            lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
+            if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+        }
+        GC_PROF_MARK(2)
         __syncthreads();
+        GC_PROF_MARK(3)
+    }
+    if constexpr (PROF) {
+        if (threadIdx.x == 0 || threadIdx.x == kFusedThreads - 64)
+            for (int i = 0; i < 4; i++) prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
     }
 }
 
-template <int NR>
+template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__restrict__ descs,
                                                               const Step *__restrict__ steps, uint32_t nsteps,
                                                               uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
                                                               size_t t_tile, uint4 *__restrict__ W,
                                                               const uint4 *__restrict__ T,
                                                               const uint32_t *__restrict__ rk,
-                                                              const uint32_t *__restrict__ g_te0) {
-    __shared__ uint32_t te[kTeReplWords];
-    load_te_replicated(te, g_te0);
+                                                              const uint32_t *__restrict__ g_te0,
+                                                              uint64_t *__restrict__ prof) {
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    load_te_dual(te, g_te0);
+    uint32_t rkr[4 * (NR + 1)];
+    load_round_keys<NR>(rkr, rk);
     __syncthreads();
     const uint32_t lo = te_lane_off();
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
     uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
     const uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
+    Step st_next = steps[0];
+    LanePos lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
+    GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
     for (uint32_t lv = 0; lv < nsteps; lv++) {
-        const Step st = steps[lv];
-        const uint32_t l_and = (st.n_and << ti_log2) << 1, l_or = st.n_or << ti_log2, l_inv = st.n_inv << ti_log2,
-                       l_free = (st.count - st.nonfree) << ti_log2;
-        const uint32_t e_and = l_and, e_or = e_and + l_or, e_inv = e_or + l_inv, e_all = e_inv + l_free;
+        const Step st = st_next;
+        const uint32_t e_all = level_lanes<1, 0, 0>(st, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += kFusedThreads) {
-            const uint32_t t = t0 + threadIdx.x;
-            int kind = K_NONE;
-            uint32_t g = 0, inst = 0, q = 0;
-            if (t < e_and) {
-                kind = K_AND;
-                g = t >> (ti_log2 + 1);
-                inst = (t >> 1) & tim;
-                q = t & 1;
-            } else if (t < e_or) {
-                const uint32_t u = t - e_and;
-                kind = K_OR;
-                g = st.n_and + (u >> ti_log2);
-                inst = u & tim;
-            } else if (t < e_inv) {
-                const uint32_t u = t - e_or;
-                kind = K_INV;
-                g = st.n_and + st.n_or + (u >> ti_log2);
-                inst = u & tim;
-            } else if (t < e_all) {
-                const uint32_t u = t - e_inv;
-                kind = K_FREE;
-                g = st.nonfree + (u >> ti_log2);
-                inst = u & tim;
-            }
+            const LanePos lp = t0 == 0 ? lp_next : classify<1, 0, 0>(st, t0 + threadIdx.x, ti_log2, tim);
+            const int kind = lp.kind;
+            const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
             if (kind == K_NONE) continue;
-            const GateDesc d = descs[st.first + g];
+            const GateDesc d = t0 == 0 ? d_next : descs[st.first + g];
+            GC_PROF_MARK(0)
             const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
             const uint4 va = Wt[((size_t)d.in0 << ti_log2) + inst];
             if (kind == K_FREE) {  // eval.go:49-51
@@ -242,7 +274,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
                 vb = Wt[((size_t)d.in1 << ti_log2) + inst];
                 make_k(va, vb, d.tweak, k);
             }
-            const uint4 h = hash1<NR>(k, rk, te, lo);
+            GC_PROF_MARK(1)
+            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
             if (kind == K_AND) {  // eval.go:53-78
                 const uint4 tab = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
                 const uint4 a = dpp128<DPP_PAIR0>(x);
@@ -260,16 +293,31 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
                 Wt[o_out] = lxor(h, c);
             }
         }
+        if (lv + 1 < nsteps) {  // prefetch the next level's step + this thread's first descriptor
+            st_next = steps[lv + 1];
+            lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
+            if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+        }
+        GC_PROF_MARK(2)
         __syncthreads();
+        GC_PROF_MARK(3)
+    }
+    if constexpr (PROF) {
+        if (threadIdx.x == 0 || threadIdx.x == kFusedThreads - 64)
+            for (int i = 0; i < 4; i++) prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
     }
 }
 
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
-#define GC_GF(NR)                                                                                              \
-    hipLaunchKernelGGL((k_garble_fused<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, g.ti_log2, \
-                       g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0)
+#define GC_GF(NR)                                                                                               \
+    if (a.prof)                                                                                                 \
+        hipLaunchKernelGGL((k_garble_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,    \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof);  \
+    else                                                                                                        \
+        hipLaunchKernelGGL((k_garble_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,   \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof)
     switch (a.rounds) {
     case 10: GC_GF(10); break;
     case 12: GC_GF(12); break;
@@ -281,9 +329,15 @@ void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) 
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
-#define GC_EF(NR)                                                                                            \
-    hipLaunchKernelGGL((k_eval_fused<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, g.ti_log2, \
-                       g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0)
+#define GC_EF(NR)                                                                                               \
+    if (a.prof)                                                                                                 \
+        hipLaunchKernelGGL((k_eval_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,      \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
+                           a.prof);                                                                             \
+    else                                                                                                        \
+        hipLaunchKernelGGL((k_eval_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,     \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
+                           a.prof)
     switch (a.rounds) {
     case 10: GC_EF(10); break;
     case 12: GC_EF(12); break;

@@ -68,6 +68,7 @@ struct FusedArgs {
     const uint32_t *rk;
     const uint32_t *te0;
     int rounds;
+    uint64_t *prof;  // optional [ntiles][8] cycle breakdown (debug), nullptr in production
 };
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);

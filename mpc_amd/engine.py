@@ -100,6 +100,7 @@ def lib():
         "gc_batch_gather_outputs": (i32, [vp, vp]),
         "gc_batch_last_ms": (C.c_float, [vp]),
         "gc_batch_last_launches": (u32, [vp]),
+        "gc_batch_debug_profile": (i32, [vp, i32, vp]),
         "gc_iknp_receiver_create": (vp, [vp, vp, ip]),
         "gc_iknp_sender_create": (vp, [vp, vp, vp, ip]),
         "gc_iknp_free": (None, [vp]),
@@ -320,6 +321,11 @@ class Batch:
 
     def gather_outputs(self, d_out):
         _check(lib().gc_batch_gather_outputs(self.h, C.c_void_p(d_out)), "gc_batch_gather_outputs")
+
+    def debug_profile(self, enable=True, read=False):
+        out = np.zeros(8, np.uint64) if read else None
+        _check(lib().gc_batch_debug_profile(self.h, 1 if enable else 0, _p(out)), "gc_batch_debug_profile")
+        return out
 
     @property
     def last_ms(self):

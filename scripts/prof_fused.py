@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Cycle breakdown of the fused garble / eval kernels (s_memtime instrumentation, developer aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mpc_amd import engine, parse_file
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+keylen = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+c = parse_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "aes_128.gcf"))
+ctx = engine.Context(0)
+dc = engine.DeviceCircuit(ctx, c)
+gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+key = bytes(range(keylen))
+d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda")
+d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda")
+for _ in range(3):
+    gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+ctx.sync()
+print("plain: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
+gb.debug_profile(True); ev.debug_profile(True)
+gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+ctx.sync()
+print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
+names = ["desc", "loads", "hash+st", "barrier"]
+for nm, b in (("garble", gb), ("eval", ev)):
+    p = b.debug_profile(True, read=True)
+    tot0, tot1 = sum(p[:4]), sum(p[4:])
+    print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:4])}, "total", int(tot0), "cycles =", "%.3f ms @100MHz" % (tot0 / 1e5))
+    print(nm, "waveN:", {n: int(v) for n, v in zip(names, p[4:])}, "total", int(tot1))
