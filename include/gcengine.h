@@ -72,7 +72,10 @@ typedef struct gc_plan_info {
     uint32_t slab_rows; /* table labels per instance: AND 2, OR 3, INV 1 */
     uint32_t n_xor, n_xnor, n_and, n_or, n_inv;
     uint32_t nslots;    /* device wire slots = ninputs + ngates */
-    uint32_t n_steps;   /* kernel launches per garble (fused schedule) */
+    uint32_t n_steps;   /* dependency levels = launches per pass of schedule 0 */
+    uint32_t n_hash_phases; /* fused schedule: steps that hash (non-free depth of the circuit) */
+    uint32_t n_fused_steps; /* fused schedule: hash phases + XOR sub-levels */
+    uint32_t n_lds_slots;   /* fused schedule: peak number of live wire labels (0xffffffff: > 65534) */
 } gc_plan_info;
 
 gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
@@ -156,6 +159,10 @@ uint32_t gc_batch_stride(const gc_batch *);
  *               walks all levels with workgroup barriers; labels laid out [tile][wire][instance].
  * Results are bit-identical.  Changing the schedule re-allocates the batch's device arrays. */
 int gc_batch_set_schedule(gc_batch *, int schedule);
+/* fused schedule only: also write EVERY wire label to the global wire array (needed by
+ * gc_batch_read_wires / gc_batch_read_labels; gc_garble / gc_eval switch it on when the caller asks
+ * for Garbled.Wires / the full wires slice).  Off by default: only input and output wires are kept. */
+int gc_batch_set_store_all(gc_batch *, int on);
 /* use a captured hipGraph for the per-level launches (default on) */
 int gc_batch_set_graph(gc_batch *, int on);
 
@@ -177,8 +184,8 @@ int gc_batch_decode(const gc_batch *garbler, const gc_batch *evaluator, void *d_
 /* read-backs (synchronous; host pointers) */
 int gc_batch_read_r(gc_batch *, gc_label *r_out);                     /* [batch] */
 int gc_batch_read_slab(gc_batch *, gc_label *slab_out);               /* [batch][slab_rows] (reference order) */
-int gc_batch_read_wires(gc_batch *, gc_wire *wires_out);              /* garbler: [batch][nwires] */
-int gc_batch_read_labels(gc_batch *, gc_label *labels_out);           /* evaluator: [batch][nwires] */
+int gc_batch_read_wires(gc_batch *, gc_wire *wires_out);              /* garbler: [batch][nwires]; needs store_all */
+int gc_batch_read_labels(gc_batch *, gc_label *labels_out);           /* evaluator: [batch][nwires]; needs store_all */
 int gc_batch_read_outputs(gc_batch *, gc_label *out);                 /* [batch][noutputs] active/L0 labels */
 int gc_batch_write_slab(gc_batch *, const gc_label *slab);            /* host [batch][slab_rows] -> device layout */
 /* raw device pointers (for RCCL gathers / the caller's own kernels) */

@@ -118,6 +118,10 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_out_slots, p.out_slots.data(), p.out_slots.size() * sizeof(uint32_t));
         up((void **)&c->d_slot_of_wire, p.slot_of_wire.data(), p.slot_of_wire.size() * sizeof(uint32_t));
         up((void **)&c->d_steps, p.levels.data(), p.levels.size() * sizeof(Step));
+        up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
+        up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
+        up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -140,6 +144,10 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_out_slots) (void)hipFree(c->d_out_slots);
     if (c->d_slot_of_wire) (void)hipFree(c->d_slot_of_wire);
     if (c->d_steps) (void)hipFree(c->d_steps);
+    if (c->d_fdescs) (void)hipFree(c->d_fdescs);
+    if (c->d_fgslot) (void)hipFree(c->d_fgslot);
+    if (c->d_fsteps) (void)hipFree(c->d_fsteps);
+    if (c->d_in_lds) (void)hipFree(c->d_in_lds);
     delete c;
 }
 
@@ -168,7 +176,7 @@ static void free_buffers(gc_batch *b) {
 // (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
 static hipError_t alloc_buffers(gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows);
+    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, p.n_lds_slots);
     const size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
     const size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
     hipError_t e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
@@ -285,7 +293,30 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
 static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
-    if (b->schedule == 1) {  // fused: one launch walks every level
+    if (b->schedule == 1 && b->g.lds_wires) {  // fused, LDS-resident wires, hash-phase order
+        FusedLdsArgs f{};
+        f.descs = b->circ->d_fdescs;
+        f.gslot = b->circ->d_fgslot;
+        f.steps = b->circ->d_fsteps;
+        f.in_lds = b->circ->d_in_lds;
+        f.nsteps = (uint32_t)p.fsteps.size();
+        f.ninputs = p.info.ninputs;
+        f.nls = p.n_lds_slots;
+        f.W = b->d_W;
+        f.R = b->d_R;
+        f.T = const_cast<uint4 *>(T);
+        f.rk = b->d_rk;
+        f.te0 = b->circ->ctx->d_te0;
+        f.rounds = b->rounds;
+        f.store_all = b->store_all;
+        f.prof = b->d_prof;
+        GC_HIP(launch_fused_lds(eval, f, b->g, s));
+        b->last_launches = f.nsteps ? 1 : 0;
+        b->have_all_wires = b->store_all;
+        return GC_OK;
+    }
+    b->have_all_wires = true;
+    if (b->schedule == 1) {  // fused with global-memory wires (circuits whose live set exceeds LDS)
         FusedArgs a{};
         a.descs = b->circ->d_descs;
         a.steps = b->circ->d_steps;
@@ -458,13 +489,19 @@ int gc_batch_read_slab(gc_batch *b, gc_label *slab_out) {
     return read_gather(b, b->d_T, b->g.lt, nullptr, 0, b->circ->plan.p.info.slab_rows, 0, slab_out);
 }
 
+int gc_batch_set_store_all(gc_batch *b, int on) {
+    if (!b) return GC_E_ARG;
+    b->store_all = on != 0;
+    return GC_OK;
+}
+
 int gc_batch_read_wires(gc_batch *b, gc_wire *wires_out) {
-    if (!b || !wires_out) return GC_E_ARG;
+    if (!b || !wires_out || !b->have_all_wires) return GC_E_ARG;
     return read_gather(b, b->d_W, b->g.lw, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 1, wires_out);
 }
 
 int gc_batch_read_labels(gc_batch *b, gc_label *labels_out) {
-    if (!b || !labels_out) return GC_E_ARG;
+    if (!b || !labels_out || !b->have_all_wires) return GC_E_ARG;
     return read_gather(b, b->d_W, b->g.lw, b->circ->d_slot_of_wire, 0, b->circ->plan.p.info.nwires, 0, labels_out);
 }
 
@@ -614,6 +651,7 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
             break;
         }
+        b->store_all = wires_out != nullptr;
         rc = gc_batch_garble(b, key, keylen, d_rnd.p);
         if (rc != GC_OK) break;
         if (r_out && (rc = gc_batch_read_r(b, r_out)) != GC_OK) break;
@@ -664,6 +702,7 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
         else
             rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         if (rc != GC_OK) break;
+        b->store_all = wires_inout != nullptr;
         rc = gc_batch_eval(b, key, keylen, b);
         if (rc != GC_OK) break;
         if (wires_inout && (rc = gc_batch_read_labels(b, wires_inout)) != GC_OK) break;

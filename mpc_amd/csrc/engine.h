@@ -40,6 +40,10 @@ struct gc_circ {
     uint32_t *d_out_slots = nullptr;
     uint32_t *d_slot_of_wire = nullptr;
     gc::Step *d_steps = nullptr;
+    gc::FDesc *d_fdescs = nullptr;   // LDS schedule
+    uint32_t *d_fgslot = nullptr;
+    gc::Step *d_fsteps = nullptr;
+    uint16_t *d_in_lds = nullptr;
     int schedule = 1;  // default schedule of pooled batches
     std::mutex pool_mu;
     std::vector<gc_batch *> pool;  // idle batches reused by gc_garble / gc_eval (cf. garble.go:195-225)
@@ -65,6 +69,8 @@ struct gc_batch {
     int rounds = 0;
     int schedule = 1;
     bool use_graph = true;
+    bool store_all = false;      // fused-LDS passes also write every wire to the global array
+    bool have_all_wires = false; // the global wire array holds every wire of the last pass
     std::vector<gc_graph_entry> graphs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;

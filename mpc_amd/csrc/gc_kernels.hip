@@ -10,7 +10,7 @@
 
 namespace gc {
 
-BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows) {
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls) {
     BatchGeom g{};
     g.batch = batch;
     if (batch >= 256) {
@@ -32,6 +32,11 @@ BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab
         // instances per workgroup tile: aim at >= 256 workgroups (one per CU), at most 64 lanes wide
         uint32_t t = 0;
         while (t < 6 && (batch >> (t + 1)) >= 256) t++;
+        // LDS-resident wires: the tile's live labels (+R) must fit beside the 64 KiB AES table
+        const size_t lds_budget = 160 * 1024;
+        g.lds_wires = nls != 0xffffffffu && fused_lds_bytes(nls, 0) <= lds_budget;
+        if (g.lds_wires)
+            while (t > 0 && fused_lds_bytes(nls, t) > lds_budget) t--;
         g.ti_log2 = t;
         const uint32_t ti = 1u << t;
         g.ntiles = (batch + ti - 1) / ti;

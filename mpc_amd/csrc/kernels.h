@@ -36,11 +36,13 @@ struct BatchGeom {
     uint32_t yblocks;  // level kernels: instance blocks of 256 (1 when batch <= 256)
     uint32_t ti_log2;  // fused kernels: log2 of the instances per workgroup tile
     uint32_t ntiles;
+    bool lds_wires;    // fused kernels: wire labels live in LDS (hash-phase schedule)
     Layout lw;         // wire labels  [nslots][...]
     Layout lt;         // table rows   [slab_rows][...]
 };
 // schedule 0 = level layout, 1 = tiled layout
-BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows);
+// nls: live-label high-water mark of the LDS schedule (0xffffffff: does not fit -> global-memory wires)
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls);
 
 struct LevelArgs {
     const GateDesc *descs;  // device, already offset to the step
@@ -72,6 +74,25 @@ struct FusedArgs {
 };
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
+
+// Fused schedule with LDS-resident wires (fused_lds_kernels.hip)
+struct FusedLdsArgs {
+    const FDesc *descs;
+    const uint32_t *gslot;
+    const Step *steps;
+    const uint16_t *in_lds;
+    uint32_t nsteps, ninputs, nls;
+    uint4 *W;
+    const uint4 *R;
+    uint4 *T;
+    const uint32_t *rk;
+    const uint32_t *te0;
+    int rounds;
+    bool store_all;  // also write every wire label to the global array (debug / Garbled.Wires)
+    uint64_t *prof;
+};
+size_t fused_lds_bytes(uint32_t nls, uint32_t ti_log2);
+hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &a, const BatchGeom &g, hipStream_t s);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);

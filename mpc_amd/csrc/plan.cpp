@@ -119,6 +119,116 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
         if (s == NONE) return GC_E_WIRE;
         p.out_slots[j] = s;
     }
+
+    // ---- hash-phase schedule + LDS slot allocation -------------------------------------------------
+    // key of a value = (a, x): available after hash phase a and x XOR sub-levels following it.
+    //   table-producing gate: runs in hash phase max_a(inputs) + 1       -> key (that, 0)
+    //   XOR / XNOR gate:      runs in sub-level x+1 of its inputs' max key -> key (a, x+1)
+    // Producer ids: < ninputs = input wire, else ninputs + gate (as in pass 1).
+    {
+        const uint32_t nprod = ninputs + ngates;
+        std::vector<uint32_t> ka(nprod, 0), kx(nprod, 0);
+        std::vector<uint64_t> gkey(ngates);
+        for (uint32_t g = 0; g < ngates; g++) {
+            const uint32_t s0 = src0[g], s1 = src1[g];
+            uint32_t a = ka[s0], x = kx[s0];
+            if (ka[s1] > a || (ka[s1] == a && kx[s1] > x)) {
+                a = ka[s1];
+                x = kx[s1];
+            }
+            if (op_class(gates[g].op) != 3) {
+                a += 1;
+                x = 0;
+            } else {
+                x += 1;
+            }
+            ka[ninputs + g] = a;
+            kx[ninputs + g] = x;
+            gkey[g] = ((uint64_t)a << 40) | ((uint64_t)x << 8) | (uint64_t)op_class(gates[g].op);
+        }
+        std::vector<uint32_t> ford(ngates);
+        std::iota(ford.begin(), ford.end(), 0u);
+        std::stable_sort(ford.begin(), ford.end(), [&](uint32_t a, uint32_t b) { return gkey[a] < gkey[b]; });
+        std::vector<uint32_t> step_of_gate(ngates);
+        for (uint32_t k = 0; k < ngates;) {
+            const uint64_t key = gkey[ford[k]] >> 8;
+            Step st{k, 0, 0, 0, 0, 0};
+            while (k < ngates && (gkey[ford[k]] >> 8) == key) {
+                const uint32_t g = ford[k];
+                if (op_class(gates[g].op) != 3) st.nonfree++;
+                if (gates[g].op == GC_AND) st.n_and++;
+                else if (gates[g].op == GC_OR) st.n_or++;
+                else if (gates[g].op == GC_INV) st.n_inv++;
+                step_of_gate[g] = (uint32_t)p.fsteps.size();
+                st.count++;
+                k++;
+            }
+            if (st.nonfree) p.n_hash_phases++;
+            p.fsteps.push_back(st);
+        }
+        // last step that reads each producer; circuit outputs stay live to the end (they are stored to
+        // the global array when produced, so they need no LDS slot beyond their last reader either)
+        const uint32_t NEVER = 0;
+        std::vector<uint32_t> last_use(nprod, NEVER);  // step index + 1
+        for (uint32_t g = 0; g < ngates; g++) {
+            const uint32_t st = step_of_gate[g] + 1;
+            last_use[src0[g]] = std::max(last_use[src0[g]], st);
+            last_use[src1[g]] = std::max(last_use[src1[g]], st);
+        }
+        std::vector<uint8_t> is_output(nprod, 0);
+        for (uint32_t j = 0; j < noutputs; j++) {
+            const uint32_t w = nwires - noutputs + j;
+            if (cur[w] != NONE) is_output[cur[w]] = 1;
+        }
+        // linear scan: slots freed after step s are reusable from step s+1
+        std::vector<uint32_t> lds_of(nprod, 0xffffu);
+        std::vector<uint32_t> free_list;
+        uint32_t high = 0;
+        std::vector<std::vector<uint32_t>> expire(p.fsteps.size() + 2);
+        auto take = [&]() {
+            if (!free_list.empty()) {
+                uint32_t s = free_list.back();
+                free_list.pop_back();
+                return s;
+            }
+            return high++;
+        };
+        p.in_lds.assign(ninputs, 0xffff);
+        bool overflow = false;
+        for (uint32_t w = 0; w < ninputs; w++) {
+            if (last_use[w] == NEVER) continue;
+            const uint32_t s = take();
+            lds_of[w] = s;
+            if (s >= 0xffff) overflow = true;
+            else p.in_lds[w] = (uint16_t)s;
+            expire[last_use[w]].push_back(s);  // last_use is step+1: free after that step
+        }
+        p.fdescs.resize(ngates);
+        p.fgslot.resize(ngates);
+        for (uint32_t si = 0, k = 0; si < p.fsteps.size(); si++) {
+            for (uint32_t s : expire[si]) free_list.push_back(s);  // freed after step si-1
+            const Step &st = p.fsteps[si];
+            for (uint32_t e = 0; e < st.count; e++, k++) {
+                const uint32_t g = ford[k];
+                const uint32_t pid = ninputs + g;
+                const uint32_t s = take();
+                if (s >= 0xffff) overflow = true;
+                lds_of[pid] = s;
+                const uint32_t lu = std::max(last_use[pid], si + 1);  // at least until its own step ends
+                expire[lu].push_back(s);
+                FDesc &d = p.fdescs[k];
+                d.lin = (lds_of[src0[g]] & 0xffffu) | ((lds_of[src1[g]] & 0xffffu) << 16);
+                d.lout = (s & 0xffffu) | (is_output[pid] ? kFStoreGlobal : 0u);
+                d.tweak = p.tweak_of_gate[g];
+                d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
+                p.fgslot[k] = p.slot_of_gate[g];
+            }
+        }
+        p.n_lds_slots = overflow ? 0xffffffffu : high;
+        p.info.n_hash_phases = p.n_hash_phases;
+        p.info.n_fused_steps = (uint32_t)p.fsteps.size();
+        p.info.n_lds_slots = p.n_lds_slots;
+    }
     return GC_OK;
 }
 

@@ -36,6 +36,17 @@ struct Step {
     uint32_t n_and, n_or, n_inv;  // sorted in this order at the front; nonfree = n_and + n_or + n_inv
 };
 
+// Descriptor of the LDS-resident fused schedule (16 bytes).  Wire labels live in LDS slots that are
+// recycled as soon as the last reader has run (linear-scan allocation over the step order).
+struct FDesc {
+    uint32_t lin;      // LDS slot of input 0 | LDS slot of input 1 << 16
+    uint32_t lout;     // LDS slot of the output | flags << 16 (bit 16: also store to the global wire array)
+    uint32_t tweak;
+    uint32_t row_op;   // first slab row | op << 29
+};
+static_assert(sizeof(FDesc) == 16, "FDesc must be 16 bytes");
+constexpr uint32_t kFStoreGlobal = 1u << 16;
+
 struct Plan {
     gc_plan_info info{};
     // original gate order
@@ -47,6 +58,16 @@ struct Plan {
     // wire id -> slot holding its final value (inputs: identity); 0xffffffff if never written
     std::vector<uint32_t> slot_of_wire;
     std::vector<uint32_t> out_slots;  // slots of wires [nwires-noutputs, nwires)
+
+    // ---- hash-phase schedule with LDS-resident wires (fused kernels) ----
+    // Steps alternate between "hash phases" (all table-producing gates of one non-free depth) and the
+    // XOR sub-levels that follow them; 89 hash phases instead of 290 hash-carrying levels for aes_128.
+    std::vector<FDesc> fdescs;          // execution order
+    std::vector<uint32_t> fgslot;       // global wire slot written by fdescs[k]
+    std::vector<Step> fsteps;
+    std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
+    uint32_t n_lds_slots = 0;           // high-water mark of live labels
+    uint32_t n_hash_phases = 0;
 };
 
 // returns GC_OK or GC_E_GATE / GC_E_WIRE / GC_E_ARG

@@ -46,7 +46,7 @@ _lib = None
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "ngates", "nwires", "ninputs", "noutputs", "nlevels", "max_width", "slab_rows", "n_xor", "n_xnor", "n_and",
-        "n_or", "n_inv", "nslots", "n_steps")]
+        "n_or", "n_inv", "nslots", "n_steps", "n_hash_phases", "n_fused_steps", "n_lds_slots")]
 
 
 def lib():
@@ -83,6 +83,7 @@ def lib():
         "gc_batch_stride": (u32, [vp]),
         "gc_batch_set_schedule": (i32, [vp, i32]),
         "gc_batch_set_graph": (i32, [vp, i32]),
+        "gc_batch_set_store_all": (i32, [vp, i32]),
         "gc_batch_garble": (i32, [vp, vp, sz, vp]),
         "gc_batch_select_inputs": (i32, [vp, vp, vp]),
         "gc_batch_set_inputs": (i32, [vp, vp]),
@@ -270,6 +271,9 @@ class Batch:
 
     def set_schedule(self, s):
         _check(lib().gc_batch_set_schedule(self.h, s), "gc_batch_set_schedule")
+
+    def set_store_all(self, on):
+        _check(lib().gc_batch_set_store_all(self.h, 1 if on else 0), "gc_batch_set_store_all")
 
     def garble(self, key, d_rnd):
         k = _u8(key)
