@@ -122,6 +122,7 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
         up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
+        up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -148,6 +149,7 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_fgslot) (void)hipFree(c->d_fgslot);
     if (c->d_fsteps) (void)hipFree(c->d_fsteps);
     if (c->d_in_lds) (void)hipFree(c->d_in_lds);
+    if (c->d_fchunks) (void)hipFree(c->d_fchunks);
     delete c;
 }
 
@@ -300,6 +302,8 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
         f.steps = b->circ->d_fsteps;
         f.in_lds = b->circ->d_in_lds;
         f.nsteps = (uint32_t)p.fsteps.size();
+        f.chunks = b->circ->d_fchunks;
+        f.nchunks = (uint32_t)p.fchunks.size();
         f.ninputs = p.info.ninputs;
         f.nls = p.n_lds_slots;
         f.W = b->d_W;

@@ -43,6 +43,7 @@ struct gc_circ {
     gc::FDesc *d_fdescs = nullptr;   // LDS schedule
     uint32_t *d_fgslot = nullptr;
     gc::Step *d_fsteps = nullptr;
+    gc::Chunk *d_fchunks = nullptr;
     uint16_t *d_in_lds = nullptr;
     int schedule = 1;  // default schedule of pooled batches
     std::mutex pool_mu;

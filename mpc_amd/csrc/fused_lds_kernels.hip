@@ -9,7 +9,11 @@
 //     hashed together (89 phases for aes_128) and the XOR sub-levels in between touch LDS only;
 //   * the inter-step barrier waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) — table
 //     stores and descriptor prefetches stay in flight across it.
-// LDS map (dynamic): [0, 64 KiB) perm-addressed dual AES table | R of the tile | wire slots.
+//   * descriptors never stall a step: the plan cuts the schedule into chunks (one hash phase + its XOR
+//     sub-levels); while chunk c executes, every thread prefetches one descriptor of chunk c+1 into
+//     registers and drops it into an LDS staging area at the chunk boundary.
+// LDS map (dynamic): [0, 64 KiB) perm-addressed dual AES table | 16 KiB descriptor stage | 2 KiB step
+// stage | R of the tile | wire slots.
 #include "aes_device.h"
 #include "kernels.h"
 
@@ -88,12 +92,40 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         plast = now__;                                               \
     }
 
+constexpr uint32_t kStageDescOff = kTeDualBytes / 16;                  // in uint4 units
+constexpr uint32_t kStageStepOff = kStageDescOff + kChunkDescs;         // 1024 descriptors x 16 B
+constexpr uint32_t kStageEnd = kStageStepOff + kChunkSteps * 2;         // 64 steps x 32 B
+
+__device__ __forceinline__ Step read_step(const uint4 *stage, uint32_t s) {
+    const uint4 lo = stage[2 * s], hi = stage[2 * s + 1];
+    Step st;
+    st.first = __builtin_amdgcn_readfirstlane(lo.x);
+    st.count = __builtin_amdgcn_readfirstlane(lo.y);
+    st.nonfree = __builtin_amdgcn_readfirstlane(lo.z);
+    st.n_and = __builtin_amdgcn_readfirstlane(lo.w);
+    st.n_or = __builtin_amdgcn_readfirstlane(hi.x);
+    st.n_inv = __builtin_amdgcn_readfirstlane(hi.y);
+    return st;
+}
+
+__device__ __forceinline__ Chunk read_chunk(const Chunk *chunks, uint32_t c, uint32_t n) {
+    Chunk ch{0, 0, 0, 0};
+    if (c < n) {
+        ch.first_step = __builtin_amdgcn_readfirstlane(chunks[c].first_step);
+        ch.nsteps = __builtin_amdgcn_readfirstlane(chunks[c].nsteps);
+        ch.first_desc = __builtin_amdgcn_readfirstlane(chunks[c].first_desc);
+        ch.ndesc = __builtin_amdgcn_readfirstlane(chunks[c].ndesc);
+    }
+    return ch;
+}
+
 struct LdsArgs {
     const FDesc *descs;
     const uint32_t *gslot;
     const Step *steps;
+    const Chunk *chunks;
     const uint16_t *in_lds;
-    uint32_t nsteps, ninputs, nls, ti_log2;
+    uint32_t nsteps, nchunks, ninputs, nls, ti_log2;
     size_t w_tile, t_tile;
     uint4 *W;
     const uint4 *R;
@@ -108,8 +140,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_garble_lds(LdsArgs a) {
     extern __shared__ uint4 smem[];
     uint32_t *te = (uint32_t *)smem;
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;
-    uint4 *rl = smem + kTeDualBytes / 16;  // R of the tile
-    uint4 *wl = rl + TI;                   // wire slots [slot][TI]
+    uint4 *stage_d = smem + kStageDescOff;
+    uint4 *stage_s = smem + kStageStepOff;
+    uint4 *rl = smem + kStageEnd;  // R of the tile
+    uint4 *wl = rl + TI;           // wire slots [slot][TI]
     load_te_dual(te, a.te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, a.rk);
@@ -120,31 +154,43 @@ __global__ __launch_bounds__(kLdsThreads) void k_garble_lds(LdsArgs a) {
         const uint32_t w = i >> ti_log2, ls = a.in_lds[w];
         if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];  // global input slots are [w][TI]
     }
+    Chunk ch = read_chunk(a.chunks, 0, a.nchunks);
+    if (threadIdx.x < ch.ndesc && ch.ndesc <= kChunkDescs)
+        stage_d[threadIdx.x] = ((const uint4 *)a.descs)[ch.first_desc + threadIdx.x];
+    if (threadIdx.x < ch.nsteps) {
+        const Step sv = a.steps[ch.first_step + threadIdx.x];
+        stage_s[2 * threadIdx.x] = make_uint4(sv.first, sv.count, sv.nonfree, sv.n_and);
+        stage_s[2 * threadIdx.x + 1] = make_uint4(sv.n_or, sv.n_inv, 0, 0);
+    }
     __syncthreads();
     const uint32_t lo = te_lane_off();
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
-    Step st_next = a.steps[0];
-    LPos lp_next = lclassify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
-    FDesc d_next = lp_next.kind ? a.descs[st_next.first + lp_next.g] : FDesc{0, 0, 0, 0};
-    for (uint32_t lv = 0; lv < a.nsteps; lv++) {
-        const Step st = st_next;
+    for (uint32_t c = 0; c < a.nchunks; c++) {
+      // prefetch chunk c+1 (one descriptor + one step record per thread) — lands in LDS at the chunk end
+      const Chunk nx = read_chunk(a.chunks, c + 1, a.nchunks);
+      const bool stage_next = nx.ndesc <= kChunkDescs;
+      uint4 pre_d = make_uint4(0, 0, 0, 0);
+      Step pre_s{0, 0, 0, 0, 0, 0};
+      if (threadIdx.x < nx.ndesc && stage_next) pre_d = ((const uint4 *)a.descs)[nx.first_desc + threadIdx.x];
+      if (threadIdx.x < nx.nsteps) pre_s = a.steps[nx.first_step + threadIdx.x];
+      const bool direct = ch.ndesc > kChunkDescs;
+      for (uint32_t sidx = 0; sidx < ch.nsteps; sidx++) {
+        const Step st = read_step(stage_s, sidx);
+        const uint32_t rel = st.first - ch.first_desc;
         const uint32_t e_all = llanes<2, 2, 1>(st, ti_log2);
-        // prefetch the next step's descriptor now: the loads fly under this step's hashing
-        LPos lp_cur = lp_next;
-        FDesc d_cur = d_next;
-        if (lv + 1 < a.nsteps) {
-            st_next = a.steps[lv + 1];
-            lp_next = lclassify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
-            if (lp_next.kind) d_next = a.descs[st_next.first + lp_next.g];
-        }
         for (uint32_t t0 = 0; t0 < e_all; t0 += kLdsThreads) {
-            const LPos lp = t0 == 0 ? lp_cur : lclassify<2, 2, 1>(st, t0 + threadIdx.x, ti_log2, tim);
+            const LPos lp = lclassify<2, 2, 1>(st, t0 + threadIdx.x, ti_log2, tim);
             const int kind = lp.kind;
             const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
             if (kind == 0) continue;
-            const FDesc d = t0 == 0 ? d_cur : a.descs[st.first + g];
+            FDesc d;
+            if (direct) d = a.descs[st.first + g];
+            else {
+                const uint4 dv = stage_d[rel + g];
+                d = FDesc{dv.x, dv.y, dv.z, dv.w};
+            }
             GC_LPROF(0)
             const uint32_t l0s = d.lin & 0xffffu, l1s = d.lin >> 16, los = d.lout & 0xffffu;
             const bool to_global = STORE_ALL || (d.lout & kFStoreGlobal);
@@ -220,6 +266,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_garble_lds(LdsArgs a) {
         GC_LPROF(2)
         lds_barrier();
         GC_LPROF(3)
+      }
+      // chunk boundary: every reader of the staging area is past the barrier above
+      if (threadIdx.x < nx.ndesc && stage_next) stage_d[threadIdx.x] = pre_d;
+      if (threadIdx.x < nx.nsteps) {
+          stage_s[2 * threadIdx.x] = make_uint4(pre_s.first, pre_s.count, pre_s.nonfree, pre_s.n_and);
+          stage_s[2 * threadIdx.x + 1] = make_uint4(pre_s.n_or, pre_s.n_inv, 0, 0);
+      }
+      lds_barrier();
+      ch = nx;
     }
     if constexpr (PROF) {
         if (threadIdx.x == 0 || threadIdx.x == kLdsThreads - 64)
@@ -232,7 +287,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_eval_lds(LdsArgs a) {
     extern __shared__ uint4 smem[];
     uint32_t *te = (uint32_t *)smem;
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;
-    uint4 *wl = smem + kTeDualBytes / 16 + TI;  // same map as the garbler (R slot unused)
+    uint4 *stage_d = smem + kStageDescOff;
+    uint4 *stage_s = smem + kStageStepOff;
+    uint4 *wl = smem + kStageEnd + TI;  // same map as the garbler (R slot unused)
     load_te_dual(te, a.te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, a.rk);
@@ -242,30 +299,42 @@ __global__ __launch_bounds__(kLdsThreads) void k_eval_lds(LdsArgs a) {
         const uint32_t w = i >> ti_log2, ls = a.in_lds[w];
         if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];
     }
+    Chunk ch = read_chunk(a.chunks, 0, a.nchunks);
+    if (threadIdx.x < ch.ndesc && ch.ndesc <= kChunkDescs)
+        stage_d[threadIdx.x] = ((const uint4 *)a.descs)[ch.first_desc + threadIdx.x];
+    if (threadIdx.x < ch.nsteps) {
+        const Step sv = a.steps[ch.first_step + threadIdx.x];
+        stage_s[2 * threadIdx.x] = make_uint4(sv.first, sv.count, sv.nonfree, sv.n_and);
+        stage_s[2 * threadIdx.x + 1] = make_uint4(sv.n_or, sv.n_inv, 0, 0);
+    }
     __syncthreads();
     const uint32_t lo = te_lane_off();
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
-    Step st_next = a.steps[0];
-    LPos lp_next = lclassify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
-    FDesc d_next = lp_next.kind ? a.descs[st_next.first + lp_next.g] : FDesc{0, 0, 0, 0};
-    for (uint32_t lv = 0; lv < a.nsteps; lv++) {
-        const Step st = st_next;
+    for (uint32_t c = 0; c < a.nchunks; c++) {
+      const Chunk nx = read_chunk(a.chunks, c + 1, a.nchunks);
+      const bool stage_next = nx.ndesc <= kChunkDescs;
+      uint4 pre_d = make_uint4(0, 0, 0, 0);
+      Step pre_s{0, 0, 0, 0, 0, 0};
+      if (threadIdx.x < nx.ndesc && stage_next) pre_d = ((const uint4 *)a.descs)[nx.first_desc + threadIdx.x];
+      if (threadIdx.x < nx.nsteps) pre_s = a.steps[nx.first_step + threadIdx.x];
+      const bool direct = ch.ndesc > kChunkDescs;
+      for (uint32_t sidx = 0; sidx < ch.nsteps; sidx++) {
+        const Step st = read_step(stage_s, sidx);
+        const uint32_t rel = st.first - ch.first_desc;
         const uint32_t e_all = llanes<1, 0, 0>(st, ti_log2);
-        LPos lp_cur = lp_next;
-        FDesc d_cur = d_next;
-        if (lv + 1 < a.nsteps) {
-            st_next = a.steps[lv + 1];
-            lp_next = lclassify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
-            if (lp_next.kind) d_next = a.descs[st_next.first + lp_next.g];
-        }
         for (uint32_t t0 = 0; t0 < e_all; t0 += kLdsThreads) {
-            const LPos lp = t0 == 0 ? lp_cur : lclassify<1, 0, 0>(st, t0 + threadIdx.x, ti_log2, tim);
+            const LPos lp = lclassify<1, 0, 0>(st, t0 + threadIdx.x, ti_log2, tim);
             const int kind = lp.kind;
             const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
             if (kind == 0) continue;
-            const FDesc d = t0 == 0 ? d_cur : a.descs[st.first + g];
+            FDesc d;
+            if (direct) d = a.descs[st.first + g];
+            else {
+                const uint4 dv = stage_d[rel + g];
+                d = FDesc{dv.x, dv.y, dv.z, dv.w};
+            }
             GC_LPROF(0)
             const uint32_t l0s = d.lin & 0xffffu, l1s = d.lin >> 16, los = d.lout & 0xffffu;
             const bool to_global = STORE_ALL || (d.lout & kFStoreGlobal);
@@ -316,6 +385,15 @@ __global__ __launch_bounds__(kLdsThreads) void k_eval_lds(LdsArgs a) {
         GC_LPROF(2)
         lds_barrier();
         GC_LPROF(3)
+      }
+      // chunk boundary: every reader of the staging area is past the barrier above
+      if (threadIdx.x < nx.ndesc && stage_next) stage_d[threadIdx.x] = pre_d;
+      if (threadIdx.x < nx.nsteps) {
+          stage_s[2 * threadIdx.x] = make_uint4(pre_s.first, pre_s.count, pre_s.nonfree, pre_s.n_and);
+          stage_s[2 * threadIdx.x + 1] = make_uint4(pre_s.n_or, pre_s.n_inv, 0, 0);
+      }
+      lds_barrier();
+      ch = nx;
     }
     if constexpr (PROF) {
         if (threadIdx.x == 0 || threadIdx.x == kLdsThreads - 64)
@@ -324,7 +402,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_eval_lds(LdsArgs a) {
 }
 
 size_t fused_lds_bytes(uint32_t nls, uint32_t ti_log2) {
-    return (size_t)kTeDualBytes + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
+    return (size_t)kStageEnd * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
 }
 
 template <typename K>
@@ -340,6 +418,8 @@ hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g
     a.descs = f.descs;
     a.gslot = f.gslot;
     a.steps = f.steps;
+    a.chunks = f.chunks;
+    a.nchunks = f.nchunks;
     a.in_lds = f.in_lds;
     a.nsteps = f.nsteps;
     a.ninputs = f.ninputs;

@@ -80,8 +80,9 @@ struct FusedLdsArgs {
     const FDesc *descs;
     const uint32_t *gslot;
     const Step *steps;
+    const Chunk *chunks;
     const uint16_t *in_lds;
-    uint32_t nsteps, ninputs, nls;
+    uint32_t nsteps, nchunks, ninputs, nls;
     uint4 *W;
     const uint4 *R;
     uint4 *T;

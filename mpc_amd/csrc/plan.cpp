@@ -225,6 +225,19 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
             }
         }
         p.n_lds_slots = overflow ? 0xffffffffu : high;
+        // chunks: cut before every hash phase, and whenever the staging capacity would overflow
+        Chunk ch{0, 0, 0, 0};
+        for (uint32_t si = 0; si < p.fsteps.size(); si++) {
+            const Step &st = p.fsteps[si];
+            const bool cut = ch.nsteps && (st.nonfree || ch.ndesc + st.count > kChunkDescs || ch.nsteps == kChunkSteps);
+            if (cut) {
+                p.fchunks.push_back(ch);
+                ch = Chunk{si, 0, st.first, 0};
+            }
+            ch.nsteps++;
+            ch.ndesc += st.count;
+        }
+        if (ch.nsteps) p.fchunks.push_back(ch);
         p.info.n_hash_phases = p.n_hash_phases;
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;

@@ -47,6 +47,16 @@ struct FDesc {
 static_assert(sizeof(FDesc) == 16, "FDesc must be 16 bytes");
 constexpr uint32_t kFStoreGlobal = 1u << 16;
 
+// Descriptor staging unit of the LDS schedule: a run of whole steps whose descriptors (<= kChunkDescs)
+// and step records (<= kChunkSteps) are copied into LDS in one go while the previous chunk executes.
+// A chunk normally is one hash phase plus the XOR sub-levels that follow it.
+constexpr uint32_t kChunkDescs = 1024;
+constexpr uint32_t kChunkSteps = 64;
+struct Chunk {
+    uint32_t first_step, nsteps;
+    uint32_t first_desc, ndesc;  // ndesc > kChunkDescs only for a single over-wide step (read from HBM directly)
+};
+
 struct Plan {
     gc_plan_info info{};
     // original gate order
@@ -65,6 +75,7 @@ struct Plan {
     std::vector<FDesc> fdescs;          // execution order
     std::vector<uint32_t> fgslot;       // global wire slot written by fdescs[k]
     std::vector<Step> fsteps;
+    std::vector<Chunk> fchunks;
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
     uint32_t n_hash_phases = 0;
