@@ -211,6 +211,24 @@ __device__ __forceinline__ void load_round_keys(uint32_t (&rk)[4 * (NR + 1)], co
     for (int i = 0; i < 4 * (NR + 1); i++) rk[i] = __builtin_amdgcn_readfirstlane(g_rk[i]);
 }
 
+// N hashes pi(K) ^ K in lock-step (N independent AES chains per lane hide the LDS latency)
+template <int NR, int N>
+__device__ __forceinline__ void hash_dual_n(const uint32_t (&k)[N][4], uint4 (&out)[N],
+                                            const uint32_t (&rk)[4 * (NR + 1)], const uint32_t *te, uint32_t lo0) {
+    uint32_t s[N][4];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i][0] = k[i][0];
+        s[i][1] = k[i][1];
+        s[i][2] = k[i][2];
+        s[i][3] = k[i][3];
+    }
+    aes_encrypt_dual<NR, N>(s, rk, te, lo0);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        out[i] = make_uint4(s[i][1] ^ k[i][1], s[i][0] ^ k[i][0], s[i][3] ^ k[i][3], s[i][2] ^ k[i][2]);
+}
+
 template <int NR>
 __device__ __forceinline__ uint4 hash_dual(const uint32_t (&k)[4], const uint32_t (&rk)[4 * (NR + 1)],
                                            const uint32_t *te, uint32_t lo0) {

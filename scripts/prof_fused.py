@@ -22,7 +22,7 @@ gb.debug_profile(True); ev.debug_profile(True)
 gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
 ctx.sync()
 print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
-names = ["desc", "loads", "hash+st", "barrier"]
+names = ["prologue", "xor", "hash", "barrier"]
 for nm, b in (("garble", gb), ("eval", ev)):
     p = b.debug_profile(True, read=True)
     tot0, tot1 = sum(p[:4]), sum(p[4:])
