@@ -165,6 +165,12 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     }                                                                                                          \
     __syncthreads();                                                                                           \
     const uint32_t lo = te_lane_off();                                                                         \
+    /* XOR sub-levels: NW worker waves, each owning OI = TI / NW instances of the tile */                      \
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;           \
+    const uint32_t nw_log2 = ti_log2 < (uint32_t)__builtin_ctz(THREADS / 64) ? ti_log2                         \
+                                                                             : (uint32_t)__builtin_ctz(THREADS / 64); \
+    const uint32_t NW = 1u << nw_log2, oi_log2 = ti_log2 - nw_log2;                                            \
+    const uint32_t xinst = (wave << oi_log2) + (lane & ((1u << oi_log2) - 1));                                 \
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;                                                                \
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -209,24 +215,14 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
 
     for (uint32_t c = 0; c < a.nchunks; c++) {
         GC_CHUNK_PREFETCH()
-        for (uint32_t sidx = 0; sidx < ch.nsteps; sidx++) {
-            const Step st = read_step(stage_s, sidx);
+        // a chunk is [hash phase]? followed by XOR sub-levels (plan.cpp cuts before every hash phase)
+        uint32_t sidx = 0;
+        {
+            const Step st = read_step(stage_s, 0);
             const uint32_t rel = st.first - ch.first_desc;
             GC_LPROF(0)
-            if (st.nonfree == 0) {
-                // ---- XOR sub-level: LDS in, LDS out (garble.go:331-351) ----
-                const uint32_t n = st.count << ti_log2;
-                for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-                    const uint32_t g = t >> ti_log2, inst = t & tim;
-                    const FDesc d = stage_desc(stage_d, a.descs, direct, rel, st.first, g);
-                    uint4 v = lxor(wl[((d.lin & 0xffffu) << ti_log2) + inst], wl[((d.lin >> 16) << ti_log2) + inst]);
-                    if ((d.row_op >> kOpShift) == GC_XNOR) v = lxor(v, rl[inst]);
-                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = v;
-                    if (STORE_ALL || (d.lout & kFStoreGlobal))
-                        Wt[((size_t)a.gslot[st.first + g] << ti_log2) + inst] = v;
-                }
-                GC_LPROF(1)
-            } else {
+            if (st.nonfree != 0) {
+                sidx = 1;
                 // ---- hash phase ----
                 const uint32_t e_and = (st.n_and << ti_log2) << 2;
                 const uint32_t e_or = e_and + ((st.n_or << ti_log2) << 2);
@@ -311,7 +307,33 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                     }
                 }
                 GC_LPROF(2)
+                lds_barrier();
+                GC_LPROF(3)
             }
+        }
+        // ---- XOR sub-levels (garble.go:331-351): LDS in, LDS out, NO workgroup barriers.  Wave w owns
+        // the instances [w*OI, (w+1)*OI) of the tile; a wave's DS operations execute in order, so the
+        // labels one sub-level writes are visible to the next one without any synchronisation.
+        if (sidx < ch.nsteps) {
+            if (wave < NW) {
+                for (uint32_t sx = sidx; sx < ch.nsteps; sx++) {
+                    const Step st = read_step(stage_s, sx);
+                    const uint32_t rel = st.first - ch.first_desc;
+                    for (uint32_t g0 = 0; g0 < st.count; g0 += 64u >> oi_log2) {
+                        const uint32_t g = g0 + (lane >> oi_log2);
+                        if (g < st.count) {
+                            const FDesc d = stage_desc(stage_d, a.descs, direct, rel, st.first, g);
+                            uint4 v = lxor(wl[((d.lin & 0xffffu) << ti_log2) + xinst],
+                                           wl[((d.lin >> 16) << ti_log2) + xinst]);
+                            if ((d.row_op >> kOpShift) == GC_XNOR) v = lxor(v, rl[xinst]);
+                            wl[((d.lout & 0xffffu) << ti_log2) + xinst] = v;
+                            if (STORE_ALL || (d.lout & kFStoreGlobal))
+                                Wt[((size_t)a.gslot[st.first + g] << ti_log2) + xinst] = v;
+                        }
+                    }
+                }
+            }
+            GC_LPROF(1)
             lds_barrier();
             GC_LPROF(3)
         }
@@ -329,23 +351,13 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
 
     for (uint32_t c = 0; c < a.nchunks; c++) {
         GC_CHUNK_PREFETCH()
-        for (uint32_t sidx = 0; sidx < ch.nsteps; sidx++) {
-            const Step st = read_step(stage_s, sidx);
+        uint32_t sidx = 0;
+        {
+            const Step st = read_step(stage_s, 0);
             const uint32_t rel = st.first - ch.first_desc;
             GC_LPROF(0)
-            if (st.nonfree == 0) {  // eval.go:49-51
-                const uint32_t n = st.count << ti_log2;
-                for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-                    const uint32_t g = t >> ti_log2, inst = t & tim;
-                    const FDesc d = stage_desc(stage_d, a.descs, direct, rel, st.first, g);
-                    const uint4 v =
-                        lxor(wl[((d.lin & 0xffffu) << ti_log2) + inst], wl[((d.lin >> 16) << ti_log2) + inst]);
-                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = v;
-                    if (STORE_ALL || (d.lout & kFStoreGlobal))
-                        Wt[((size_t)a.gslot[st.first + g] << ti_log2) + inst] = v;
-                }
-                GC_LPROF(1)
-            } else {
+            if (st.nonfree != 0) {
+                sidx = 1;
                 const uint32_t e_and = (st.n_and << ti_log2) << 1;
                 const uint32_t e_or = e_and + (st.n_or << ti_log2);
                 const uint32_t e_all = e_or + (st.n_inv << ti_log2);
@@ -410,7 +422,30 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                     }
                 }
                 GC_LPROF(2)
+                lds_barrier();
+                GC_LPROF(3)
             }
+        }
+        // ---- XOR sub-levels (eval.go:49-51), wave-local like in the garbler ----
+        if (sidx < ch.nsteps) {
+            if (wave < NW) {
+                for (uint32_t sx = sidx; sx < ch.nsteps; sx++) {
+                    const Step st = read_step(stage_s, sx);
+                    const uint32_t rel = st.first - ch.first_desc;
+                    for (uint32_t g0 = 0; g0 < st.count; g0 += 64u >> oi_log2) {
+                        const uint32_t g = g0 + (lane >> oi_log2);
+                        if (g < st.count) {
+                            const FDesc d = stage_desc(stage_d, a.descs, direct, rel, st.first, g);
+                            uint4 v = lxor(wl[((d.lin & 0xffffu) << ti_log2) + xinst],
+                                           wl[((d.lin >> 16) << ti_log2) + xinst]);
+                            wl[((d.lout & 0xffffu) << ti_log2) + xinst] = v;
+                            if (STORE_ALL || (d.lout & kFStoreGlobal))
+                                Wt[((size_t)a.gslot[st.first + g] << ti_log2) + xinst] = v;
+                        }
+                    }
+                }
+            }
+            GC_LPROF(1)
             lds_barrier();
             GC_LPROF(3)
         }
