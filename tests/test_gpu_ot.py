@@ -1,0 +1,123 @@
+"""GPU parity tests of the IKNP OT-extension kernels and MITCCRH (through the C ABI) against the CPU
+oracle, plus the reference's own properties (ot/iknp_test.go:98-113 correlation, ot/ot_test.go:83-97
+delivery, ot/mitccrh_test.go:23-30 vectors)."""
+import numpy as np
+import pytest
+
+import oracle
+from mpc_amd import engine
+from mpc_amd.circuit import LABEL, WIRE
+from tests.test_oracle_kat import MITCCRH_BLOCKS
+from tests.util import drbg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def labels(seed, n):
+    raw = drbg(seed, 16 * n)
+    out = np.zeros(n, LABEL)
+    for i in range(n):
+        out[i] = oracle.label_from_bytes(raw[16 * i:16 * i + 16])
+    return out
+
+
+def base_setup(seed):
+    base = np.zeros(128, WIRE)
+    base["l0"] = labels(seed + "l0", 128)
+    base["l1"] = labels(seed + "l1", 128)
+    delta = oracle.label_from_bytes(drbg(seed + "delta", 16))
+    k0 = np.zeros(128, LABEL)
+    for i in range(128):
+        k0[i] = base[i]["l1"] if oracle.label_bit(delta, i) else base[i]["l0"]
+    return base, delta, k0
+
+
+# iknp_test.go:32-37 chunk-size cases + ragged / sub-byte / multi-chunk sizes
+SIZES = [0, 1, 2, 7, 8, 9, 129, 511, 512, 513, 700, 1024, 1025, 2049, 2560, 65536]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_iknp_matches_oracle_and_correlates(ctx, n):
+    base, delta, k0 = base_setup("iknp%d" % n)
+    b = (np.frombuffer(drbg("b%d" % n, max(n, 1)), np.uint8)[:n] & 1).astype(np.uint8)
+    rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    orcv, osnd = oracle.IKNPReceiver(base), oracle.IKNPSender(delta, k0)
+    u, got = rcv.receive(b)
+    ou, ogot = orcv.receive(b)
+    assert u == ou, "u-matrix bytes differ from the oracle"
+    assert (got == ogot).all(), "receiver labels differ from the oracle"
+    sent = snd.send(u, n)
+    assert (sent == osnd.send(ou, n)).all(), "sender labels differ from the oracle"
+    if n:
+        x0 = sent["d0"] ^ np.where(b == 1, np.uint64(delta[0]), np.uint64(0))
+        x1 = sent["d1"] ^ np.where(b == 1, np.uint64(delta[1]), np.uint64(0))
+        assert (got["d0"] == x0).all() and (got["d1"] == x1).all()  # rcvd = sent ^ b*delta
+    rcv.close(); snd.close()
+
+
+def test_iknp_streams_persist_across_calls(ctx):
+    # column CTR streams continue across calls, also from a mid-block byte offset (iknp.go:488,632-637)
+    base, delta, k0 = base_setup("persist")
+    rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    orcv, osnd = oracle.IKNPReceiver(base), oracle.IKNPSender(delta, k0)
+    for n in (24 * 8, 5, 1000, 513, 77):
+        b = (np.frombuffer(drbg("pb%d" % n, n), np.uint8) & 1).astype(np.uint8)
+        u, got = rcv.receive(b)
+        ou, ogot = orcv.receive(b)
+        assert u == ou and (got == ogot).all()
+        assert (snd.send(u, n) == osnd.send(ou, n)).all()
+    with pytest.raises(engine.EngineError):  # "invalid chunk size" (iknp.go:207-209)
+        snd.send(b"\x00" * 100, 64)
+    rcv.close(); snd.close()
+
+
+def test_mitccrh_reference_vectors(ctx):
+    blks = np.zeros(16, LABEL)
+    out = engine.mitccrh_hash(ctx, (0, 0), 0, blks, 2)  # seed 0, keys 0..7, h = 2, zero blocks
+    for i in range(8):
+        for j in range(2):
+            assert oracle.label_to_bytes(out[2 * i + j]).hex() == MITCCRH_BLOCKS[i]
+
+
+@pytest.mark.parametrize("n,h", [(1, 1), (8, 2), (13, 1), (1000, 2), (4097, 1)])
+def test_mitccrh_matches_oracle(ctx, n, h):
+    seed = oracle.label_from_bytes(drbg("ms%d" % n, 16))
+    blks = labels("mb%d" % n, n * h)
+    got = engine.mitccrh_hash(ctx, seed, 0, blks, h)
+    m = oracle.MITCCRH(seed, 8)
+    want = blks.copy()
+    for i in range(0, n, 8):  # the Go object hashes 8 keys per call (cot.go:160-171)
+        k = min(8, n - i)
+        pad = np.zeros(8 * h, LABEL)
+        pad[: k * h] = want[i * h:(i + k) * h]
+        m.hash(pad, 8, h)
+        want[i * h:(i + k) * h] = pad[: k * h]
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("n", [1, 8, 13, 64, 3000])
+def test_cot_pipeline_delivers_chosen_label(ctx, n):
+    # ot_test.go:83-97 through IKNP + MITCCRH on the GPU; wire bytes equal the oracle's
+    base, delta, k0 = base_setup("cot%d" % n)
+    flags = np.array([i % 2 for i in range(n)], np.uint8)
+    wires = np.zeros(n, WIRE)
+    wires["l0"] = labels("w0", n)
+    wires["l1"] = labels("w1", n)
+    rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    u, got = rcv.receive(flags)
+    data = snd.send(u, n)
+    seed = oracle.label_from_bytes(drbg("cotseed", 16))
+    sent = engine.cot_send_pads(ctx, seed, delta, data, wires)
+    assert (sent == oracle.cot_send_pads(seed, delta, data, wires)).all()
+    res = engine.cot_receive_unpad(ctx, seed, flags, sent, got)
+    assert (res == oracle.cot_receive_unpad(seed, flags, sent, got)).all()
+    for i in range(n):
+        assert res[i] == (wires[i]["l1"] if flags[i] else wires[i]["l0"])
+    rcv.close(); snd.close()
