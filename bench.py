@@ -175,9 +175,21 @@ def main():
     g_avg = float(np.mean(g_ms))
     e_avg = float(np.mean(e_ms))
     launches = gb.last_launches
-    # dominant kernel: k_garble_level (one launch per level).  Algorithmic bytes per launch =
-    # garble bytes per instance x batch / launches; average launch duration = pass time / launches
+    # dominant kernel: the garble pass (schedule 1: ONE k_garble_lds launch; schedule 0: one
+    # k_garble_level launch per level).  Algorithmic bytes per launch = garble bytes per instance x batch
+    # / launches; launch duration from HIP events recorded on the engine's stream (gc_batch_last_ms).
     achieved = algb * batch / (g_avg * 1e-3) / 1e9
+    kernel_name = "k_garble_lds" if args.schedule == 1 else "k_garble_level"
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                pj = json.load(f)
+            if pj.get("batch") == batch and pj.get("schedule") == args.schedule and pj.get("key_bytes") == args.key_bytes:
+                traffic = pj.get("garble_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     res = {
         "metric": "AND-gates/sec (garble+eval), AES-128 circuit batch",
         "value": value,
@@ -197,6 +209,9 @@ def main():
             "instances_per_gpu": batch,
             "levels": int(info.nlevels),
             "launches_per_garble": int(launches),
+            "schedule": "fused-lds" if args.schedule == 1 else "level-launch",
+            "hash_phases": int(info.n_hash_phases),
+            "lds_live_labels": int(info.n_lds_slots),
             "graph": not args.no_graph,
             "outputs_ok": ok,
         },
@@ -207,12 +222,12 @@ def main():
         "hbm_alg_GBs_garble_plus_eval": 2 * algb * batch / ((g_avg + e_avg) * 1e-3) / 1e9,
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_garble_level",
+            "kernel": kernel_name,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "alg_bytes_per_launch": algb * batch / max(launches, 1),
             "avg_launch_us": g_avg * 1e3 / max(launches, 1),
         },

@@ -466,11 +466,13 @@ static hipError_t launch_lds(K kern, int threads, const LdsArgs &a, uint32_t nti
     return hipGetLastError();
 }
 
-// workgroup shape: GC_LDS_SHAPE = 0: 1024 threads x ILP 1, 1: 512 x 2, 2 (default): 256 x 4
+// workgroup shape: GC_LDS_SHAPE = 0 (default): 1024 threads x ILP 1, 1: 512 x 2, 2: 256 x 4.
+// Measured on MI355X (aes_128 x 1024, AES-256 key): garble 1.12 / 1.49 / 2.35 ms — a CDNA4 SIMD needs
+// ~4 resident waves to keep its VALU issuing every other cycle; ILP inside one wave does not replace them.
 static int lds_shape() {
     static int shape = [] {
         const char *e = getenv("GC_LDS_SHAPE");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 0;
     }();
     return shape;
 }
