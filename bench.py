@@ -115,7 +115,7 @@ def main():
     d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
     d_out = torch.zeros((batch, circ.num_outputs), dtype=torch.uint8, device="cuda")
     d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d_all = torch.zeros((world, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") if world > 1 else None
+    d_all = torch.zeros((world * batch, circ.num_outputs), dtype=torch.uint8, device="cuda") if world > 1 else None
 
     def step():
         gb.garble(key, d_rnd.data_ptr())
