@@ -216,13 +216,14 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
     for (uint32_t c = 0; c < a.nchunks; c++) {
         GC_CHUNK_PREFETCH()
         // a chunk is [hash phase]? followed by XOR sub-levels (plan.cpp cuts before every hash phase)
-        uint32_t sidx = 0;
+        uint32_t sidx = 0, xor_rel0 = 0;
         {
             const Step st = read_step(stage_s, 0);
             const uint32_t rel = st.first - ch.first_desc;
             GC_LPROF(0)
             if (st.nonfree != 0) {
                 sidx = 1;
+                xor_rel0 = st.count;
                 // ---- hash phase ----
                 const uint32_t e_and = (st.n_and << ti_log2) << 2;
                 const uint32_t e_or = e_and + ((st.n_or << ti_log2) << 2);
@@ -259,7 +260,16 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                         }
                     }
                     uint4 h[ILP];
-                    hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    if constexpr (ILP == 2) {
+                        if (__any(hp[1].kind != 0)) {
+                            hash_dual_n<NR, 2>(k, h, rkr, te, lo);
+                        } else {  // this wave only has first-lane work: single AES chain
+                            h[0] = hash_dual<NR>(k[0], rkr, te, lo);
+                            h[1] = make_uint4(0, 0, 0, 0);
+                        }
+                    } else {
+                        hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    }
 #pragma unroll
                     for (int j = 0; j < ILP; j++) {
                         const uint32_t kind = hp[j].kind, inst = hp[j].inst, q = hp[j].q;
@@ -315,7 +325,34 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
         // the instances [w*OI, (w+1)*OI) of the tile; a wave's DS operations execute in order, so the
         // labels one sub-level writes are visible to the next one without any synchronisation.
         if (sidx < ch.nsteps) {
-            if (wave < NW) {
+            if (wave < NW && !direct) {
+                // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
+                // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
+                // from the LDS stage before the current labels are touched
+                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
+                uint32_t p = xor_rel0;
+                const uint32_t end = ch.ndesc;
+                uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
+                while (p < end) {
+                    const bool cut = gl > 0 && p + gl < end && (dv.y & kFLevelStart);
+                    const uint64_t m = __ballot(cut);
+                    uint32_t n = end - p < gpi ? end - p : gpi;
+                    if (m) {
+                        const uint32_t first = (uint32_t)__builtin_ctzll(m) >> oi_log2;
+                        n = first < n ? first : n;
+                    }
+                    const uint4 dn = p + n + gl < end ? stage_d[p + n + gl] : make_uint4(0, 0, 0, 0);
+                    if (gl < n) {
+                        uint4 v = lxor(wl[((dv.x & 0xffffu) << ti_log2) + xinst], wl[((dv.x >> 16) << ti_log2) + xinst]);
+                        if ((dv.w >> kOpShift) == GC_XNOR) v = lxor(v, rl[xinst]);
+                        wl[((dv.y & 0xffffu) << ti_log2) + xinst] = v;
+                        if (STORE_ALL || (dv.y & kFStoreGlobal))
+                            Wt[((size_t)a.gslot[ch.first_desc + p + gl] << ti_log2) + xinst] = v;
+                    }
+                    p += n;
+                    dv = dn;
+                }
+            } else if (wave < NW) {
                 for (uint32_t sx = sidx; sx < ch.nsteps; sx++) {
                     const Step st = read_step(stage_s, sx);
                     const uint32_t rel = st.first - ch.first_desc;
@@ -351,13 +388,14 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
 
     for (uint32_t c = 0; c < a.nchunks; c++) {
         GC_CHUNK_PREFETCH()
-        uint32_t sidx = 0;
+        uint32_t sidx = 0, xor_rel0 = 0;
         {
             const Step st = read_step(stage_s, 0);
             const uint32_t rel = st.first - ch.first_desc;
             GC_LPROF(0)
             if (st.nonfree != 0) {
                 sidx = 1;
+                xor_rel0 = st.count;
                 const uint32_t e_and = (st.n_and << ti_log2) << 1;
                 const uint32_t e_or = e_and + (st.n_or << ti_log2);
                 const uint32_t e_all = e_or + (st.n_inv << ti_log2);
@@ -395,7 +433,16 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                         }
                     }
                     uint4 h[ILP];
-                    hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    if constexpr (ILP == 2) {
+                        if (__any(hp[1].kind != 0)) {
+                            hash_dual_n<NR, 2>(k, h, rkr, te, lo);
+                        } else {  // this wave only has first-lane work: single AES chain
+                            h[0] = hash_dual<NR>(k[0], rkr, te, lo);
+                            h[1] = make_uint4(0, 0, 0, 0);
+                        }
+                    } else {
+                        hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    }
 #pragma unroll
                     for (int j = 0; j < ILP; j++) {
                         const uint32_t kind = hp[j].kind, inst = hp[j].inst, q = hp[j].q;
@@ -428,7 +475,33 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
         }
         // ---- XOR sub-levels (eval.go:49-51), wave-local like in the garbler ----
         if (sidx < ch.nsteps) {
-            if (wave < NW) {
+            if (wave < NW && !direct) {
+                // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
+                // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
+                // from the LDS stage before the current labels are touched
+                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
+                uint32_t p = xor_rel0;
+                const uint32_t end = ch.ndesc;
+                uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
+                while (p < end) {
+                    const bool cut = gl > 0 && p + gl < end && (dv.y & kFLevelStart);
+                    const uint64_t m = __ballot(cut);
+                    uint32_t n = end - p < gpi ? end - p : gpi;
+                    if (m) {
+                        const uint32_t first = (uint32_t)__builtin_ctzll(m) >> oi_log2;
+                        n = first < n ? first : n;
+                    }
+                    const uint4 dn = p + n + gl < end ? stage_d[p + n + gl] : make_uint4(0, 0, 0, 0);
+                    if (gl < n) {
+                        uint4 v = lxor(wl[((dv.x & 0xffffu) << ti_log2) + xinst], wl[((dv.x >> 16) << ti_log2) + xinst]);
+                        wl[((dv.y & 0xffffu) << ti_log2) + xinst] = v;
+                        if (STORE_ALL || (dv.y & kFStoreGlobal))
+                            Wt[((size_t)a.gslot[ch.first_desc + p + gl] << ti_log2) + xinst] = v;
+                    }
+                    p += n;
+                    dv = dn;
+                }
+            } else if (wave < NW) {
                 for (uint32_t sx = sidx; sx < ch.nsteps; sx++) {
                     const Step st = read_step(stage_s, sx);
                     const uint32_t rel = st.first - ch.first_desc;
@@ -466,7 +539,8 @@ static hipError_t launch_lds(K kern, int threads, const LdsArgs &a, uint32_t nti
     return hipGetLastError();
 }
 
-// workgroup shape: GC_LDS_SHAPE = 0 (default): 1024 threads x ILP 1, 1: 512 x 2, 2: 256 x 4.
+// workgroup shape: GC_LDS_SHAPE = 0 (default): 1024 threads x ILP 1, 1: 512 x 2, 2: 256 x 4, 3: 1024 x 2
+// (second lanes folded into the waves that have them).
 // Measured on MI355X (aes_128 x 1024, AES-256 key): garble 1.12 / 1.49 / 2.35 ms — a CDNA4 SIMD needs
 // ~4 resident waves to keep its VALU issuing every other cycle; ILP inside one wave does not replace them.
 static int lds_shape() {
@@ -504,8 +578,9 @@ hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g
     (f.prof ? launch_lds(KERN<NR, TH, IL, false, true>, TH, a, g.ntiles, lds, s)                 \
             : f.store_all ? launch_lds(KERN<NR, TH, IL, true, false>, TH, a, g.ntiles, lds, s)   \
                           : launch_lds(KERN<NR, TH, IL, false, false>, TH, a, g.ntiles, lds, s))
-#define GC_L3(KERN, NR) \
-    (shape == 0 ? GC_L4(KERN, NR, 1024, 1) : shape == 1 ? GC_L4(KERN, NR, 512, 2) : GC_L4(KERN, NR, 256, 4))
+#define GC_L3(KERN, NR)                                                               \
+    (shape == 0 ? GC_L4(KERN, NR, 1024, 1) : shape == 1 ? GC_L4(KERN, NR, 512, 2)     \
+                                          : shape == 2 ? GC_L4(KERN, NR, 256, 4) : GC_L4(KERN, NR, 1024, 2))
 #define GC_L2(KERN) (f.rounds == 10 ? GC_L3(KERN, 10) : f.rounds == 12 ? GC_L3(KERN, 12) : GC_L3(KERN, 14))
     return eval ? GC_L2(k_eval_lds) : GC_L2(k_garble_lds);
 #undef GC_L2

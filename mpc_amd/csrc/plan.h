@@ -46,6 +46,7 @@ struct FDesc {
 };
 static_assert(sizeof(FDesc) == 16, "FDesc must be 16 bytes");
 constexpr uint32_t kFStoreGlobal = 1u << 16;
+constexpr uint32_t kFLevelStart = 1u << 17;  // first descriptor of an XOR sub-level (flat XOR streams)
 
 // Descriptor staging unit of the LDS schedule: a run of whole steps whose descriptors (<= kChunkDescs)
 // and step records (<= kChunkSteps) are copied into LDS in one go while the previous chunk executes.
