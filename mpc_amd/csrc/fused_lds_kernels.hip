@@ -334,16 +334,19 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
                 while (p < end) {
-                    const bool cut = gl > 0 && p + gl < end && (dv.y & kFLevelStart);
-                    const uint64_t m = __ballot(cut);
-                    uint32_t n = end - p < gpi ? end - p : gpi;
-                    if (m) {
-                        const uint32_t first = (uint32_t)__builtin_ctzll(m) >> oi_log2;
-                        n = first < n ? first : n;
+                    // lanes whose descriptor belongs to the sub-level of the first lane take part; the label
+                    // reads are issued first, the bookkeeping for the next iteration overlaps their latency
+                    const uint32_t lvl = __builtin_amdgcn_readfirstlane(dv.z);
+                    const bool act = p + gl < end && dv.z == lvl;
+                    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+                    if (act) {
+                        va = wl[((dv.x & 0xffffu) << ti_log2) + xinst];
+                        vb = wl[((dv.x >> 16) << ti_log2) + xinst];
                     }
+                    const uint32_t n = (uint32_t)__builtin_popcountll(__ballot(act)) >> oi_log2;
                     const uint4 dn = p + n + gl < end ? stage_d[p + n + gl] : make_uint4(0, 0, 0, 0);
-                    if (gl < n) {
-                        uint4 v = lxor(wl[((dv.x & 0xffffu) << ti_log2) + xinst], wl[((dv.x >> 16) << ti_log2) + xinst]);
+                    if (act) {
+                        uint4 v = lxor(va, vb);
                         if ((dv.w >> kOpShift) == GC_XNOR) v = lxor(v, rl[xinst]);
                         wl[((dv.y & 0xffffu) << ti_log2) + xinst] = v;
                         if (STORE_ALL || (dv.y & kFStoreGlobal))
@@ -484,16 +487,19 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
                 while (p < end) {
-                    const bool cut = gl > 0 && p + gl < end && (dv.y & kFLevelStart);
-                    const uint64_t m = __ballot(cut);
-                    uint32_t n = end - p < gpi ? end - p : gpi;
-                    if (m) {
-                        const uint32_t first = (uint32_t)__builtin_ctzll(m) >> oi_log2;
-                        n = first < n ? first : n;
+                    // lanes whose descriptor belongs to the sub-level of the first lane take part; the label
+                    // reads are issued first, the bookkeeping for the next iteration overlaps their latency
+                    const uint32_t lvl = __builtin_amdgcn_readfirstlane(dv.z);
+                    const bool act = p + gl < end && dv.z == lvl;
+                    uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+                    if (act) {
+                        va = wl[((dv.x & 0xffffu) << ti_log2) + xinst];
+                        vb = wl[((dv.x >> 16) << ti_log2) + xinst];
                     }
+                    const uint32_t n = (uint32_t)__builtin_popcountll(__ballot(act)) >> oi_log2;
                     const uint4 dn = p + n + gl < end ? stage_d[p + n + gl] : make_uint4(0, 0, 0, 0);
-                    if (gl < n) {
-                        uint4 v = lxor(wl[((dv.x & 0xffffu) << ti_log2) + xinst], wl[((dv.x >> 16) << ti_log2) + xinst]);
+                    if (act) {
+                        uint4 v = lxor(va, vb);
                         wl[((dv.y & 0xffffu) << ti_log2) + xinst] = v;
                         if (STORE_ALL || (dv.y & kFStoreGlobal))
                             Wt[((size_t)a.gslot[ch.first_desc + p + gl] << ti_log2) + xinst] = v;

@@ -219,7 +219,9 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
                 FDesc &d = p.fdescs[k];
                 d.lin = (lds_of[src0[g]] & 0xffffu) | ((lds_of[src1[g]] & 0xffffu) << 16);
                 d.lout = (s & 0xffffu) | (is_output[pid] ? kFStoreGlobal : 0u) | (e == 0 ? kFLevelStart : 0u);
-                d.tweak = p.tweak_of_gate[g];
+                // XOR/XNOR gates have no tweak: the field carries the step index so that the flat XOR stream
+                // of the kernels can tell sub-levels apart without scalar bookkeeping
+                d.tweak = op_class(gates[g].op) == 3 ? si : p.tweak_of_gate[g];
                 d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
                 p.fgslot[k] = p.slot_of_gate[g];
             }
