@@ -238,121 +238,6 @@ __device__ __forceinline__ uint4 hash_dual(const uint32_t (&k)[4], const uint32_
     return make_uint4(o[1], o[0], o[3], o[2]);
 }
 
-// ---- unified AES front-end of the fused LDS kernels ----------------------------------------------------
-// Round keys live in ONE VGPR (lane i holds word i) and are pulled into an SGPR with v_readlane right
-// where they are used: 60 pinned SGPRs would cap the kernel at 6 waves per SIMD (MI355X_MICROARCH.md,
-// "Residency"), v_readlane costs one VALU slot per word and keeps the SGPR count under 80.
-//   TAB = 0: perm-addressed dual table, 64 KiB (fastest per block; one 1024-thread workgroup per CU)
-//   TAB = 1: Te0 replicated 32x, 32 KiB (+24 VALU per round) — leaves room for TWO workgroups per CU,
-//            whose hash phases / XOR runs / barriers then overlap each other
-template <int TAB>
-struct AesLds {
-    static constexpr int kBytes = TAB == 0 ? kTeDualBytes : kTeReplWords * 4;
-    __device__ static __forceinline__ void load(uint32_t *te, const uint32_t *__restrict__ g_te0) {
-        if (TAB == 0) load_te_dual(te, g_te0);
-        else load_te_replicated(te, g_te0);
-    }
-    template <int NR, int N>
-    __device__ static __forceinline__ void encrypt(uint32_t (&s)[N][4], uint32_t rkv, const uint32_t *te,
-                                                   uint32_t lo0) {
-#define GC_RK(i) ((uint32_t)__builtin_amdgcn_readlane((int)rkv, (i)))
-        const uint32_t lo2 = lo0 + 128u;
-        const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
-        (void)lo2; (void)sel0; (void)sel1; (void)sel2; (void)sel3;
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            s[k][0] ^= GC_RK(0);
-            s[k][1] ^= GC_RK(1);
-            s[k][2] ^= GC_RK(2);
-            s[k][3] ^= GC_RK(3);
-        }
-#pragma unroll
-        for (int r = 1; r < NR; r++) {
-            const uint32_t k0 = GC_RK(4 * r), k1 = GC_RK(4 * r + 1), k2 = GC_RK(4 * r + 2), k3 = GC_RK(4 * r + 3);
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
-                if (TAB == 0) {
-#define GC_COL(c0, c1, c2, c3, key)                                                                   \
-    ((te_dual(te, c0, sel3, lo0) ^ te_dual(te, c2, sel1, lo2)) ^                                      \
-     rotr32(te_dual(te, c1, sel2, lo0) ^ te_dual(te, c3, sel0, lo2), 8) ^ (key))
-                    s[k][0] = GC_COL(a0, a1, a2, a3, k0);
-                    s[k][1] = GC_COL(a1, a2, a3, a0, k1);
-                    s[k][2] = GC_COL(a2, a3, a0, a1, k2);
-                    s[k][3] = GC_COL(a3, a0, a1, a2, k3);
-#undef GC_COL
-                } else {
-                    // col = T[b3(c0)] ^ rotr8(T[b2(c1)] ^ rotr8(T[b1(c2)] ^ rotr8(T[b0(c3)])))  (Horner form)
-#define GC_COL(c0, c1, c2, c3, key)                                                                          \
-    (te_at(te, (c0) >> 24, lo0) ^                                                                            \
-     rotr32(te_at(te, ((c1) >> 16) & 0xff, lo0) ^                                                            \
-                rotr32(te_at(te, ((c2) >> 8) & 0xff, lo0) ^ rotr32(te_at(te, (c3)&0xff, lo0), 8), 8),        \
-            8) ^                                                                                             \
-     (key))
-                    s[k][0] = GC_COL(a0, a1, a2, a3, k0);
-                    s[k][1] = GC_COL(a1, a2, a3, a0, k1);
-                    s[k][2] = GC_COL(a2, a3, a0, a1, k2);
-                    s[k][3] = GC_COL(a3, a0, a1, a2, k3);
-#undef GC_COL
-                }
-            }
-        }
-        {
-            const uint32_t k0 = GC_RK(4 * NR), k1 = GC_RK(4 * NR + 1), k2 = GC_RK(4 * NR + 2), k3 = GC_RK(4 * NR + 3);
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
-                if (TAB == 0) {
-#define GC_LAST(c0, c1, c2, c3, key)                                                                       \
-    (((te_dual(te, c0, sel3, lo2) & 0xff000000u) | (te_dual(te, c1, sel2, lo0) & 0x00ff0000u) |           \
-      (te_dual(te, c2, sel1, lo0) & 0x0000ff00u) | (te_dual(te, c3, sel0, lo2) & 0x000000ffu)) ^ (key))
-                    s[k][0] = GC_LAST(a0, a1, a2, a3, k0);
-                    s[k][1] = GC_LAST(a1, a2, a3, a0, k1);
-                    s[k][2] = GC_LAST(a2, a3, a0, a1, k2);
-                    s[k][3] = GC_LAST(a3, a0, a1, a2, k3);
-#undef GC_LAST
-                } else {
-                    // S[x] = byte 1 of Te0[x]: take it in place for byte positions 2,1 and shifted for 3,0
-#define GC_T(v) te_at(te, (v), lo0)
-#define GC_LAST(c0, c1, c2, c3, key)                                                                          \
-    ((((GC_T((c0) >> 24) << 16) & 0xff000000u) | (GC_T(((c1) >> 16) & 0xff) & 0x00ff0000u) |                  \
-      (GC_T(((c2) >> 8) & 0xff) & 0x0000ff00u) | ((GC_T((c3)&0xff) >> 8) & 0x000000ffu)) ^ (key))
-                    s[k][0] = GC_LAST(a0, a1, a2, a3, k0);
-                    s[k][1] = GC_LAST(a1, a2, a3, a0, k1);
-                    s[k][2] = GC_LAST(a2, a3, a0, a1, k2);
-                    s[k][3] = GC_LAST(a3, a0, a1, a2, k3);
-#undef GC_LAST
-#undef GC_T
-                }
-            }
-        }
-#undef GC_RK
-    }
-    // N hashes pi(K) ^ K in lock-step
-    template <int NR, int N>
-    __device__ static __forceinline__ void hash(const uint32_t (&k)[N][4], uint4 (&out)[N], uint32_t rkv,
-                                                const uint32_t *te, uint32_t lo0) {
-        uint32_t s[N][4];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            s[i][0] = k[i][0];
-            s[i][1] = k[i][1];
-            s[i][2] = k[i][2];
-            s[i][3] = k[i][3];
-        }
-        encrypt<NR, N>(s, rkv, te, lo0);
-#pragma unroll
-        for (int i = 0; i < N; i++)
-            out[i] = make_uint4(s[i][1] ^ k[i][1], s[i][0] ^ k[i][0], s[i][3] ^ k[i][3], s[i][2] ^ k[i][2]);
-    }
-};
-
-// lane i of the returned VGPR holds round-key word i
-__device__ __forceinline__ uint32_t load_round_keys_vgpr(const uint32_t *__restrict__ g_rk) {
-    const uint32_t l = threadIdx.x & 63u;
-    return l < 60u ? g_rk[l] : 0u;
-}
-
 // ---- label arithmetic (ot/label.go) on the uint4 form --------------------------------------
 
 __device__ __forceinline__ uint4 lxor(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }

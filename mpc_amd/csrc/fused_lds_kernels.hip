@@ -57,13 +57,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         plast = now__;                                               \
     }
 
-// LDS map in uint4 units: [AES table | kChunkDescs descriptors | kChunkSteps steps (32 B each) | R | wires]
-template <int TAB>
-struct LdsMap {
-    static constexpr uint32_t kDesc = AesLds<TAB>::kBytes / 16;
-    static constexpr uint32_t kStep = kDesc + kChunkDescs;
-    static constexpr uint32_t kEnd = kStep + kChunkSteps * 2;
-};
+constexpr uint32_t kStageDescOff = kTeDualBytes / 16;            // in uint4 units
+constexpr uint32_t kStageStepOff = kStageDescOff + kChunkDescs;  // 1024 descriptors x 16 B
+constexpr uint32_t kStageEnd = kStageStepOff + kChunkSteps * 2;  // 64 steps x 32 B
 
 __device__ __forceinline__ Step read_step(const uint4 *stage, uint32_t s) {
     const uint4 lo = stage[2 * s], hi = stage[2 * s + 1];
@@ -145,12 +141,13 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     extern __shared__ uint4 smem[];                                                                            \
     uint32_t *te = (uint32_t *)smem;                                                                           \
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;                                      \
-    uint4 *stage_d = smem + LdsMap<TAB>::kDesc;                                                                \
-    uint4 *stage_s = smem + LdsMap<TAB>::kStep;                                                                \
-    uint4 *rl = smem + LdsMap<TAB>::kEnd;                                                                      \
+    uint4 *stage_d = smem + kStageDescOff;                                                                     \
+    uint4 *stage_s = smem + kStageStepOff;                                                                     \
+    uint4 *rl = smem + kStageEnd;                                                                              \
     uint4 *wl = rl + TI;                                                                                       \
-    AesLds<TAB>::load(te, a.te0);                                                                              \
-    const uint32_t rkv = load_round_keys_vgpr(a.rk);                                                           \
+    load_te_dual(te, a.te0);                                                                                   \
+    uint32_t rkr[4 * (NR + 1)];                                                                                \
+    load_round_keys<NR>(rkr, a.rk);                                                                            \
     uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                           \
     if (LOAD_R && threadIdx.x < TI) rl[threadIdx.x] = a.R[(size_t)blockIdx.x * TI + threadIdx.x];             \
     for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += THREADS) {                                 \
@@ -210,9 +207,9 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     }
 
 // ------------------------------------------------------------------------------------------------------
-template <int NR, int THREADS, int ILP, int TAB, bool STORE_ALL, bool PROF>
-__global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 256) void k_garble_lds(LdsArgs a) {
-    constexpr int PF = ((int)kChunkDescs + THREADS - 1) / THREADS;
+template <int NR, int THREADS, int ILP, bool STORE_ALL, bool PROF>
+__global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
+    constexpr int PF = (int)kChunkDescs / THREADS;
     GC_LDS_PROLOGUE(true)
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
 
@@ -263,7 +260,16 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
                         }
                     }
                     uint4 h[ILP];
-                    AesLds<TAB>::template hash<NR, ILP>(k, h, rkv, te, lo);
+                    if constexpr (ILP == 2) {
+                        if (__any(hp[1].kind != 0)) {
+                            hash_dual_n<NR, 2>(k, h, rkr, te, lo);
+                        } else {  // this wave only has first-lane work: single AES chain
+                            h[0] = hash_dual<NR>(k[0], rkr, te, lo);
+                            h[1] = make_uint4(0, 0, 0, 0);
+                        }
+                    } else {
+                        hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    }
 #pragma unroll
                     for (int j = 0; j < ILP; j++) {
                         const uint32_t kind = hp[j].kind, inst = hp[j].inst, q = hp[j].q;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
                 // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
                 // from the LDS stage before the current labels are touched
-                const uint32_t gl = lane >> oi_log2;
+                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
                 uint32_t p = xor_rel0;
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
@@ -377,9 +383,9 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <int NR, int THREADS, int ILP, int TAB, bool STORE_ALL, bool PROF>
-__global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 256) void k_eval_lds(LdsArgs a) {
-    constexpr int PF = ((int)kChunkDescs + THREADS - 1) / THREADS;
+template <int NR, int THREADS, int ILP, bool STORE_ALL, bool PROF>
+__global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
+    constexpr int PF = (int)kChunkDescs / THREADS;
     GC_LDS_PROLOGUE(false)
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
 
@@ -430,7 +436,16 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
                         }
                     }
                     uint4 h[ILP];
-                    AesLds<TAB>::template hash<NR, ILP>(k, h, rkv, te, lo);
+                    if constexpr (ILP == 2) {
+                        if (__any(hp[1].kind != 0)) {
+                            hash_dual_n<NR, 2>(k, h, rkr, te, lo);
+                        } else {  // this wave only has first-lane work: single AES chain
+                            h[0] = hash_dual<NR>(k[0], rkr, te, lo);
+                            h[1] = make_uint4(0, 0, 0, 0);
+                        }
+                    } else {
+                        hash_dual_n<NR, ILP>(k, h, rkr, te, lo);
+                    }
 #pragma unroll
                     for (int j = 0; j < ILP; j++) {
                         const uint32_t kind = hp[j].kind, inst = hp[j].inst, q = hp[j].q;
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
                 // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
                 // from the LDS stage before the current labels are touched
-                const uint32_t gl = lane >> oi_log2;
+                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
                 uint32_t p = xor_rel0;
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
@@ -518,22 +533,9 @@ __global__ __launch_bounds__(THREADS, TAB == 1 ? 2 * THREADS / 256 : THREADS / 2
     GC_PROF_EPILOGUE()
 }
 
-// table mode: GC_LDS_TAB = 0: 64 KiB dual table, one workgroup per CU; 1 (default): 32 KiB table, two
-// workgroups per CU whose hash phases, XOR runs and barriers overlap each other
-int fused_lds_tab() {
-    static int tab = [] {
-        const char *e = getenv("GC_LDS_TAB");
-        return e ? atoi(e) : 1;
-    }();
-    return tab;
-}
-
 size_t fused_lds_bytes(uint32_t nls, uint32_t ti_log2) {
-    const size_t fixed = (fused_lds_tab() == 1 ? LdsMap<1>::kEnd : LdsMap<0>::kEnd) * sizeof(uint4);
-    return fixed + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
+    return (size_t)kStageEnd * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
 }
-
-size_t fused_lds_budget() { return fused_lds_tab() == 1 ? 80 * 1024 : 160 * 1024; }
 
 template <typename K>
 static hipError_t launch_lds(K kern, int threads, const LdsArgs &a, uint32_t ntiles, size_t lds, hipStream_t s) {
@@ -541,6 +543,18 @@ static hipError_t launch_lds(K kern, int threads, const LdsArgs &a, uint32_t nti
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(threads), lds, s, a);
     return hipGetLastError();
+}
+
+// workgroup shape: GC_LDS_SHAPE = 0 (default): 1024 threads x ILP 1, 1: 512 x 2, 2: 256 x 4, 3: 1024 x 2
+// (second lanes folded into the waves that have them).
+// Measured on MI355X (aes_128 x 1024, AES-256 key): garble 1.12 / 1.49 / 2.35 ms — a CDNA4 SIMD needs
+// ~4 resident waves to keep its VALU issuing every other cycle; ILP inside one wave does not replace them.
+static int lds_shape() {
+    static int shape = [] {
+        const char *e = getenv("GC_LDS_SHAPE");
+        return e ? atoi(e) : 0;
+    }();
+    return shape;
 }
 
 hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g, hipStream_t s) {
@@ -565,12 +579,14 @@ hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g
     a.prof = f.prof;
     if (a.nsteps == 0) return hipSuccess;
     const size_t lds = fused_lds_bytes(f.nls, g.ti_log2);
-    const int tab = fused_lds_tab();
-#define GC_L4(KERN, NR, TB)                                                                        \
-    (f.prof ? launch_lds(KERN<NR, 1024, 1, TB, false, true>, 1024, a, g.ntiles, lds, s)             \
-            : f.store_all ? launch_lds(KERN<NR, 1024, 1, TB, true, false>, 1024, a, g.ntiles, lds, s) \
-                          : launch_lds(KERN<NR, 1024, 1, TB, false, false>, 1024, a, g.ntiles, lds, s))
-#define GC_L3(KERN, NR) (tab == 1 ? GC_L4(KERN, NR, 1) : GC_L4(KERN, NR, 0))
+    const int shape = lds_shape();
+#define GC_L4(KERN, NR, TH, IL)                                                                  \
+    (f.prof ? launch_lds(KERN<NR, TH, IL, false, true>, TH, a, g.ntiles, lds, s)                 \
+            : f.store_all ? launch_lds(KERN<NR, TH, IL, true, false>, TH, a, g.ntiles, lds, s)   \
+                          : launch_lds(KERN<NR, TH, IL, false, false>, TH, a, g.ntiles, lds, s))
+#define GC_L3(KERN, NR)                                                               \
+    (shape == 0 ? GC_L4(KERN, NR, 1024, 1) : shape == 1 ? GC_L4(KERN, NR, 512, 2)     \
+                                          : shape == 2 ? GC_L4(KERN, NR, 256, 4) : GC_L4(KERN, NR, 1024, 2))
 #define GC_L2(KERN) (f.rounds == 10 ? GC_L3(KERN, 10) : f.rounds == 12 ? GC_L3(KERN, 12) : GC_L3(KERN, 14))
     return eval ? GC_L2(k_eval_lds) : GC_L2(k_garble_lds);
 #undef GC_L2

@@ -33,7 +33,7 @@ BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab
         uint32_t t = 0;
         while (t < 6 && (batch >> (t + 1)) >= 256) t++;
         // LDS-resident wires: the tile's live labels (+R) must fit beside the 64 KiB AES table
-        const size_t lds_budget = fused_lds_budget();
+        const size_t lds_budget = 160 * 1024;
         g.lds_wires = nls != 0xffffffffu && fused_lds_bytes(nls, 0) <= lds_budget;
         if (g.lds_wires)
             while (t > 0 && fused_lds_bytes(nls, t) > lds_budget) t--;

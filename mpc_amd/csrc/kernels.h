@@ -93,7 +93,6 @@ struct FusedLdsArgs {
     uint64_t *prof;
 };
 size_t fused_lds_bytes(uint32_t nls, uint32_t ti_log2);
-size_t fused_lds_budget();  // LDS a workgroup of the fused kernels may use (depends on the table mode)
 hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &a, const BatchGeom &g, hipStream_t s);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
