@@ -329,7 +329,7 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
                 // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
                 // from the LDS stage before the current labels are touched
-                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
+                const uint32_t gl = lane >> oi_log2;
                 uint32_t p = xor_rel0;
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
                 // and stops at the next sub-level start (kFLevelStart); the next descriptors are fetched
                 // from the LDS stage before the current labels are touched
-                const uint32_t gl = lane >> oi_log2, gpi = 64u >> oi_log2;
+                const uint32_t gl = lane >> oi_log2;
                 uint32_t p = xor_rel0;
                 const uint32_t end = ch.ndesc;
                 uint4 dv = p + gl < end ? stage_d[p + gl] : make_uint4(0, 0, 0, 0);
@@ -545,18 +545,11 @@ static hipError_t launch_lds(K kern, int threads, const LdsArgs &a, uint32_t nti
     return hipGetLastError();
 }
 
-// workgroup shape: GC_LDS_SHAPE = 0 (default): 1024 threads x ILP 1, 1: 512 x 2, 2: 256 x 4, 3: 1024 x 2
-// (second lanes folded into the waves that have them).
-// Measured on MI355X (aes_128 x 1024, AES-256 key): garble 1.12 / 1.49 / 2.35 ms — a CDNA4 SIMD needs
-// ~4 resident waves to keep its VALU issuing every other cycle; ILP inside one wave does not replace them.
-static int lds_shape() {
-    static int shape = [] {
-        const char *e = getenv("GC_LDS_SHAPE");
-        return e ? atoi(e) : 0;
-    }();
-    return shape;
-}
-
+// Workgroup shape: 1024 threads, ONE AES chain per hash lane.  Measured alternatives on MI355X (aes_128 x
+// 1024, AES-256 key, garble pass): 1024 x ILP1 1.12 ms | 512 x ILP2 1.49 ms | 256 x ILP4 2.35 ms | 1024 x ILP2
+// with per-wave narrowing 1.26 ms | two 1024-thread workgroups per CU on a 32 KiB table 1.45 ms.  A CDNA4
+// SIMD needs ~4 resident waves to keep issuing; ILP inside a wave does not replace them, and a second
+// co-resident workgroup slows the serial XOR runs more than its overlap wins back.
 hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g, hipStream_t s) {
     LdsArgs a{};
     a.descs = f.descs;
@@ -579,19 +572,14 @@ hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &f, const BatchGeom &g
     a.prof = f.prof;
     if (a.nsteps == 0) return hipSuccess;
     const size_t lds = fused_lds_bytes(f.nls, g.ti_log2);
-    const int shape = lds_shape();
-#define GC_L4(KERN, NR, TH, IL)                                                                  \
-    (f.prof ? launch_lds(KERN<NR, TH, IL, false, true>, TH, a, g.ntiles, lds, s)                 \
-            : f.store_all ? launch_lds(KERN<NR, TH, IL, true, false>, TH, a, g.ntiles, lds, s)   \
-                          : launch_lds(KERN<NR, TH, IL, false, false>, TH, a, g.ntiles, lds, s))
-#define GC_L3(KERN, NR)                                                               \
-    (shape == 0 ? GC_L4(KERN, NR, 1024, 1) : shape == 1 ? GC_L4(KERN, NR, 512, 2)     \
-                                          : shape == 2 ? GC_L4(KERN, NR, 256, 4) : GC_L4(KERN, NR, 1024, 2))
+#define GC_L3(KERN, NR)                                                                      \
+    (f.prof ? launch_lds(KERN<NR, 1024, 1, false, true>, 1024, a, g.ntiles, lds, s)              \
+            : f.store_all ? launch_lds(KERN<NR, 1024, 1, true, false>, 1024, a, g.ntiles, lds, s) \
+                          : launch_lds(KERN<NR, 1024, 1, false, false>, 1024, a, g.ntiles, lds, s))
 #define GC_L2(KERN) (f.rounds == 10 ? GC_L3(KERN, 10) : f.rounds == 12 ? GC_L3(KERN, 12) : GC_L3(KERN, 14))
     return eval ? GC_L2(k_eval_lds) : GC_L2(k_garble_lds);
 #undef GC_L2
 #undef GC_L3
-#undef GC_L4
 }
 
 }  // namespace gc
