@@ -139,6 +139,30 @@ int gc_garble(gc_circ *, const uint8_t *key, size_t keylen, const uint8_t *rnd, 
 int gc_eval(gc_circ *, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
             const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels);
 
+/* Garble ONE instance whose R and input-wire L0 labels are given instead of drawn from a random
+ * stream (what Streaming.Garble needs: the inputs of an SSA-step circuit are wires garbled earlier).
+ *  r        the stream's R (S bit already set)        inputs   [ninputs] L0 labels
+ *  slab_out [slab_rows]                               out_l0   [noutputs] L0 of the output wires */
+int gc_garble_labels(gc_circ *, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
+                     gc_label *slab_out, gc_label *out_l0);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming garbler (config 5) — circuit/stream_garble.go
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_stream gc_stream;
+/* Replaces NewStreaming(cfg, key, inputs, conn)   circuit/stream_garble.go:41-75
+ *  rnd = the bytes cfg.GetRandom() would deliver: R (16 B) then one L0 per entry of inputs[] */
+gc_stream *gc_stream_create(gc_ctx *, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen,
+                            const uint32_t *inputs, uint32_t ninputs, int *status);
+void gc_stream_free(gc_stream *);
+/* Replaces (*Streaming).GetInput(w)   stream_garble.go:117-119 */
+int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
+/* Replaces (*Streaming).Garble(c, in, out)   stream_garble.go:161-192: garbles the circuit (tweak restarts
+ * at 0, :174) and appends the serialised gates — op|flags, 16/32-bit wire indexes, table rows, exactly as
+ * :391-446 writes them into conn.WriteBuf — to buf.  *written = bytes needed; GC_E_ARG if cap is smaller. */
+int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                     uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
+
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,
  * additive to the reference API) calls; also what bench.py times.  All d_* arguments are

@@ -687,6 +687,36 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
     return rc;
 }
 
+int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
+                     gc_label *slab_out, gc_label *out_l0) {
+    if (!c || !r) return GC_E_ARG;
+    const Plan &p = c->plan.p;
+    if (p.info.ninputs && !inputs) return GC_E_ARG;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, 1, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_garble_labels", e);
+            rc = GC_E_HIP;
+            break;
+        }
+        if (p.info.ninputs) rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
+        if (rc != GC_OK) break;
+        if ((rc = set_key(b, key, keylen)) != GC_OK) break;
+        b->store_all = false;
+        if ((rc = run_levels(b, false, b->d_T)) != GC_OK) break;
+        if (slab_out && (rc = gc_batch_read_slab(b, slab_out)) != GC_OK) break;
+        if (out_l0 && (rc = gc_batch_read_outputs(b, out_l0)) != GC_OK) break;
+    } while (0);
+    pool_put(c, b);
+    return rc;
+}
+
 int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
             const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels) {
     if (!c || batch == 0 || (!wires_inout && !inputs)) return GC_E_ARG;

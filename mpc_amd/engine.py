@@ -78,6 +78,11 @@ def lib():
         "gc_circ_set_schedule": (i32, [vp, i32]),
         "gc_garble": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, vp]),
         "gc_eval": (i32, [vp, vp, sz, u32, vp, vp, vp, sz, vp]),
+        "gc_garble_labels": (i32, [vp, vp, sz, vp, vp, vp, vp]),
+        "gc_stream_create": (vp, [vp, vp, sz, vp, sz, vp, u32, ip]),
+        "gc_stream_free": (None, [vp]),
+        "gc_stream_get_wire": (i32, [vp, u32, vp]),
+        "gc_stream_garble": (i32, [vp, vp, u32, u32, vp, u32, vp, u32, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
         "gc_batch_stride": (u32, [vp]),
@@ -342,6 +347,38 @@ class Batch:
     def close(self):
         if self.h:
             lib().gc_batch_free(self.h)
+            self.h = None
+
+
+class Stream:
+    """gc_stream: NewStreaming / Streaming.Garble / GetInput (circuit/stream_garble.go)"""
+
+    def __init__(self, ctx, key, rnd, inputs):
+        k, r = _u8(key), _u8(rnd)
+        inp = np.ascontiguousarray(inputs, dtype=np.uint32)
+        st = C.c_int(0)
+        self.h = lib().gc_stream_create(ctx.h, _p(k), len(k), _p(r), len(r), _p(inp), len(inp), C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_stream_create")
+
+    def get(self, w):
+        out = np.zeros(1, WIRE)
+        _check(lib().gc_stream_get_wire(self.h, w, _p(out)), "gc_stream_get_wire")
+        return out[0]
+
+    def garble(self, gates, nwires, in_, out_):
+        g = np.ascontiguousarray(gates, dtype=GATE)
+        i = np.ascontiguousarray(in_, dtype=np.uint32)
+        o = np.ascontiguousarray(out_, dtype=np.uint32)
+        buf = np.zeros(len(g) * 61 + 16, np.uint8)
+        n = C.c_size_t(0)
+        _check(lib().gc_stream_garble(self.h, _p(g), len(g), nwires, _p(i), len(i), _p(o), len(o), _p(buf), len(buf),
+                                      C.byref(n)), "gc_stream_garble")
+        return buf[: n.value].tobytes()
+
+    def close(self):
+        if self.h:
+            lib().gc_stream_free(self.h)
             self.h = None
 
 

@@ -36,7 +36,7 @@ class OracleError(RuntimeError):
 
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
-    srcs = [os.path.join(HERE, f) for f in ("aes_oracle.c", "gc_oracle.c", "ot_oracle.c", "oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("aes_oracle.c", "gc_oracle.c", "ot_oracle.c", "stream_oracle.c", "oracle.h")]
     stale = force or not os.path.exists(LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs
     )
@@ -387,3 +387,85 @@ def inner_product(a, b):
     r1, r2 = _Label(), _Label()
     lib().orc_inner_product(_p(a), _p(b), C.c_size_t(min(len(a), len(b))), C.byref(r1), C.byref(r2))
     return (r1.d0, r1.d1), (r2.d0, r2.d1)
+
+
+# ---- streaming garbler / evaluator ----------------------------------------------------------
+
+
+class Stream:
+    """circuit.Streaming (stream_garble.go): NewStreaming + Garble + GetInput"""
+
+    def __init__(self, key, rnd, inputs):
+        L = lib()
+        L.orc_stream_new.restype = C.c_void_p
+        L.orc_stream_garble.restype = C.c_long
+        k, r = _u8(key), _u8(rnd)
+        inp = np.ascontiguousarray(inputs, dtype=np.uint32)
+        st = C.c_int(0)
+        self.h = L.orc_stream_new(_p(k), C.c_size_t(len(k)), _p(r), C.c_size_t(len(r)), _p(inp), C.c_uint32(len(inp)),
+                                  C.byref(st))
+        if not self.h:
+            raise OracleError(st.value, "stream_new")
+
+    def get(self, w):
+        out = np.zeros(1, WIRE)
+        rc = lib().orc_stream_get(C.c_void_p(self.h), C.c_uint32(w), _p(out))
+        if rc:
+            raise OracleError(rc, "stream_get")
+        return out[0]
+
+    def garble(self, gates, nwires, in_, out_):
+        g = np.ascontiguousarray(gates, dtype=GATE)
+        i = np.ascontiguousarray(in_, dtype=np.uint32)
+        o = np.ascontiguousarray(out_, dtype=np.uint32)
+        buf = np.zeros(len(g) * 61 + 16, np.uint8)
+        n = lib().orc_stream_garble(C.c_void_p(self.h), _p(g), C.c_uint32(len(g)), C.c_uint32(nwires), _p(i),
+                                    C.c_uint32(len(i)), _p(o), C.c_uint32(len(o)), _p(buf), C.c_size_t(len(buf)))
+        if n < 0:
+            raise OracleError(n, "stream_garble")
+        return buf[:n].tobytes()
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_stream_free(C.c_void_p(self.h))
+            self.h = None
+
+
+class StreamEval:
+    """StreamEval store + the per-gate loop of stream_evaluator.go:271-432"""
+
+    def __init__(self, key):
+        L = lib()
+        L.orc_stream_eval_new.restype = C.c_void_p
+        L.orc_stream_eval_circuit.restype = C.c_long
+        k = _u8(key)
+        st = C.c_int(0)
+        self.h = L.orc_stream_eval_new(_p(k), C.c_size_t(len(k)), C.byref(st))
+        if not self.h:
+            raise OracleError(st.value, "stream_eval_new")
+
+    def set(self, w, label):
+        lib().orc_stream_eval_set.argtypes = [C.c_void_p, C.c_uint32, _Label]
+        rc = lib().orc_stream_eval_set(C.c_void_p(self.h), C.c_uint32(w), _lab(label))
+        if rc:
+            raise OracleError(rc, "stream_eval_set")
+
+    def get(self, w):
+        out = _Label()
+        rc = lib().orc_stream_eval_get(C.c_void_p(self.h), C.c_uint32(w), C.byref(out))
+        if rc:
+            raise OracleError(rc, "stream_eval_get")
+        return (out.d0, out.d1)
+
+    def circuit(self, ngates, ntmp, nwires, data):
+        b = _u8(data) if len(data) else np.zeros(1, np.uint8)
+        n = lib().orc_stream_eval_circuit(C.c_void_p(self.h), C.c_uint32(ngates), C.c_uint32(ntmp), C.c_uint32(nwires),
+                                          _p(b), C.c_size_t(len(data)))
+        if n < 0:
+            raise OracleError(n, "stream_eval_circuit")
+        return n
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.orc_stream_eval_free(C.c_void_p(self.h))
+            self.h = None

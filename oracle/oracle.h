@@ -158,6 +158,28 @@ void orc_mul128(orc_label a, orc_label b, orc_label *lo, orc_label *hi);
 void orc_mul128_ref(orc_label a, orc_label b, orc_label *lo, orc_label *hi); /* mul128_ref.go:9 */
 void orc_inner_product(const orc_label *a, const orc_label *b, size_t n, orc_label *r1, orc_label *r2);
 
+/* ---- Streaming garbler / evaluator: circuit/stream_garble.go, circuit/stream_evaluator.go ---- */
+typedef struct orc_stream orc_stream;
+/* NewStreaming (stream_garble.go:41-75): rnd = R (16 B) then one L0 per entry of inputs[] */
+orc_stream *orc_stream_new(const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen,
+                           const uint32_t *inputs, uint32_t ninputs, int *status);
+void orc_stream_free(orc_stream *);
+/* Streaming.GetInput (stream_garble.go:117-119) */
+int orc_stream_get(orc_stream *, uint32_t w, orc_wire *out);
+/* Streaming.Garble (stream_garble.go:161-192): appends the serialised gates (:391-446) to buf;
+ * returns bytes written or a negative error (ORC_E_ARG if cap is too small) */
+long orc_stream_garble(orc_stream *, const orc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                       uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap);
+/* evaluator: StreamEval state + the per-gate loop of stream_evaluator.go:271-432 over one circuit's bytes */
+typedef struct orc_stream_eval orc_stream_eval;
+orc_stream_eval *orc_stream_eval_new(const uint8_t *key, size_t keylen, int *status);
+void orc_stream_eval_free(orc_stream_eval *);
+int orc_stream_eval_set(orc_stream_eval *, uint32_t w, orc_label l);
+int orc_stream_eval_get(orc_stream_eval *, uint32_t w, orc_label *l);
+/* returns bytes consumed or negative error */
+long orc_stream_eval_circuit(orc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
+                             size_t len);
+
 /* ---- CPU baseline helper: garble+eval `reps` instances on `threads` ---- */
 /* returns elapsed seconds; checks every evaluated output label against the
  * garbler's wire labels (returns negative on mismatch). */

@@ -1,0 +1,44 @@
+"""GPU streaming garbler (gc_stream_*, config 5 shape): the byte stream must equal the oracle's
+restatement of circuit/stream_garble.go byte for byte, for a sequence of per-step circuits."""
+import numpy as np
+import pytest
+
+import oracle
+from mpc_amd import engine
+from tests.test_oracle_stream import make_program
+from tests.util import drbg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("base,keylen", [(0, 32), (0x20000, 16), (70000, 24)])
+def test_stream_bytes_match_oracle(base, keylen):
+    ctx = engine.Context(0)
+    steps, prim = make_program(base)
+    key = drbg("skey", keylen)
+    rnd = drbg("gs%d" % base, 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    gg = engine.Stream(ctx, key, rnd, prim)
+    for rep in range(2):  # second pass re-uses the cached plans
+        for c, in_, out_ in steps:
+            want = og.garble(c.Gates, c.NumWires, in_, out_)
+            got = gg.garble(c.Gates, c.NumWires, in_, out_)
+            assert got == want
+            for o in out_:
+                assert gg.get(o) == og.get(o)
+    for w in prim:
+        assert gg.get(w) == og.get(w)
+    gg.close()
+    ctx.close()
+
+
+def test_stream_errors():
+    ctx = engine.Context(0)
+    steps, prim = make_program(0)
+    with pytest.raises(engine.EngineError) as e:
+        engine.Stream(ctx, bytes(5), drbg("r", 16 * (len(prim) + 1)), prim)
+    assert e.value.code == engine.GC_E_KEYSIZE
+    with pytest.raises(engine.EngineError) as e:
+        engine.Stream(ctx, bytes(16), drbg("r", 16 * len(prim)), prim)
+    assert e.value.code == engine.GC_E_RAND
+    ctx.close()
