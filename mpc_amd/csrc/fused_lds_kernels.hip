@@ -57,9 +57,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         plast = now__;                                               \
     }
 
-constexpr uint32_t kStageDescOff = kTeDualBytes / 16;            // in uint4 units
-constexpr uint32_t kStageStepOff = kStageDescOff + kChunkDescs;  // 1024 descriptors x 16 B
-constexpr uint32_t kStageEnd = kStageStepOff + kChunkSteps * 2;  // 64 steps x 32 B
+// staging area, in uint4 units: TWO buffers of [kChunkDescs descriptors | kChunkSteps steps (32 B each)];
+// chunk c reads buffer c&1 while the prefetched chunk c+1 is committed into the other one
+constexpr uint32_t kStageBuf = kChunkDescs + kChunkSteps * 2;
+constexpr uint32_t kStageOff = kTeDualBytes / 16;
+constexpr uint32_t kStageEnd = kStageOff + 2 * kStageBuf;
 
 __device__ __forceinline__ Step read_step(const uint4 *stage, uint32_t s) {
     const uint4 lo = stage[2 * s], hi = stage[2 * s + 1];
@@ -141,8 +143,8 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     extern __shared__ uint4 smem[];                                                                            \
     uint32_t *te = (uint32_t *)smem;                                                                           \
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;                                      \
-    uint4 *stage_d = smem + kStageDescOff;                                                                     \
-    uint4 *stage_s = smem + kStageStepOff;                                                                     \
+    uint4 *stage_d = smem + kStageOff;                                                                         \
+    uint4 *stage_s = stage_d + kChunkDescs;                                                                    \
     uint4 *rl = smem + kStageEnd;                                                                              \
     uint4 *wl = rl + TI;                                                                                       \
     load_te_dual(te, a.te0);                                                                                   \
@@ -175,6 +177,9 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
 #define GC_CHUNK_PREFETCH()                                                                                    \
+    stage_d = smem + kStageOff + (c & 1u) * kStageBuf;                                                         \
+    stage_s = stage_d + kChunkDescs;                                                                           \
+    uint4 *stage_dn = smem + kStageOff + ((c + 1) & 1u) * kStageBuf, *stage_sn = stage_dn + kChunkDescs;       \
     const Chunk nx = read_chunk(a.chunks, c + 1, a.nchunks);                                                   \
     const bool stage_next = nx.ndesc <= kChunkDescs;                                                           \
     uint4 pre_d[PF];                                                                                           \
@@ -188,17 +193,15 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
     const bool direct = ch.ndesc > kChunkDescs;
 
 #define GC_CHUNK_COMMIT()                                                                                      \
-    /* every reader of the staging area is past the last step's barrier */                                    \
+    /* the other staging buffer was last read by chunk c-1, which ended with a barrier: safe to fill now */  \
     _Pragma("unroll") for (int i = 0; i < PF; i++) {                                                           \
         const uint32_t kk = threadIdx.x + i * THREADS;                                                         \
-        if (stage_next && kk < nx.ndesc) stage_d[kk] = pre_d[i];                                               \
+        if (stage_next && kk < nx.ndesc) stage_dn[kk] = pre_d[i];                                              \
     }                                                                                                          \
     if (threadIdx.x < nx.nsteps) {                                                                             \
-        stage_s[2 * threadIdx.x] = make_uint4(pre_s.first, pre_s.count, pre_s.nonfree, pre_s.n_and);           \
-        stage_s[2 * threadIdx.x + 1] = make_uint4(pre_s.n_or, pre_s.n_inv, 0, 0);                             \
-    }                                                                                                          \
-    lds_barrier();                                                                                             \
-    ch = nx;
+        stage_sn[2 * threadIdx.x] = make_uint4(pre_s.first, pre_s.count, pre_s.nonfree, pre_s.n_and);          \
+        stage_sn[2 * threadIdx.x + 1] = make_uint4(pre_s.n_or, pre_s.n_inv, 0, 0);                            \
+    }
 
 #define GC_PROF_EPILOGUE()                                                                                     \
     if constexpr (PROF) {                                                                                      \
@@ -209,7 +212,7 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
 // ------------------------------------------------------------------------------------------------------
 template <int NR, int THREADS, int ILP, bool STORE_ALL, bool PROF>
 __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
-    constexpr int PF = (int)kChunkDescs / THREADS;
+    constexpr int PF = ((int)kChunkDescs + THREADS - 1) / THREADS;
     GC_LDS_PROLOGUE(true)
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
 
@@ -317,13 +320,16 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                     }
                 }
                 GC_LPROF(2)
-                lds_barrier();
-                GC_LPROF(3)
+                if (sidx < ch.nsteps) {
+                    lds_barrier();
+                    GC_LPROF(3)
+                }
             }
         }
         // ---- XOR sub-levels (garble.go:331-351): LDS in, LDS out, NO workgroup barriers.  Wave w owns
         // the instances [w*OI, (w+1)*OI) of the tile; a wave's DS operations execute in order, so the
         // labels one sub-level writes are visible to the next one without any synchronisation.
+        GC_CHUNK_COMMIT()
         if (sidx < ch.nsteps) {
             if (wave < NW && !direct) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
@@ -374,10 +380,10 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                 }
             }
             GC_LPROF(1)
-            lds_barrier();
-            GC_LPROF(3)
         }
-        GC_CHUNK_COMMIT()
+        lds_barrier();  // ends the chunk: XOR results and the freshly staged descriptors become visible
+        GC_LPROF(3)
+        ch = nx;
     }
     GC_PROF_EPILOGUE()
 }
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
 // ------------------------------------------------------------------------------------------------------
 template <int NR, int THREADS, int ILP, bool STORE_ALL, bool PROF>
 __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
-    constexpr int PF = (int)kChunkDescs / THREADS;
+    constexpr int PF = ((int)kChunkDescs + THREADS - 1) / THREADS;
     GC_LDS_PROLOGUE(false)
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
 
@@ -472,11 +478,14 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                     }
                 }
                 GC_LPROF(2)
-                lds_barrier();
-                GC_LPROF(3)
+                if (sidx < ch.nsteps) {
+                    lds_barrier();
+                    GC_LPROF(3)
+                }
             }
         }
         // ---- XOR sub-levels (eval.go:49-51), wave-local like in the garbler ----
+        GC_CHUNK_COMMIT()
         if (sidx < ch.nsteps) {
             if (wave < NW && !direct) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
@@ -525,10 +534,10 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                 }
             }
             GC_LPROF(1)
-            lds_barrier();
-            GC_LPROF(3)
         }
-        GC_CHUNK_COMMIT()
+        lds_barrier();  // ends the chunk: XOR results and the freshly staged descriptors become visible
+        GC_LPROF(3)
+        ch = nx;
     }
     GC_PROF_EPILOGUE()
 }

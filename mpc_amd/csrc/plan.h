@@ -51,8 +51,8 @@ constexpr uint32_t kFLevelStart = 1u << 17;  // first descriptor of an XOR sub-l
 // Descriptor staging unit of the LDS schedule: a run of whole steps whose descriptors (<= kChunkDescs)
 // and step records (<= kChunkSteps) are copied into LDS in one go while the previous chunk executes.
 // A chunk normally is one hash phase plus the XOR sub-levels that follow it.
-constexpr uint32_t kChunkDescs = 1024;
-constexpr uint32_t kChunkSteps = 64;
+constexpr uint32_t kChunkDescs = 768;
+constexpr uint32_t kChunkSteps = 32;
 struct Chunk {
     uint32_t first_step, nsteps;
     uint32_t first_desc, ndesc;  // ndesc > kChunkDescs only for a single over-wide step (read from HBM directly)
