@@ -225,9 +225,10 @@ float gc_batch_last_ms(gc_batch *);
 /* kernel launches issued by the most recent garble / eval */
 uint32_t gc_batch_last_launches(gc_batch *);
 /* developer aid: s_memtime breakdown of the fused kernels.  enable != 0 switches the instrumented
- * build of the kernel on for subsequent passes; out8 (may be NULL) receives, averaged over
- * workgroups, cycles of wave 0 in {descriptor fetch, label loads, hash+stores, barrier wait} followed
- * by the same four for the last wave, from the most recent instrumented pass. */
+ * build of the kernel on for subsequent passes; out16 (may be NULL) receives, averaged over
+ * workgroups, 8 cycle counters of wave 0 {prologue, hash phase, barrier after hash, staging commit,
+ * XOR run, chunk-end barrier, -, -} followed by the same 8 for wave 3, from the most recent
+ * instrumented pass. */
 int gc_batch_debug_profile(gc_batch *, int enable, uint64_t *out8);
 
 /* ------------------------------------------------------------------------------------------

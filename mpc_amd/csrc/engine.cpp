@@ -561,13 +561,13 @@ int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     GC_HIP(hipStreamSynchronize(ctx->stream));
-    const size_t n = (size_t)b->g.ntiles * 8;
-    if (out8 && b->d_prof) {  // average over workgroups
+    const size_t n = (size_t)b->g.ntiles * 16;
+    if (out8 && b->d_prof) {  // average over workgroups (16 counters per workgroup)
         std::vector<uint64_t> h(n);
         GC_HIP(hipMemcpy(h.data(), b->d_prof, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < 16; k++) {
             unsigned __int128 acc = 0;
-            for (uint32_t t = 0; t < b->g.ntiles; t++) acc += h[(size_t)t * 8 + k];
+            for (uint32_t t = 0; t < b->g.ntiles; t++) acc += h[(size_t)t * 16 + k];
             out8[k] = (uint64_t)(acc / b->g.ntiles);
         }
     }

@@ -173,7 +173,7 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
                                                                              : (uint32_t)__builtin_ctz(THREADS / 64); \
     const uint32_t NW = 1u << nw_log2, oi_log2 = ti_log2 - nw_log2;                                            \
     const uint32_t xinst = (wave << oi_log2) + (lane & ((1u << oi_log2) - 1));                                 \
-    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;                                                                \
+    uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;                                                                \
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
 #define GC_CHUNK_PREFETCH()                                                                                    \
@@ -205,8 +205,8 @@ __device__ __forceinline__ FDesc stage_desc(const uint4 *stage_d, const FDesc *d
 
 #define GC_PROF_EPILOGUE()                                                                                     \
     if constexpr (PROF) {                                                                                      \
-        if (threadIdx.x == 0 || threadIdx.x == THREADS - 64)                                                   \
-            for (int i = 0; i < 4; i++) a.prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];  \
+        if (threadIdx.x == 0 || threadIdx.x == 192)                                                   \
+            for (int i = 0; i < 8; i++) a.prof[(size_t)blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + i] = pacc[i]; \
     }
 
 // ------------------------------------------------------------------------------------------------------
@@ -319,10 +319,10 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                         }
                     }
                 }
-                GC_LPROF(2)
+                GC_LPROF(1)
                 if (sidx < ch.nsteps) {
                     lds_barrier();
-                    GC_LPROF(3)
+                    GC_LPROF(2)
                 }
             }
         }
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
         // the instances [w*OI, (w+1)*OI) of the tile; a wave's DS operations execute in order, so the
         // labels one sub-level writes are visible to the next one without any synchronisation.
         GC_CHUNK_COMMIT()
+        GC_LPROF(3)
         if (sidx < ch.nsteps) {
             if (wave < NW && !direct) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
@@ -379,10 +380,10 @@ __global__ __launch_bounds__(THREADS) void k_garble_lds(LdsArgs a) {
                     }
                 }
             }
-            GC_LPROF(1)
+            GC_LPROF(4)
         }
         lds_barrier();  // ends the chunk: XOR results and the freshly staged descriptors become visible
-        GC_LPROF(3)
+        GC_LPROF(5)
         ch = nx;
     }
     GC_PROF_EPILOGUE()
@@ -477,15 +478,16 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                         }
                     }
                 }
-                GC_LPROF(2)
+                GC_LPROF(1)
                 if (sidx < ch.nsteps) {
                     lds_barrier();
-                    GC_LPROF(3)
+                    GC_LPROF(2)
                 }
             }
         }
         // ---- XOR sub-levels (eval.go:49-51), wave-local like in the garbler ----
         GC_CHUNK_COMMIT()
+        GC_LPROF(3)
         if (sidx < ch.nsteps) {
             if (wave < NW && !direct) {
                 // flat stream over all XOR descriptors of the chunk: an iteration takes up to 64>>oi gates
@@ -533,10 +535,10 @@ __global__ __launch_bounds__(THREADS) void k_eval_lds(LdsArgs a) {
                     }
                 }
             }
-            GC_LPROF(1)
+            GC_LPROF(4)
         }
         lds_barrier();  // ends the chunk: XOR results and the freshly staged descriptors become visible
-        GC_LPROF(3)
+        GC_LPROF(5)
         ch = nx;
     }
     GC_PROF_EPILOGUE()

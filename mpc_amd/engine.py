@@ -332,7 +332,7 @@ class Batch:
         _check(lib().gc_batch_gather_outputs(self.h, C.c_void_p(d_out)), "gc_batch_gather_outputs")
 
     def debug_profile(self, enable=True, read=False):
-        out = np.zeros(8, np.uint64) if read else None
+        out = np.zeros(16, np.uint64) if read else None
         _check(lib().gc_batch_debug_profile(self.h, 1 if enable else 0, _p(out)), "gc_batch_debug_profile")
         return out
 

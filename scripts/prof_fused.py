@@ -22,9 +22,9 @@ gb.debug_profile(True); ev.debug_profile(True)
 gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
 ctx.sync()
 print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
-names = ["prologue", "xor", "hash", "barrier"]
+names = ["prologue", "hash", "barA", "commit", "xor", "barB"]
 for nm, b in (("garble", gb), ("eval", ev)):
     p = b.debug_profile(True, read=True)
-    tot0, tot1 = sum(p[:4]), sum(p[4:])
-    print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:4])}, "total", int(tot0), "cycles =", "%.3f ms @100MHz" % (tot0 / 1e5))
-    print(nm, "waveN:", {n: int(v) for n, v in zip(names, p[4:])}, "total", int(tot1))
+    tot0, tot1 = sum(p[:8]), sum(p[8:])
+    print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:6])}, "total", int(tot0))
+    print(nm, "wave3:", {n: int(v) for n, v in zip(names, p[8:14])}, "total", int(tot1))
