@@ -219,6 +219,18 @@ void *gc_batch_dev_r(gc_batch *);
 /* output-wire labels gathered into a dense device buffer gc_label [noutputs][bstride] */
 int gc_batch_gather_outputs(gc_batch *, void *d_out);
 
+/* Table egress / ingest in the wire format of the 2-party driver, on the device:
+ * replaces the per-gate SendUint32(len) + SendLabel loop of circuit.Garbler (circuit/garbler.go:69-82) and the
+ * receive loop of circuit.Evaluator (circuit/evaluator.go:40-66).  Per instance:
+ *   BE32(#gates) | per gate: BE32(#rows) rows x BE(D0)||BE(D1)        = gc_tables_wire_bytes() bytes
+ * so the host hands the buffer to conn.Write / fills it from the conn in one piece.
+ * d_out / d_in: device byte buffers, `stride` bytes between instances (multiple of 4, >= the size).
+ * ingest: *d_bad (u32, device) counts headers that do not match the circuit ("wrong number of gates",
+ * evaluator.go:44-47; row counts that Eval would reject, eval.go:54-56,86-89). */
+size_t gc_tables_wire_bytes(const gc_circ *);
+int gc_batch_egress_tables(gc_batch *, void *d_out, size_t stride);
+int gc_batch_ingest_tables(gc_batch *, const void *d_in, size_t stride, void *d_bad);
+
 /* timing of the most recent garble / eval on this batch, measured with HIP events recorded on
  * the ctx stream around the level launches (ms); negative if none */
 float gc_batch_last_ms(gc_batch *);

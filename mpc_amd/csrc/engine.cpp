@@ -118,6 +118,12 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_out_slots, p.out_slots.data(), p.out_slots.size() * sizeof(uint32_t));
         up((void **)&c->d_slot_of_wire, p.slot_of_wire.data(), p.slot_of_wire.size() * sizeof(uint32_t));
         up((void **)&c->d_steps, p.levels.data(), p.levels.size() * sizeof(Step));
+        {
+            std::vector<uint8_t> ops(ngates);
+            for (uint32_t i = 0; i < ngates; i++) ops[i] = gates[i].op;
+            up((void **)&c->d_ops, ops.data(), ops.size());
+            up((void **)&c->d_row_of_gate, p.row_of_gate.data(), p.row_of_gate.size() * sizeof(uint32_t));
+        }
         up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
         up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
@@ -145,6 +151,8 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_out_slots) (void)hipFree(c->d_out_slots);
     if (c->d_slot_of_wire) (void)hipFree(c->d_slot_of_wire);
     if (c->d_steps) (void)hipFree(c->d_steps);
+    if (c->d_ops) (void)hipFree(c->d_ops);
+    if (c->d_row_of_gate) (void)hipFree(c->d_row_of_gate);
     if (c->d_fdescs) (void)hipFree(c->d_fdescs);
     if (c->d_fgslot) (void)hipFree(c->d_fgslot);
     if (c->d_fsteps) (void)hipFree(c->d_fsteps);
@@ -578,6 +586,32 @@ int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
         (void)hipFree(b->d_prof);
         b->d_prof = nullptr;
     }
+    return GC_OK;
+}
+
+size_t gc_tables_wire_bytes(const gc_circ *c) {
+    if (!c) return 0;
+    const gc_plan_info &i = c->plan.p.info;
+    return 4 + 4 * (size_t)i.ngates + 16 * (size_t)i.slab_rows;
+}
+
+int gc_batch_egress_tables(gc_batch *b, void *d_out, size_t stride) {
+    if (!b || !d_out || stride < gc_tables_wire_bytes(b->circ) || (stride & 3)) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_tables_egress(b->d_T, b->g.lt, b->circ->d_ops, b->circ->d_row_of_gate, b->circ->plan.p.info.ngates,
+                         b->g.batch, (uint8_t *)d_out, stride, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_batch_ingest_tables(gc_batch *b, const void *d_in, size_t stride, void *d_bad) {
+    if (!b || !d_in || !d_bad || stride < gc_tables_wire_bytes(b->circ) || (stride & 3)) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_tables_ingest(b->d_T, b->g.lt, b->circ->d_ops, b->circ->d_row_of_gate, b->circ->plan.p.info.ngates,
+                         b->g.batch, (const uint8_t *)d_in, stride, (uint32_t *)d_bad, ctx->stream);
+    GC_HIP(hipGetLastError());
     return GC_OK;
 }
 

@@ -40,6 +40,8 @@ struct gc_circ {
     uint32_t *d_out_slots = nullptr;
     uint32_t *d_slot_of_wire = nullptr;
     gc::Step *d_steps = nullptr;
+    uint8_t *d_ops = nullptr;            // op of every gate, original order (table egress / ingest)
+    uint32_t *d_row_of_gate = nullptr;   // first slab row of every gate, original order
     gc::FDesc *d_fdescs = nullptr;   // LDS schedule
     uint32_t *d_fgslot = nullptr;
     gc::Step *d_fsteps = nullptr;

@@ -453,4 +453,62 @@ void launch_gather_rows(const uint4 *W, const uint32_t *slots, uint32_t n, uint4
     hipLaunchKernelGGL(k_gather_rows, grid, dim3(256), 0, s, W, slots, n, dst, g.batch, g.bstride, g.lw);
 }
 
+// ---- table egress / ingest (wire format of garbler.go:69-82 / evaluator.go:40-66) -----------------------
+
+__device__ __forceinline__ uint32_t rows_of_op(uint32_t op) { return op == GC_AND ? 2u : op == GC_OR ? 3u : op == GC_INV ? 1u : 0u; }
+
+// thread = (gate, instance); consecutive threads of a wave = consecutive gates of one instance, so the 4..52
+// bytes each thread writes are adjacent to its neighbours'
+__global__ __launch_bounds__(256) void k_tables_egress(const uint4 *__restrict__ T, Layout lt,
+                                                       const uint8_t *__restrict__ ops,
+                                                       const uint32_t *__restrict__ row_of_gate, uint32_t ngates,
+                                                       uint8_t *__restrict__ out, size_t stride) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, inst = blockIdx.y;
+    uint32_t *base = (uint32_t *)(out + (size_t)inst * stride);
+    if (g == 0) base[0] = bswap32(ngates);
+    if (g >= ngates) return;
+    const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
+    uint32_t *p = base + 1 + g + 4 * (size_t)row;  // byte offset 4 + 4g + 16 row
+    p[0] = bswap32(n);
+    for (uint32_t r = 0; r < n; r++) {
+        const uint4 v = T[lt.at(row + r, inst)];
+        p[1 + 4 * r] = bswap32(v.y);  // BE(D0) || BE(D1)
+        p[2 + 4 * r] = bswap32(v.x);
+        p[3 + 4 * r] = bswap32(v.w);
+        p[4 + 4 * r] = bswap32(v.z);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tables_ingest(uint4 *__restrict__ T, Layout lt, const uint8_t *__restrict__ ops,
+                                                       const uint32_t *__restrict__ row_of_gate, uint32_t ngates,
+                                                       const uint8_t *__restrict__ in, size_t stride,
+                                                       uint32_t *__restrict__ bad) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, inst = blockIdx.y;
+    const uint32_t *base = (const uint32_t *)(in + (size_t)inst * stride);
+    if (g == 0 && bswap32(base[0]) != ngates) atomicAdd(bad, 1u);
+    if (g >= ngates) return;
+    const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
+    const uint32_t *p = base + 1 + g + 4 * (size_t)row;
+    if (bswap32(p[0]) != n) {
+        atomicAdd(bad, 1u);
+        return;
+    }
+    for (uint32_t r = 0; r < n; r++)
+        T[lt.at(row + r, inst)] =
+            make_uint4(bswap32(p[2 + 4 * r]), bswap32(p[1 + 4 * r]), bswap32(p[4 + 4 * r]), bswap32(p[3 + 4 * r]));
+}
+
+void launch_tables_egress(const uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
+                          uint32_t ngates, uint32_t batch, uint8_t *out, size_t stride, hipStream_t s) {
+    dim3 grid((ngates + 256) / 256, batch);
+    hipLaunchKernelGGL(k_tables_egress, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, out, stride);
+}
+
+void launch_tables_ingest(uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
+                          uint32_t ngates, uint32_t batch, const uint8_t *in, size_t stride, uint32_t *bad,
+                          hipStream_t s) {
+    dim3 grid((ngates + 256) / 256, batch);
+    hipLaunchKernelGGL(k_tables_ingest, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, in, stride, bad);
+}
+
 }  // namespace gc

@@ -115,6 +115,16 @@ void launch_decode(const uint4 *Wg, const uint4 *R, const uint4 *We, const uint3
 void launch_gather_rows(const uint4 *W, const uint32_t *slots, uint32_t n, uint4 *dst, const BatchGeom &g,
                         hipStream_t s);
 
+// Table egress / ingest in the wire format of circuit.Garbler / circuit.Evaluator (garbler.go:69-82,
+// evaluator.go:40-66): per instance  BE32(#gates) | per gate BE32(#rows) + rows as BE(D0)||BE(D1).
+// ops[g] / rows[g] are in ORIGINAL gate order.  stride = bytes between instances in the byte buffer.
+void launch_tables_egress(const uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
+                          uint32_t ngates, uint32_t batch, uint8_t *out, size_t stride, hipStream_t s);
+// *bad is incremented for every header that does not match (gate count, per-gate row count)
+void launch_tables_ingest(uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
+                          uint32_t ngates, uint32_t batch, const uint8_t *in, size_t stride, uint32_t *bad,
+                          hipStream_t s);
+
 // ---- OT kernels (ot_kernels.hip) -------------------------------------------------------------
 // Column AES-128-CTR PRG of IKNP.  rk0/rk1: [128][44] expanded column keys (big-endian words);
 // pos0: bytes every column stream has already produced; n OTs -> chunks of 512.

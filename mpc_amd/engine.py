@@ -104,6 +104,9 @@ def lib():
         "gc_batch_dev_slab": (vp, [vp]),
         "gc_batch_dev_r": (vp, [vp]),
         "gc_batch_gather_outputs": (i32, [vp, vp]),
+        "gc_tables_wire_bytes": (sz, [vp]),
+        "gc_batch_egress_tables": (i32, [vp, vp, sz]),
+        "gc_batch_ingest_tables": (i32, [vp, vp, sz, vp]),
         "gc_batch_last_ms": (C.c_float, [vp]),
         "gc_batch_last_launches": (u32, [vp]),
         "gc_batch_debug_profile": (i32, [vp, i32, vp]),
@@ -219,6 +222,10 @@ class DeviceCircuit:
     def set_schedule(self, schedule):
         _check(lib().gc_circ_set_schedule(self.h, schedule), "gc_circ_set_schedule")
 
+    @property
+    def tables_wire_bytes(self):
+        return int(lib().gc_tables_wire_bytes(self.h))
+
     # -- host-buffer API: Circuit.Garble / Circuit.Eval with a batch dimension --
 
     def garble(self, key, rnd, batch=1, want_wires=False, want_io=True):
@@ -327,6 +334,13 @@ class Batch:
         s = np.ascontiguousarray(slab, dtype=LABEL)
         assert s.size == self.batch * self.dc.info.slab_rows
         _check(lib().gc_batch_write_slab(self.h, _p(s)), "gc_batch_write_slab")
+
+    def egress_tables(self, d_out, stride):
+        _check(lib().gc_batch_egress_tables(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables")
+
+    def ingest_tables(self, d_in, stride, d_bad):
+        _check(lib().gc_batch_ingest_tables(self.h, C.c_void_p(d_in), stride, C.c_void_p(d_bad)),
+               "gc_batch_ingest_tables")
 
     def gather_outputs(self, d_out):
         _check(lib().gc_batch_gather_outputs(self.h, C.c_void_p(d_out)), "gc_batch_gather_outputs")

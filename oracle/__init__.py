@@ -469,3 +469,26 @@ class StreamEval:
         if getattr(self, "h", None) and _lib is not None:
             _lib.orc_stream_eval_free(C.c_void_p(self.h))
             self.h = None
+
+
+# ---- table wire format ---------------------------------------------------------------------------
+
+
+def tables_serialize(gates, slab):
+    g = np.ascontiguousarray(gates, dtype=GATE)
+    sl = np.ascontiguousarray(slab, dtype=LABEL)
+    out = np.zeros(4 + 4 * len(g) + 16 * len(sl), np.uint8)
+    lib().orc_tables_serialize.restype = C.c_size_t
+    n = lib().orc_tables_serialize(_p(g), C.c_uint32(len(g)), _p(sl) if len(sl) else None, _p(out))
+    return out[:n].tobytes()
+
+
+def tables_parse(gates, data):
+    g = np.ascontiguousarray(gates, dtype=GATE)
+    b = _u8(data)
+    slab = np.zeros(max(slab_rows(g), 1), LABEL)
+    lib().orc_tables_parse.restype = C.c_long
+    n = lib().orc_tables_parse(_p(g), C.c_uint32(len(g)), _p(b), C.c_size_t(len(b)), _p(slab))
+    if n < 0:
+        raise OracleError(n, "tables_parse")
+    return slab[:n]

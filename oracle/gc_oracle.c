@@ -384,6 +384,52 @@ uint32_t orc_assign_levels(orc_gate *gates, uint32_t ngates, uint32_t nwires, ui
     return max;
 }
 
+/* ---- table wire format: garbler.go:69-82 / evaluator.go:40-66 ------------------------------------ */
+
+static void put_be32(uint8_t *p, uint32_t v) {
+    p[0] = (uint8_t)(v >> 24);
+    p[1] = (uint8_t)(v >> 16);
+    p[2] = (uint8_t)(v >> 8);
+    p[3] = (uint8_t)v;
+}
+static uint32_t get_be32(const uint8_t *p) {
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+}
+static int rows_of(uint8_t op) { return op == ORC_AND ? 2 : op == ORC_OR ? 3 : op == ORC_INV ? 1 : 0; }
+
+size_t orc_tables_serialize(const orc_gate *gates, uint32_t ngates, const orc_label *slab, uint8_t *out) {
+    size_t pos = 0, row = 0;
+    put_be32(out, ngates); /* conn.SendUint32(len(garbled.Gates)) */
+    pos = 4;
+    for (uint32_t i = 0; i < ngates; i++) {
+        int n = rows_of(gates[i].op);
+        put_be32(out + pos, (uint32_t)n); /* SendUint32(len(data)) */
+        pos += 4;
+        for (int r = 0; r < n; r++) { /* SendLabel */
+            orc_label_get_data(&slab[row++], out + pos);
+            pos += 16;
+        }
+    }
+    return pos;
+}
+
+long orc_tables_parse(const orc_gate *gates, uint32_t ngates, const uint8_t *in, size_t len, orc_label *slab) {
+    if (len < 4 || get_be32(in) != ngates) return ORC_E_ARG; /* "wrong number of gates" */
+    size_t pos = 4, row = 0;
+    for (uint32_t i = 0; i < ngates; i++) {
+        if (pos + 4 > len) return ORC_E_ROWS;
+        uint32_t n = get_be32(in + pos);
+        pos += 4;
+        if ((int)n != rows_of(gates[i].op)) return ORC_E_ROWS; /* surfaces in Eval (eval.go:54-56,86-89) */
+        for (uint32_t r = 0; r < n; r++) {
+            if (pos + 16 > len) return ORC_E_ROWS;
+            orc_label_set_data(&slab[row++], in + pos);
+            pos += 16;
+        }
+    }
+    return (long)row;
+}
+
 /* ---- CPU baseline: serial garble+eval loop, one instance per iteration --- */
 
 #include <pthread.h>

@@ -158,6 +158,14 @@ void orc_mul128(orc_label a, orc_label b, orc_label *lo, orc_label *hi);
 void orc_mul128_ref(orc_label a, orc_label b, orc_label *lo, orc_label *hi); /* mul128_ref.go:9 */
 void orc_inner_product(const orc_label *a, const orc_label *b, size_t n, orc_label *r1, orc_label *r2);
 
+/* ---- garbled-table wire format of the 2-party driver ------------------------------------------- */
+/* circuit/garbler.go:69-82: SendUint32(#gates), then per gate SendUint32(len) + SendLabel per row
+ * (big-endian u32, labels as BE(D0)||BE(D1)).  Returns bytes written (4 + 4*ngates + 16*rows). */
+size_t orc_tables_serialize(const orc_gate *gates, uint32_t ngates, const orc_label *slab, uint8_t *out);
+/* circuit/evaluator.go:40-66: parse the same bytes back into a dense slab; negative on a gate count
+ * mismatch ("wrong number of gates") or a row count that does not fit the gate type */
+long orc_tables_parse(const orc_gate *gates, uint32_t ngates, const uint8_t *in, size_t len, orc_label *slab);
+
 /* ---- Streaming garbler / evaluator: circuit/stream_garble.go, circuit/stream_evaluator.go ---- */
 typedef struct orc_stream orc_stream;
 /* NewStreaming (stream_garble.go:41-75): rnd = R (16 B) then one L0 per entry of inputs[] */
