@@ -267,6 +267,20 @@ int gc_iknp_receive(gc_iknp *, const uint8_t *choice, size_t n, uint8_t *u_out, 
 /* Replaces the body of (*IKNPSender).send(n)   ot/iknp.go:197-226 (u_in = the received chunks, concatenated) */
 int gc_iknp_send(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out);
 
+/* KOS consistency check of the malicious variant: the chi-PRG + GF(2^128) inner products of
+ * (*IKNPReceiver).Receive (ot/iknp.go:405-465) and (*IKNPSender).Send (ot/iknp.go:138-194; gf128.go:14-27,
+ * mul128_generic.go).  chi_i = label i of the AES-128-CTR stream keyed by seed2: 0..n-1 for `result`,
+ * n..n+255 for the 256-label random choice vector.
+ *  receiver: x = XOR_{b_i} chi_i, (t0,t1) = XOR_i chi_i * result_i (256-bit, no reduction)
+ *  sender:   *ok = ((q0,q1) ^ x*Delta == (t0,t1)) with (q0,q1) the same sum over its own labels;
+ *            ok == 0 is the reference's "OT extension check failed" */
+int gc_kos_receiver_tags(gc_ctx *, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
+                         const gc_label *choice_vec, const uint8_t *bcv /*256*/, gc_label *x, gc_label *t0,
+                         gc_label *t1);
+int gc_kos_sender_check(gc_ctx *, const gc_label *seed2, const gc_label *result, size_t n,
+                        const gc_label *choice_vec /*256*/, const gc_label *delta, const gc_label *x,
+                        const gc_label *t0, const gc_label *t1, int *ok);
+
 /* Replaces (*MITCCRH).Hash over a whole COT/ROT run (mitccrh.go:93-128 as driven by cot.go:160-171,
  * 203-211): OT j (key index gid0+j, key = BE(Label{D0:gid,D1:0} ^ seed)) hashes its h consecutive
  * blocks in place: blk ^= AES_key(blk).  blks = [n][h] */

@@ -136,6 +136,9 @@ void launch_iknp_prg(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64
 // createLabels over all chunks of tbuf
 void launch_iknp_transpose(const uint8_t *tbuf, size_t n, uint4 *labels, hipStream_t s);
 void launch_pack_bits(const uint8_t *b, size_t n, uint8_t *out, hipStream_t s);
+// KOS check accumulators: acc[0..3] ^= XOR chi_i * v_i (256 bit), acc[4..5] ^= XOR_{bits_i} chi_i
+void launch_kos_accumulate(const uint32_t *rk, uint64_t idx0, const uint4 *v, const uint8_t *bits, size_t n,
+                           unsigned long long *acc, const uint32_t *te0, hipStream_t s);
 // blk[j*h + t] ^= AES_{key(gid0+j)}(blk[j*h+t])
 void launch_mitccrh(uint4 seed, uint64_t gid0, uint4 *blks, size_t n, uint32_t h, const uint32_t *te0,
                     hipStream_t s);

@@ -165,6 +165,81 @@ int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_lab
     return GC_OK;
 }
 
+// ---- KOS consistency check --------------------------------------------------------------------------------
+
+static void host_clmul128(const gc_label &a, const gc_label &b, uint64_t out[4]) {  // mul128_generic.go
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const uint64_t aw[2] = {a.d0, a.d1}, bw[2] = {b.d0, b.d1};
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) {
+            uint64_t lo = 0, hi = 0;
+            for (int k = 0; k < 64; k++)
+                if ((bw[j] >> k) & 1) {
+                    lo ^= aw[i] << k;
+                    if (k) hi ^= aw[i] >> (64 - k);
+                }
+            out[i + j] ^= lo;
+            out[i + j + 1] ^= hi;
+        }
+}
+
+// acc[6] <- sums over (result, b) then (choice_vec, bcv); shared by both roles
+static int kos_sums(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
+                    const gc_label *choice_vec, const uint8_t *bcv, uint64_t acc[6]) {
+    GC_HIP(hipSetDevice(ctx->device));
+    uint32_t rk[44];
+    expand_label_key(*seed2, rk);  // newPrg(seed2) (iknp.go:150, 411)
+    DevBuf d_rk, d_v, d_b, d_acc;
+    const size_t m = n + 256;
+    GC_HIP(d_rk.alloc(sizeof rk));
+    GC_HIP(d_v.alloc(m * sizeof(uint4)));
+    GC_HIP(d_b.alloc(m));
+    GC_HIP(d_acc.alloc(6 * sizeof(uint64_t)));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipMemcpyAsync(d_rk.p, rk, sizeof rk, hipMemcpyHostToDevice, s));
+    if (n) GC_HIP(hipMemcpyAsync(d_v.p, result, n * sizeof(uint4), hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemcpyAsync((uint4 *)d_v.p + n, choice_vec, 256 * sizeof(uint4), hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemsetAsync(d_b.p, 0, m, s));
+    if (b && n) GC_HIP(hipMemcpyAsync(d_b.p, b, n, hipMemcpyHostToDevice, s));
+    if (bcv) GC_HIP(hipMemcpyAsync((uint8_t *)d_b.p + n, bcv, 256, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemsetAsync(d_acc.p, 0, 6 * sizeof(uint64_t), s));
+    // chi labels are consecutive in the stream: results first, then the choice vector (iknp.go:159-174)
+    launch_kos_accumulate((const uint32_t *)d_rk.p, 0, (const uint4 *)d_v.p, (const uint8_t *)d_b.p, m,
+                          (unsigned long long *)d_acc.p, ctx->d_te0, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(acc, d_acc.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GC_HIP(hipStreamSynchronize(s));
+    return GC_OK;
+}
+
+int gc_kos_receiver_tags(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
+                         const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) {
+    if (!ctx || !seed2 || !choice_vec || !bcv || !x || !t0 || !t1 || (n && (!result || !b))) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint64_t acc[6];
+    int rc = kos_sums(ctx, seed2, result, b, n, choice_vec, bcv, acc);
+    if (rc != GC_OK) return rc;
+    *t0 = gc_label{acc[0], acc[1]};
+    *t1 = gc_label{acc[2], acc[3]};
+    *x = gc_label{acc[4], acc[5]};
+    return GC_OK;
+}
+
+int gc_kos_sender_check(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, size_t n,
+                        const gc_label *choice_vec, const gc_label *delta, const gc_label *x, const gc_label *t0,
+                        const gc_label *t1, int *ok) {
+    if (!ctx || !seed2 || !choice_vec || !delta || !x || !t0 || !t1 || !ok || (n && !result)) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint64_t acc[6];
+    int rc = kos_sums(ctx, seed2, result, nullptr, n, choice_vec, nullptr, acc);
+    if (rc != GC_OK) return rc;
+    uint64_t r[4];
+    host_clmul128(*x, *delta, r);  // mul128(x, s.Delta) (iknp.go:186)
+    *ok = (acc[0] ^ r[0]) == t0->d0 && (acc[1] ^ r[1]) == t0->d1 && (acc[2] ^ r[2]) == t1->d0 &&
+          (acc[3] ^ r[3]) == t1->d1;
+    return GC_OK;
+}
+
 int gc_mitccrh_hash(gc_ctx *ctx, const gc_label *seed, uint64_t gid0, gc_label *blks, size_t n, uint32_t h) {
     if (!ctx || !seed || (n && !blks)) return GC_E_ARG;
     if (n == 0 || h == 0) return GC_OK;

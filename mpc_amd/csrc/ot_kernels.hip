@@ -330,6 +330,72 @@ void launch_cot_recv(uint4 seed, const uint8_t *flags, const uint4 *sent, uint4 
                        te0);
 }
 
+// ---- KOS consistency check (ot/iknp.go:138-194, 373-465; ot/gf128.go:14-27; ot/mul128_generic.go) --------
+// acc[0..3] ^= XOR_i chi_i * v_i (256-bit carry-less product, no reduction), acc[4..5] ^= XOR_{bits_i} chi_i,
+// chi_i = label (idx0 + i) of the AES-128-CTR stream keyed by seed2 (prgLabels, iknp.go:639-645).
+// 128-bit values are little-endian word vectors here: for mul128 D0 is the LOW limb (mul128_generic.go:10-11),
+// which is exactly the uint4 component order x,y,z,w.
+__global__ __launch_bounds__(256) void k_kos_accumulate(const uint32_t *__restrict__ rk, uint64_t idx0,
+                                                        const uint4 *__restrict__ v, const uint8_t *__restrict__ bits,
+                                                        size_t n, unsigned long long *__restrict__ acc,
+                                                        const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeWords];
+    load_te_tables(te, g_te0);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xs[4] = {0, 0, 0, 0};
+    if (i < n) {
+        uint64_t j[1] = {idx0 + i};
+        uint4 o[1];
+        ctr_blocks<1>(j, o, rk, te);  // stream bytes, little-endian packed
+        // Label.SetBytes: D0 = BE(bytes 0..7), D1 = BE(bytes 8..15)
+        const uint4 chi = make_uint4(bswap32d(o[0].y), bswap32d(o[0].x), bswap32d(o[0].w), bswap32d(o[0].z));
+        const uint4 b = v[i];
+        // carry-less 128 x 128 -> 256: shift-and-add over the bits of b (clmul64 loop of mul128_generic.go:30-46)
+        uint32_t cur[8] = {chi.x, chi.y, chi.z, chi.w, 0, 0, 0, 0};
+        const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll 1
+        for (int w = 0; w < 4; w++) {
+            uint32_t word = bw[w];
+#pragma unroll 4
+            for (int k = 0; k < 32; k++) {
+                const uint32_t m = 0u - (word & 1u);
+                word >>= 1;
+#pragma unroll
+                for (int q = 0; q < 8; q++) p[q] ^= cur[q] & m;
+#pragma unroll
+                for (int q = 7; q > 0; q--) cur[q] = __builtin_amdgcn_alignbit(cur[q], cur[q - 1], 31);
+                cur[0] <<= 1;
+            }
+        }
+        if (bits && bits[i]) {
+            xs[0] = chi.x;
+            xs[1] = chi.y;
+            xs[2] = chi.z;
+            xs[3] = chi.w;
+        }
+    }
+    // XOR-reduce over the wave, one 64-bit atomic per accumulator limb per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) p[q] ^= __shfl_xor(p[q], off, 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) xs[q] ^= __shfl_xor(xs[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int q = 0; q < 4; q++) atomicXor(&acc[q], ((unsigned long long)p[2 * q + 1] << 32) | p[2 * q]);
+        for (int q = 0; q < 2; q++) atomicXor(&acc[4 + q], ((unsigned long long)xs[2 * q + 1] << 32) | xs[2 * q]);
+    }
+}
+
+void launch_kos_accumulate(const uint32_t *rk, uint64_t idx0, const uint4 *v, const uint8_t *bits, size_t n,
+                           unsigned long long *acc, const uint32_t *te0, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_kos_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rk, idx0, v, bits, n, acc,
+                       te0);
+}
+
 // ---- IKNP launchers ----------------------------------------------------------------------------
 
 void launch_iknp_prg(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64_t pos0, size_t n,

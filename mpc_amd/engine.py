@@ -116,6 +116,8 @@ def lib():
         "gc_iknp_u_bytes": (sz, [sz]),
         "gc_iknp_receive": (i32, [vp, vp, sz, vp, vp]),
         "gc_iknp_send": (i32, [vp, vp, sz, sz, vp]),
+        "gc_kos_receiver_tags": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
+        "gc_kos_sender_check": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp, ip]),
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
@@ -477,3 +479,24 @@ def cot_receive_unpad(ctx, seed, flags, sent, result):
     r = np.ascontiguousarray(result, dtype=LABEL).copy()
     _check(lib().gc_cot_receive_unpad(ctx.h, _p(_lab1(seed)), _p(f), _p(s), _p(r), len(f)), "gc_cot_receive_unpad")
     return r
+
+
+def kos_receiver_tags(ctx, seed2, result, b, choice_vec, bcv):
+    r = np.ascontiguousarray(result, dtype=LABEL)
+    bb = np.ascontiguousarray(b, dtype=np.uint8)
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    bc = np.ascontiguousarray(bcv, dtype=np.uint8)
+    x, t0, t1 = np.zeros(1, LABEL), np.zeros(1, LABEL), np.zeros(1, LABEL)
+    _check(lib().gc_kos_receiver_tags(ctx.h, _p(_lab1(seed2)), _p(r) if len(r) else None, _p(bb) if len(r) else None,
+                                      len(r), _p(cv), _p(bc), _p(x), _p(t0), _p(t1)), "gc_kos_receiver_tags")
+    f = lambda a: (int(a[0]["d0"]), int(a[0]["d1"]))
+    return f(x), f(t0), f(t1)
+
+
+def kos_sender_check(ctx, seed2, result, choice_vec, delta, x, t0, t1):
+    r = np.ascontiguousarray(result, dtype=LABEL)
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    ok = C.c_int(0)
+    _check(lib().gc_kos_sender_check(ctx.h, _p(_lab1(seed2)), _p(r) if len(r) else None, len(r), _p(cv), _p(_lab1(delta)),
+                                     _p(_lab1(x)), _p(_lab1(t0)), _p(_lab1(t1)), C.byref(ok)), "gc_kos_sender_check")
+    return bool(ok.value)

@@ -492,3 +492,35 @@ def tables_parse(gates, data):
     if n < 0:
         raise OracleError(n, "tables_parse")
     return slab[:n]
+
+
+# ---- KOS consistency check ---------------------------------------------------------------------------
+
+
+def kos_receiver_tags(seed2, result, b, choice_vec, bcv):
+    r = np.ascontiguousarray(result, dtype=LABEL)
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    bb = np.ascontiguousarray(b, dtype=np.uint8)
+    bc = np.ascontiguousarray(bcv, dtype=np.uint8)
+    assert len(cv) == 256 and len(bc) == 256
+    x, t0, t1 = _Label(), _Label(), _Label()
+    if len(r) == 0:
+        r = np.zeros(1, LABEL)
+        bb = np.zeros(1, np.uint8)
+        n = 0
+    else:
+        n = len(result)
+    lib().orc_kos_receiver_tags(_lab(seed2), _p(r), _p(bb), C.c_size_t(n), _p(cv), _p(bc), C.byref(x), C.byref(t0),
+                                C.byref(t1))
+    return (x.d0, x.d1), (t0.d0, t0.d1), (t1.d0, t1.d1)
+
+
+def kos_sender_check(seed2, result, choice_vec, delta, x, t0, t1):
+    r = np.ascontiguousarray(result, dtype=LABEL)
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    n = len(r)
+    if n == 0:
+        r = np.zeros(1, LABEL)
+    lib().orc_kos_sender_check.argtypes = [_Label, C.c_void_p, C.c_size_t, C.c_void_p, _Label, _Label, _Label, _Label]
+    return bool(lib().orc_kos_sender_check(_lab(seed2), _p(r), C.c_size_t(n), _p(cv), _lab(delta), _lab(x), _lab(t0),
+                                           _lab(t1)))

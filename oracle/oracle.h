@@ -158,6 +158,17 @@ void orc_mul128(orc_label a, orc_label b, orc_label *lo, orc_label *hi);
 void orc_mul128_ref(orc_label a, orc_label b, orc_label *lo, orc_label *hi); /* mul128_ref.go:9 */
 void orc_inner_product(const orc_label *a, const orc_label *b, size_t n, orc_label *r1, orc_label *r2);
 
+/* ---- KOS consistency check of the malicious IKNP variant: ot/iknp.go:138-194 (sender), :373-465 (receiver) ----
+ * chi_i = i-th label of the AES-128-CTR stream keyed by seed2 (prgLabels, iknp.go:639-645): indices
+ * 0..n-1 for the extension results, n..n+255 for the 256-label random choice vector.
+ * receiver: t = XOR_i chi_i * result_i (256-bit, no reduction, gf128.go:14-27), x = XOR_{b_i} chi_i */
+void orc_kos_receiver_tags(orc_label seed2, const orc_label *result, const uint8_t *b, size_t n,
+                           const orc_label *choice_vec, const uint8_t *bcv /* 256 */, orc_label *x,
+                           orc_label *t0, orc_label *t1);
+/* sender: q = XOR_i chi_i * result_i ^ x * Delta; returns 1 iff (q0,q1) == (t0,t1)  ("OT extension check failed") */
+int orc_kos_sender_check(orc_label seed2, const orc_label *result, size_t n, const orc_label *choice_vec,
+                         orc_label delta, orc_label x, orc_label t0, orc_label t1);
+
 /* ---- garbled-table wire format of the 2-party driver ------------------------------------------- */
 /* circuit/garbler.go:69-82: SendUint32(#gates), then per gate SendUint32(len) + SendLabel per row
  * (big-endian u32, labels as BE(D0)||BE(D1)).  Returns bytes written (4 + 4*ngates + 16*rows). */

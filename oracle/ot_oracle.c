@@ -294,3 +294,52 @@ void orc_inner_product(const orc_label *a, const orc_label *b, size_t n, orc_lab
         r2->d1 ^= hi.d1;
     }
 }
+
+/* ---- KOS check: iknp.go:138-194, 373-465 ------------------------------------------------------------ */
+
+static void kos_accumulate(orc_prg *chi_prg, const orc_label *v, const uint8_t *bits, size_t n, orc_label *a0,
+                           orc_label *a1, orc_label *x) {
+    orc_label chi[1024];
+    for (size_t i = 0; i < n; i += 1024) { /* :159-168 / :428-447: blocks of len(chi) = 1024 */
+        size_t count = n - i < 1024 ? n - i : 1024;
+        orc_prg_labels(chi_prg, chi, count);
+        orc_label r0, r1;
+        orc_inner_product(chi, v + i, count, &r0, &r1);
+        a0->d0 ^= r0.d0;
+        a0->d1 ^= r0.d1;
+        a1->d0 ^= r1.d0;
+        a1->d1 ^= r1.d1;
+        if (bits && x)
+            for (size_t j = 0; j < count; j++)
+                if (bits[i + j]) {
+                    x->d0 ^= chi[j].d0;
+                    x->d1 ^= chi[j].d1;
+                }
+    }
+}
+
+void orc_kos_receiver_tags(orc_label seed2, const orc_label *result, const uint8_t *b, size_t n,
+                           const orc_label *choice_vec, const uint8_t *bcv, orc_label *x, orc_label *t0,
+                           orc_label *t1) {
+    orc_prg chi_prg;
+    orc_prg_init(&chi_prg, seed2);
+    x->d0 = x->d1 = t0->d0 = t0->d1 = t1->d0 = t1->d1 = 0;
+    kos_accumulate(&chi_prg, result, b, n, t0, t1, x);
+    kos_accumulate(&chi_prg, choice_vec, bcv, 256, t0, t1, x); /* :450-462 */
+}
+
+int orc_kos_sender_check(orc_label seed2, const orc_label *result, size_t n, const orc_label *choice_vec,
+                         orc_label delta, orc_label x, orc_label t0, orc_label t1) {
+    orc_prg chi_prg;
+    orc_prg_init(&chi_prg, seed2);
+    orc_label q0 = {0, 0}, q1 = {0, 0};
+    kos_accumulate(&chi_prg, result, NULL, n, &q0, &q1, NULL);
+    kos_accumulate(&chi_prg, choice_vec, NULL, 256, &q0, &q1, NULL);
+    orc_label r0, r1;
+    orc_mul128(x, delta, &r0, &r1); /* :186-188 */
+    q0.d0 ^= r0.d0;
+    q0.d1 ^= r0.d1;
+    q1.d0 ^= r1.d0;
+    q1.d1 ^= r1.d1;
+    return q0.d0 == t0.d0 && q0.d1 == t0.d1 && q1.d0 == t1.d0 && q1.d1 == t1.d1;
+}

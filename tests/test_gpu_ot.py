@@ -121,3 +121,26 @@ def test_cot_pipeline_delivers_chosen_label(ctx, n):
     for i in range(n):
         assert res[i] == (wires[i]["l1"] if flags[i] else wires[i]["l0"])
     rcv.close(); snd.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 129, 700, 5000])
+def test_kos_check_matches_oracle(ctx, n):
+    base, delta, k0 = base_setup("kos%d" % n)
+    rcv, snd = oracle.IKNPReceiver(base), oracle.IKNPSender(delta, k0)
+    b = (np.frombuffer(drbg("kb%d" % n, max(n, 1)), np.uint8)[:n] & 1).astype(np.uint8)
+    u, got = rcv.receive(b)
+    sent = snd.send(u, n)
+    bcv = (np.frombuffer(drbg("kbcv", 256), np.uint8) & 1).astype(np.uint8)
+    u2, cvr = rcv.receive(bcv)
+    cvs = snd.send(u2, 256)
+    seed2 = oracle.label_from_bytes(drbg("seed2", 16))
+    want = oracle.kos_receiver_tags(seed2, got, b, cvr, bcv)
+    have = engine.kos_receiver_tags(ctx, seed2, got, b, cvr, bcv)
+    assert have == want
+    x, t0, t1 = have
+    assert engine.kos_sender_check(ctx, seed2, sent, cvs, delta, x, t0, t1)
+    assert not engine.kos_sender_check(ctx, seed2, sent, cvs, delta, x, (t0[0] ^ 1, t0[1]), t1)
+    if n:
+        bad = sent.copy()
+        bad[n // 2]["d1"] ^= 1 << 40
+        assert not engine.kos_sender_check(ctx, seed2, bad, cvs, delta, x, t0, t1)

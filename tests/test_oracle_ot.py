@@ -83,3 +83,27 @@ def test_cot_delivers_chosen_label(n):
     res = oracle.cot_receive_unpad(seed, flags, sent, got)
     for i in range(n):
         assert res[i] == (wires[i]["l1"] if flags[i] else wires[i]["l0"])
+
+
+def test_kos_check_accepts_honest_rejects_tampered():
+    # malicious variant (iknp.go:138-194, 373-465): the sender's check passes on an honest run and fails when
+    # one receiver label is flipped ("OT extension check failed")
+    rcv, snd, delta = setup("kos")
+    n = 700
+    b = np.frombuffer(drbg("kb", n), np.uint8) & 1
+    u, got = rcv.receive(b)
+    sent = snd.send(u, n)
+    bcv = np.frombuffer(drbg("kbcv", 256), np.uint8) & 1
+    u2, cvr = rcv.receive(bcv)
+    cvs = snd.send(u2, 256)
+    seed2 = oracle.label_from_bytes(drbg("seed2", 16))
+    x, t0, t1 = oracle.kos_receiver_tags(seed2, got, b, cvr, bcv)
+    assert oracle.kos_sender_check(seed2, sent, cvs, delta, x, t0, t1)
+    bad = got.copy()
+    bad[5]["d0"] ^= 1
+    x2, t0b, t1b = oracle.kos_receiver_tags(seed2, bad, b, cvr, bcv)
+    assert not oracle.kos_sender_check(seed2, sent, cvs, delta, x2, t0b, t1b)
+    # x is the XOR of the chi labels selected by the choice bits
+    chi = oracle.Prg(seed2).labels(n + 256)
+    sel = np.concatenate([b, bcv]).astype(bool)
+    assert x == (int(np.bitwise_xor.reduce(chi["d0"][sel])), int(np.bitwise_xor.reduce(chi["d1"][sel])))
