@@ -267,6 +267,12 @@ int gc_iknp_receive(gc_iknp *, const uint8_t *choice, size_t n, uint8_t *u_out, 
 /* Replaces the body of (*IKNPSender).send(n)   ot/iknp.go:197-226 (u_in = the received chunks, concatenated) */
 int gc_iknp_send(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out);
 
+/* bit-COT: bodies of (*IKNPReceiver).ReceiveBits (ot/iknp.go:554-620) and
+ * (*IKNPSender).SendBits (ot/iknp.go:259-310); choices / result are packed little-endian u64 bit vectors.
+ * The reference only folds WHOLE 64-bit choice words into u (iknp.go:583-597); reproduced as is. */
+int gc_iknp_receive_bits(gc_iknp *, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result);
+int gc_iknp_send_bits(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, uint64_t *result);
+
 /* KOS consistency check of the malicious variant: the chi-PRG + GF(2^128) inner products of
  * (*IKNPReceiver).Receive (ot/iknp.go:405-465) and (*IKNPSender).Send (ot/iknp.go:138-194; gf128.go:14-27,
  * mul128_generic.go).  chi_i = label i of the AES-128-CTR stream keyed by seed2: 0..n-1 for `result`,

@@ -113,23 +113,21 @@ size_t gc_iknp_u_bytes(size_t n) {
 
 static size_t stream_advance(size_t n) { return (n / 512) * 64 + ((n % 512) + 7) / 8; }
 
-int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out) {
-    if (!k || !k->receiver || (n && (!choice || !u_out || !labels_out))) return GC_E_ARG;
-    if (n == 0) return GC_OK;
+// receive() with the choice bits already packed LSB-first, 64 bytes per chunk (bbuf[chunks*64])
+static int iknp_receive_packed(gc_iknp *k, const std::vector<uint8_t> &bbuf, size_t n, uint8_t *u_out,
+                               gc_label *labels_out) {
     gc_ctx *ctx = k->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     GC_HIP(hipSetDevice(ctx->device));
     const size_t chunks = (n + 511) / 512, ub = gc_iknp_u_bytes(n);
-    DevBuf d_choice, d_bits, d_t, d_u, d_lab;
-    GC_HIP(d_choice.alloc(n));
+    DevBuf d_bits, d_t, d_u, d_lab;
     GC_HIP(d_bits.alloc(chunks * 64 + 16));
     GC_HIP(d_t.alloc(chunks * 8192));
     GC_HIP(d_u.alloc(chunks * 8192));
     GC_HIP(d_lab.alloc(n * sizeof(uint4)));
     hipStream_t s = ctx->stream;
-    GC_HIP(hipMemcpyAsync(d_choice.p, choice, n, hipMemcpyHostToDevice, s));
     GC_HIP(hipMemsetAsync(d_bits.p, 0, chunks * 64 + 16, s));
-    launch_pack_bits((const uint8_t *)d_choice.p, n, (uint8_t *)d_bits.p, s);
+    GC_HIP(hipMemcpyAsync(d_bits.p, bbuf.data(), std::min(bbuf.size(), chunks * 64), hipMemcpyHostToDevice, s));
     launch_iknp_prg(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_bits.p, nullptr, k->delta,
                     (uint8_t *)d_t.p, (uint8_t *)d_u.p, ctx->d_te0, s);
     launch_iknp_transpose((const uint8_t *)d_t.p, n, (uint4 *)d_lab.p, s);
@@ -138,6 +136,37 @@ int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out,
     GC_HIP(hipMemcpyAsync(labels_out, d_lab.p, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
     k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out) {
+    if (!k || !k->receiver || (n && (!choice || !u_out || !labels_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    std::vector<uint8_t> bbuf(((n + 511) / 512) * 64, 0);  // iknp.go:472-477
+    for (size_t i = 0; i < n; i++)
+        if (choice[i]) bbuf[i / 8] |= (uint8_t)(1u << (i % 8));
+    return iknp_receive_packed(k, bbuf, n, u_out, labels_out);
+}
+
+// (*IKNPReceiver).ReceiveBits (iknp.go:554-620): same matrix, result = bit 0 of every label.  The reference
+// folds the choice vector in as whole little-endian 64-bit words only (words = byteRows/8, :583-597): the
+// choice bits of a trailing partial word do NOT enter u — reproduced here bit for bit.
+int gc_iknp_receive_bits(gc_iknp *k, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result) {
+    if (!k || !k->receiver || (n && (!choices || !u_out || !result))) return GC_E_ARG;
+    for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
+    if (n == 0) return GC_OK;
+    const size_t chunks = (n + 511) / 512;
+    std::vector<uint8_t> bbuf(chunks * 64, 0);
+    for (size_t c = 0; c < chunks; c++) {
+        const size_t ofs = c * 512, rows = std::min<size_t>(512, n - ofs), words = ((rows + 7) / 8) / 8;
+        for (size_t w = 0; w < words; w++)
+            for (int b = 0; b < 8; b++) bbuf[c * 64 + w * 8 + b] = (uint8_t)(choices[ofs / 64 + w] >> (8 * b));
+    }
+    std::vector<gc_label> labels(n);
+    int rc = iknp_receive_packed(k, bbuf, n, u_out, labels.data());
+    if (rc != GC_OK) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (labels[i].d0 & 1) result[i / 64] |= (uint64_t)1 << (i % 64);  // labelsBuf[row].Bit(0) (:609-614)
     return GC_OK;
 }
 
@@ -237,6 +266,19 @@ int gc_kos_sender_check(gc_ctx *ctx, const gc_label *seed2, const gc_label *resu
     host_clmul128(*x, *delta, r);  // mul128(x, s.Delta) (iknp.go:186)
     *ok = (acc[0] ^ r[0]) == t0->d0 && (acc[1] ^ r[1]) == t0->d1 && (acc[2] ^ r[2]) == t1->d0 &&
           (acc[3] ^ r[3]) == t1->d1;
+    return GC_OK;
+}
+
+// (*IKNPSender).SendBits (iknp.go:259-310): column 0 of the q-matrix == bit 0 of every label of send()
+int gc_iknp_send_bits(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, uint64_t *result) {
+    if (!k || k->receiver || (n && (!u_in || !result))) return GC_E_ARG;
+    for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
+    if (n == 0) return GC_OK;
+    std::vector<gc_label> labels(n);
+    int rc = gc_iknp_send(k, u_in, u_len, n, labels.data());
+    if (rc != GC_OK) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (labels[i].d0 & 1) result[i / 64] |= (uint64_t)1 << (i % 64);
     return GC_OK;
 }
 

@@ -116,6 +116,8 @@ def lib():
         "gc_iknp_u_bytes": (sz, [sz]),
         "gc_iknp_receive": (i32, [vp, vp, sz, vp, vp]),
         "gc_iknp_send": (i32, [vp, vp, sz, sz, vp]),
+        "gc_iknp_receive_bits": (i32, [vp, vp, sz, vp, vp]),
+        "gc_iknp_send_bits": (i32, [vp, vp, sz, sz, vp]),
         "gc_kos_receiver_tags": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "gc_kos_sender_check": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp, ip]),
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
@@ -426,6 +428,13 @@ class IKNPReceiver:
         _check(lib().gc_iknp_receive(self.h, _p(bb), n, _p(u), _p(res)), "gc_iknp_receive")
         return u[: lib().gc_iknp_u_bytes(n)].tobytes(), res[:n]
 
+    def receive_bits(self, choices, n):
+        ch = np.ascontiguousarray(choices, dtype=np.uint64)
+        u = np.zeros(max(lib().gc_iknp_u_bytes(n), 1), np.uint8)
+        res = np.zeros(max((n + 63) // 64, 1), np.uint64)
+        _check(lib().gc_iknp_receive_bits(self.h, _p(ch), n, _p(u), _p(res)), "gc_iknp_receive_bits")
+        return u[: lib().gc_iknp_u_bytes(n)].tobytes(), res[: (n + 63) // 64]
+
     def close(self):
         if self.h:
             lib().gc_iknp_free(self.h)
@@ -449,6 +458,12 @@ class IKNPSender:
         res = np.zeros(max(n, 1), LABEL)
         _check(lib().gc_iknp_send(self.h, _p(ub), len(u), n, _p(res)), "gc_iknp_send")
         return res[:n]
+
+    def send_bits(self, u, n):
+        ub = np.frombuffer(bytes(u), np.uint8) if len(u) else np.zeros(1, np.uint8)
+        res = np.zeros(max((n + 63) // 64, 1), np.uint64)
+        _check(lib().gc_iknp_send_bits(self.h, _p(ub), len(u), n, _p(res)), "gc_iknp_send_bits")
+        return res[: (n + 63) // 64]
 
     def close(self):
         if self.h:

@@ -524,3 +524,22 @@ def kos_sender_check(seed2, result, choice_vec, delta, x, t0, t1):
     lib().orc_kos_sender_check.argtypes = [_Label, C.c_void_p, C.c_size_t, C.c_void_p, _Label, _Label, _Label, _Label]
     return bool(lib().orc_kos_sender_check(_lab(seed2), _p(r), C.c_size_t(n), _p(cv), _lab(delta), _lab(x), _lab(t0),
                                            _lab(t1)))
+
+
+def iknp_receive_bits(rcv, choices, n):
+    """ReceiveBits (iknp.go:554-620); rcv is an oracle.IKNPReceiver"""
+    ch = np.ascontiguousarray(choices, dtype=np.uint64)
+    u = np.zeros(max(u_bytes(n), 1), np.uint8)
+    res = np.zeros(max((n + 63) // 64, 1), np.uint64)
+    lib().orc_iknp_receive_bits.restype = C.c_size_t
+    w = lib().orc_iknp_receive_bits(C.byref(rcv.s), _p(ch), C.c_size_t(n), _p(u), _p(res))
+    return u[:w].tobytes(), res[: (n + 63) // 64]
+
+
+def iknp_send_bits(snd, u, n):
+    """SendBits (iknp.go:259-310); snd is an oracle.IKNPSender"""
+    ub = _u8(u) if len(u) else np.zeros(1, np.uint8)
+    res = np.zeros(max((n + 63) // 64, 1), np.uint64)
+    lib().orc_iknp_send_bits.restype = C.c_size_t
+    lib().orc_iknp_send_bits(C.byref(snd.s), _p(ub), C.c_size_t(n), _p(res))
+    return res[: (n + 63) // 64]

@@ -133,6 +133,11 @@ size_t orc_iknp_receive(orc_iknp_receiver *r, const uint8_t *b, size_t n, uint8_
 /* send(): iknp.go:197-226, consuming the concatenated chunks in u_in.
  * chunk boundaries are recomputed the way the receiver produced them. */
 size_t orc_iknp_send(orc_iknp_sender *s, const uint8_t *u_in, size_t n, orc_label *result);
+/* bit-COT: (*IKNPSender).SendBits iknp.go:259-310 / (*IKNPReceiver).ReceiveBits iknp.go:554-620.
+ * choices / result are packed little-endian bit vectors (bit i = word i/64, position i%64).
+ * Only column 0 of the matrix survives: r_i = s_i ^ (b_i & Delta.Bit(0)). */
+size_t orc_iknp_receive_bits(orc_iknp_receiver *r, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result);
+size_t orc_iknp_send_bits(orc_iknp_sender *s, const uint8_t *u_in, size_t n, uint64_t *result);
 /* createLabels(): iknp.go:647-683 */
 void orc_create_labels(orc_label *l, size_t nl, const uint8_t *buf, int w);
 

@@ -343,3 +343,65 @@ int orc_kos_sender_check(orc_label seed2, const orc_label *result, size_t n, con
     q1.d1 ^= r1.d1;
     return q0.d0 == t0.d0 && q0.d1 == t0.d1 && q1.d0 == t1.d0 && q1.d1 == t1.d1;
 }
+
+/* ---- bit-COT: iknp.go:259-310, 554-620 ---------------------------------------------------------------- */
+
+size_t orc_iknp_receive_bits(orc_iknp_receiver *r, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result) {
+    uint8_t *chunk = malloc(ORC_IKNP_CHUNK), *tmp = malloc(ORC_IKNP_CHUNK), *ucol = malloc(ORC_IKNP_CHUNK);
+    orc_label *labels = malloc(sizeof(orc_label) * 512);
+    size_t written = 0;
+    for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
+    for (size_t ofs = 0; ofs < n;) {
+        size_t rows = 512;
+        if (rows > n - ofs) rows = n - ofs;
+        size_t byte_rows = (rows + 7) / 8;
+        size_t word_offset = ofs / 64, words = byte_rows / 8; /* :583-584: only whole 64-bit words are folded in */
+        for (int i = 0; i < ORC_IKNP_K; i++) {
+            orc_prg_bytes(&r->g0[i], chunk + (size_t)i * byte_rows, byte_rows);
+            orc_prg_bytes(&r->g1[i], tmp, byte_rows);
+            for (size_t k = 0; k < byte_rows; k++) tmp[k] ^= chunk[(size_t)i * byte_rows + k];
+            for (size_t w = 0; w < words; w++) {
+                uint64_t c = choices[word_offset + w];
+                for (int k = 0; k < 8; k++) tmp[w * 8 + k] ^= (uint8_t)(c >> (8 * k)); /* little-endian words :593-597 */
+            }
+            memcpy(ucol + (size_t)i * byte_rows, tmp, byte_rows);
+        }
+        memcpy(u_out + written, ucol, byte_rows * ORC_IKNP_K);
+        written += byte_rows * ORC_IKNP_K;
+        memset(labels, 0, sizeof(orc_label) * 512);
+        orc_create_labels(labels, 512, chunk, (int)byte_rows);
+        for (size_t row = 0; row < rows; row++)
+            if (orc_label_bit(&labels[row], 0)) result[(ofs + row) / 64] |= (uint64_t)1 << ((ofs + row) % 64);
+        ofs += rows;
+    }
+    free(chunk);
+    free(tmp);
+    free(ucol);
+    free(labels);
+    return written;
+}
+
+size_t orc_iknp_send_bits(orc_iknp_sender *s, const uint8_t *u_in, size_t n, uint64_t *result) {
+    uint8_t *t = malloc(ORC_IKNP_CHUNK);
+    size_t consumed = 0;
+    for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
+    for (size_t ofs = 0; ofs < n;) {
+        size_t rows = 512;
+        if (rows > n - ofs) rows = n - ofs;
+        size_t byte_rows = (rows + 7) / 8;
+        const uint8_t *chunk = u_in + consumed;
+        for (int i = 0; i < ORC_IKNP_K; i++) {
+            orc_prg_bytes(&s->g0[i], t + (size_t)i * byte_rows, byte_rows);
+            if (orc_label_bit(&s->delta, i) == 1)
+                for (size_t k = 0; k < byte_rows; k++) t[(size_t)i * byte_rows + k] ^= chunk[(size_t)i * byte_rows + k];
+        }
+        consumed += byte_rows * ORC_IKNP_K;
+        size_t max_rows = byte_rows * 8; /* :288-292 */
+        if (max_rows > n - ofs) max_rows = n - ofs;
+        for (size_t row = 0; row < max_rows; row++) /* column 0, no transpose :294-303 */
+            if ((t[row / 8] >> (row % 8)) & 1) result[(ofs + row) / 64] |= (uint64_t)1 << ((ofs + row) % 64);
+        ofs += max_rows;
+    }
+    free(t);
+    return consumed;
+}

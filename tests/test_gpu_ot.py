@@ -144,3 +144,20 @@ def test_kos_check_matches_oracle(ctx, n):
         bad = sent.copy()
         bad[n // 2]["d1"] ^= 1 << 40
         assert not engine.kos_sender_check(ctx, seed2, bad, cvs, delta, x, t0, t1)
+
+
+@pytest.mark.parametrize("n", [64, 1024, 1000, 70, 513])
+def test_bitcot_matches_oracle(ctx, n):
+    base, delta, k0 = base_setup("bit%d" % n)
+    choices = np.frombuffer(drbg("bc%d" % n, 8 * ((n + 63) // 64)), "<u8").copy()
+    rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    orcv, osnd = oracle.IKNPReceiver(base), oracle.IKNPSender(delta, k0)
+    u, r = rcv.receive_bits(choices, n)
+    ou, orr = oracle.iknp_receive_bits(orcv, choices, n)
+    assert u == ou and (r == orr).all()
+    s = snd.send_bits(u, n)
+    assert (s == oracle.iknp_send_bits(osnd, ou, n)).all()
+    if n % 64 == 0:  # bitcot_test.go: s ^ r == Delta.Bit(0) & c
+        d0 = np.uint64(0xFFFFFFFFFFFFFFFF) if oracle.label_bit(delta, 0) else np.uint64(0)
+        assert ((s ^ r) == (choices & d0)).all()
+    rcv.close(); snd.close()

@@ -107,3 +107,15 @@ def test_kos_check_accepts_honest_rejects_tampered():
     chi = oracle.Prg(seed2).labels(n + 256)
     sel = np.concatenate([b, bcv]).astype(bool)
     assert x == (int(np.bitwise_xor.reduce(chi["d0"][sel])), int(np.bitwise_xor.reduce(chi["d1"][sel])))
+
+
+def test_bitcot_correlation():
+    # ot/bitcot_test.go:14-87: s ^ r == Delta.Bit(0) & c  for 1024 bits (multiples of 64 — the reference folds
+    # whole choice words only)
+    rcv, snd, delta = setup("bitcot")
+    n = 1024
+    choices = np.frombuffer(drbg("bc", n // 8), "<u8").copy()
+    u, r = oracle.iknp_receive_bits(rcv, choices, n)
+    s = oracle.iknp_send_bits(snd, u, n)
+    d0 = np.uint64(0xFFFFFFFFFFFFFFFF) if oracle.label_bit(delta, 0) else np.uint64(0)
+    assert ((s ^ r) == (choices & d0)).all()
