@@ -163,6 +163,19 @@ int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
 int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
 
+/* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
+ * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
+ * reading the framing (OpCircuit header: step, numGates, numTmpWires, numWires) and hands the gate bytes over;
+ * the gates are parsed back into a circuit, levelised and evaluated with the same kernels as Circuit.Eval. */
+typedef struct gc_stream_eval gc_stream_eval;
+gc_stream_eval *gc_stream_eval_create(gc_ctx *, const uint8_t *key, size_t keylen, int *status);
+void gc_stream_eval_free(gc_stream_eval *);
+int gc_stream_eval_set_wire(gc_stream_eval *, uint32_t w, const gc_label *l); /* input labels (OT results etc.) */
+int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /* OpReturn / OpResult reads */
+/* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream */
+int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
+                           size_t len, size_t *consumed);
+
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,
  * additive to the reference API) calls; also what bench.py times.  All d_* arguments are

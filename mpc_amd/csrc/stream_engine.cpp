@@ -199,4 +199,150 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     return pos == need ? GC_OK : GC_E_ARG;
 }
 
+// ---- streaming evaluator ----------------------------------------------------------------
+
+}  // extern "C"
+
+struct gc_stream_eval {
+    gc_ctx *ctx = nullptr;
+    std::vector<uint8_t> key;
+    std::vector<gc_label> wires;  // StreamEval.wires (global store)
+    std::vector<gc_label> tmp;    // StreamEval.tmp
+    std::unordered_map<uint64_t, gc_circ *> cache;
+};
+
+extern "C" {
+
+gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, int *status) {
+    int rc = GC_OK;
+    AesKey k;
+    gc_stream_eval *e = nullptr;
+    if (!ctx) rc = GC_E_ARG;
+    else if (!key || !aes_expand_key(key, keylen, &k)) rc = GC_E_KEYSIZE;
+    else if (!(e = new (std::nothrow) gc_stream_eval)) rc = GC_E_NOMEM;
+    if (e) {
+        e->ctx = ctx;
+        e->key.assign(key, key + keylen);
+    }
+    if (status) *status = rc;
+    return e;
+}
+
+void gc_stream_eval_free(gc_stream_eval *e) {
+    if (!e) return;
+    for (auto &kv : e->cache) gc_circ_free(kv.second);
+    delete e;
+}
+
+int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) {
+    if (!e || !l) return GC_E_ARG;
+    if (w >= e->wires.size()) e->wires.resize((size_t)w + 1, gc_label{0, 0});
+    e->wires[w] = *l;
+    return GC_OK;
+}
+
+int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
+    if (!e || !l || w >= e->wires.size()) return GC_E_ARG;
+    *l = e->wires[w];
+    return GC_OK;
+}
+
+int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
+                           size_t len, size_t *consumed) {
+    if (!e || (!buf && len) || !consumed) return GC_E_ARG;
+    if (e->wires.size() < nwires) e->wires.resize(nwires, gc_label{0, 0});  // InitCircuit(numWires, numTmpWires)
+    if (e->tmp.size() < ntmp) e->tmp.assign(ntmp, gc_label{0, 0});
+    *consumed = 0;
+    if (ngates == 0) return GC_OK;
+    // parse the gate stream (stream_evaluator.go:272-345) into an SSA gate list:
+    //   ids [0, nin) = wires read before this circuit writes them (in order of first use), nin + g = output of gate g
+    struct Ref { bool tmp; uint32_t idx; };
+    std::vector<gc_gate> gates(ngates);
+    std::vector<Ref> dst(ngates), inputs;
+    std::vector<gc_label> slab;
+    std::unordered_map<uint64_t, uint32_t> cur;  // (tmp, idx) -> current id; inputs get 0x80000000|k until numbered
+    auto keyof = [](bool t, uint32_t i) { return ((uint64_t)(t ? 1 : 0) << 32) | i; };
+    size_t pos = 0;
+    for (uint32_t g = 0; g < ngates; g++) {
+        if (pos + 1 > len) return GC_E_ROWS;
+        uint8_t gop = buf[pos++];
+        const bool at = gop & 0x80, bt = gop & 0x40, ct = gop & 0x20, shortf = gop & 0x10;
+        gop &= 0x0f;
+        if (gop > GC_INV) return GC_E_GATE;  // "invalid operation"
+        const int nw = gop == GC_INV ? 2 : 3;
+        uint32_t w[3] = {0, 0, 0};
+        for (int i = 0; i < nw; i++) {
+            const size_t sz = shortf ? 2 : 4;
+            if (pos + sz > len) return GC_E_ROWS;
+            for (size_t b = 0; b < sz; b++) w[i] = (w[i] << 8) | buf[pos + b];
+            pos += sz;
+        }
+        const uint32_t rows = gop == GC_AND ? 2 : gop == GC_OR ? 3 : gop == GC_INV ? 1 : 0;
+        for (uint32_t r = 0; r < rows; r++) {
+            if (pos + 16 > len) return GC_E_ROWS;
+            slab.push_back(gc_label{be64(buf + pos), be64(buf + pos + 8)});
+            pos += 16;
+        }
+        auto use = [&](bool t, uint32_t idx) -> uint32_t {
+            auto it = cur.find(keyof(t, idx));
+            if (it != cur.end()) return it->second;
+            const uint32_t id = 0x80000000u | (uint32_t)inputs.size();
+            inputs.push_back(Ref{t, idx});
+            cur.emplace(keyof(t, idx), id);
+            return id;
+        };
+        gates[g].in0 = use(at, w[0]);
+        gates[g].in1 = nw == 3 ? use(bt, w[1]) : gates[g].in0;
+        gates[g].op = gop;
+        gates[g].level = 0;
+        dst[g] = Ref{ct, w[nw - 1]};
+        cur[keyof(ct, w[nw - 1])] = g;  // gate index for now; renumbered below
+        gates[g].out = g;
+    }
+    const uint32_t nin = (uint32_t)inputs.size();
+    for (uint32_t g = 0; g < ngates; g++) {
+        auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : nin + v; };
+        gates[g].in0 = fix(gates[g].in0);
+        gates[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
+        gates[g].out = nin + g;
+    }
+    const uint32_t cw = nin + ngates;
+    // device circuit, cached by content
+    const uint64_t h = circuit_hash(gates.data(), ngates, cw, nin, 0);
+    gc_circ *circ = nullptr;
+    auto it = e->cache.find(h);
+    if (it != e->cache.end()) circ = it->second;
+    else {
+        int st = GC_OK;
+        circ = gc_circ_load(e->ctx, gates.data(), ngates, cw, nin, 0, &st);
+        if (!circ) return st;
+        e->cache.emplace(h, circ);
+    }
+    std::vector<gc_label> wl(cw, gc_label{0, 0});
+    for (uint32_t i = 0; i < nin; i++) {
+        const Ref &r = inputs[i];
+        if (r.tmp) {
+            if (r.idx >= e->tmp.size()) return GC_E_ARG;
+            wl[i] = e->tmp[r.idx];
+        } else {
+            if (r.idx >= e->wires.size()) e->wires.resize((size_t)r.idx + 1, gc_label{0, 0});
+            wl[i] = e->wires[r.idx];
+        }
+    }
+    int rc = gc_eval(circ, e->key.data(), e->key.size(), 1, wl.data(), nullptr, slab.data(), slab.size(), nullptr);
+    if (rc != GC_OK) return rc;
+    for (uint32_t g = 0; g < ngates; g++) {  // streaming.Set(cTmp, cIndex, output), in gate order
+        const Ref &d = dst[g];
+        if (d.tmp) {
+            if (d.idx >= e->tmp.size()) return GC_E_ARG;
+            e->tmp[d.idx] = wl[nin + g];
+        } else {
+            if (d.idx >= e->wires.size()) e->wires.resize((size_t)d.idx + 1, gc_label{0, 0});
+            e->wires[d.idx] = wl[nin + g];
+        }
+    }
+    *consumed = pos;
+    return GC_OK;
+}
+
 }  // extern "C"

@@ -83,6 +83,11 @@ def lib():
         "gc_stream_free": (None, [vp]),
         "gc_stream_get_wire": (i32, [vp, u32, vp]),
         "gc_stream_garble": (i32, [vp, vp, u32, u32, vp, u32, vp, u32, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
+        "gc_stream_eval_free": (None, [vp]),
+        "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
+        "gc_stream_eval_get_wire": (i32, [vp, u32, vp]),
+        "gc_stream_eval_circuit": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
         "gc_batch_stride": (u32, [vp]),
@@ -397,6 +402,37 @@ class Stream:
     def close(self):
         if self.h:
             lib().gc_stream_free(self.h)
+            self.h = None
+
+
+class StreamEval:
+    """gc_stream_eval: StreamEval store + the per-gate loop of one OpCircuit block (stream_evaluator.go)"""
+
+    def __init__(self, ctx, key):
+        k = _u8(key)
+        st = C.c_int(0)
+        self.h = lib().gc_stream_eval_create(ctx.h, _p(k), len(k), C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_stream_eval_create")
+
+    def set(self, w, label):
+        _check(lib().gc_stream_eval_set_wire(self.h, w, _p(_lab1(label))), "gc_stream_eval_set_wire")
+
+    def get(self, w):
+        out = np.zeros(1, LABEL)
+        _check(lib().gc_stream_eval_get_wire(self.h, w, _p(out)), "gc_stream_eval_get_wire")
+        return (int(out[0]["d0"]), int(out[0]["d1"]))
+
+    def circuit(self, ngates, ntmp, nwires, data):
+        b = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+        n = C.c_size_t(0)
+        _check(lib().gc_stream_eval_circuit(self.h, ngates, ntmp, nwires, _p(b), len(data), C.byref(n)),
+               "gc_stream_eval_circuit")
+        return n.value
+
+    def close(self):
+        if self.h:
+            lib().gc_stream_eval_free(self.h)
             self.h = None
 
 

@@ -42,3 +42,40 @@ def test_stream_errors():
         engine.Stream(ctx, bytes(16), drbg("r", 16 * len(prim)), prim)
     assert e.value.code == engine.GC_E_RAND
     ctx.close()
+
+
+@pytest.mark.parametrize("base,keylen", [(0, 32), (0x20000, 16)])
+def test_stream_evaluator_matches_oracle_and_plaintext(base, keylen):
+    """garble on the GPU, evaluate the byte stream on the GPU (gc_stream_eval_*) and with the oracle's restatement
+    of stream_evaluator.go; both must decode to the plaintext result"""
+    from tests.test_oracle_stream import plain_program
+    ctx = engine.Context(0)
+    steps, prim = make_program(base)
+    key = drbg("skey", keylen)
+    rnd = drbg("ge%d" % base, 16 * (len(prim) + 1))
+    gg = engine.Stream(ctx, key, rnd, prim)
+    ge = engine.StreamEval(ctx, key)
+    oe = oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("sbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = gg.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    for c, in_, out_ in steps:
+        data = gg.garble(c.Gates, c.NumWires, in_, out_)
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        for o in out_:
+            assert ge.get(o) == oe.get(o)
+    val = plain_program(steps, prim, bits)
+    for c, in_, out_ in steps:
+        for o in out_:
+            wire = gg.get(o)
+            want = wire["l1"] if val[o] else wire["l0"]
+            assert ge.get(o) == (int(want["d0"]), int(want["d1"]))
+    with pytest.raises(engine.EngineError) as e:  # truncated stream
+        ge.circuit(steps[0][0].NumGates, steps[0][0].NumWires, 600, data[: len(data) // 2])
+    assert e.value.code in (engine.GC_E_ROWS, engine.GC_E_GATE, engine.GC_E_ARG)
+    gg.close(); ge.close(); ctx.close()
