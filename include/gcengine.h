@@ -109,7 +109,8 @@ gc_circ *gc_circ_load(gc_ctx *, const gc_gate *gates, uint32_t ngates, uint32_t 
 void gc_circ_free(gc_circ *);
 const gc_plan *gc_circ_plan(const gc_circ *);
 /* execution schedule used by gc_garble / gc_eval on this circuit (see gc_batch_set_schedule):
- * 0 = one launch per dependency level, 1 = fused single launch (default).  Bit-identical results. */
+ * 0 = one launch per dependency level, 1 = fused single launch (default), 2 = fused, single-phase kernel.
+ * Bit-identical results. */
 int gc_circ_set_schedule(gc_circ *, int schedule);
 
 /* ------------------------------------------------------------------------------------------
@@ -193,7 +194,11 @@ uint32_t gc_batch_stride(const gc_batch *);
 /* schedule: 0 = one launch per dependency level (the reference's AssignLevels order), labels laid
  *               out [wire][instance];
  *           1 = fused (default): ONE launch per pass, every workgroup owns a tile of instances and
- *               walks all levels with workgroup barriers; labels laid out [tile][wire][instance].
+ *               walks all levels with workgroup barriers; labels laid out [tile][wire][instance].  When the
+ *               live labels fit in LDS the tile's two halves run one stage apart (one half's XOR chain
+ *               hides behind the other half's hashing);
+ *           2 = as 1 (same layout) but with the single-phase kernel: every instance of the tile in lock
+ *               step (what tiles of one instance use anyway; kept selectable for comparison and tests).
  * Results are bit-identical.  Changing the schedule re-allocates the batch's device arrays. */
 int gc_batch_set_schedule(gc_batch *, int schedule);
 /* fused schedule only: also write EVERY wire label to the global wire array (needed by

@@ -140,10 +140,14 @@ __device__ __forceinline__ void aes_encrypt_repl(uint32_t (&s)[N][4], const uint
 // (state byte -> address byte 1, lane offset -> address byte 0) instead of a bfe + shift-or pair,
 // and Te1/Te3 = rotr8(Te0/Te2) cost one v_alignbit per COLUMN:
 //     col = Te0[b3(a0)] ^ Te2[b1(a2)] ^ rotr8(Te0[b2(a1)] ^ Te2[b0(a3)]) ^ rk
-// -> 9 VALU + 4 ds_read_b32 per column (36 + 16 per round) versus ~70 + 16 for the classic form.
+// -> 8 VALU (4 perm, xor3 with the key, xor, alignbit, xor) + 4 ds_read_b32 per column: 32 + 16 per round
+// versus ~70 + 16 for the classic form.
 constexpr int kTeDualBytes = 256 * 256;
 
+__device__ __forceinline__ void te_dual_check(const uint32_t *te);
+
 __device__ __forceinline__ void load_te_dual(uint32_t *te, const uint32_t *__restrict__ g_te0) {
+    te_dual_check(te);
     const uint32_t c = threadIdx.x & 31;
     for (uint32_t x = threadIdx.x >> 5; x < 256; x += blockDim.x >> 5) {
         const uint32_t t = g_te0[x];
@@ -156,9 +160,24 @@ __device__ __forceinline__ void load_te_dual(uint32_t *te, const uint32_t *__res
 // (S1 byte 0), upper bytes zero (0x0c)
 #define GC_PERM_SEL(k) (0x0c0c0000u | ((4u + (k)) << 8))
 
-__device__ __forceinline__ uint32_t te_dual(const uint32_t *te, uint32_t word, uint32_t sel, uint32_t lane_off) {
+// The table MUST sit at LDS offset 0 (the kernels place it first in their only LDS allocation and call
+// te_dual_check): the permuted word then IS the LDS byte address and the load needs no base add — with a
+// pointer base the compiler spends one v_add per lookup, 16 of 52 VALU per round (tools/aes_model_ubench.hip:
+// the round is VALU-bound at 4 waves/SIMD, 929 -> ~620 cycles per round per CU).
+using lds_u32 = __attribute__((address_space(3))) const uint32_t;
+
+__device__ __forceinline__ void te_dual_check(const uint32_t *te) {
+    if ((uint32_t)(uintptr_t)te != 0u) __builtin_trap();  // low 32 bits of a flat LDS address = LDS offset
+}
+
+__device__ __forceinline__ uint32_t te_dual(uint32_t word, uint32_t sel, uint32_t lane_off) {
     const uint32_t addr = __builtin_amdgcn_perm(word, lane_off, sel);
-    return *(const uint32_t *)((const char *)te + addr);
+    return *(lds_u32 *)(uintptr_t)addr;
+}
+
+// three-input XOR: one v_bitop3_b32 (gfx950)
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
 // rk: NR+1 round keys as big-endian words, expected in SGPRs (see load_round_keys)
@@ -180,8 +199,8 @@ __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint
         for (int k = 0; k < N; k++) {
             const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
 #define GC_COL(c0, c1, c2, c3, key)                                                                   \
-    ((te_dual(te, c0, sel3, lo0) ^ te_dual(te, c2, sel1, lo2)) ^                                      \
-     rotr32(te_dual(te, c1, sel2, lo0) ^ te_dual(te, c3, sel0, lo2), 8) ^ (key))
+    (xor3(te_dual(c0, sel3, lo0), te_dual(c2, sel1, lo2), (key)) ^                                    \
+     rotr32(te_dual(c1, sel2, lo0) ^ te_dual(c3, sel0, lo2), 8))
             s[k][0] = GC_COL(a0, a1, a2, a3, rk[4 * r + 0]);
             s[k][1] = GC_COL(a1, a2, a3, a0, rk[4 * r + 1]);
             s[k][2] = GC_COL(a2, a3, a0, a1, rk[4 * r + 2]);
@@ -194,8 +213,8 @@ __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint
     for (int k = 0; k < N; k++) {
         const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
 #define GC_LAST(c0, c1, c2, c3, key)                                                                       \
-    (((te_dual(te, c0, sel3, lo2) & 0xff000000u) | (te_dual(te, c1, sel2, lo0) & 0x00ff0000u) |           \
-      (te_dual(te, c2, sel1, lo0) & 0x0000ff00u) | (te_dual(te, c3, sel0, lo2) & 0x000000ffu)) ^ (key))
+    (((te_dual(c0, sel3, lo2) & 0xff000000u) | (te_dual(c1, sel2, lo0) & 0x00ff0000u) |                   \
+      (te_dual(c2, sel1, lo0) & 0x0000ff00u) | (te_dual(c3, sel0, lo2) & 0x000000ffu)) ^ (key))
         s[k][0] = GC_LAST(a0, a1, a2, a3, rk[4 * NR + 0]);
         s[k][1] = GC_LAST(a1, a2, a3, a0, rk[4 * NR + 1]);
         s[k][2] = GC_LAST(a2, a3, a0, a1, rk[4 * NR + 2]);

@@ -129,6 +129,11 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
         up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
         up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
+        up((void **)&c->d_shdescs, p.shdescs.data(), p.shdescs.size() * sizeof(FDesc));
+        up((void **)&c->d_shgslot, p.shgslot.data(), p.shgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_sxdescs, p.sxdescs.data(), p.sxdescs.size() * sizeof(XDesc));
+        up((void **)&c->d_sxgslot, p.sxgslot.data(), p.sxgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_schunks, p.schunks.data(), p.schunks.size() * sizeof(SChunk));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -158,15 +163,21 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_fsteps) (void)hipFree(c->d_fsteps);
     if (c->d_in_lds) (void)hipFree(c->d_in_lds);
     if (c->d_fchunks) (void)hipFree(c->d_fchunks);
+    if (c->d_shdescs) (void)hipFree(c->d_shdescs);
+    if (c->d_shgslot) (void)hipFree(c->d_shgslot);
+    if (c->d_sxdescs) (void)hipFree(c->d_sxdescs);
+    if (c->d_sxgslot) (void)hipFree(c->d_sxgslot);
+    if (c->d_schunks) (void)hipFree(c->d_schunks);
     delete c;
 }
 
 const gc_plan *gc_circ_plan(const gc_circ *c) { return c ? &c->plan : nullptr; }
 
 int gc_circ_set_schedule(gc_circ *c, int schedule) {
-    if (!c || schedule < 0 || schedule > 1) return GC_E_ARG;
+    if (!c || schedule < 0 || schedule > 2) return GC_E_ARG;
     std::lock_guard<std::mutex> lk(c->pool_mu);
-    c->schedule = schedule;
+    c->schedule = schedule ? 1 : 0;
+    c->single_phase = schedule == 2;
     return GC_OK;
 }
 
@@ -250,11 +261,11 @@ void gc_batch_free(gc_batch *b) {
 uint32_t gc_batch_stride(const gc_batch *b) { return b ? b->g.bstride : 0; }
 
 int gc_batch_set_schedule(gc_batch *b, int schedule) {
-    if (!b || schedule < 0 || schedule > 1) return GC_E_ARG;
+    if (!b || schedule < 0 || schedule > 2) return GC_E_ARG;
+    b->single_phase = schedule == 2;  // 1 and 2 share the tiled layout; only the kernel differs
+    schedule = schedule ? 1 : 0;
     if (schedule == b->schedule) return GC_OK;
     // the schedule fixes the HBM layout: start over with fresh arrays (contents are per-pass anyway)
-    GC_HIP(hipSetDevice(b->circ->ctx->device));
-    GC_HIP(hipStreamSynchronize(b->circ->ctx->stream));
     drop_graphs(b);
     free_buffers(b);
     b->schedule = schedule;
@@ -303,6 +314,32 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
 static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
+    // fused, LDS-resident wires, staggered half-tiles (the production path whenever a tile has >= 2 instances);
+    // the debug cycle profile only exists in the single-phase kernel below
+    if (b->schedule == 1 && b->g.lds_wires && b->g.ti_log2 >= 1 && !p.schunks.empty() && !b->d_prof &&
+        !b->single_phase) {
+        FusedLds2Args f{};
+        f.hdescs = b->circ->d_shdescs;
+        f.hgslot = b->circ->d_shgslot;
+        f.xdescs = b->circ->d_sxdescs;
+        f.xgslot = b->circ->d_sxgslot;
+        f.chunks = b->circ->d_schunks;
+        f.in_lds = b->circ->d_in_lds;
+        f.nchunks = (uint32_t)p.schunks.size();
+        f.ninputs = p.info.ninputs;
+        f.nls = p.n_lds_slots;
+        f.W = b->d_W;
+        f.R = b->d_R;
+        f.T = const_cast<uint4 *>(T);
+        f.rk = b->d_rk;
+        f.te0 = b->circ->ctx->d_te0;
+        f.rounds = b->rounds;
+        f.store_all = b->store_all;
+        GC_HIP(launch_fused_lds2(eval, f, b->g, s));
+        b->last_launches = 1;
+        b->have_all_wires = b->store_all;
+        return GC_OK;
+    }
     if (b->schedule == 1 && b->g.lds_wires) {  // fused, LDS-resident wires, hash-phase order
         FusedLdsArgs f{};
         f.descs = b->circ->d_fdescs;
@@ -630,13 +667,16 @@ uint32_t gc_batch_last_launches(gc_batch *b) { return b ? b->last_launches : 0; 
 
 static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
     int schedule;
+    bool single_phase;
     {
         std::lock_guard<std::mutex> lk(c->pool_mu);
         schedule = c->schedule;
+        single_phase = c->single_phase;
         for (size_t i = 0; i < c->pool.size(); i++) {
             if (c->pool[i]->g.batch == batch && c->pool[i]->schedule == schedule) {
                 gc_batch *b = c->pool[i];
                 c->pool.erase(c->pool.begin() + (long)i);
+                b->single_phase = single_phase;
                 return b;
             }
         }
@@ -650,6 +690,7 @@ static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
             return nullptr;
         }
     }
+    if (b) b->single_phase = single_phase;
     return b;
 }
 

@@ -240,6 +240,54 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
             ch.ndesc += st.count;
         }
         if (ch.nsteps) p.fchunks.push_back(ch);
+
+        // stagger chunks: [<= kSHash hash gates][<= kSXor XOR gates]; only meaningful when slots fit 13 bits
+        if (!overflow && high < 8192) {
+            SChunk sc{0, 0, 0, 0, 0, 0, {0, 0}};
+            bool open_ = false;
+            auto flush = [&]() {
+                if (open_) p.schunks.push_back(sc);
+                sc = SChunk{(uint32_t)p.shdescs.size(), 0, 0, 0, (uint32_t)p.sxdescs.size(), 0, {0, 0}};
+                open_ = false;
+            };
+            flush();
+            for (uint32_t si = 0; si < p.fsteps.size(); si++) {
+                const Step &st = p.fsteps[si];
+                if (st.nonfree) {
+                    // a hash phase always opens a new chunk; phases wider than kSHash are cut into pieces
+                    // (independent gates; the AND / OR / INV grouping is re-counted per piece)
+                    for (uint32_t k = 0; k < st.count;) {
+                        flush();
+                        const uint32_t n = std::min(kSHash, st.count - k);
+                        for (uint32_t e = 0; e < n; e++) {
+                            const FDesc &d = p.fdescs[st.first + k + e];
+                            const uint32_t op = d.row_op >> kOpShift;
+                            if (op == GC_AND) sc.n_and++;
+                            else if (op == GC_OR) sc.n_or++;
+                            else sc.n_inv++;
+                            p.shdescs.push_back(d);
+                            p.shgslot.push_back(p.fgslot[st.first + k + e]);
+                        }
+                        open_ = true;
+                        k += n;
+                    }
+                } else {
+                    for (uint32_t k = 0; k < st.count; k++) {
+                        if (sc.nx == kSXor) flush();
+                        const FDesc &d = p.fdescs[st.first + k];
+                        XDesc x;
+                        x.lin = d.lin;
+                        x.lout = (d.lout & 0x1fffu) | ((d.lout & kFStoreGlobal) ? kXStoreGlobal : 0u) |
+                                 (((d.row_op >> kOpShift) == GC_XNOR) ? kXXnor : 0u) | ((si & 0xffffu) << 16);
+                        p.sxdescs.push_back(x);
+                        p.sxgslot.push_back(p.fgslot[st.first + k]);
+                        sc.nx++;
+                        open_ = true;
+                    }
+                }
+            }
+            if (open_) p.schunks.push_back(sc);
+        }
         p.info.n_hash_phases = p.n_hash_phases;
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;

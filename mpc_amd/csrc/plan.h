@@ -58,6 +58,25 @@ struct Chunk {
     uint32_t first_desc, ndesc;  // ndesc > kChunkDescs only for a single over-wide step (read from HBM directly)
 };
 
+// ---- staggered half-tile schedule (fused_lds2_kernels.hip) ----------------------------------------------
+// Same hash-phase order, re-cut into "stagger chunks": at most kSHash table-producing gates (one hash
+// stage) followed by at most kSXor XOR gates (one XOR stage).  The two halves of a tile run one stage apart,
+// so one half always hashes while the other walks its XOR sub-levels.
+struct XDesc {           // 8 bytes
+    uint32_t lin;        // LDS slot of input 0 | LDS slot of input 1 << 16
+    uint32_t lout;       // bits 0-12 LDS slot of the output, bit 13 store-global, bit 14 XNOR, bits 16-31 sub-level id
+};
+constexpr uint32_t kXStoreGlobal = 1u << 13;
+constexpr uint32_t kXXnor = 1u << 14;
+constexpr uint32_t kSHash = 256;
+constexpr uint32_t kSXor = 768;
+struct SChunk {          // 32 bytes
+    uint32_t hfirst, n_and, n_or, n_inv;  // hash descriptors [hfirst, hfirst + n_and + n_or + n_inv) of shdescs
+    uint32_t xfirst, nx;                  // XOR descriptors [xfirst, xfirst + nx) of sxdescs
+    uint32_t pad_[2];
+};
+static_assert(sizeof(SChunk) == 32, "SChunk must be 32 bytes");
+
 struct Plan {
     gc_plan_info info{};
     // original gate order
@@ -77,6 +96,12 @@ struct Plan {
     std::vector<uint32_t> fgslot;       // global wire slot written by fdescs[k]
     std::vector<Step> fsteps;
     std::vector<Chunk> fchunks;
+    // staggered schedule
+    std::vector<FDesc> shdescs;      // hash descriptors (AND, OR, INV order inside a chunk)
+    std::vector<uint32_t> shgslot;
+    std::vector<XDesc> sxdescs;
+    std::vector<uint32_t> sxgslot;
+    std::vector<SChunk> schunks;
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
     uint32_t n_hash_phases = 0;

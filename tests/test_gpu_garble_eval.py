@@ -40,21 +40,22 @@ def oracle_instance(c, key, rnd, i):
     return oracle.garble(c.Gates, c.NumWires, c.num_inputs, key, rnd[i * stride:(i + 1) * stride])
 
 
-SCHEDULES = [0, 1]  # 0 = one launch per level, 1 = fused single launch (gcengine.h)
+SCHEDULES = [0, 1, 2]  # 0 = one launch per level, 1 = fused (staggered halves), 2 = fused single-phase (gcengine.h)
 
 
-def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True, schedule=1):
-    """host-buffer API vs oracle, every instance, every byte"""
+def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True, schedule=1, sample=None):
+    """host-buffer API vs oracle, every instance (or the sampled ones), every byte"""
     dc = engine.DeviceCircuit(ctx, c, schedule=schedule)
     rnd = rnd_for(c, seed, batch)
     g = dc.garble(key, rnd, batch=batch, want_wires=check_all_wires, want_io=True)
     bits = (np.frombuffer(drbg(seed + "/bits", c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
     wires = np.zeros((batch, c.NumWires), LABEL)
-    refs = []
+    refs = {}
     nin, nout = c.num_inputs, c.num_outputs
-    for i in range(batch):
+    which = range(batch) if sample is None else sample
+    for i in which:
         ref = oracle_instance(c, key, rnd, i)
-        refs.append(ref)
+        refs[i] = ref
         assert g["R"][i] == ref["R"], "R of instance %d" % i
         assert (g["slab"][i] == ref["slab"]).all(), "slab of instance %d" % i
         if check_all_wires:
@@ -62,9 +63,12 @@ def check_garble_eval(ctx, c, key, batch, seed, check_all_wires=True, schedule=1
         assert (g["io"][i][:nin] == ref["wires"][:nin]).all()
         assert (g["io"][i][nin:] == ref["wires"][c.NumWires - nout:]).all()
         wires[i, :nin] = np.where(bits[i].astype(bool), ref["wires"]["l1"][:nin], ref["wires"]["l0"][:nin])
+    if sample is not None:  # unsampled instances: any valid input labels (the garbler's zero labels)
+        rest = np.setdiff1d(np.arange(batch), np.asarray(list(sample)))
+        wires[rest, :nin] = g["io"][rest, :nin]["l0"]
     inputs = wires[:, :nin].copy()
     out = dc.eval(key, g["slab"], wires=wires, batch=batch)
-    for i in range(batch):
+    for i in which:
         w = np.zeros(c.NumWires, LABEL)
         w[:nin] = inputs[i]
         oracle.eval_(c.Gates, c.NumWires, key, w, refs[i]["slab"])
@@ -94,6 +98,14 @@ def test_wide_levels(ctx, schedule):
     c = synthetic_levelised(4, 700, 0.4, seed=13, ninputs=64, or_frac=0.05, inv_frac=0.1, xnor_frac=0.05)
     for batch in (3, 520, 2100):
         check_garble_eval(ctx, c, KEY128, batch, "wide%d" % batch, check_all_wires=(batch < 1000), schedule=schedule)
+
+
+@pytest.mark.parametrize("schedule", [1, 2])
+@pytest.mark.parametrize("batch", [4099, 16389])
+def test_large_tiles(ctx, add64_circ, batch, schedule):
+    # tiles of 8 and 64 instances per workgroup (small live set): halves of 4 / 32 instances
+    sample = list(range(0, batch, 37)) + list(range(batch - 70, batch))
+    check_garble_eval(ctx, add64_circ, KEY128, batch, "tiles%d" % batch, schedule=schedule, sample=sorted(set(sample)))
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
