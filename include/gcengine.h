@@ -76,6 +76,12 @@ typedef struct gc_plan_info {
     uint32_t n_hash_phases; /* fused schedule: steps that hash (non-free depth of the circuit) */
     uint32_t n_fused_steps; /* fused schedule: hash phases + XOR sub-levels */
     uint32_t n_lds_slots;   /* fused schedule: peak number of live wire labels (0xffffffff: > 65534) */
+    /* flattened fused schedule: every NEEDED XOR output is one XOR over a list of earlier labels */
+    uint32_t n_flat_slots;  /* peak live labels + the zero slot (0xffffffff: not available) */
+    uint32_t n_flat_outs;   /* XOR outputs that are materialised (of n_xor + n_xnor gates) */
+    uint32_t n_flat_terms;  /* labels read by them in total */
+    uint32_t n_flat_steps;  /* hash phases + XOR rounds = workgroup barriers per pass */
+    uint32_t n_flat_units;  /* staging units */
 } gc_plan_info;
 
 gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,

@@ -129,11 +129,11 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
         up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
         up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
-        up((void **)&c->d_shdescs, p.shdescs.data(), p.shdescs.size() * sizeof(FDesc));
-        up((void **)&c->d_shgslot, p.shgslot.data(), p.shgslot.size() * sizeof(uint32_t));
-        up((void **)&c->d_sxdescs, p.sxdescs.data(), p.sxdescs.size() * sizeof(XDesc));
-        up((void **)&c->d_sxgslot, p.sxgslot.data(), p.sxgslot.size() * sizeof(uint32_t));
-        up((void **)&c->d_schunks, p.schunks.data(), p.schunks.size() * sizeof(SChunk));
+        up((void **)&c->d_fl_prog, p.fl_prog.data(), p.fl_prog.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_units, p.fl_units.data(), p.fl_units.size() * sizeof(FUnit));
+        up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -163,11 +163,11 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_fsteps) (void)hipFree(c->d_fsteps);
     if (c->d_in_lds) (void)hipFree(c->d_in_lds);
     if (c->d_fchunks) (void)hipFree(c->d_fchunks);
-    if (c->d_shdescs) (void)hipFree(c->d_shdescs);
-    if (c->d_shgslot) (void)hipFree(c->d_shgslot);
-    if (c->d_sxdescs) (void)hipFree(c->d_sxdescs);
-    if (c->d_sxgslot) (void)hipFree(c->d_sxgslot);
-    if (c->d_schunks) (void)hipFree(c->d_schunks);
+    if (c->d_fl_prog) (void)hipFree(c->d_fl_prog);
+    if (c->d_fl_units) (void)hipFree(c->d_fl_units);
+    if (c->d_fl_hgslot) (void)hipFree(c->d_fl_hgslot);
+    if (c->d_fl_ogslot) (void)hipFree(c->d_fl_ogslot);
+    if (c->d_fl_in_lds) (void)hipFree(c->d_fl_in_lds);
     delete c;
 }
 
@@ -197,7 +197,7 @@ static void free_buffers(gc_batch *b) {
 // (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
 static hipError_t alloc_buffers(gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, p.n_lds_slots);
+    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, std::max(p.n_lds_slots, p.n_flat_slots));
     const size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
     const size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
     hipError_t e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
@@ -314,30 +314,27 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
 static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
-    // fused, LDS-resident wires, staggered half-tiles (the production path whenever a tile has >= 2 instances);
-    // the debug cycle profile only exists in the single-phase kernel below
-    if (b->schedule == 1 && b->g.lds_wires && b->g.ti_log2 >= 1 && !p.schunks.empty() && !b->d_prof &&
-        !b->single_phase) {
-        FusedLds2Args f{};
-        f.hdescs = b->circ->d_shdescs;
-        f.hgslot = b->circ->d_shgslot;
-        f.xdescs = b->circ->d_sxdescs;
-        f.xgslot = b->circ->d_sxgslot;
-        f.chunks = b->circ->d_schunks;
-        f.in_lds = b->circ->d_in_lds;
-        f.nchunks = (uint32_t)p.schunks.size();
+    // fused, LDS-resident wires, flattened XOR (the production path).  The level-walking kernel below keeps
+    // every intermediate wire (store_all / Garbled.Wires) and carries the debug cycle profile.
+    if (b->schedule == 1 && b->g.lds_wires && !b->store_all && !b->d_prof && !b->single_phase) {
+        FusedFlatArgs f{};
+        f.prog = b->circ->d_fl_prog;
+        f.units = b->circ->d_fl_units;
+        f.hgslot = b->circ->d_fl_hgslot;
+        f.ogslot = b->circ->d_fl_ogslot;
+        f.in_lds = b->circ->d_fl_in_lds;
+        f.nunits = (uint32_t)p.fl_units.size();
         f.ninputs = p.info.ninputs;
-        f.nls = p.n_lds_slots;
+        f.nls = p.n_flat_slots;
         f.W = b->d_W;
         f.R = b->d_R;
         f.T = const_cast<uint4 *>(T);
         f.rk = b->d_rk;
         f.te0 = b->circ->ctx->d_te0;
         f.rounds = b->rounds;
-        f.store_all = b->store_all;
-        GC_HIP(launch_fused_lds2(eval, f, b->g, s));
-        b->last_launches = 1;
-        b->have_all_wires = b->store_all;
+        GC_HIP(launch_fused_flat(eval, f, b->g, s));
+        b->last_launches = f.nunits ? 1 : 0;
+        b->have_all_wires = false;
         return GC_OK;
     }
     if (b->schedule == 1 && b->g.lds_wires) {  // fused, LDS-resident wires, hash-phase order

@@ -47,11 +47,10 @@ struct gc_circ {
     gc::Step *d_fsteps = nullptr;
     gc::Chunk *d_fchunks = nullptr;
     uint16_t *d_in_lds = nullptr;
-    gc::FDesc *d_shdescs = nullptr;  // staggered half-tile schedule (Plan::schunks)
-    uint32_t *d_shgslot = nullptr;
-    gc::XDesc *d_sxdescs = nullptr;
-    uint32_t *d_sxgslot = nullptr;
-    gc::SChunk *d_schunks = nullptr;
+    uint32_t *d_fl_prog = nullptr;   // flattened schedule (Plan::fl_*)
+    gc::FUnit *d_fl_units = nullptr;
+    uint32_t *d_fl_hgslot = nullptr, *d_fl_ogslot = nullptr;
+    uint16_t *d_fl_in_lds = nullptr;
     int schedule = 1;  // default schedule of pooled batches
     bool single_phase = false;
     std::mutex pool_mu;
@@ -79,7 +78,7 @@ struct gc_batch {
     int schedule = 1;
     bool use_graph = true;
     bool store_all = false;      // fused-LDS passes also write every wire to the global array
-    bool single_phase = false;   // fused-LDS passes use the single-phase kernel (fused_lds_kernels.hip)
+    bool single_phase = false;   // fused-LDS passes walk the XOR levels (fused_lds_kernels.hip) instead of the flat plan
     bool have_all_wires = false; // the global wire array holds every wire of the last pass
     std::vector<gc_graph_entry> graphs;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

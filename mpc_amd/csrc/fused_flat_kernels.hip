@@ -1,0 +1,354 @@
+// fused_flat_kernels.hip — fused, LDS-resident, FLATTENED schedule: the production garble / eval kernels.
+//
+// One launch per pass; a 1024-thread workgroup owns a tile of TI instances; wire labels live in recycled LDS
+// slots next to the perm-addressed AES table.  The plan (plan.h, "flattened schedule") has already expanded
+// every XOR output that is needed into a list of chunk-entry labels, so a pass is
+//
+//     for every unit:   hash part  (all table-producing gates of a hash phase: 2-4 lanes per gate-instance,
+//                                   joined by DPP; LDS/VALU-bound AES)
+//                       barrier
+//                       XOR part   (one lane per needed XOR output and instance: XOR of its term list)
+//                       barrier
+//
+// i.e. two workgroup barriers per hash phase and NO serial XOR chain (the level-by-level XOR walk of
+// fused_lds_kernels.hip cost ~20 % of a pass in dependent LDS round trips with the AES pipe idle).
+// The next unit's image (descriptors + XOuts + terms, <= 13 KiB) is fetched into one register per thread
+// while the current unit executes and committed to the other LDS buffer before the closing barrier.
+// LDS map: 64 KiB AES table | 2 x kUnit16 uint4 stage | R[TI] | wires [slot][TI] (last slot = zero label).
+#include "aes_device.h"
+#include "kernels.h"
+
+namespace gc {
+
+namespace {
+
+constexpr int TF = 1024;
+
+constexpr int DPP_XOR1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;   // [2,3,0,1]
+constexpr int DPP_XOR3 = 0x1B;   // [3,2,1,0]
+constexpr int DPP_BC0 = 0x00;    // [0,0,0,0]
+constexpr int DPP_BC2 = 0xAA;    // [2,2,2,2]
+constexpr int DPP_PAIR0 = 0xA0;  // [0,0,2,2]
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ uint4 dpp128(uint4 v) {
+    return make_uint4(dpp32<CTRL>(v.x), dpp32<CTRL>(v.y), dpp32<CTRL>(v.z), dpp32<CTRL>(v.w));
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr uint32_t kStageOff = kTeDualBytes / 16;
+constexpr uint32_t kStageEnd = kStageOff + 2 * kUnit16;
+
+struct FlArgs {
+    const uint4 *prog;
+    const FUnit *units;
+    const uint32_t *hgslot, *ogslot;
+    const uint16_t *in_lds;
+    uint32_t nunits, ninputs, ti_log2, zslot;
+    size_t w_tile, t_tile;
+    uint4 *W;
+    const uint4 *R;
+    uint4 *T;
+    const uint32_t *rk;
+    const uint32_t *te0;
+};
+
+__device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t n) {
+    FUnit u{};
+    if (i < n) {
+        const uint32_t *p = (const uint32_t *)(units + i);
+        u.off16 = __builtin_amdgcn_readfirstlane(p[0]);
+        u.n16 = __builtin_amdgcn_readfirstlane(p[1]);
+        u.n_and = __builtin_amdgcn_readfirstlane(p[2]);
+        u.n_or = __builtin_amdgcn_readfirstlane(p[3]);
+        u.n_inv = __builtin_amdgcn_readfirstlane(p[4]);
+        u.nout = __builtin_amdgcn_readfirstlane(p[5]);
+        u.outs_off16 = __builtin_amdgcn_readfirstlane(p[6]);
+        u.terms_off16 = __builtin_amdgcn_readfirstlane(p[7]);
+        u.hfirst = __builtin_amdgcn_readfirstlane(p[8]);
+        u.ofirst = __builtin_amdgcn_readfirstlane(p[9]);
+    }
+    return u;
+}
+
+// hash-part lane -> (kind, gate, instance, sub-lane); kinds: 0 none, 1 AND, 2 OR, 3 INV
+struct HP {
+    uint32_t kind, g, inst, q;
+};
+template <int LQA, int LQO, int LQI>
+__device__ __forceinline__ HP hpos(uint32_t t, const FUnit &c, uint32_t ti_log2, uint32_t tim) {
+    HP p{0, 0, 0, 0};
+    const uint32_t e_and = (c.n_and << ti_log2) << LQA;
+    const uint32_t e_or = e_and + ((c.n_or << ti_log2) << LQO);
+    const uint32_t e_all = e_or + ((c.n_inv << ti_log2) << LQI);
+    if (t < e_and) {
+        p.kind = 1;
+        p.g = t >> (ti_log2 + LQA);
+        p.inst = (t >> LQA) & tim;
+        p.q = t & ((1u << LQA) - 1);
+    } else if (t < e_or) {
+        const uint32_t u = t - e_and;
+        p.kind = 2;
+        p.g = c.n_and + (u >> (ti_log2 + LQO));
+        p.inst = (u >> LQO) & tim;
+        p.q = u & ((1u << LQO) - 1);
+    } else if (t < e_all) {
+        const uint32_t u = t - e_or;
+        p.kind = 3;
+        p.g = c.n_and + c.n_or + (u >> (ti_log2 + LQI));
+        p.inst = (u >> LQI) & tim;
+        p.q = u & ((1u << LQI) - 1);
+    }
+    return p;
+}
+template <int LQA, int LQO, int LQI>
+__device__ __forceinline__ uint32_t hlanes(const FUnit &c, uint32_t ti_log2) {
+    return ((c.n_and << ti_log2) << LQA) + ((c.n_or << ti_log2) << LQO) + ((c.n_inv << ti_log2) << LQI);
+}
+
+// XOR part: one lane per (XOut, instance); the label is the XOR of its term list (groups of four LDS slots,
+// padded with the zero slot).  garble.go:331-351 / eval.go:49-51 restated over the expanded terms.
+template <bool GARBLE>
+__device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const uint32_t *ogslot, uint4 *wl,
+                                         const uint4 *rl, uint4 *Wt, uint32_t ti_log2, uint32_t tim) {
+    const uint2 *outs = (const uint2 *)(buf + u.outs_off16);
+    const uint2 *terms = (const uint2 *)(buf + u.terms_off16);
+    const uint32_t nitems = u.nout << ti_log2;
+    for (uint32_t t = threadIdx.x; t < nitems; t += TF) {
+        const uint32_t o = t >> ti_log2, inst = t & tim;
+        const uint2 od = outs[o];
+        const uint2 *tp = terms + (od.x & 0xffffu);
+        const uint32_t n4 = od.x >> 16;
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        for (uint32_t j = 0; j < n4; j++) {
+            const uint2 ix = tp[j];
+            const uint4 v0 = wl[((ix.x & 0xffffu) << ti_log2) + inst], v1 = wl[((ix.x >> 16) << ti_log2) + inst];
+            const uint4 v2 = wl[((ix.y & 0xffffu) << ti_log2) + inst], v3 = wl[((ix.y >> 16) << ti_log2) + inst];
+            acc = lxor(lxor(acc, lxor(v0, v1)), lxor(v2, v3));
+        }
+        const uint32_t flags = od.y >> 16;
+        if (GARBLE && (flags & kXoRpar)) acc = lxor(acc, rl[inst]);
+        wl[((od.y & 0xffffu) << ti_log2) + inst] = acc;
+        if (flags & kXoStore) Wt[((size_t)ogslot[u.ofirst + o] << ti_log2) + inst] = acc;
+    }
+}
+
+#define GC_FL_PROLOGUE(LOAD_R)                                                                               \
+    extern __shared__ uint4 smem[];                                                                          \
+    uint32_t *te = (uint32_t *)smem;                                                                         \
+    const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;                                    \
+    uint4 *stage = smem + kStageOff;                                                                         \
+    uint4 *rl = smem + kStageEnd;                                                                            \
+    uint4 *wl = rl + TI;                                                                                     \
+    load_te_dual(te, a.te0);                                                                                 \
+    uint32_t rkr[4 * (NR + 1)];                                                                              \
+    load_round_keys<NR>(rkr, a.rk);                                                                          \
+    uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
+    if (threadIdx.x < TI) {                                                                                  \
+        if (LOAD_R) rl[threadIdx.x] = a.R[(size_t)blockIdx.x * TI + threadIdx.x];                            \
+        wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                                     \
+    }                                                                                                        \
+    for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                    \
+        const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                                   \
+        if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                          \
+    }                                                                                                        \
+    FUnit u = load_unit(a.units, 0, a.nunits);                                                               \
+    if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
+    __syncthreads();                                                                                         \
+    const uint32_t lo = te_lane_off();
+
+}  // namespace
+
+template <int NR>
+__global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
+    GC_FL_PROLOGUE(true)
+    uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
+    for (uint32_t ui = 0; ui < a.nunits; ui++) {
+        const uint4 *buf = stage + (ui & 1u) * kUnit16;
+        const FUnit un = load_unit(a.units, ui + 1, a.nunits);
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
+        const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        if (nh) {
+            const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
+        for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
+            const HP hp = hpos<2, 2, 1>(t0 + threadIdx.x, u, ti_log2, tim);
+            if (hp.kind == 0) continue;
+            const uint4 dv = buf[hp.g];
+            const FDesc d{dv.x, dv.y, dv.z, dv.w};
+            const uint32_t inst = hp.inst, q = hp.q;
+            const uint4 R = rl[inst];
+            const uint4 va = wl[((d.lin & 0xffffu) << ti_log2) + inst];
+            uint4 base;
+            uint32_t k[4];
+            if (hp.kind == 2) {  // OR: e[2u+v] = enc(a_u, b_v, 0, id)  (garble.go:74-83, 421-424)
+                const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
+                const uint4 x = lxor(va, land(R, (q & 2) ? ~0u : 0u));
+                const uint4 y = lxor(vb, land(R, (q & 1) ? ~0u : 0u));
+                base = make_uint4(x.y, y.y, 0, 0);
+                make_k(x, y, d.tweak, k);
+            } else {  // AND q=0..3 -> a0,a1,b0,b1 ; INV q=0,1 -> a0,a1 ; K = 2x ^ tweak
+                const bool second = (hp.kind == 1) && (q & 2);
+                base = second ? wl[((d.lin >> 16) << ti_log2) + inst] : va;
+                const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
+                make_k_half(x, d.tweak + (second ? 1u : 0u), k);
+            }
+            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
+            uint4 out_label;
+            if (hp.kind == 1) {  // garble.go:353-395
+                const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));  // lanes 0,1: Ha0^Ha1 ; lanes 2,3: Hb0^Hb1
+                const uint4 a0 = dpp128<DPP_BC0>(base);
+                const uint32_t pa = smask(a0);
+                const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
+                uint4 v, tab;
+                if (q & 2) {
+                    tab = lxor(p, a0);                     // TE = Hb0^Hb1^a0
+                    v = lxor(h, land(lxor(tab, a0), pb));  // WE0 = Hb0 ^ (pb ? TE^a0 : 0)
+                } else {
+                    tab = lxor(p, land(R, pb));            // TG = Ha0^Ha1^(pb?R:0)
+                    v = lxor(h, land(tab, pa));            // WG0 = Ha0 ^ (pa ? TG : 0)
+                }
+                out_label = lxor(v, dpp128<DPP_XOR2>(v));
+                if (q == 0) row[0] = tab;
+                else if (q == 2) row[TI] = tab;
+            } else if (hp.kind == 3) {  // garble.go:446-474
+                const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));       // E0 ^ E1
+                out_label = lbit_s(base) ? lxor(p, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
+                if (q == 0) row[0] = lxor(p, R);
+            } else {  // OR: garble.go:412-444
+                const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
+                const uint32_t l0 = 2 * pa + pb;
+                const uint4 x1 = dpp128<DPP_XOR1>(h), x2 = dpp128<DPP_XOR2>(h), x3 = dpp128<DPP_XOR3>(h);
+                const uint4 tk = l0 == 0 ? h : l0 == 1 ? x1 : l0 == 2 ? x2 : x3;  // table[q] = e[q ^ l0]
+                const uint4 t0v = dpp128<DPP_BC0>(tk);
+                const uint32_t m0 = l0 == 0 ? ~0u : 0u;
+                const uint4 c0 = lxor(t0v, land(R, ~m0)), c1 = lxor(t0v, land(R, m0));
+                out_label = c0;
+                if (q != 0) row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
+            }
+            if (q == 0) {
+                wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                if (d.lout & kFStoreGlobal)
+                    Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+            }
+        }
+        }
+        if (nh && u.nout) lds_barrier();
+        if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        lds_barrier();
+        u = un;
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
+    GC_FL_PROLOGUE(false)
+    const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
+    for (uint32_t ui = 0; ui < a.nunits; ui++) {
+        const uint4 *buf = stage + (ui & 1u) * kUnit16;
+        const FUnit un = load_unit(a.units, ui + 1, a.nunits);
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
+        const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        if (nh) {
+            const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
+        for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
+            const HP hp = hpos<1, 0, 0>(t0 + threadIdx.x, u, ti_log2, tim);
+            if (hp.kind == 0) continue;
+            const uint4 dv = buf[hp.g];
+            const FDesc d{dv.x, dv.y, dv.z, dv.w};
+            const uint32_t inst = hp.inst, q = hp.q;
+            const uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
+            const uint4 va = wl[((d.lin & 0xffffu) << ti_log2) + inst];
+            uint4 x = va, tab = make_uint4(0, 0, 0, 0);
+            uint32_t k[4];
+            if (hp.kind == 1) {
+                if (q) x = wl[((d.lin >> 16) << ti_log2) + inst];
+                tab = row[q ? TI : 0];  // issued before the hash: arrives while the AES runs
+                make_k_half(x, d.tweak + q, k);
+            } else if (hp.kind == 3) {
+                tab = row[0];
+                make_k_half(va, d.tweak, k);
+            } else {
+                const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
+                const uint32_t index = (lbit_s(va) ? 2u : 0u) | (lbit_s(vb) ? 1u : 0u);
+                if (index > 0) tab = row[(size_t)(index - 1) << ti_log2];
+                make_k(va, vb, d.tweak, k);
+            }
+            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            uint4 out_label;
+            bool writer = true;
+            if (hp.kind == 1) {  // eval.go:53-78
+                const uint4 av = dpp128<DPP_PAIR0>(x);
+                uint4 v;
+                if (q) v = lxor(h, land(lxor(tab, av), smask(x)));  // WE = H(b) ^ (sb ? TE^a : 0)
+                else v = lxor(h, land(tab, smask(x)));              // WG = H(a) ^ (sa ? TG : 0)
+                out_label = lxor(v, dpp128<DPP_XOR1>(v));
+                writer = q == 0;
+            } else if (hp.kind == 3) {  // eval.go:96-109
+                out_label = lxor(h, land(tab, smask(x)));
+            } else {  // eval.go:80-94 (tab is zero for index 0)
+                out_label = lxor(h, tab);
+            }
+            if (writer) {
+                wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                if (d.lout & kFStoreGlobal)
+                    Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+            }
+        }
+        }
+        if (nh && u.nout) lds_barrier();
+        if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        lds_barrier();
+        u = un;
+    }
+}
+
+size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2) {
+    return (size_t)kStageEnd * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
+}
+
+template <typename K>
+static hipError_t launch_fl(K kern, const FlArgs &a, uint32_t ntiles, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(TF), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom &g, hipStream_t s) {
+    FlArgs a{};
+    a.prog = (const uint4 *)f.prog;
+    a.units = f.units;
+    a.hgslot = f.hgslot;
+    a.ogslot = f.ogslot;
+    a.in_lds = f.in_lds;
+    a.nunits = f.nunits;
+    a.ninputs = f.ninputs;
+    a.ti_log2 = g.ti_log2;
+    a.zslot = f.nls - 1;
+    a.w_tile = g.lw.tile_stride;
+    a.t_tile = g.lt.tile_stride;
+    a.W = f.W;
+    a.R = f.R;
+    a.T = f.T;
+    a.rk = f.rk;
+    a.te0 = f.te0;
+    if (a.nunits == 0) return hipSuccess;
+    const size_t lds = fused_flat_bytes(f.nls, g.ti_log2);
+#define GC_M2(KERN) \
+    (f.rounds == 10 ? launch_fl(KERN<10>, a, g.ntiles, lds, s) : f.rounds == 12 ? launch_fl(KERN<12>, a, g.ntiles, lds, s) : launch_fl(KERN<14>, a, g.ntiles, lds, s))
+    return eval ? GC_M2(k_eval_flat) : GC_M2(k_garble_flat);
+#undef GC_M2
+}
+
+}  // namespace gc

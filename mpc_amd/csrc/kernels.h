@@ -95,25 +95,22 @@ struct FusedLdsArgs {
 size_t fused_lds_bytes(uint32_t nls, uint32_t ti_log2);
 hipError_t launch_fused_lds(bool eval, const FusedLdsArgs &a, const BatchGeom &g, hipStream_t s);
 
-// Fused LDS schedule with staggered half-tiles (fused_lds2_kernels.hip); needs ti_log2 >= 1 and Plan::schunks
-struct FusedLds2Args {
-    const FDesc *hdescs;
-    const uint32_t *hgslot;
-    const XDesc *xdescs;
-    const uint32_t *xgslot;
-    const SChunk *chunks;
+// Fused, LDS-resident, flattened schedule (fused_flat_kernels.hip): the production path
+struct FusedFlatArgs {
+    const uint32_t *prog;  // Plan::fl_prog
+    const FUnit *units;
+    const uint32_t *hgslot, *ogslot;
     const uint16_t *in_lds;
-    uint32_t nchunks, ninputs, nls;
+    uint32_t nunits, ninputs, nls;  // nls = Plan::n_flat_slots (zero slot included)
     uint4 *W;
     const uint4 *R;
     uint4 *T;
     const uint32_t *rk;
     const uint32_t *te0;
     int rounds;
-    bool store_all;
 };
-size_t fused_lds2_bytes(uint32_t nls, uint32_t ti_log2);
-hipError_t launch_fused_lds2(bool eval, const FusedLds2Args &a, const BatchGeom &g, hipStream_t s);
+size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2);
+hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &a, const BatchGeom &g, hipStream_t s);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);

@@ -17,6 +17,235 @@ static inline int op_class(uint8_t op) {
     }
 }
 
+
+// ---- flattened schedule (see plan.h) -----------------------------------------------------------------
+static void symdiff(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, std::vector<uint32_t> *o) {
+    o->clear();
+    size_t i = 0, j = 0;
+    while (i < a.size() || j < b.size()) {
+        if (j == b.size() || (i < a.size() && a[i] < b[j])) o->push_back(a[i++]);
+        else if (i == a.size() || b[j] < a[i]) o->push_back(b[j++]);
+        else i++, j++;  // x ^ x = 0
+    }
+}
+
+static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+                       const std::vector<uint32_t> &src0, const std::vector<uint32_t> &src1,
+                       const std::vector<uint32_t> &cur, Plan *out) {
+    Plan &p = *out;
+    const uint32_t NONE = 0xffffffffu;
+    const uint32_t nprod = ninputs + ngates;
+    // chunk a (= hash phases before the value exists) and XOR round r (0: input / hashed gate) of every producer
+    std::vector<uint32_t> A(nprod, 0), Rr(nprod, 0);
+    std::vector<uint8_t> is_free(nprod, 0), rpar(ngates, 0);
+    std::vector<std::vector<uint32_t>> ex(ngates);  // sorted term list of every XOR gate
+    std::vector<uint32_t> t0, t1, tmp;
+    for (uint32_t g = 0; g < ngates; g++) {
+        const uint32_t pid = ninputs + g, s0 = src0[g], s1 = src1[g];
+        const uint32_t a = std::max(A[s0], A[s1]);
+        if (op_class(gates[g].op) != 3) {
+            A[pid] = a + 1;
+            continue;
+        }
+        is_free[pid] = 1;
+        A[pid] = a;
+        auto rnd = [&](uint32_t s) { return (is_free[s] && A[s] == a) ? Rr[s] : 0u; };
+        uint32_t r = std::max(std::max(rnd(s0), rnd(s1)), 1u);
+        uint8_t par = gates[g].op == GC_XNOR;
+        auto terms_of = [&](uint32_t s, std::vector<uint32_t> *t) {
+            if (is_free[s] && A[s] == a && Rr[s] == r) {  // same round: substitute its expansion
+                *t = ex[s - ninputs];
+                par ^= rpar[s - ninputs];
+            } else {
+                t->assign(1, s);
+            }
+        };
+        terms_of(s0, &t0);
+        terms_of(s1, &t1);
+        symdiff(t0, t1, &tmp);
+        if (tmp.size() > kFlatMaxTerms) {  // materialise the operands, continue in the next round
+            r += 1;
+            par = gates[g].op == GC_XNOR;
+            t0.assign(1, s0);
+            t1.assign(1, s1);
+            symdiff(t0, t1, &tmp);
+        }
+        Rr[pid] = r;
+        rpar[g] = par;
+        ex[g] = tmp;
+    }
+    // what has to exist as a label: operands of hashed gates, circuit outputs, and the terms of those
+    std::vector<uint8_t> need(nprod, 0), is_output(nprod, 0);
+    std::vector<uint32_t> stack;
+    for (uint32_t j = 0; j < noutputs; j++) {
+        const uint32_t w = nwires - noutputs + j;
+        if (cur[w] != NONE) {
+            is_output[cur[w]] = 1;
+            stack.push_back(cur[w]);
+        }
+    }
+    for (uint32_t g = 0; g < ngates; g++)
+        if (!is_free[ninputs + g]) {
+            need[ninputs + g] = 1;  // every table-producing gate runs (its rows are part of the output)
+            stack.push_back(src0[g]);
+            stack.push_back(src1[g]);
+        }
+    while (!stack.empty()) {
+        const uint32_t s = stack.back();
+        stack.pop_back();
+        if (need[s] && (s < ninputs || !is_free[s])) continue;
+        if (need[s]) continue;
+        need[s] = 1;
+        if (s >= ninputs && is_free[s])
+            for (uint32_t t : ex[s - ninputs]) stack.push_back(t);
+    }
+    // steps: (a, r) in order; r = 0 is the hash phase of chunk a
+    std::vector<uint32_t> gl;  // needed gates
+    for (uint32_t g = 0; g < ngates; g++)
+        if (need[ninputs + g]) gl.push_back(g);
+    auto key_of = [&](uint32_t g) { return ((uint64_t)A[ninputs + g] << 32) | ((uint64_t)Rr[ninputs + g] << 8); };
+    auto sub_of = [&](uint32_t g) -> uint64_t {  // order inside a step
+        if (!is_free[ninputs + g]) return (uint64_t)op_class(gates[g].op);
+        return 0xffu - std::min<uint64_t>(0xfeu, (ex[g].size() + 3) / 4);  // longest term lists first
+    };
+    std::stable_sort(gl.begin(), gl.end(), [&](uint32_t x, uint32_t y) {
+        const uint64_t kx = key_of(x) | sub_of(x), ky = key_of(y) | sub_of(y);
+        return kx < ky;
+    });
+    std::vector<uint32_t> step_first;  // index into gl
+    std::vector<uint32_t> step_of(ngates, 0);
+    for (uint32_t k = 0; k < gl.size(); k++) {
+        if (k == 0 || key_of(gl[k]) != key_of(gl[k - 1])) step_first.push_back(k);
+        step_of[gl[k]] = (uint32_t)step_first.size() - 1;
+    }
+    const uint32_t nsteps = (uint32_t)step_first.size();
+    step_first.push_back((uint32_t)gl.size());
+    p.n_flat_steps = nsteps;
+    // last reader (step + 1; 0 = never read)
+    std::vector<uint32_t> last_use(nprod, 0);
+    for (uint32_t g : gl) {
+        const uint32_t st = step_of[g] + 1;
+        if (is_free[ninputs + g]) {
+            for (uint32_t t : ex[g]) last_use[t] = std::max(last_use[t], st);
+        } else {
+            last_use[src0[g]] = std::max(last_use[src0[g]], st);
+            last_use[src1[g]] = std::max(last_use[src1[g]], st);
+        }
+    }
+    // linear scan over the steps; slots freed after step s are reusable from step s + 1
+    std::vector<uint32_t> lds_of(nprod, 0xffffu), free_list;
+    std::vector<std::vector<uint32_t>> expire((size_t)nsteps + 2);
+    uint32_t high = 0;
+    auto take = [&]() {
+        if (!free_list.empty()) {
+            const uint32_t s = free_list.back();
+            free_list.pop_back();
+            return s;
+        }
+        return high++;
+    };
+    p.fl_in_lds.assign(ninputs, 0xffff);
+    for (uint32_t w = 0; w < ninputs; w++) {
+        if (last_use[w] == 0) continue;
+        const uint32_t s = take();
+        lds_of[w] = s;
+        expire[last_use[w]].push_back(s);
+    }
+    for (uint32_t si = 0; si < nsteps; si++) {
+        for (uint32_t s : expire[si]) free_list.push_back(s);  // freed after step si - 1
+        for (uint32_t k = step_first[si]; k < step_first[si + 1]; k++) {
+            const uint32_t pid = ninputs + gl[k];
+            const uint32_t s = take();
+            lds_of[pid] = s;
+            expire[std::max(last_use[pid], si + 1)].push_back(s);
+        }
+    }
+    const uint32_t zslot = high;  // holds the zero label (padding of term lists)
+    if (high + 1 >= 0xffffu) {
+        p.fl_in_lds.clear();
+        return;  // does not fit 16-bit slot numbers: the flat schedule is not offered for this circuit
+    }
+    p.n_flat_slots = high + 1;
+    for (uint32_t w = 0; w < ninputs; w++)
+        if (lds_of[w] != 0xffffu) p.fl_in_lds[w] = (uint16_t)lds_of[w];
+
+    // units
+    std::vector<FDesc> uh;
+    std::vector<XOut> uo;
+    std::vector<uint16_t> ut;
+    std::vector<uint32_t> uhg, uog;
+    FUnit u{};
+    auto emit = [&]() {
+        if (uh.empty() && uo.empty()) return;
+        u.off16 = (uint32_t)(p.fl_prog.size() / 4);
+        u.hfirst = (uint32_t)p.fl_hgslot.size();
+        u.ofirst = (uint32_t)p.fl_ogslot.size();
+        u.nout = (uint32_t)uo.size();
+        for (const FDesc &d : uh) {
+            p.fl_prog.push_back(d.lin);
+            p.fl_prog.push_back(d.lout);
+            p.fl_prog.push_back(d.tweak);
+            p.fl_prog.push_back(d.row_op);
+        }
+        u.outs_off16 = (uint32_t)uh.size();
+        if (uo.size() & 1) uo.push_back(XOut{0, 0, (uint16_t)zslot, 0});  // pad to 16 bytes (never executed)
+        for (const XOut &x : uo) {
+            p.fl_prog.push_back((uint32_t)x.toff4 | ((uint32_t)x.n4 << 16));
+            p.fl_prog.push_back((uint32_t)x.out | ((uint32_t)x.flags << 16));
+        }
+        u.terms_off16 = u.outs_off16 + (uint32_t)uo.size() / 2;
+        while (ut.size() & 7) ut.push_back((uint16_t)zslot);
+        for (size_t i = 0; i < ut.size(); i += 2) p.fl_prog.push_back((uint32_t)ut[i] | ((uint32_t)ut[i + 1] << 16));
+        u.n16 = (uint32_t)(p.fl_prog.size() / 4) - u.off16;
+        p.fl_hgslot.insert(p.fl_hgslot.end(), uhg.begin(), uhg.end());
+        p.fl_ogslot.insert(p.fl_ogslot.end(), uog.begin(), uog.end());
+        p.fl_units.push_back(u);
+        uh.clear(), uo.clear(), ut.clear(), uhg.clear(), uog.clear();
+        u = FUnit{};
+    };
+    for (uint32_t si = 0; si < nsteps; si++) {
+        const uint32_t k0 = step_first[si], k1 = step_first[si + 1];
+        if (!is_free[ninputs + gl[k0]]) {
+            emit();  // a hash phase never shares a unit with what came before it
+            for (uint32_t k = k0; k < k1; k++) {
+                if (uh.size() == kUHash) emit();
+                const uint32_t g = gl[k], pid = ninputs + g;
+                FDesc d;
+                d.lin = lds_of[src0[g]] | (lds_of[src1[g]] << 16);
+                d.lout = lds_of[pid] | (is_output[pid] ? kFStoreGlobal : 0u);
+                d.tweak = p.tweak_of_gate[g];
+                d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
+                uh.push_back(d);
+                uhg.push_back(p.slot_of_gate[g]);
+                if (gates[g].op == GC_AND) u.n_and++;
+                else if (gates[g].op == GC_OR) u.n_or++;
+                else u.n_inv++;
+            }
+        } else {
+            // an XOR round: needs a barrier after whatever produced its terms -> it may share the unit of the
+            // hash phase right before it (hash part | barrier | XOR part) but not a unit that already has XOuts
+            if (!uo.empty()) emit();
+            for (uint32_t k = k0; k < k1; k++) {
+                const uint32_t g = gl[k], pid = ninputs + g;
+                const uint32_t n4 = (uint32_t)(ex[g].size() + 3) / 4;
+                if (uo.size() == kUOuts || ut.size() + 4 * n4 > kUTerms) emit();
+                XOut x;
+                x.toff4 = (uint16_t)(ut.size() / 4);
+                x.n4 = (uint16_t)n4;
+                x.out = (uint16_t)lds_of[pid];
+                x.flags = (uint16_t)((is_output[pid] ? kXoStore : 0) | (rpar[g] ? kXoRpar : 0));
+                for (uint32_t t : ex[g]) ut.push_back((uint16_t)lds_of[t]);
+                while (ut.size() & 3) ut.push_back((uint16_t)zslot);
+                uo.push_back(x);
+                uog.push_back(p.slot_of_gate[g]);
+                p.n_flat_outs++;
+                p.n_flat_terms += (uint32_t)ex[g].size();
+            }
+        }
+    }
+    emit();
+}
+
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
                Plan *out) {
     if ((!gates && ngates) || !out) return GC_E_ARG;
@@ -241,57 +470,16 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
         }
         if (ch.nsteps) p.fchunks.push_back(ch);
 
-        // stagger chunks: [<= kSHash hash gates][<= kSXor XOR gates]; only meaningful when slots fit 13 bits
-        if (!overflow && high < 8192) {
-            SChunk sc{0, 0, 0, 0, 0, 0, {0, 0}};
-            bool open_ = false;
-            auto flush = [&]() {
-                if (open_) p.schunks.push_back(sc);
-                sc = SChunk{(uint32_t)p.shdescs.size(), 0, 0, 0, (uint32_t)p.sxdescs.size(), 0, {0, 0}};
-                open_ = false;
-            };
-            flush();
-            for (uint32_t si = 0; si < p.fsteps.size(); si++) {
-                const Step &st = p.fsteps[si];
-                if (st.nonfree) {
-                    // a hash phase always opens a new chunk; phases wider than kSHash are cut into pieces
-                    // (independent gates; the AND / OR / INV grouping is re-counted per piece)
-                    for (uint32_t k = 0; k < st.count;) {
-                        flush();
-                        const uint32_t n = std::min(kSHash, st.count - k);
-                        for (uint32_t e = 0; e < n; e++) {
-                            const FDesc &d = p.fdescs[st.first + k + e];
-                            const uint32_t op = d.row_op >> kOpShift;
-                            if (op == GC_AND) sc.n_and++;
-                            else if (op == GC_OR) sc.n_or++;
-                            else sc.n_inv++;
-                            p.shdescs.push_back(d);
-                            p.shgslot.push_back(p.fgslot[st.first + k + e]);
-                        }
-                        open_ = true;
-                        k += n;
-                    }
-                } else {
-                    for (uint32_t k = 0; k < st.count; k++) {
-                        if (sc.nx == kSXor) flush();
-                        const FDesc &d = p.fdescs[st.first + k];
-                        XDesc x;
-                        x.lin = d.lin;
-                        x.lout = (d.lout & 0x1fffu) | ((d.lout & kFStoreGlobal) ? kXStoreGlobal : 0u) |
-                                 (((d.row_op >> kOpShift) == GC_XNOR) ? kXXnor : 0u) | ((si & 0xffffu) << 16);
-                        p.sxdescs.push_back(x);
-                        p.sxgslot.push_back(p.fgslot[st.first + k]);
-                        sc.nx++;
-                        open_ = true;
-                    }
-                }
-            }
-            if (open_) p.schunks.push_back(sc);
-        }
         p.info.n_hash_phases = p.n_hash_phases;
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;
     }
+    build_flat(gates, ngates, nwires, ninputs, noutputs, src0, src1, cur, &p);
+    p.info.n_flat_slots = p.n_flat_slots;
+    p.info.n_flat_outs = p.n_flat_outs;
+    p.info.n_flat_terms = p.n_flat_terms;
+    p.info.n_flat_steps = p.n_flat_steps;
+    p.info.n_flat_units = (uint32_t)p.fl_units.size();
     return GC_OK;
 }
 

@@ -58,24 +58,39 @@ struct Chunk {
     uint32_t first_desc, ndesc;  // ndesc > kChunkDescs only for a single over-wide step (read from HBM directly)
 };
 
-// ---- staggered half-tile schedule (fused_lds2_kernels.hip) ----------------------------------------------
-// Same hash-phase order, re-cut into "stagger chunks": at most kSHash table-producing gates (one hash
-// stage) followed by at most kSXor XOR gates (one XOR stage).  The two halves of a tile run one stage apart,
-// so one half always hashes while the other walks its XOR sub-levels.
-struct XDesc {           // 8 bytes
-    uint32_t lin;        // LDS slot of input 0 | LDS slot of input 1 << 16
-    uint32_t lout;       // bits 0-12 LDS slot of the output, bit 13 store-global, bit 14 XNOR, bits 16-31 sub-level id
+// ---- flattened schedule (fused_flat_kernels.hip; the production path) ---------------------------------
+// Free-XOR makes every XOR/XNOR output a GF(2) combination of labels that exist when the preceding hash
+// phase has finished ("chunk-entry" labels: input wires, table-producing gates, XOR outputs of earlier
+// chunks).  Instead of walking the XOR gates level by level — a serial, latency-bound chain of ~8 dependent
+// LDS round trips per hash phase — the plan expands each XOR output that somebody actually needs (a hashed
+// gate, a later chunk, a circuit output) into its term list and the kernels compute all of them in ONE
+// parallel step per hash phase; intermediate XOR wires are never materialised.  Term lists longer than
+// kFlatMaxTerms are cut by materialising the operands and opening a second XOR round in that chunk.
+// (garble.go:331-351 / eval.go:49-51 compute the same labels gate by gate.)
+constexpr uint32_t kFlatMaxTerms = 32;
+struct XOut {            // 8 bytes: one materialised XOR output
+    uint16_t toff4;      // first 4-term group inside the unit's term area
+    uint16_t n4;         // number of 4-term groups (lists are padded with the zero slot)
+    uint16_t out;        // LDS slot of the result
+    uint16_t flags;      // kXoStore | kXoRpar
 };
-constexpr uint32_t kXStoreGlobal = 1u << 13;
-constexpr uint32_t kXXnor = 1u << 14;
-constexpr uint32_t kSHash = 256;
-constexpr uint32_t kSXor = 768;
-struct SChunk {          // 32 bytes
-    uint32_t hfirst, n_and, n_or, n_inv;  // hash descriptors [hfirst, hfirst + n_and + n_or + n_inv) of shdescs
-    uint32_t xfirst, nx;                  // XOR descriptors [xfirst, xfirst + nx) of sxdescs
+static_assert(sizeof(XOut) == 8, "XOut must be 8 bytes");
+constexpr uint16_t kXoStore = 1;  // also store to the global wire array (circuit output)
+constexpr uint16_t kXoRpar = 2;   // garbler: odd number of XNORs in the expansion -> XOR R once
+// A unit is what the kernels stage into LDS in one go: [hash descriptors][XOuts][terms], executed as
+// hash part -> barrier -> XOR part -> barrier.  Capacities chosen so that a unit is <= 832 uint4 (one per
+// thread with room to spare) and two buffers cost 26 KiB of LDS.
+constexpr uint32_t kUHash = 256, kUOuts = 384, kUTerms = 3072;
+constexpr uint32_t kUnit16 = kUHash + kUOuts / 2 + kUTerms / 8;  // 832
+struct FUnit {           // 48 bytes
+    uint32_t off16, n16;             // position / size of the unit in Plan::fl_prog (uint4 units)
+    uint32_t n_and, n_or, n_inv;     // hash descriptors (16 B each) at the start of the unit, in this order
+    uint32_t nout;                   // XOuts
+    uint32_t outs_off16, terms_off16;  // relative to the unit start
+    uint32_t hfirst, ofirst;         // index of the first hash desc / XOut in fl_hgslot / fl_ogslot
     uint32_t pad_[2];
 };
-static_assert(sizeof(SChunk) == 32, "SChunk must be 32 bytes");
+static_assert(sizeof(FUnit) == 48, "FUnit must be 48 bytes");
 
 struct Plan {
     gc_plan_info info{};
@@ -96,12 +111,13 @@ struct Plan {
     std::vector<uint32_t> fgslot;       // global wire slot written by fdescs[k]
     std::vector<Step> fsteps;
     std::vector<Chunk> fchunks;
-    // staggered schedule
-    std::vector<FDesc> shdescs;      // hash descriptors (AND, OR, INV order inside a chunk)
-    std::vector<uint32_t> shgslot;
-    std::vector<XDesc> sxdescs;
-    std::vector<uint32_t> sxgslot;
-    std::vector<SChunk> schunks;
+    // flattened schedule (empty / n_flat_slots == 0xffffffff when the live set does not fit 16-bit slots)
+    std::vector<uint32_t> fl_prog;      // unit images, 16-byte aligned pieces (see FUnit)
+    std::vector<FUnit> fl_units;
+    std::vector<uint32_t> fl_hgslot, fl_ogslot;  // global wire slot of every hash desc / XOut
+    std::vector<uint16_t> fl_in_lds;    // LDS slot of every input wire (0xffff: never read)
+    uint32_t n_flat_slots = 0xffffffffu;  // live labels incl. the zero slot (= slot n_flat_slots - 1)
+    uint32_t n_flat_outs = 0, n_flat_terms = 0, n_flat_steps = 0;
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
     uint32_t n_hash_phases = 0;

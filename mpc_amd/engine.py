@@ -46,7 +46,8 @@ _lib = None
 class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "ngates", "nwires", "ninputs", "noutputs", "nlevels", "max_width", "slab_rows", "n_xor", "n_xnor", "n_and",
-        "n_or", "n_inv", "nslots", "n_steps", "n_hash_phases", "n_fused_steps", "n_lds_slots")]
+        "n_or", "n_inv", "nslots", "n_steps", "n_hash_phases", "n_fused_steps", "n_lds_slots", "n_flat_slots",
+        "n_flat_outs", "n_flat_terms", "n_flat_steps", "n_flat_units")]
 
 
 def lib():
