@@ -22,6 +22,11 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per gate per side (SURVEY.md §8d / DESIGN.md): 16-byte labels, L1 never stored
 ALG_BYTES = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+# Secondary bound (SURVEY.md §8d "LDS bandwidth / VALU issue on AND-dense levels"): the fixed-key hash is a
+# T-table AES out of LDS.  tools/aes_ubench measures the production AES core alone at 10.67 cycles per block per
+# CU with 16 waves/CU (57.6 G blocks/s on 256 CUs; profiles/r01_aes_ubench.txt).
+AES_CORE_PEAK_BLOCKS = 57.6e9
+AES_BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}  # (garble, eval) distinct AES blocks per gate
 
 
 def alg_bytes_per_instance(info):
@@ -133,6 +138,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    torch.cuda.synchronize()  # inputs were generated on torch's stream; the engine runs on its own
     for _ in range(args.warmup):
         step()
     fence()
@@ -175,11 +181,14 @@ def main():
     g_avg = float(np.mean(g_ms))
     e_avg = float(np.mean(e_ms))
     launches = gb.last_launches
-    # dominant kernel: the garble pass (schedule 1: ONE k_garble_lds launch; schedule 0: one
+    # dominant kernel: the garble pass (schedule 1: ONE k_garble_flat launch; schedule 0: one
     # k_garble_level launch per level).  Algorithmic bytes per launch = garble bytes per instance x batch
     # / launches; launch duration from HIP events recorded on the engine's stream (gc_batch_last_ms).
     achieved = algb * batch / (g_avg * 1e-3) / 1e9
-    kernel_name = "k_garble_lds" if args.schedule == 1 else "k_garble_level"
+    kernel_name = {0: "k_garble_level", 1: "k_garble_flat", 2: "k_garble_lds"}[args.schedule]
+    sched_name = {0: "level-launch", 1: "fused-flat", 2: "fused-levels"}[args.schedule]
+    blocks_g = sum(getattr(info, "n_" + k) * v[0] for k, v in AES_BLOCKS.items())
+    blocks_e = sum(getattr(info, "n_" + k) * v[1] for k, v in AES_BLOCKS.items())
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
     if os.path.exists(pmc):
@@ -209,9 +218,9 @@ def main():
             "instances_per_gpu": batch,
             "levels": int(info.nlevels),
             "launches_per_garble": int(launches),
-            "schedule": "fused-lds" if args.schedule == 1 else "level-launch",
+            "schedule": sched_name,
             "hash_phases": int(info.n_hash_phases),
-            "lds_live_labels": int(info.n_lds_slots),
+            "lds_live_labels": int(info.n_flat_slots if args.schedule == 1 else info.n_lds_slots),
             "graph": not args.no_graph,
             "outputs_ok": ok,
         },
@@ -230,6 +239,14 @@ def main():
             "traffic": traffic,
             "alg_bytes_per_launch": algb * batch / max(launches, 1),
             "avg_launch_us": g_avg * 1e3 / max(launches, 1),
+        },
+        # what actually limits the kernels: AES blocks through the LDS T-table core (VALU issue + LDS address path)
+        "aes_core": {
+            "garble_blocks_per_s": blocks_g * batch / (g_avg * 1e-3),
+            "eval_blocks_per_s": blocks_e * batch / (e_avg * 1e-3),
+            "peak_blocks_per_s": AES_CORE_PEAK_BLOCKS,
+            "frac_garble": blocks_g * batch / (g_avg * 1e-3) / AES_CORE_PEAK_BLOCKS,
+            "frac_eval": blocks_e * batch / (e_avg * 1e-3) / AES_CORE_PEAK_BLOCKS,
         },
     }
     if rank == 0:

@@ -256,9 +256,10 @@ int gc_batch_egress_tables(gc_batch *, void *d_out, size_t stride);
 int gc_batch_ingest_tables(gc_batch *, const void *d_in, size_t stride, void *d_bad);
 
 /* timing of the most recent garble / eval on this batch, measured with HIP events recorded on
- * the ctx stream around the level launches (ms); negative if none */
+ * the ctx stream around the gate kernels (the one fused launch, or the level launches; the few-microsecond
+ * label initialisation kernel of a garble is outside) (ms); negative if none */
 float gc_batch_last_ms(gc_batch *);
-/* kernel launches issued by the most recent garble / eval */
+/* gate-kernel launches issued by the most recent garble / eval (1 for the fused schedules) */
 uint32_t gc_batch_last_launches(gc_batch *);
 /* developer aid: s_memtime breakdown of the fused kernels.  enable != 0 switches the instrumented
  * build of the kernel on for subsequent passes; out16 (may be NULL) receives, averaged over

@@ -45,6 +45,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr uint32_t kStageOff = kTeDualBytes / 16;
 constexpr uint32_t kStageEnd = kStageOff + 2 * kUnit16;
 
+#define GC_FPROF(slot)                                               \
+    if constexpr (PROF) {                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+        const uint64_t now__ = __builtin_amdgcn_s_memtime();         \
+        pacc[slot] += now__ - plast;                                 \
+        plast = now__;                                               \
+    }
+// debug cycle breakdown (gc_batch_debug_profile): 0 unit header / prefetch issue, 1 hash part, 2 barrier A,
+// 3 commit, 4 XOR part, 5 barrier B; written for wave 0 (counters 0-7) and wave 15 (8-15) of every workgroup
+#define GC_FPROF_EPILOGUE()                                                                                  \
+    if constexpr (PROF) {                                                                                    \
+        if (threadIdx.x == 0 || threadIdx.x == 960)                                                          \
+            for (int i = 0; i < 8; i++) a.prof[(size_t)blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + i] = pacc[i]; \
+    }
+
 struct FlArgs {
     const uint4 *prog;
     const FUnit *units;
@@ -57,6 +72,7 @@ struct FlArgs {
     uint4 *T;
     const uint32_t *rk;
     const uint32_t *te0;
+    uint64_t *prof;
 };
 
 __device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t n) {
@@ -159,22 +175,27 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
         if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                          \
     }                                                                                                        \
     FUnit u = load_unit(a.units, 0, a.nunits);                                                               \
+    FUnit un = load_unit(a.units, 1, a.nunits); /* headers run two units ahead: their scalar loads */       \
+                                                /* return while the previous unit hashes            */       \
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
     __syncthreads();                                                                                         \
-    const uint32_t lo = te_lane_off();
+    const uint32_t lo = te_lane_off();                                                                       \
+    uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;                                                  \
+    if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
 }  // namespace
 
-template <int NR>
+template <int NR, bool PROF>
 __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     GC_FL_PROLOGUE(true)
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * kUnit16;
-        const FUnit un = load_unit(a.units, ui + 1, a.nunits);
+        const FUnit unn = load_unit(a.units, ui + 2, a.nunits);
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        GC_FPROF(0)
         if (nh) {
             const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
@@ -240,24 +261,32 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             }
         }
         }
+        GC_FPROF(1)
         if (nh && u.nout) lds_barrier();
+        GC_FPROF(2)
         if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
+        GC_FPROF(4)
         if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        GC_FPROF(3)
         lds_barrier();
+        GC_FPROF(5)
         u = un;
+        un = unn;
     }
+    GC_FPROF_EPILOGUE()
 }
 
-template <int NR>
+template <int NR, bool PROF>
 __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     GC_FL_PROLOGUE(false)
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * kUnit16;
-        const FUnit un = load_unit(a.units, ui + 1, a.nunits);
+        const FUnit unn = load_unit(a.units, ui + 2, a.nunits);
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        GC_FPROF(0)
         if (nh) {
             const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
@@ -305,12 +334,19 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             }
         }
         }
+        GC_FPROF(1)
         if (nh && u.nout) lds_barrier();
+        GC_FPROF(2)
         if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
+        GC_FPROF(4)
         if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        GC_FPROF(3)
         lds_barrier();
+        GC_FPROF(5)
         u = un;
+        un = unn;
     }
+    GC_FPROF_EPILOGUE()
 }
 
 size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2) {
@@ -343,12 +379,15 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     a.T = f.T;
     a.rk = f.rk;
     a.te0 = f.te0;
+    a.prof = f.prof;
     if (a.nunits == 0) return hipSuccess;
     const size_t lds = fused_flat_bytes(f.nls, g.ti_log2);
-#define GC_M2(KERN) \
-    (f.rounds == 10 ? launch_fl(KERN<10>, a, g.ntiles, lds, s) : f.rounds == 12 ? launch_fl(KERN<12>, a, g.ntiles, lds, s) : launch_fl(KERN<14>, a, g.ntiles, lds, s))
+#define GC_M3(KERN, NR) \
+    (f.prof ? launch_fl(KERN<NR, true>, a, g.ntiles, lds, s) : launch_fl(KERN<NR, false>, a, g.ntiles, lds, s))
+#define GC_M2(KERN) (f.rounds == 10 ? GC_M3(KERN, 10) : f.rounds == 12 ? GC_M3(KERN, 12) : GC_M3(KERN, 14))
     return eval ? GC_M2(k_eval_flat) : GC_M2(k_garble_flat);
 #undef GC_M2
+#undef GC_M3
 }
 
 }  // namespace gc

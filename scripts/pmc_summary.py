@@ -9,6 +9,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+per = {}  # (pass, kernel prefix) -> KiB per dispatch
 for tag, counter in (("pmc_r", "FETCH_SIZE"), ("pmc_w", "WRITE_SIZE")):
     files = glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True)
     tot = defaultdict(float)
@@ -24,3 +25,27 @@ for tag, counter in (("pmc_r", "FETCH_SIZE"), ("pmc_w", "WRITE_SIZE")):
         corr = 2.0 if counter == "FETCH_SIZE" else 1.0
         print("%-80s dispatches=%6d  raw=%14.0f KiB  per-dispatch=%10.1f KiB  corrected(x%g)=%10.1f KiB" % (
             k, cnt[k], tot[k], tot[k] / cnt[k], corr, corr * tot[k] / cnt[k]))
+    for k in tot:
+        per[(tag, k)] = tot[k] / cnt[k]
+
+# machine-readable per-launch HBM traffic of the dominant kernels (bench.py reads profiles/latest_pmc.json)
+if len(sys.argv) > 5:
+    import json
+    batch, schedule, key_bytes, tag_name = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+
+    def pick(tag, frag):
+        for (t, k), v in per.items():
+            if t == tag and frag in k:
+                return v
+        return None
+
+    j = {"batch": batch, "schedule": schedule, "key_bytes": key_bytes,
+         "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                   "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tag_name}
+    for nm in ("garble", "eval"):
+        r, w = pick("pmc_r", "k_%s_" % nm), pick("pmc_w", "k_%s_" % nm)
+        if r is not None and w is not None:
+            j["%s_fetch_kib_raw" % nm] = round(r, 1)
+            j["%s_write_kib" % nm] = round(w, 1)
+            j["%s_hbm_bytes_per_launch" % nm] = int((2.0 * r + w) * 1024)
+    json.dump(j, open(os.path.join(out, "latest_pmc.json"), "w"), indent=1)

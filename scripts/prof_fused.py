@@ -14,6 +14,7 @@ gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
 key = bytes(range(keylen))
 d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda")
 d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
 for _ in range(3):
     gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
 ctx.sync()
@@ -27,4 +28,4 @@ for nm, b in (("garble", gb), ("eval", ev)):
     p = b.debug_profile(True, read=True)
     tot0, tot1 = sum(p[:8]), sum(p[8:])
     print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:6])}, "total", int(tot0))
-    print(nm, "wave3:", {n: int(v) for n, v in zip(names, p[8:14])}, "total", int(tot1))
+    print(nm, "wave15:", {n: int(v) for n, v in zip(names, p[8:14])}, "total", int(tot1))

@@ -25,11 +25,13 @@ def test_egress_ingest(schedule, aes_circ):
         stride_rnd = 16 * (c.num_inputs + 1)
         rnd = drbg("eg%d" % batch, stride_rnd * batch)
         d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()  # torch's stream -> engine stream hand-over (the engine runs on its own stream)
         gb.garble(key, d_rnd.data_ptr())
         nbytes = dc.tables_wire_bytes
         assert nbytes == 4 + 4 * c.NumGates + 16 * c.slab_rows()
         stride = (nbytes + 63) // 64 * 64
         d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         gb.egress_tables(d_wire.data_ptr(), stride)
         ctx.sync()
         wire = d_wire.cpu().numpy().reshape(batch, stride)
@@ -48,6 +50,7 @@ def test_egress_ingest(schedule, aes_circ):
         d_bits = torch.from_numpy(bits.copy()).cuda()
         d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
         d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
         ev.select_inputs(gb, d_bits.data_ptr())
         ev.eval(key, ev)  # evaluator's OWN ingested tables
         gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
@@ -63,6 +66,7 @@ def test_egress_ingest(schedule, aes_circ):
         w2[min(1, batch - 1), 7] ^= 1
         d_w2 = torch.from_numpy(w2.reshape(-1)).cuda()
         d_bad.zero_()
+        torch.cuda.synchronize()
         ev.ingest_tables(d_w2.data_ptr(), stride, d_bad.data_ptr())
         ctx.sync()
         assert int(d_bad.cpu()[0]) == 2

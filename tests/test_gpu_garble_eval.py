@@ -265,7 +265,7 @@ def test_graph_and_direct_launch_agree(ctx):
         b.garble(KEY256, d_rnd.data_ptr())
         b.garble(KEY256, d_rnd.data_ptr())  # second call replays the captured graph
         slabs.append(b.read_slab().copy())
-        assert b.last_ms > 0 and b.last_launches == dc.info.n_steps + 1
+        assert b.last_ms > 0 and b.last_launches == dc.info.n_steps  # gate kernels only
         b.close()
     assert (slabs[0] == slabs[1]).all() and (slabs[0] == slabs[2]).all()
     ref = oracle_instance(c, KEY256, rnd, 77)
