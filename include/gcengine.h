@@ -197,6 +197,10 @@ typedef struct gc_batch gc_batch;
 gc_batch *gc_batch_create(gc_circ *, uint32_t batch, int *status);
 void gc_batch_free(gc_batch *);
 uint32_t gc_batch_stride(const gc_batch *);
+/* geometry the fused schedules chose for this batch: instances per workgroup tile (1 for schedule 0), and
+ * whether the live wire labels fit in LDS (otherwise the fused kernel keeps them in HBM) */
+uint32_t gc_batch_tile_instances(const gc_batch *);
+int gc_batch_wires_in_lds(const gc_batch *);
 /* schedule: 0 = one launch per dependency level (the reference's AssignLevels order), labels laid
  *               out [wire][instance];
  *           1 = fused (default): ONE launch per pass, every workgroup owns a tile of instances and
@@ -291,6 +295,14 @@ size_t gc_iknp_u_bytes(size_t n);
 int gc_iknp_receive(gc_iknp *, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out);
 /* Replaces the body of (*IKNPSender).send(n)   ot/iknp.go:197-226 (u_in = the received chunks, concatenated) */
 int gc_iknp_send(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out);
+/* Device-resident forms of the two calls above (pipelines that keep the u-matrix and the labels in HBM, e.g.
+ * labels that feed gc_batch_set_inputs / the COT kernels directly): all pointers are DEVICE pointers,
+ * d_choice_packed = the choice bits packed LSB-first, 64 bytes per 512-OT chunk (iknp.go:472-477; zero-padded to
+ * a whole chunk); asynchronous on the ctx stream, no allocation after the first call of a given size.
+ * gc_iknp_last_ms: HIP-event time of the kernels of the most recent *_dev call. */
+int gc_iknp_receive_dev(gc_iknp *, const void *d_choice_packed, size_t n, void *d_u_out, void *d_labels_out);
+int gc_iknp_send_dev(gc_iknp *, const void *d_u_in, size_t n, void *d_labels_out);
+float gc_iknp_last_ms(gc_iknp *);
 
 /* bit-COT: bodies of (*IKNPReceiver).ReceiveBits (ot/iknp.go:554-620) and
  * (*IKNPSender).SendBits (ot/iknp.go:259-310); choices / result are packed little-endian u64 bit vectors.

@@ -195,9 +195,17 @@ static void free_buffers(gc_batch *b) {
 }
 
 // (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
+// live labels the kernel of this batch keeps in LDS: the flattened plan normally, the level-walking plan when
+// every wire has to be materialised (store_all) or schedule 2 was asked for
+static BatchGeom geom_for(const gc_batch *b) {
+    const Plan &p = b->circ->plan.p;
+    const uint32_t nls = (b->store_all || b->single_phase) ? p.n_lds_slots : p.n_flat_slots;
+    return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls);
+}
+
 static hipError_t alloc_buffers(gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    b->g = make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, std::max(p.n_lds_slots, p.n_flat_slots));
+    b->g = geom_for(b);
     const size_t wbytes = (size_t)p.info.nslots * b->g.bstride * sizeof(uint4);
     const size_t tbytes = (size_t)std::max<uint32_t>(p.info.slab_rows, 1) * b->g.bstride * sizeof(uint4);
     hipError_t e = hipMalloc((void **)&b->d_W, wbytes ? wbytes : 16);
@@ -260,18 +268,32 @@ void gc_batch_free(gc_batch *b) {
 
 uint32_t gc_batch_stride(const gc_batch *b) { return b ? b->g.bstride : 0; }
 
-int gc_batch_set_schedule(gc_batch *b, int schedule) {
-    if (!b || schedule < 0 || schedule > 2) return GC_E_ARG;
-    b->single_phase = schedule == 2;  // 1 and 2 share the tiled layout; only the kernel differs
-    schedule = schedule ? 1 : 0;
-    if (schedule == b->schedule) return GC_OK;
-    // the schedule fixes the HBM layout: start over with fresh arrays (contents are per-pass anyway)
+uint32_t gc_batch_tile_instances(const gc_batch *b) { return !b ? 0 : b->schedule == 0 ? 1u : 1u << b->g.ti_log2; }
+int gc_batch_wires_in_lds(const gc_batch *b) { return b && b->schedule != 0 && b->g.lds_wires; }
+
+// the schedule / kernel choice fixes the HBM layout (tile size): when it changes, start over with fresh arrays
+// (contents are per-pass anyway)
+static int relayout(gc_batch *b) {
+    const BatchGeom g = geom_for(b);
+    if (b->d_W && g.ti_log2 == b->g.ti_log2 && g.bstride == b->g.bstride && g.ntiles == b->g.ntiles) {
+        b->g = g;  // same arrays; lds_wires may differ
+        return GC_OK;
+    }
+    GC_HIP(hipSetDevice(b->circ->ctx->device));
+    GC_HIP(hipStreamSynchronize(b->circ->ctx->stream));
     drop_graphs(b);
     free_buffers(b);
-    b->schedule = schedule;
     b->timed = false;
+    b->have_all_wires = false;
     GC_HIP(alloc_buffers(b));
     return GC_OK;
+}
+
+int gc_batch_set_schedule(gc_batch *b, int schedule) {
+    if (!b || schedule < 0 || schedule > 2) return GC_E_ARG;
+    b->single_phase = schedule == 2;  // 1 and 2 share the tiled layout; the kernel (and maybe the tile) differs
+    b->schedule = schedule ? 1 : 0;
+    return relayout(b);
 }
 
 int gc_batch_set_graph(gc_batch *b, int on) {
@@ -434,10 +456,14 @@ int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *
     return GC_OK;
 }
 
+// two batches can exchange labels / tables only if their HBM layouts agree (same schedule class and tile size)
+static bool same_layout(const gc_batch *a, const gc_batch *b) {
+    return a->circ == b->circ && a->g.batch == b->g.batch && a->schedule == b->schedule &&
+           a->g.ti_log2 == b->g.ti_log2 && a->g.bstride == b->g.bstride;
+}
+
 int gc_batch_select_inputs(gc_batch *ev, const gc_batch *gb, const void *d_bits) {
-    if (!ev || !gb || !d_bits || ev->circ != gb->circ || ev->g.batch != gb->g.batch ||
-        ev->schedule != gb->schedule)
-        return GC_E_ARG;
+    if (!ev || !gb || !d_bits || !same_layout(ev, gb)) return GC_E_ARG;
     gc_ctx *ctx = ev->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     launch_select_inputs(ev->d_W, gb->d_W, gb->d_R, (const uint8_t *)d_bits, ev->circ->plan.p.info.ninputs, ev->g,
@@ -457,9 +483,7 @@ int gc_batch_set_inputs(gc_batch *ev, const void *d_labels) {
 }
 
 int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batch *tables) {
-    if (!ev || !tables || tables->circ != ev->circ || tables->g.bstride != ev->g.bstride ||
-        tables->schedule != ev->schedule)
-        return GC_E_ARG;
+    if (!ev || !tables || !same_layout(ev, tables)) return GC_E_ARG;
     gc_ctx *ctx = ev->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     int rc = set_key(ev, key, keylen);
@@ -473,9 +497,7 @@ int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batc
 }
 
 int gc_batch_decode(const gc_batch *gb, const gc_batch *ev, void *d_bits_out, void *d_mismatch) {
-    if (!gb || !ev || !d_bits_out || gb->circ != ev->circ || gb->g.batch != ev->g.batch ||
-        gb->schedule != ev->schedule)
-        return GC_E_ARG;
+    if (!gb || !ev || !d_bits_out || !same_layout(gb, ev)) return GC_E_ARG;
     gc_ctx *ctx = gb->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     launch_decode(gb->d_W, gb->d_R, ev->d_W, gb->circ->d_out_slots, gb->circ->plan.p.info.noutputs,
@@ -539,7 +561,7 @@ int gc_batch_read_slab(gc_batch *b, gc_label *slab_out) {
 int gc_batch_set_store_all(gc_batch *b, int on) {
     if (!b) return GC_E_ARG;
     b->store_all = on != 0;
-    return GC_OK;
+    return relayout(b);
 }
 
 int gc_batch_read_wires(gc_batch *b, gc_wire *wires_out) {
@@ -674,21 +696,27 @@ static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
             if (c->pool[i]->g.batch == batch && c->pool[i]->schedule == schedule) {
                 gc_batch *b = c->pool[i];
                 c->pool.erase(c->pool.begin() + (long)i);
-                b->single_phase = single_phase;
+                if (b->single_phase != single_phase) {
+                    b->single_phase = single_phase;
+                    if (relayout(b) != GC_OK) {
+                        gc_batch_free(b);
+                        if (rc) *rc = GC_E_HIP;
+                        return nullptr;
+                    }
+                }
                 return b;
             }
         }
     }
     gc_batch *b = gc_batch_create(c, batch, rc);
-    if (b && b->schedule != schedule) {
-        int r2 = gc_batch_set_schedule(b, schedule);
+    if (b && (b->schedule != schedule || b->single_phase != single_phase)) {
+        int r2 = gc_batch_set_schedule(b, schedule == 0 ? 0 : single_phase ? 2 : 1);
         if (r2 != GC_OK) {
             gc_batch_free(b);
             if (rc) *rc = r2;
             return nullptr;
         }
     }
-    if (b) b->single_phase = single_phase;
     return b;
 }
 

@@ -13,6 +13,11 @@ struct gc_iknp {
     uint32_t *d_rk0 = nullptr, *d_rk1 = nullptr;  // [128][44]
     uint64_t pos = 0;                             // bytes drawn so far from every column stream
     uint4 delta{};
+    // device-resident API (gc_iknp_*_dev): workspace kept across calls, events around the kernels
+    void *d_ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
 };
 
 namespace {
@@ -102,6 +107,9 @@ void gc_iknp_free(gc_iknp *k) {
     if (k->ctx) (void)hipSetDevice(k->ctx->device);
     if (k->d_rk0) (void)hipFree(k->d_rk0);
     if (k->d_rk1) (void)hipFree(k->d_rk1);
+    if (k->d_ws) (void)hipFree(k->d_ws);
+    if (k->ev0) (void)hipEventDestroy(k->ev0);
+    if (k->ev1) (void)hipEventDestroy(k->ev1);
     delete k;
 }
 
@@ -192,6 +200,72 @@ int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_lab
     GC_HIP(hipStreamSynchronize(s));
     k->pos += stream_advance(n);
     return GC_OK;
+}
+
+// ---- device-resident entry points: no host staging, no allocation after the first call, asynchronous on the
+// ctx stream (gc_ctx_sync to wait).  Same kernels, same bytes as gc_iknp_receive / gc_iknp_send.
+static int iknp_ws(gc_iknp *k, size_t bytes) {
+    if (!k->ev0) {
+        GC_HIP(hipEventCreate(&k->ev0));
+        GC_HIP(hipEventCreate(&k->ev1));
+    }
+    if (bytes <= k->ws_bytes) return GC_OK;
+    GC_HIP(hipStreamSynchronize(k->ctx->stream));
+    if (k->d_ws) (void)hipFree(k->d_ws);
+    k->d_ws = nullptr;
+    k->ws_bytes = 0;
+    GC_HIP(hipMalloc(&k->d_ws, bytes));
+    k->ws_bytes = bytes;
+    return GC_OK;
+}
+
+int gc_iknp_receive_dev(gc_iknp *k, const void *d_choice_packed, size_t n, void *d_u_out, void *d_labels_out) {
+    if (!k || !k->receiver || (n && (!d_choice_packed || !d_u_out || !d_labels_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = k->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t chunks = (n + 511) / 512;
+    int rc = iknp_ws(k, chunks * 8192);
+    if (rc != GC_OK) return rc;
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipEventRecord(k->ev0, s));
+    launch_iknp_prg(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_choice_packed, nullptr, k->delta,
+                    (uint8_t *)k->d_ws, (uint8_t *)d_u_out, ctx->d_te0, s);
+    launch_iknp_transpose((const uint8_t *)k->d_ws, n, (uint4 *)d_labels_out, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipEventRecord(k->ev1, s));
+    k->timed = true;
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+int gc_iknp_send_dev(gc_iknp *k, const void *d_u_in, size_t n, void *d_labels_out) {
+    if (!k || k->receiver || (n && (!d_u_in || !d_labels_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = k->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t chunks = (n + 511) / 512;
+    int rc = iknp_ws(k, chunks * 8192);
+    if (rc != GC_OK) return rc;
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipEventRecord(k->ev0, s));
+    launch_iknp_prg(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u_in, k->delta,
+                    (uint8_t *)k->d_ws, nullptr, ctx->d_te0, s);
+    launch_iknp_transpose((const uint8_t *)k->d_ws, n, (uint4 *)d_labels_out, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipEventRecord(k->ev1, s));
+    k->timed = true;
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+float gc_iknp_last_ms(gc_iknp *k) {
+    if (!k || !k->timed) return -1.0f;
+    if (hipSetDevice(k->ctx->device) != hipSuccess) return -1.0f;
+    if (hipEventSynchronize(k->ev1) != hipSuccess) return -1.0f;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, k->ev0, k->ev1) != hipSuccess) return -1.0f;
+    return ms;
 }
 
 // ---- KOS consistency check --------------------------------------------------------------------------------

@@ -92,6 +92,8 @@ def lib():
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
         "gc_batch_stride": (u32, [vp]),
+        "gc_batch_tile_instances": (u32, [vp]),
+        "gc_batch_wires_in_lds": (i32, [vp]),
         "gc_batch_set_schedule": (i32, [vp, i32]),
         "gc_batch_set_graph": (i32, [vp, i32]),
         "gc_batch_set_store_all": (i32, [vp, i32]),
@@ -122,6 +124,9 @@ def lib():
         "gc_iknp_u_bytes": (sz, [sz]),
         "gc_iknp_receive": (i32, [vp, vp, sz, vp, vp]),
         "gc_iknp_send": (i32, [vp, vp, sz, sz, vp]),
+        "gc_iknp_receive_dev": (i32, [vp, vp, sz, vp, vp]),
+        "gc_iknp_send_dev": (i32, [vp, vp, sz, vp]),
+        "gc_iknp_last_ms": (C.c_float, [vp]),
         "gc_iknp_receive_bits": (i32, [vp, vp, sz, vp, vp]),
         "gc_iknp_send_bits": (i32, [vp, vp, sz, sz, vp]),
         "gc_kos_receiver_tags": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
@@ -287,6 +292,14 @@ class Batch:
         if not self.h:
             raise EngineError(st.value, "gc_batch_create")
         self.stride = lib().gc_batch_stride(self.h)
+
+    @property
+    def tile_instances(self):
+        return int(lib().gc_batch_tile_instances(self.h))
+
+    @property
+    def lds_wires(self):
+        return bool(lib().gc_batch_wires_in_lds(self.h))
 
     def set_graph(self, on):
         _check(lib().gc_batch_set_graph(self.h, 1 if on else 0), "gc_batch_set_graph")
@@ -465,6 +478,14 @@ class IKNPReceiver:
         _check(lib().gc_iknp_receive(self.h, _p(bb), n, _p(u), _p(res)), "gc_iknp_receive")
         return u[: lib().gc_iknp_u_bytes(n)].tobytes(), res[:n]
 
+    def receive_dev(self, d_choice_packed, n, d_u_out, d_labels_out):
+        """device pointers (ints); asynchronous on the ctx stream"""
+        _check(lib().gc_iknp_receive_dev(self.h, d_choice_packed, n, d_u_out, d_labels_out), "gc_iknp_receive_dev")
+
+    @property
+    def last_ms(self):
+        return float(lib().gc_iknp_last_ms(self.h))
+
     def receive_bits(self, choices, n):
         ch = np.ascontiguousarray(choices, dtype=np.uint64)
         u = np.zeros(max(lib().gc_iknp_u_bytes(n), 1), np.uint8)
@@ -495,6 +516,14 @@ class IKNPSender:
         res = np.zeros(max(n, 1), LABEL)
         _check(lib().gc_iknp_send(self.h, _p(ub), len(u), n, _p(res)), "gc_iknp_send")
         return res[:n]
+
+    def send_dev(self, d_u_in, n, d_labels_out):
+        """device pointers (ints); asynchronous on the ctx stream"""
+        _check(lib().gc_iknp_send_dev(self.h, d_u_in, n, d_labels_out), "gc_iknp_send_dev")
+
+    @property
+    def last_ms(self):
+        return float(lib().gc_iknp_last_ms(self.h))
 
     def send_bits(self, u, n):
         ub = np.frombuffer(bytes(u), np.uint8) if len(u) else np.zeros(1, np.uint8)

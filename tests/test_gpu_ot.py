@@ -161,3 +161,34 @@ def test_bitcot_matches_oracle(ctx, n):
         d0 = np.uint64(0xFFFFFFFFFFFFFFFF) if oracle.label_bit(delta, 0) else np.uint64(0)
         assert ((s ^ r) == (choices & d0)).all()
     rcv.close(); snd.close()
+
+
+def test_iknp_device_resident_api_matches_host_api(ctx):
+    """gc_iknp_receive_dev / gc_iknp_send_dev (HBM in, HBM out, asynchronous) produce the bytes of the host calls,
+    including the persistent stream position across calls of ragged sizes."""
+    import torch
+    base, delta, k0 = base_setup("dev")
+    rx_h, tx_h = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    rx_d, tx_d = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    for n in (700, 512, 5, 3000):
+        b = np.frombuffer(drbg("devb%d" % n, n), np.uint8) & 1
+        u, lr = rx_h.receive(b)
+        ls = tx_h.send(u, n)
+        chunks = (n + 511) // 512
+        packed = np.zeros(chunks * 64, np.uint8)
+        pb = np.packbits(b, bitorder="little")
+        packed[:len(pb)] = pb
+        d_c = torch.from_numpy(packed).cuda()
+        d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
+        d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+        d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rx_d.receive_dev(d_c.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
+        tx_d.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+        ctx.sync()
+        assert d_u.cpu().numpy()[:len(u)].tobytes() == u
+        assert d_lr.cpu().numpy().tobytes() == lr.tobytes()
+        assert d_ls.cpu().numpy().tobytes() == ls.tobytes()
+        assert rx_d.last_ms > 0 and tx_d.last_ms > 0
+    for o in (rx_h, tx_h, rx_d, tx_d):
+        o.close()
