@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--circuit", default=os.path.join(ROOT, "tests", "golden", "aes_128.gcf"))
     ap.add_argument("--key-bytes", type=int, default=32, choices=[16, 24, 32])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--schedule", type=int, default=1)
     ap.add_argument("--check", action="store_true", help="verify decoded outputs against plaintext evaluation")
@@ -250,6 +251,10 @@ def main():
         },
     }
     if rank == 0:
+        if world == 1 and not args.no_iknp:
+            # second kernel pair of the path (ot/iknp.go): OT extension on the device-resident API, 4 Mi OTs
+            from scripts.bench_iknp import run as iknp_run
+            res["iknp"] = iknp_run(1 << 22, 5, ctx=ctx)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
         print(json.dumps(res))

@@ -144,15 +144,15 @@ void launch_tables_ingest(uint4 *T, const Layout &lt, const uint8_t *ops, const 
                           hipStream_t s);
 
 // ---- OT kernels (ot_kernels.hip) -------------------------------------------------------------
-// Column AES-128-CTR PRG of IKNP.  rk0/rk1: [128][44] expanded column keys (big-endian words);
-// pos0: bytes every column stream has already produced; n OTs -> chunks of 512.
-//   recv: tbuf = PRG(g0), u_out = PRG(g0)^PRG(g1)^choice bytes (bbuf packed LSB first)
-//   send: tbuf = PRG(g0) ^ (delta.Bit(col) ? u_in : 0)
-void launch_iknp_prg(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64_t pos0, size_t n,
-                     const uint8_t *bbuf, const uint8_t *u_in, uint4 delta, uint8_t *tbuf, uint8_t *u_out,
-                     const uint32_t *te0, hipStream_t s);
-// createLabels over all chunks of tbuf
-void launch_iknp_transpose(const uint8_t *tbuf, size_t n, uint4 *labels, hipStream_t s);
+// IKNP OT extension, fused (iknp_fused_kernels.hip): column AES-128-CTR PRG + u-matrix / delta fold + createLabels.
+// rk0/rk1: [128][44] expanded column keys (big-endian words); pos0: bytes every column stream has already
+// produced; n OTs in chunks of 512.
+//   recv: u_out = PRG(g0)^PRG(g1)^choice bytes (bbuf: choice bits packed LSB first, 64 bytes per chunk),
+//         labels = transpose(PRG(g0))
+//   send: labels = transpose(PRG(g0) ^ (delta.Bit(col) ? u_in : 0))
+hipError_t launch_iknp_fused(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64_t pos0, size_t n,
+                             const uint8_t *bbuf, const uint8_t *u_in, uint4 delta, uint8_t *u_out, uint4 *labels,
+                             const uint32_t *te0, hipStream_t s);
 void launch_pack_bits(const uint8_t *b, size_t n, uint8_t *out, hipStream_t s);
 // KOS check accumulators: acc[0..3] ^= XOR chi_i * v_i (256 bit), acc[4..5] ^= XOR_{bits_i} chi_i
 void launch_kos_accumulate(const uint32_t *rk, uint64_t idx0, const uint4 *v, const uint8_t *bits, size_t n,

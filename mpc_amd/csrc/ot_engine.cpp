@@ -128,18 +128,15 @@ static int iknp_receive_packed(gc_iknp *k, const std::vector<uint8_t> &bbuf, siz
     std::lock_guard<std::mutex> lk(ctx->mu);
     GC_HIP(hipSetDevice(ctx->device));
     const size_t chunks = (n + 511) / 512, ub = gc_iknp_u_bytes(n);
-    DevBuf d_bits, d_t, d_u, d_lab;
+    DevBuf d_bits, d_u, d_lab;
     GC_HIP(d_bits.alloc(chunks * 64 + 16));
-    GC_HIP(d_t.alloc(chunks * 8192));
     GC_HIP(d_u.alloc(chunks * 8192));
     GC_HIP(d_lab.alloc(n * sizeof(uint4)));
     hipStream_t s = ctx->stream;
     GC_HIP(hipMemsetAsync(d_bits.p, 0, chunks * 64 + 16, s));
     GC_HIP(hipMemcpyAsync(d_bits.p, bbuf.data(), std::min(bbuf.size(), chunks * 64), hipMemcpyHostToDevice, s));
-    launch_iknp_prg(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_bits.p, nullptr, k->delta,
-                    (uint8_t *)d_t.p, (uint8_t *)d_u.p, ctx->d_te0, s);
-    launch_iknp_transpose((const uint8_t *)d_t.p, n, (uint4 *)d_lab.p, s);
-    GC_HIP(hipGetLastError());
+    GC_HIP(launch_iknp_fused(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_bits.p, nullptr, k->delta,
+                             (uint8_t *)d_u.p, (uint4 *)d_lab.p, ctx->d_te0, s));
     GC_HIP(hipMemcpyAsync(u_out, d_u.p, ub, hipMemcpyDeviceToHost, s));
     GC_HIP(hipMemcpyAsync(labels_out, d_lab.p, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
@@ -186,16 +183,13 @@ int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_lab
     std::lock_guard<std::mutex> lk(ctx->mu);
     GC_HIP(hipSetDevice(ctx->device));
     const size_t chunks = (n + 511) / 512;
-    DevBuf d_t, d_u, d_lab;
-    GC_HIP(d_t.alloc(chunks * 8192));
+    DevBuf d_u, d_lab;
     GC_HIP(d_u.alloc(chunks * 8192));
     GC_HIP(d_lab.alloc(n * sizeof(uint4)));
     hipStream_t s = ctx->stream;
     GC_HIP(hipMemcpyAsync(d_u.p, u_in, u_len, hipMemcpyHostToDevice, s));
-    launch_iknp_prg(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u.p, k->delta, (uint8_t *)d_t.p,
-                    nullptr, ctx->d_te0, s);
-    launch_iknp_transpose((const uint8_t *)d_t.p, n, (uint4 *)d_lab.p, s);
-    GC_HIP(hipGetLastError());
+    GC_HIP(launch_iknp_fused(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u.p, k->delta, nullptr,
+                             (uint4 *)d_lab.p, ctx->d_te0, s));
     GC_HIP(hipMemcpyAsync(labels_out, d_lab.p, n * sizeof(uint4), hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
     k->pos += stream_advance(n);
@@ -224,15 +218,12 @@ int gc_iknp_receive_dev(gc_iknp *k, const void *d_choice_packed, size_t n, void 
     if (n == 0) return GC_OK;
     gc_ctx *ctx = k->ctx;
     GC_HIP(hipSetDevice(ctx->device));
-    const size_t chunks = (n + 511) / 512;
-    int rc = iknp_ws(k, chunks * 8192);
+    int rc = iknp_ws(k, 0);
     if (rc != GC_OK) return rc;
     hipStream_t s = ctx->stream;
     GC_HIP(hipEventRecord(k->ev0, s));
-    launch_iknp_prg(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_choice_packed, nullptr, k->delta,
-                    (uint8_t *)k->d_ws, (uint8_t *)d_u_out, ctx->d_te0, s);
-    launch_iknp_transpose((const uint8_t *)k->d_ws, n, (uint4 *)d_labels_out, s);
-    GC_HIP(hipGetLastError());
+    GC_HIP(launch_iknp_fused(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)d_choice_packed, nullptr, k->delta,
+                             (uint8_t *)d_u_out, (uint4 *)d_labels_out, ctx->d_te0, s));
     GC_HIP(hipEventRecord(k->ev1, s));
     k->timed = true;
     k->pos += stream_advance(n);
@@ -244,15 +235,12 @@ int gc_iknp_send_dev(gc_iknp *k, const void *d_u_in, size_t n, void *d_labels_ou
     if (n == 0) return GC_OK;
     gc_ctx *ctx = k->ctx;
     GC_HIP(hipSetDevice(ctx->device));
-    const size_t chunks = (n + 511) / 512;
-    int rc = iknp_ws(k, chunks * 8192);
+    int rc = iknp_ws(k, 0);
     if (rc != GC_OK) return rc;
     hipStream_t s = ctx->stream;
     GC_HIP(hipEventRecord(k->ev0, s));
-    launch_iknp_prg(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u_in, k->delta,
-                    (uint8_t *)k->d_ws, nullptr, ctx->d_te0, s);
-    launch_iknp_transpose((const uint8_t *)k->d_ws, n, (uint4 *)d_labels_out, s);
-    GC_HIP(hipGetLastError());
+    GC_HIP(launch_iknp_fused(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u_in, k->delta, nullptr,
+                             (uint4 *)d_labels_out, ctx->d_te0, s));
     GC_HIP(hipEventRecord(k->ev1, s));
     k->timed = true;
     k->pos += stream_advance(n);

@@ -1,7 +1,6 @@
 // ot_kernels.hip — CDNA4 kernels for the IKNP OT extension and MITCCRH.
 //
-//   k_iknp_prg        column AES-128-CTR PRG (+ u-matrix / delta fold)   ot/iknp.go:490-498, :214-219, :622-637
-//   k_iknp_transpose  128 x w bit-matrix transpose -> labels (createLabels) ot/iknp.go:647-683
+//   (the IKNP PRG + transpose live in iknp_fused_kernels.hip)
 //   k_mitccrh / k_cot_send / k_cot_recv                                    ot/mitccrh.go:70-128, ot/cot.go:155-232
 //
 // A chunk is the reference's 8 KiB message: 128 columns x byteRows bytes, column-major.  Every
@@ -15,7 +14,7 @@ namespace gc {
 
 __device__ __forceinline__ uint32_t bswap32d(uint32_t v) { return __builtin_bswap32(v); }
 
-// keystream block j of a column: AES-128_rk(BE128(j)) as 16 stream bytes packed little-endian
+// keystream block j of a stream: AES-128_rk(BE128(j)) as 16 stream bytes packed little-endian
 template <int N>
 __device__ __forceinline__ void ctr_blocks(const uint64_t (&j)[N], uint4 (&out)[N], const uint32_t *__restrict__ rk,
                                            const uint32_t *te) {
@@ -30,152 +29,6 @@ __device__ __forceinline__ void ctr_blocks(const uint64_t (&j)[N], uint4 (&out)[
     aes_encrypt_n<10, N>(s, rk, te);
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = make_uint4(bswap32d(s[k][0]), bswap32d(s[k][1]), bswap32d(s[k][2]), bswap32d(s[k][3]));
-}
-
-// bytes [sh, sh+16) of the 32-byte concatenation lo || hi
-__device__ __forceinline__ uint4 shift_bytes(uint4 lo, uint4 hi, uint32_t sh) {
-    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    const uint32_t ws = sh >> 2, bs = (sh & 3) * 8;
-    uint32_t o[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t a = 0, b = 0;
-#pragma unroll
-        for (int t = 0; t < 8; t++) {  // register-only select of w[ws+k], w[ws+k+1]
-            a = (uint32_t)t == ws + k ? w[t] : a;
-            b = (uint32_t)t == ws + k + 1 ? w[t] : b;
-        }
-        o[k] = bs ? ((a >> bs) | (b << (32 - bs))) : a;
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-__device__ __forceinline__ void store_bytes(uint8_t *dst, uint4 v, uint32_t nbytes) {
-    if (nbytes == 16 && (((uintptr_t)dst) & 15) == 0) {
-        *(uint4 *)dst = v;
-        return;
-    }
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    for (uint32_t t = 0; t < nbytes; t++) dst[t] = (uint8_t)(w[t >> 2] >> ((t & 3) * 8));
-}
-
-__device__ __forceinline__ uint4 load_bytes(const uint8_t *src, uint32_t nbytes) {
-    if (nbytes == 16 && (((uintptr_t)src) & 15) == 0) return *(const uint4 *)src;
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t t = 0; t < nbytes; t++) w[t >> 2] |= (uint32_t)src[t] << ((t & 3) * 8);
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// One thread = one 16-byte segment of one column of one chunk.
-//   RECV:  t = PRG(g0); u = PRG(g1) ^ t ^ choice-bytes   -> tbuf, u_out      (iknp.go:490-498)
-//   SEND:  t = PRG(g0) ^ (delta bit ? u_in : 0)          -> tbuf             (iknp.go:214-219)
-// grid.y = column (block-uniform round keys -> scalar loads)
-template <bool RECV>
-__global__ __launch_bounds__(256) void k_iknp_prg(const uint32_t *__restrict__ rk0, const uint32_t *__restrict__ rk1,
-                                                  uint64_t pos0, size_t n, const uint8_t *__restrict__ bbuf,
-                                                  const uint8_t *__restrict__ u_in, uint4 delta,
-                                                  uint8_t *__restrict__ tbuf, uint8_t *__restrict__ u_out,
-                                                  const uint32_t *__restrict__ g_te0) {
-    __shared__ uint32_t te[kTeWords];
-    load_te_tables(te, g_te0);
-    __syncthreads();
-    const uint32_t col = blockIdx.y;
-    const size_t seg = (size_t)blockIdx.x * 256 + threadIdx.x;  // global segment index: chunk*4 + q
-    const size_t chunk = seg >> 2;
-    const uint32_t q = (uint32_t)(seg & 3);
-    const size_t ofs = chunk * 512;  // first OT of the chunk
-    if (ofs >= n) return;
-    const size_t rows = (n - ofs) < 512 ? (n - ofs) : 512;
-    const uint32_t byte_rows = (uint32_t)((rows + 7) / 8);
-    if (16 * q >= byte_rows) return;
-    const uint32_t nbytes = byte_rows - 16 * q < 16 ? byte_rows - 16 * q : 16;
-    // all earlier chunks of this call are full (64 bytes per column)
-    const uint64_t p = pos0 + 64 * (uint64_t)chunk + 16 * q;  // stream byte position of this segment
-    const uint32_t sh = (uint32_t)(p & 15);
-    const uint64_t j0 = p >> 4;
-    const uint32_t *k0 = rk0 + 44 * col;
-    uint4 t;
-    if (sh == 0) {  // launch-uniform: every segment of a call has the same misalignment
-        uint64_t j[1] = {j0};
-        uint4 o[1];
-        ctr_blocks<1>(j, o, k0, te);
-        t = o[0];
-    } else {
-        uint64_t j[2] = {j0, j0 + 1};
-        uint4 o[2];
-        ctr_blocks<2>(j, o, k0, te);
-        t = shift_bytes(o[0], o[1], sh);
-    }
-    const size_t at = chunk * 8192 + (size_t)col * byte_rows + 16 * q;
-    if (RECV) {
-        const uint32_t *k1 = rk1 + 44 * col;
-        uint4 t1;
-        if (sh == 0) {
-            uint64_t j[1] = {j0};
-            uint4 o[1];
-            ctr_blocks<1>(j, o, k1, te);
-            t1 = o[0];
-        } else {
-            uint64_t j[2] = {j0, j0 + 1};
-            uint4 o[2];
-            ctr_blocks<2>(j, o, k1, te);
-            t1 = shift_bytes(o[0], o[1], sh);
-        }
-        const uint4 b = load_bytes(bbuf + ofs / 8 + 16 * q, nbytes);
-        store_bytes(tbuf + at, t, nbytes);
-        store_bytes(u_out + at, lxor(lxor(t, t1), b), nbytes);
-    } else {
-        // Delta.Bit(i): bit i of D0 for i < 64 (label.go:129-141) — D0 is the LOW limb here
-        const uint32_t word = col < 32 ? delta.x : col < 64 ? delta.y : col < 96 ? delta.z : delta.w;
-        if ((word >> (col & 31)) & 1) t = lxor(t, load_bytes(u_in + at, nbytes));
-        store_bytes(tbuf + at, t, nbytes);
-    }
-}
-
-// createLabels (iknp.go:647-683): label 8*row+bit has bit j = bit `bit` of chunk[j*w + row];
-// j < 64 -> D0 bit j, else D1 bit j-64.  One block per chunk: the chunk is staged in LDS with a
-// padded column stride, every wave turns 8 byte-rows into 64 labels with wave-wide ballots
-// (the 64-bit ballot of "bit b of column j's byte" IS limb D0 / D1 of label 8*row+b).
-constexpr uint32_t kColStride = 68;  // bytes; 17 dwords -> conflict-free byte reads across columns
-
-__global__ __launch_bounds__(256) void k_iknp_transpose(const uint8_t *__restrict__ tbuf, size_t n,
-                                                        uint4 *__restrict__ labels) {
-    __shared__ uint8_t lds[128 * kColStride];
-    const size_t chunk = blockIdx.x;
-    const size_t ofs = chunk * 512;
-    if (ofs >= n) return;
-    const size_t rows = (n - ofs) < 512 ? (n - ofs) : 512;
-    const uint32_t w = (uint32_t)((rows + 7) / 8);
-    const uint8_t *src = tbuf + chunk * 8192;
-    for (uint32_t t = threadIdx.x; t < 128 * w; t += 256) {
-        uint32_t col = t / w, r = t - col * w;
-        lds[col * kColStride + r] = src[t];
-    }
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t r0 = wave * 8; r0 < w; r0 += 32) {  // 8 byte-rows per wave pass
-        uint64_t my0 = 0, my1 = 0;
-#pragma unroll
-        for (uint32_t rr = 0; rr < 8; rr++) {
-            const uint32_t row = r0 + rr;
-            uint32_t lo = 0, hi = 0;
-            if (row < w) {
-                lo = lds[lane * kColStride + row];
-                hi = lds[(64 + lane) * kColStride + row];
-            }
-#pragma unroll
-            for (uint32_t b = 0; b < 8; b++) {
-                const uint64_t d0 = __ballot((lo >> b) & 1);
-                const uint64_t d1 = __ballot((hi >> b) & 1);
-                if (lane == rr * 8 + b) {
-                    my0 = d0;
-                    my1 = d1;
-                }
-            }
-        }
-        const size_t idx = (size_t)r0 * 8 + lane;  // label index inside the chunk
-        if (idx < rows) labels[ofs + idx] = make_uint4((uint32_t)my0, (uint32_t)(my0 >> 32), (uint32_t)my1, (uint32_t)(my1 >> 32));
-    }
 }
 
 // choice bools -> bytes, LSB first (iknp.go:472-477)
@@ -397,25 +250,6 @@ void launch_kos_accumulate(const uint32_t *rk, uint64_t idx0, const uint4 *v, co
 }
 
 // ---- IKNP launchers ----------------------------------------------------------------------------
-
-void launch_iknp_prg(bool recv, const uint32_t *rk0, const uint32_t *rk1, uint64_t pos0, size_t n,
-                     const uint8_t *bbuf, const uint8_t *u_in, uint4 delta, uint8_t *tbuf, uint8_t *u_out,
-                     const uint32_t *te0, hipStream_t s) {
-    if (n == 0) return;
-    const size_t chunks = (n + 511) / 512;
-    dim3 grid((unsigned)((chunks * 4 + 255) / 256), 128);
-    if (recv)
-        hipLaunchKernelGGL(k_iknp_prg<true>, grid, dim3(256), 0, s, rk0, rk1, pos0, n, bbuf, u_in, delta, tbuf, u_out,
-                           te0);
-    else
-        hipLaunchKernelGGL(k_iknp_prg<false>, grid, dim3(256), 0, s, rk0, rk1, pos0, n, bbuf, u_in, delta, tbuf,
-                           u_out, te0);
-}
-
-void launch_iknp_transpose(const uint8_t *tbuf, size_t n, uint4 *labels, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_iknp_transpose, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, s, tbuf, n, labels);
-}
 
 void launch_pack_bits(const uint8_t *b, size_t n, uint8_t *out, hipStream_t s) {
     if (n == 0) return;

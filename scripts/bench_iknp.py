@@ -12,41 +12,52 @@ import torch
 from mpc_amd import engine
 from mpc_amd.circuit import LABEL, WIRE
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-rng = np.random.default_rng(7)
-ctx = engine.Context(0)
-base = np.zeros(128, WIRE)
-for f in ("l0", "l1"):
-    base[f]["d0"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
-    base[f]["d1"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
-delta = np.zeros(1, LABEL)
-delta["d0"], delta["d1"] = rng.integers(0, 1 << 63, 2, dtype=np.uint64)
-dbits = [(int(delta["d0"][0]) >> i) & 1 if i < 64 else (int(delta["d1"][0]) >> (i - 64)) & 1 for i in range(128)]
-k0 = np.array([base[i]["l1"] if dbits[i] else base[i]["l0"] for i in range(128)], dtype=LABEL)
-rx = engine.IKNPReceiver(ctx, base)
-tx = engine.IKNPSender(ctx, delta[0], k0)
-chunks = (n + 511) // 512
-d_choice = torch.randint(0, 256, (chunks * 64,), dtype=torch.uint8, device="cuda")
-d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
-d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-torch.cuda.synchronize()
-rms, sms = [], []
-for it in range(reps + 2):
-    rx.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-    tx.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
-    ctx.sync()
-    if it >= 2:
-        rms.append(rx.last_ms)
-        sms.append(tx.last_ms)
-# correlation check on the last round (iknp_test.go:98-113): rcvd = sent ^ b*delta
-lr = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
-ls = d_ls.cpu().numpy().view(np.uint64).reshape(n, 2)
-ch = np.unpackbits(d_choice.cpu().numpy(), bitorder="little")[:n].astype(bool)
-dv = np.array([int(delta["d0"][0]), int(delta["d1"][0])], dtype=np.uint64)
-ok = bool(((lr ^ ls) == np.where(ch[:, None], dv[None, :], 0)).all())
-r, s = float(np.mean(rms)), float(np.mean(sms))
-print(json.dumps({"n_ots": n, "receiver_ms": r, "sender_ms": s, "receiver_ot_per_s": n / (r * 1e-3),
-                  "sender_ot_per_s": n / (s * 1e-3), "alg_GBs_receiver": 32 * n / (r * 1e-3) / 1e9,
-                  "alg_GBs_sender": 32 * n / (s * 1e-3) / 1e9, "correlation_ok": ok}))
+
+
+def run(n=1 << 22, reps=10, device=0, ctx=None):
+    rng = np.random.default_rng(7)
+    own = ctx is None
+    if own:
+        ctx = engine.Context(device)
+    base = np.zeros(128, WIRE)
+    for f in ("l0", "l1"):
+        base[f]["d0"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
+        base[f]["d1"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
+    delta = np.zeros(1, LABEL)
+    delta["d0"], delta["d1"] = rng.integers(0, 1 << 63, 2, dtype=np.uint64)
+    dbits = [(int(delta["d0"][0]) >> i) & 1 if i < 64 else (int(delta["d1"][0]) >> (i - 64)) & 1 for i in range(128)]
+    k0 = np.array([base[i]["l1"] if dbits[i] else base[i]["l0"] for i in range(128)], dtype=LABEL)
+    rx = engine.IKNPReceiver(ctx, base)
+    tx = engine.IKNPSender(ctx, delta[0], k0)
+    chunks = (n + 511) // 512
+    d_choice = torch.randint(0, 256, (chunks * 64,), dtype=torch.uint8, device="cuda")
+    d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
+    d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+    d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    rms, sms = [], []
+    for it in range(reps + 2):
+        rx.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
+        tx.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+        ctx.sync()
+        if it >= 2:
+            rms.append(rx.last_ms)
+            sms.append(tx.last_ms)
+    # correlation check on the last round (iknp_test.go:98-113): rcvd = sent ^ b*delta
+    lr = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
+    ls = d_ls.cpu().numpy().view(np.uint64).reshape(n, 2)
+    ch = np.unpackbits(d_choice.cpu().numpy(), bitorder="little")[:n].astype(bool)
+    dv = np.array([int(delta["d0"][0]), int(delta["d1"][0])], dtype=np.uint64)
+    ok = bool(((lr ^ ls) == np.where(ch[:, None], dv[None, :], 0)).all())
+    r, s = float(np.mean(rms)), float(np.mean(sms))
+    rx.close()
+    tx.close()
+    if own:
+        ctx.close()
+    return {"n_ots": n, "receiver_ms": r, "sender_ms": s, "receiver_ot_per_s": n / (r * 1e-3),
+            "sender_ot_per_s": n / (s * 1e-3), "alg_GBs_receiver": 32 * n / (r * 1e-3) / 1e9,
+            "alg_GBs_sender": 32 * n / (s * 1e-3) / 1e9, "correlation_ok": ok}
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22, int(sys.argv[2]) if len(sys.argv) > 2 else 10)))
