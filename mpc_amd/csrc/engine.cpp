@@ -199,8 +199,11 @@ static void free_buffers(gc_batch *b) {
 // every wire has to be materialised (store_all) or schedule 2 was asked for
 static BatchGeom geom_for(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    const uint32_t nls = (b->store_all || b->single_phase) ? p.n_lds_slots : p.n_flat_slots;
-    return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls);
+    const bool flat = !(b->store_all || b->single_phase);
+    const uint32_t nls = flat ? p.n_flat_slots : p.n_lds_slots;
+    // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
+    const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
+    return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat);
 }
 
 static hipError_t alloc_buffers(gc_batch *b) {

@@ -12,9 +12,9 @@
 //
 // i.e. two workgroup barriers per hash phase and NO serial XOR chain (the level-by-level XOR walk of
 // fused_lds_kernels.hip cost ~20 % of a pass in dependent LDS round trips with the AES pipe idle).
-// The next unit's image (descriptors + XOuts + terms, <= 13 KiB) is fetched into one register per thread
+// The next unit's image (descriptors + XOuts, <= 14.5 KiB) is fetched into one register per thread
 // while the current unit executes and committed to the other LDS buffer before the closing barrier.
-// LDS map: 64 KiB AES table | 2 x kUnit16 uint4 stage | R[TI] | wires [slot][TI] (last slot = zero label).
+// LDS map: 64 KiB AES table | 2 x kUnit16 uint4 stage (29 KiB) | R[TI] | wires [slot][TI] (last slot = zero label).
 #include "aes_device.h"
 #include "kernels.h"
 
@@ -75,21 +75,34 @@ struct FlArgs {
     uint64_t *prof;
 };
 
-__device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t n) {
+// Unit header i.  Loaded with VECTOR loads on purpose (vz is a zero the compiler cannot see through): scalar loads
+// share the lgkm counter with LDS and return out of order, so with a header in flight the first LDS read of the
+// next unit would have to wait for it (s_waitcnt lgkmcnt(0)); vector loads are tracked by vmcnt and cost nothing
+// until their values are used one unit later.
+__device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t n, uint32_t vz) {
     FUnit u{};
     if (i < n) {
-        const uint32_t *p = (const uint32_t *)(units + i);
-        u.off16 = __builtin_amdgcn_readfirstlane(p[0]);
-        u.n16 = __builtin_amdgcn_readfirstlane(p[1]);
-        u.n_and = __builtin_amdgcn_readfirstlane(p[2]);
-        u.n_or = __builtin_amdgcn_readfirstlane(p[3]);
-        u.n_inv = __builtin_amdgcn_readfirstlane(p[4]);
-        u.nout = __builtin_amdgcn_readfirstlane(p[5]);
-        u.outs_off16 = __builtin_amdgcn_readfirstlane(p[6]);
-        u.terms_off16 = __builtin_amdgcn_readfirstlane(p[7]);
-        u.hfirst = __builtin_amdgcn_readfirstlane(p[8]);
-        u.ofirst = __builtin_amdgcn_readfirstlane(p[9]);
+        const uint4 *p = (const uint4 *)(units + i) + vz;
+        const uint4 a = p[0], b = p[1], c = p[2];
+        u.off16 = a.x, u.n16 = a.y, u.n_and = a.z, u.n_or = a.w;
+        u.n_inv = b.x, u.nout = b.y, u.outs_off16 = b.z, u.xparts = b.w;
+        u.hfirst = c.x, u.ofirst = c.y;
     }
+    return u;
+}
+// wave-uniform copy in SGPRs (readfirstlane) of a header whose loads have landed
+__device__ __forceinline__ FUnit uniform_unit(const FUnit &v) {
+    FUnit u{};
+    u.off16 = __builtin_amdgcn_readfirstlane(v.off16);
+    u.n16 = __builtin_amdgcn_readfirstlane(v.n16);
+    u.n_and = __builtin_amdgcn_readfirstlane(v.n_and);
+    u.n_or = __builtin_amdgcn_readfirstlane(v.n_or);
+    u.n_inv = __builtin_amdgcn_readfirstlane(v.n_inv);
+    u.nout = __builtin_amdgcn_readfirstlane(v.nout);
+    u.outs_off16 = __builtin_amdgcn_readfirstlane(v.outs_off16);
+    u.hfirst = __builtin_amdgcn_readfirstlane(v.hfirst);
+    u.ofirst = __builtin_amdgcn_readfirstlane(v.ofirst);
+    u.xparts = __builtin_amdgcn_readfirstlane(v.xparts);
     return u;
 }
 
@@ -128,29 +141,62 @@ __device__ __forceinline__ uint32_t hlanes(const FUnit &c, uint32_t ti_log2) {
     return ((c.n_and << ti_log2) << LQA) + ((c.n_or << ti_log2) << LQO) + ((c.n_inv << ti_log2) << LQI);
 }
 
-// XOR part: one lane per (XOut, instance); the label is the XOR of its term list (groups of four LDS slots,
-// padded with the zero slot).  garble.go:331-351 / eval.go:49-51 restated over the expanded terms.
+// value of the lane SH further on inside its row of 16 lanes (DPP row_shl: register to register, no LDS)
+template <int SH>
+__device__ __forceinline__ uint4 row_down(uint4 v) {
+    return make_uint4((uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x100 + SH, 0xf, 0xf, true),
+                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x100 + SH, 0xf, 0xf, true),
+                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x100 + SH, 0xf, 0xf, true),
+                      (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x100 + SH, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint4 sel4(bool c, uint4 a, uint4 b) {
+    return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+// leader of a list spread over 2 / 4 lanes TI apart (all inside one row: parts * TI <= 16, plan.h / geom_for): its own
+// partial sum plus those of the following parts; every other lane keeps its value
+template <int TIV>
+__device__ __forceinline__ uint4 join_parts(uint4 acc, uint32_t flags, bool four) {
+    const uint4 a1 = lxor(acc, row_down<TIV>(acc));
+    uint4 r = sel4((flags & (kXoJoin2 | kXoJoin4)) != 0, a1, acc);
+    if constexpr (2 * TIV < 16) {
+        if (four) {
+            const uint4 a2 = lxor(a1, row_down<2 * TIV>(a1));
+            r = sel4((flags & kXoJoin4) != 0, a2, r);
+        }
+    }
+    return r;
+}
+
+// XOR part: one lane per (XOut, instance): the label is the XOR of up to 8 terms whose LDS slots sit in the XOut
+// itself (one LDS round trip for the item, one for its labels); lists of more than 8 terms come as 2 / 4 parts.
+// garble.go:331-351 / eval.go:49-51 restated over the expanded terms.
 template <bool GARBLE>
 __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const uint32_t *ogslot, uint4 *wl,
                                          const uint4 *rl, uint4 *Wt, uint32_t ti_log2, uint32_t tim) {
-    const uint2 *outs = (const uint2 *)(buf + u.outs_off16);
-    const uint2 *terms = (const uint2 *)(buf + u.terms_off16);
+    const uint2 *outs = (const uint2 *)(buf + u.outs_off16);  // 3 x 8 bytes per XOut
     const uint32_t nitems = u.nout << ti_log2;
     for (uint32_t t = threadIdx.x; t < nitems; t += TF) {
         const uint32_t o = t >> ti_log2, inst = t & tim;
-        const uint2 od = outs[o];
-        const uint2 *tp = terms + (od.x & 0xffffu);
-        const uint32_t n4 = od.x >> 16;
-        uint4 acc = make_uint4(0, 0, 0, 0);
-        for (uint32_t j = 0; j < n4; j++) {
-            const uint2 ix = tp[j];
-            const uint4 v0 = wl[((ix.x & 0xffffu) << ti_log2) + inst], v1 = wl[((ix.x >> 16) << ti_log2) + inst];
-            const uint4 v2 = wl[((ix.y & 0xffffu) << ti_log2) + inst], v3 = wl[((ix.y >> 16) << ti_log2) + inst];
-            acc = lxor(lxor(acc, lxor(v0, v1)), lxor(v2, v3));
+        const uint2 d0 = outs[3 * o], d1 = outs[3 * o + 1], d2 = outs[3 * o + 2];
+        const uint32_t flags = d2.x >> 16, n = d2.y & 0xffffu;
+        const uint4 v0 = wl[((d0.x & 0xffffu) << ti_log2) + inst], v1 = wl[((d0.x >> 16) << ti_log2) + inst];
+        const uint4 v2 = wl[((d0.y & 0xffffu) << ti_log2) + inst], v3 = wl[((d0.y >> 16) << ti_log2) + inst];
+        uint4 acc = lxor(lxor(v0, v1), lxor(v2, v3));
+        if (n > 4) {  // items are sorted by length: whole waves skip this
+            const uint4 v4 = wl[((d1.x & 0xffffu) << ti_log2) + inst], v5 = wl[((d1.x >> 16) << ti_log2) + inst];
+            const uint4 v6 = wl[((d1.y & 0xffffu) << ti_log2) + inst], v7 = wl[((d1.y >> 16) << ti_log2) + inst];
+            acc = lxor(acc, lxor(lxor(v4, v5), lxor(v6, v7)));
         }
-        const uint32_t flags = od.y >> 16;
+        if (u.xparts > 1) {  // unit-uniform: collect the partial sums of lists that were spread over 2 / 4 lanes
+            const bool four = u.xparts > 2;
+            if (ti_log2 == 0) acc = join_parts<1>(acc, flags, four);
+            else if (ti_log2 == 1) acc = join_parts<2>(acc, flags, four);
+            else if (ti_log2 == 2) acc = join_parts<4>(acc, flags, four);
+            else acc = join_parts<8>(acc, flags, false);
+        }
+        if (flags & kXoPart) continue;
         if (GARBLE && (flags & kXoRpar)) acc = lxor(acc, rl[inst]);
-        wl[((od.y & 0xffffu) << ti_log2) + inst] = acc;
+        wl[((d2.x & 0xffffu) << ti_log2) + inst] = acc;
         if (flags & kXoStore) Wt[((size_t)ogslot[u.ofirst + o] << ti_log2) + inst] = acc;
     }
 }
@@ -174,9 +220,10 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
         const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                                   \
         if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                          \
     }                                                                                                        \
-    FUnit u = load_unit(a.units, 0, a.nunits);                                                               \
-    FUnit un = load_unit(a.units, 1, a.nunits); /* headers run two units ahead: their scalar loads */       \
-                                                /* return while the previous unit hashes            */       \
+    uint32_t vz;                                                                                             \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
+    FUnit u = uniform_unit(load_unit(a.units, 0, a.nunits, vz));                                             \
+    FUnit un = uniform_unit(load_unit(a.units, 1, a.nunits, vz)); /* headers run two units ahead */          \
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
     __syncthreads();                                                                                         \
     const uint32_t lo = te_lane_off();                                                                       \
@@ -191,7 +238,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * kUnit16;
-        const FUnit unn = load_unit(a.units, ui + 2, a.nunits);
+        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
@@ -220,7 +267,9 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
                 make_k_half(x, d.tweak + (second ? 1u : 0u), k);
             }
+            GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
             const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            GC_FPROF(7)
             uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
             uint4 out_label;
             if (hp.kind == 1) {  // garble.go:353-395
@@ -271,7 +320,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         lds_barrier();
         GC_FPROF(5)
         u = un;
-        un = unn;
+        un = uniform_unit(unn_v);
     }
     GC_FPROF_EPILOGUE()
 }
@@ -282,7 +331,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * kUnit16;
-        const FUnit unn = load_unit(a.units, ui + 2, a.nunits);
+        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
@@ -312,7 +361,9 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
                 if (index > 0) tab = row[(size_t)(index - 1) << ti_log2];
                 make_k(va, vb, d.tweak, k);
             }
+            GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
             const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            GC_FPROF(7)
             uint4 out_label;
             bool writer = true;
             if (hp.kind == 1) {  // eval.go:53-78
@@ -344,7 +395,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         lds_barrier();
         GC_FPROF(5)
         u = un;
-        un = unn;
+        un = uniform_unit(unn_v);
     }
     GC_FPROF_EPILOGUE()
 }

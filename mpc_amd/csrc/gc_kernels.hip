@@ -10,7 +10,8 @@
 
 namespace gc {
 
-BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls) {
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls,
+                    uint32_t max_ti_log2, bool flat) {
     BatchGeom g{};
     g.batch = batch;
     if (batch >= 256) {
@@ -31,12 +32,13 @@ BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab
     } else {
         // instances per workgroup tile: aim at >= 256 workgroups (one per CU), at most 64 lanes wide
         uint32_t t = 0;
-        while (t < 6 && (batch >> (t + 1)) >= 256) t++;
+        while (t < max_ti_log2 && (batch >> (t + 1)) >= 256) t++;
         // LDS-resident wires: the tile's live labels (+R) must fit beside the 64 KiB AES table
         const size_t lds_budget = 160 * 1024;
-        g.lds_wires = nls != 0xffffffffu && fused_lds_bytes(nls, 0) <= lds_budget;
+        auto need = [&](uint32_t tt) { return flat ? fused_flat_bytes(nls, tt) : fused_lds_bytes(nls, tt); };
+        g.lds_wires = nls != 0xffffffffu && need(0) <= lds_budget;
         if (g.lds_wires)
-            while (t > 0 && fused_lds_bytes(nls, t) > lds_budget) t--;
+            while (t > 0 && need(t) > lds_budget) t--;
         g.ti_log2 = t;
         const uint32_t ti = 1u << t;
         g.ntiles = (batch + ti - 1) / ti;

@@ -42,7 +42,9 @@ struct BatchGeom {
 };
 // schedule 0 = level layout, 1 = tiled layout
 // nls: live-label high-water mark of the LDS schedule (0xffffffff: does not fit -> global-memory wires)
-BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls);
+// nls: live labels of the LDS plan that will run (0xffffffff: none); flat: size them for the flattened kernels
+BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls,
+                    uint32_t max_ti_log2 = 6, bool flat = false);
 
 struct LevelArgs {
     const GateDesc *descs;  // device, already offset to the step

@@ -106,7 +106,7 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
     auto key_of = [&](uint32_t g) { return ((uint64_t)A[ninputs + g] << 32) | ((uint64_t)Rr[ninputs + g] << 8); };
     auto sub_of = [&](uint32_t g) -> uint64_t {  // order inside a step
         if (!is_free[ninputs + g]) return (uint64_t)op_class(gates[g].op);
-        return 0xffu - std::min<uint64_t>(0xfeu, (ex[g].size() + 3) / 4);  // longest term lists first
+        return 0xffu - std::min<uint64_t>(0xfeu, ex[g].size());  // longest term lists first
     };
     std::stable_sort(gl.begin(), gl.end(), [&](uint32_t x, uint32_t y) {
         const uint64_t kx = key_of(x) | sub_of(x), ky = key_of(y) | sub_of(y);
@@ -172,9 +172,9 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
     // units
     std::vector<FDesc> uh;
     std::vector<XOut> uo;
-    std::vector<uint16_t> ut;
     std::vector<uint32_t> uhg, uog;
     FUnit u{};
+    u.xparts = 1;
     auto emit = [&]() {
         if (uh.empty() && uo.empty()) return;
         u.off16 = (uint32_t)(p.fl_prog.size() / 4);
@@ -188,20 +188,19 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
             p.fl_prog.push_back(d.row_op);
         }
         u.outs_off16 = (uint32_t)uh.size();
-        if (uo.size() & 1) uo.push_back(XOut{0, 0, (uint16_t)zslot, 0});  // pad to 16 bytes (never executed)
-        for (const XOut &x : uo) {
-            p.fl_prog.push_back((uint32_t)x.toff4 | ((uint32_t)x.n4 << 16));
+        for (const XOut &x : uo) {  // 6 dwords each
+            for (int i = 0; i < 8; i += 2) p.fl_prog.push_back((uint32_t)x.t[i] | ((uint32_t)x.t[i + 1] << 16));
             p.fl_prog.push_back((uint32_t)x.out | ((uint32_t)x.flags << 16));
+            p.fl_prog.push_back((uint32_t)x.n);
         }
-        u.terms_off16 = u.outs_off16 + (uint32_t)uo.size() / 2;
-        while (ut.size() & 7) ut.push_back((uint16_t)zslot);
-        for (size_t i = 0; i < ut.size(); i += 2) p.fl_prog.push_back((uint32_t)ut[i] | ((uint32_t)ut[i + 1] << 16));
+        while (p.fl_prog.size() & 3) p.fl_prog.push_back(0);
         u.n16 = (uint32_t)(p.fl_prog.size() / 4) - u.off16;
         p.fl_hgslot.insert(p.fl_hgslot.end(), uhg.begin(), uhg.end());
         p.fl_ogslot.insert(p.fl_ogslot.end(), uog.begin(), uog.end());
         p.fl_units.push_back(u);
-        uh.clear(), uo.clear(), ut.clear(), uhg.clear(), uog.clear();
+        uh.clear(), uo.clear(), uhg.clear(), uog.clear();
         u = FUnit{};
+        u.xparts = 1;
     };
     for (uint32_t si = 0; si < nsteps; si++) {
         const uint32_t k0 = step_first[si], k1 = step_first[si + 1];
@@ -227,17 +226,34 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
             if (!uo.empty()) emit();
             for (uint32_t k = k0; k < k1; k++) {
                 const uint32_t g = gl[k], pid = ninputs + g;
-                const uint32_t n4 = (uint32_t)(ex[g].size() + 3) / 4;
-                if (uo.size() == kUOuts || ut.size() + 4 * n4 > kUTerms) emit();
-                XOut x;
-                x.toff4 = (uint16_t)(ut.size() / 4);
-                x.n4 = (uint16_t)n4;
-                x.out = (uint16_t)lds_of[pid];
-                x.flags = (uint16_t)((is_output[pid] ? kXoStore : 0) | (rpar[g] ? kXoRpar : 0));
-                for (uint32_t t : ex[g]) ut.push_back((uint16_t)lds_of[t]);
-                while (ut.size() & 3) ut.push_back((uint16_t)zslot);
-                uo.push_back(x);
-                uog.push_back(p.slot_of_gate[g]);
+                const uint32_t nt = (uint32_t)ex[g].size();
+                // parts: at most 8 terms per lane (kFlatMaxTerms = 32 -> 1, 2 or 4 parts)
+                const uint32_t P = nt <= 8 ? 1 : nt <= 16 ? 2 : 4;
+                if (uo.size() + (P + 3) > kUOuts) emit();
+                XOut dummy{};
+                for (int i = 0; i < 8; i++) dummy.t[i] = (uint16_t)zslot;
+                dummy.out = (uint16_t)zslot;
+                dummy.flags = kXoPart;
+                while (uo.size() % P) {  // the leader's index must be a multiple of P (lists are sorted longest first,
+                    uo.push_back(dummy);  // so this only pads after a unit break)
+                    uog.push_back(0);
+                }
+                const uint32_t per = (nt + P - 1) / P;
+                for (uint32_t part = 0; part < P; part++) {
+                    const uint32_t t0 = std::min(nt, per * part), t1 = std::min(nt, per * (part + 1));
+                    XOut x = dummy;
+                    x.n = (uint16_t)(t1 - t0);
+                    for (uint32_t t = t0; t < t1; t++) x.t[t - t0] = (uint16_t)lds_of[ex[g][t]];
+                    if (part == 0) {
+                        x.out = (uint16_t)lds_of[pid];
+                        x.flags = (uint16_t)((is_output[pid] ? kXoStore : 0) | (rpar[g] ? kXoRpar : 0) |
+                                             (P == 2 ? kXoJoin2 : P == 4 ? kXoJoin4 : 0));
+                    }
+                    uo.push_back(x);
+                    uog.push_back(part == 0 ? p.slot_of_gate[g] : 0);
+                }
+                u.xparts = std::max(u.xparts, P);
+                p.fl_max_parts = std::max(p.fl_max_parts, P);
                 p.n_flat_outs++;
                 p.n_flat_terms += (uint32_t)ex[g].size();
             }

@@ -68,25 +68,34 @@ struct Chunk {
 // kFlatMaxTerms are cut by materialising the operands and opening a second XOR round in that chunk.
 // (garble.go:331-351 / eval.go:49-51 compute the same labels gate by gate.)
 constexpr uint32_t kFlatMaxTerms = 32;
-struct XOut {            // 8 bytes: one materialised XOR output
-    uint16_t toff4;      // first 4-term group inside the unit's term area
-    uint16_t n4;         // number of 4-term groups (lists are padded with the zero slot)
-    uint16_t out;        // LDS slot of the result
-    uint16_t flags;      // kXoStore | kXoRpar
+// One XOR work item (24 bytes, self-contained: a lane needs ONE LDS round trip for it and one for its labels).
+// An output with more than 8 terms is spread over 2 or 4 consecutive XOuts ("parts", index of the first a multiple
+// of the count): every lane reads at most 8 labels and the leader (part 0) collects the partial sums of the lanes
+// TI, 2 TI, 3 TI further on with DPP row shifts (parts x TI <= 16).
+struct XOut {
+    uint16_t t[8];       // LDS slots of the terms, unused ones = the zero slot
+    uint16_t out;        // LDS slot of the result (leader only)
+    uint16_t flags;      // kXo*
+    uint16_t n;          // number of terms of this part (terms 4..7 are only read when n > 4)
+    uint16_t pad_;
 };
-static_assert(sizeof(XOut) == 8, "XOut must be 8 bytes");
+static_assert(sizeof(XOut) == 24, "XOut must be 24 bytes");
 constexpr uint16_t kXoStore = 1;  // also store to the global wire array (circuit output)
 constexpr uint16_t kXoRpar = 2;   // garbler: odd number of XNORs in the expansion -> XOR R once
-// A unit is what the kernels stage into LDS in one go: [hash descriptors][XOuts][terms], executed as
-// hash part -> barrier -> XOR part -> barrier.  Capacities chosen so that a unit is <= 832 uint4 (one per
-// thread with room to spare) and two buffers cost 26 KiB of LDS.
-constexpr uint32_t kUHash = 256, kUOuts = 384, kUTerms = 3072;
-constexpr uint32_t kUnit16 = kUHash + kUOuts / 2 + kUTerms / 8;  // 832
+constexpr uint16_t kXoJoin2 = 4;  // leader of 2 parts
+constexpr uint16_t kXoJoin4 = 8;  // leader of 4 parts
+constexpr uint16_t kXoPart = 16;  // parts 1..3: partial sum only, nothing is written
+// A unit is what the kernels stage into LDS in one go: [hash descriptors][XOuts], executed as
+// hash part -> barrier -> XOR part -> barrier.  Capacities chosen so that a unit is <= 928 uint4 (one per
+// thread) and two buffers cost 29 KiB of LDS.
+constexpr uint32_t kUHash = 256, kUOuts = 448;
+constexpr uint32_t kUnit16 = kUHash + kUOuts * 24 / 16;  // 928
 struct FUnit {           // 48 bytes
     uint32_t off16, n16;             // position / size of the unit in Plan::fl_prog (uint4 units)
     uint32_t n_and, n_or, n_inv;     // hash descriptors (16 B each) at the start of the unit, in this order
     uint32_t nout;                   // XOuts
-    uint32_t outs_off16, terms_off16;  // relative to the unit start
+    uint32_t outs_off16;             // relative to the unit start
+    uint32_t xparts;                 // largest part count of an XOut in this unit (1, 2 or 4)
     uint32_t hfirst, ofirst;         // index of the first hash desc / XOut in fl_hgslot / fl_ogslot
     uint32_t pad_[2];
 };
@@ -118,6 +127,7 @@ struct Plan {
     std::vector<uint16_t> fl_in_lds;    // LDS slot of every input wire (0xffff: never read)
     uint32_t n_flat_slots = 0xffffffffu;  // live labels incl. the zero slot (= slot n_flat_slots - 1)
     uint32_t n_flat_outs = 0, n_flat_terms = 0, n_flat_steps = 0;
+    uint32_t fl_max_parts = 1;          // largest XOut part count: a tile may hold at most 16 / fl_max_parts instances
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
     uint32_t n_hash_phases = 0;

@@ -23,9 +23,9 @@ gb.debug_profile(True); ev.debug_profile(True)
 gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
 ctx.sync()
 print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
-names = ["prologue", "hash", "barA", "commit", "xor", "barB"]
+names = ["header", "hash-post", "barA", "commit", "xor", "barB", "hash-pre", "aes"]
 for nm, b in (("garble", gb), ("eval", ev)):
     p = b.debug_profile(True, read=True)
     tot0, tot1 = sum(p[:8]), sum(p[8:])
-    print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:6])}, "total", int(tot0))
-    print(nm, "wave15:", {n: int(v) for n, v in zip(names, p[8:14])}, "total", int(tot1))
+    print(nm, "wave0:", {n: int(v) for n, v in zip(names, p[:8])}, "total", int(tot0))
+    print(nm, "wave15:", {n: int(v) for n, v in zip(names, p[8:16])}, "total", int(tot1))
