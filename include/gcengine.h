@@ -110,6 +110,17 @@ int gc_ctx_sync(gc_ctx *);
 /* the ctx's HIP stream as an opaque pointer (hipStream_t) for callers that enqueue their own work */
 void *gc_ctx_stream(gc_ctx *);
 
+/* Pipeline graphs (hipGraph): record a sequence of DEVICE-RESIDENT calls on this ctx (gc_batch_garble,
+ * _select_inputs, _eval, _decode, _egress_tables, gc_iknp_*_dev, ...; same pointers every time) once, then replay it
+ * with a single launch — removes the host launch latency between the five-odd kernels of a step.
+ * Between begin and end nothing executes; host-buffer calls (gc_garble, gc_eval, read_*, ...) and changes of key,
+ * schedule or batch geometry are not allowed inside a capture; gc_batch_last_ms is not updated by replays. */
+typedef struct gc_graph gc_graph;
+int gc_ctx_capture_begin(gc_ctx *);
+int gc_ctx_capture_end(gc_ctx *, gc_graph **out);
+int gc_graph_launch(gc_graph *);
+void gc_graph_free(gc_graph *);
+
 gc_circ *gc_circ_load(gc_ctx *, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
                       uint32_t ninputs, uint32_t noutputs, int *status);
 void gc_circ_free(gc_circ *);

@@ -91,6 +91,52 @@ int gc_ctx_sync(gc_ctx *c) {
 
 void *gc_ctx_stream(gc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+// ---- pipeline graphs: record a sequence of device-resident calls once, replay it with one launch ------------
+int gc_ctx_capture_begin(gc_ctx *c) {
+    if (!c || c->capturing) return GC_E_ARG;
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    c->capturing = true;
+    return GC_OK;
+}
+
+int gc_ctx_capture_end(gc_ctx *c, gc_graph **out) {
+    if (!c || !c->capturing || !out) return GC_E_ARG;
+    *out = nullptr;
+    c->capturing = false;
+    hipGraph_t graph = nullptr;
+    GC_HIP(hipStreamEndCapture(c->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        set_error("hipGraphInstantiate", e);
+        return GC_E_HIP;
+    }
+    gc_graph *g = new (std::nothrow) gc_graph;
+    if (!g) {
+        (void)hipGraphExecDestroy(exec);
+        return GC_E_NOMEM;
+    }
+    g->ctx = c;
+    g->exec = exec;
+    *out = g;
+    return GC_OK;
+}
+
+int gc_graph_launch(gc_graph *g) {
+    if (!g || !g->exec) return GC_E_ARG;
+    GC_HIP(hipSetDevice(g->ctx->device));
+    GC_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+    return GC_OK;
+}
+
+void gc_graph_free(gc_graph *g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    delete g;
+}
+
 // ---- circuit ---------------------------------------------------------------------------------
 
 gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
@@ -451,11 +497,11 @@ int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *
     const Plan &p = b->circ->plan.p;
     launch_init_garble((const uint4 *)d_rnd, p.info.ninputs, b->d_W, b->d_R, b->g, ctx->stream);
     // the events bracket the gate kernels only (the label-initialisation kernel above is a few microseconds)
-    GC_HIP(hipEventRecord(b->ev0, ctx->stream));
+    if (!ctx->capturing) GC_HIP(hipEventRecord(b->ev0, ctx->stream));
     rc = run_levels(b, false, b->d_T);
     if (rc != GC_OK) return rc;
-    GC_HIP(hipEventRecord(b->ev1, ctx->stream));
-    b->timed = true;
+    if (!ctx->capturing) GC_HIP(hipEventRecord(b->ev1, ctx->stream));
+    b->timed = !ctx->capturing;
     return GC_OK;
 }
 
@@ -491,11 +537,11 @@ int gc_batch_eval(gc_batch *ev, const uint8_t *key, size_t keylen, const gc_batc
     GC_HIP(hipSetDevice(ctx->device));
     int rc = set_key(ev, key, keylen);
     if (rc != GC_OK) return rc;
-    GC_HIP(hipEventRecord(ev->ev0, ctx->stream));
+    if (!ctx->capturing) GC_HIP(hipEventRecord(ev->ev0, ctx->stream));
     rc = run_levels(ev, true, tables->d_T);
     if (rc != GC_OK) return rc;
-    GC_HIP(hipEventRecord(ev->ev1, ctx->stream));
-    ev->timed = true;
+    if (!ctx->capturing) GC_HIP(hipEventRecord(ev->ev1, ctx->stream));
+    ev->timed = !ctx->capturing;
     return GC_OK;
 }
 

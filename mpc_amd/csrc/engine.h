@@ -31,6 +31,12 @@ struct gc_ctx {
     hipStream_t stream = nullptr;
     uint32_t *d_te0 = nullptr;  // Te0 (1 KiB), L2-resident source of the LDS tables
     std::mutex mu;              // serialises host-buffer calls sharing this ctx's stream
+    bool capturing = false;     // between gc_ctx_capture_begin / _end: launches are recorded, not run
+};
+
+struct gc_graph {
+    gc_ctx *ctx = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 struct gc_circ {

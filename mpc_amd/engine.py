@@ -91,6 +91,10 @@ def lib():
         "gc_stream_eval_circuit": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
+        "gc_ctx_capture_begin": (i32, [vp]),
+        "gc_ctx_capture_end": (i32, [vp, C.POINTER(vp)]),
+        "gc_graph_launch": (i32, [vp]),
+        "gc_graph_free": (None, [vp]),
         "gc_batch_stride": (u32, [vp]),
         "gc_batch_tile_instances": (u32, [vp]),
         "gc_batch_wires_in_lds": (i32, [vp]),
@@ -211,9 +215,33 @@ class Context:
     def stream(self):
         return lib().gc_ctx_stream(self.h)
 
+    def capture(self, fn):
+        """record the device-resident calls fn() makes on this ctx into a Graph (gc_ctx_capture_*)"""
+        _check(lib().gc_ctx_capture_begin(self.h), "gc_ctx_capture_begin")
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            rc = lib().gc_ctx_capture_end(self.h, C.byref(g))
+        _check(rc, "gc_ctx_capture_end")
+        return Graph(g)
+
     def close(self):
         if self.h:
             lib().gc_ctx_destroy(self.h)
+            self.h = None
+
+
+class Graph:
+    def __init__(self, h):
+        self.h = h
+
+    def launch(self):
+        _check(lib().gc_graph_launch(self.h), "gc_graph_launch")
+
+    def close(self):
+        if self.h:
+            lib().gc_graph_free(self.h)
             self.h = None
 
 

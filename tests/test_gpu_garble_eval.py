@@ -314,3 +314,45 @@ def test_device_resident_pipeline_full_size(ctx, aes_circ, schedule):
         assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all()
     assert gb.last_ms > 0 and ev.last_ms > 0
     gb.close(); ev.close(); dc.close()
+
+
+def test_pipeline_graph_replay(ctx, add64_circ):
+    """gc_ctx_capture_*: the garble -> select -> eval -> decode sequence recorded once and replayed gives the bytes of
+    the direct calls, also after the inputs (same device buffers) changed."""
+    import torch
+    c = add64_circ
+    batch = 600
+    dc = engine.DeviceCircuit(ctx, c)
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    d_rnd = torch.frombuffer(bytearray(rnd_for(c, "graph0", batch)), dtype=torch.uint8).cuda()
+    d_bits = torch.zeros((batch, c.num_inputs), dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
+    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        gb.garble(KEY256, d_rnd.data_ptr())
+        ev.select_inputs(gb, d_bits.data_ptr())
+        ev.eval(KEY256, gb)
+        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+
+    step()  # uploads the key; not capturable
+    ctx.sync()
+    g = ctx.capture(step)
+    for rep in range(2):
+        rnd = rnd_for(c, "graph%d" % (rep + 1), batch)
+        bits = (np.frombuffer(drbg("gbits%d" % rep, batch * c.num_inputs), np.uint8) & 1).reshape(batch, -1)
+        d_rnd.copy_(torch.frombuffer(bytearray(rnd), dtype=torch.uint8))
+        d_bits.copy_(torch.from_numpy(bits.copy()))
+        torch.cuda.synchronize()
+        g.launch()
+        ctx.sync()
+        assert int(d_mis.cpu()[0]) == 0
+        out = d_out.cpu().numpy()
+        slab, R = gb.read_slab(), gb.read_r()
+        for i in (0, 1, 299, 599):
+            ref = oracle_instance(c, KEY256, rnd, i)
+            assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all()
+            plain = oracle.compute(c.Gates, c.NumWires, c.num_inputs, bits[i])
+            assert (out[i] == plain[c.NumWires - c.num_outputs:]).all()
+    g.close(); gb.close(); ev.close(); dc.close()
