@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
     ap.add_argument("--check", action="store_true", help="verify decoded outputs against plaintext evaluation")
     args = ap.parse_args()
@@ -98,8 +99,10 @@ def main():
     from mpc_amd import engine, parse_file
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:  # --force-collective without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     circ = parse_file(args.circuit)
@@ -119,26 +122,45 @@ def main():
     gen.manual_seed(1234 + rank)
     d_rnd = torch.randint(0, 256, (batch, circ.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
     d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
-    d_out = torch.zeros((batch, circ.num_outputs), dtype=torch.uint8, device="cuda")
+    collective = world > 1 or args.force_collective
+    nbuf = 2 if collective else 1  # decoded outputs are double-buffered so that the gather of step i overlaps step i+1
+    d_outs = [torch.zeros((batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    d_out = d_outs[0]
     d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d_all = torch.zeros((world * batch, circ.num_outputs), dtype=torch.uint8, device="cuda") if world > 1 else None
+    d_all = [torch.zeros((world * batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nbuf)] \
+        if collective else None
 
-    def device_step():
+    def device_step(k=0):
         gb.garble(key, d_rnd.data_ptr())
         ev.select_inputs(gb, d_bits.data_ptr())
         ev.eval(key, gb)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        gb.decode(ev, d_outs[k].data_ptr(), d_mis.data_ptr())
 
-    graph = None  # the step's kernels recorded once in a hipGraph (gc_ctx_capture_*): one launch per step
+    graphs = None  # the step's kernels recorded once in a hipGraph (gc_ctx_capture_*): one launch per step
+    # The only collective: all_gather of the decoded outputs over RCCL/xGMI, on torch's stream.  The engine runs on
+    # its own HIP stream; the two are chained with events (no host synchronisation inside the loop): the gather of
+    # step i waits for decode(i) and runs while step i+1 garbles; decode(i+2) waits for gather(i) (same buffer).
+    eng_stream = torch.cuda.ExternalStream(ctx.stream) if collective else None
+    done_ev = [torch.cuda.Event() for _ in range(nbuf)]
+    gathered_ev = [None] * nbuf
+    counter = [0]
 
     def step():
-        if graph is not None:
-            graph.launch()
+        k = counter[0] % nbuf
+        counter[0] += 1
+        if collective and gathered_ev[k] is not None:
+            eng_stream.wait_event(gathered_ev[k])
+        if graphs is not None:
+            graphs[k].launch()
         else:
-            device_step()
-        if world > 1:
-            ctx.sync()  # hand the engine stream's result to torch's stream
-            dist.all_gather_into_tensor(d_all, d_out)  # RCCL over xGMI: the only collective
+            device_step(k)
+        if collective:
+            done_ev[k].record(eng_stream)
+            torch.cuda.current_stream().wait_event(done_ev[k])
+            dist.all_gather_into_tensor(d_all[k], d_outs[k])
+            e = torch.cuda.Event()
+            e.record()
+            gathered_ev[k] = e
 
     def fence():
         ctx.sync()
@@ -151,7 +173,7 @@ def main():
     device_step()  # first call uploads the round keys (not capturable), and warms the allocator
     ctx.sync()
     if not args.no_graph and args.schedule != 0:
-        graph = ctx.capture(device_step)
+        graphs = [ctx.capture(lambda k=k: device_step(k)) for k in range(nbuf)]
     for _ in range(args.warmup):
         step()
     fence()
@@ -179,6 +201,9 @@ def main():
     mismatches = int(d_mis.cpu()[0])
 
     ok = mismatches == 0
+    if collective:  # the gathered tensor holds this rank's outputs at its offset
+        for k in range(nbuf):
+            ok = ok and bool(torch.equal(d_all[k][rank * batch:(rank + 1) * batch], d_outs[k]))
     if args.check:
         import oracle  # checker only
         bits = d_bits.cpu().numpy()
@@ -234,7 +259,7 @@ def main():
             "schedule": sched_name,
             "hash_phases": int(info.n_hash_phases),
             "lds_live_labels": int(info.n_flat_slots if args.schedule == 1 else info.n_lds_slots),
-            "graph": graph is not None or (args.schedule == 0 and not args.no_graph),
+            "graph": graphs is not None or (args.schedule == 0 and not args.no_graph),
             "outputs_ok": ok,
         },
         "garble_ms": g_avg,
@@ -269,13 +294,21 @@ def main():
             res["iknp"] = iknp_run(1 << 22, 5, ctx=ctx)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
-        print(json.dumps(res))
     gb.close()
     ev.close()
     dc.close()
     ctx.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: flush whatever native libraries (RCCL banner) left in C stdio first
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
