@@ -205,11 +205,10 @@ def main():
         for k in range(nbuf):
             ok = ok and bool(torch.equal(d_all[k][rank * batch:(rank + 1) * batch], d_outs[k]))
     if args.check:
-        import oracle  # checker only
         bits = d_bits.cpu().numpy()
         out = d_out.cpu().numpy()
-        for i in range(0, batch, max(1, batch // 16)):
-            plain = oracle.compute(circ.Gates, circ.NumWires, circ.num_inputs, bits[i])
+        for i in range(0, batch, max(1, batch // 16)):  # against plaintext evaluation (circuit/computer.go)
+            plain = circ.compute_bits(bits[i])
             ok = ok and bool((plain[circ.NumWires - circ.num_outputs:] == out[i]).all())
 
     n_and = info.n_and

@@ -69,6 +69,25 @@ class Circuit:
         s = self.stats()
         return 2 * s["AND"] + 3 * s["OR"] + s["INV"]
 
+    def compute_bits(self, input_bits):
+        """Plaintext evaluation, the gate loop of (*Circuit).Compute (circuit/computer.go:42-88): input bits are the
+        wires [0, Inputs.Size()) in argument order; returns the bit of every wire (outputs = the last Outputs.Size())."""
+        wires = np.zeros(self.NumWires, np.uint8)
+        bits = np.asarray(input_bits, np.uint8) & 1
+        if len(bits) != self.num_inputs:
+            raise CircuitError("invalid inputs: got %d, expected %d" % (len(bits), self.num_inputs))
+        wires[: self.num_inputs] = bits
+        g = self.Gates
+        for i0, i1, out, op in zip(g["in0"].tolist(), g["in1"].tolist(), g["out"].tolist(), g["op"].tolist()):
+            a = wires[i0]
+            if op == INV:
+                r = a ^ 1
+            else:
+                b = wires[i1]
+                r = (a ^ b) if op == XOR else (a ^ b ^ 1) if op == XNOR else (a & b) if op == AND else (a | b)
+            wires[out] = r
+        return wires
+
     def __repr__(self):
         return "#gates=%d %s #w=%d" % (self.NumGates, self.stats(), self.NumWires)
 

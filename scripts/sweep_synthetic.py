@@ -12,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-import oracle  # checker only
 from mpc_amd import engine
 from mpc_amd.circuit import and_chain, synthetic_levelised
 
@@ -47,7 +46,7 @@ for c in circs:
     ok = int(d_mis.cpu()[0]) == 0
     bits, out = d_bits.cpu().numpy(), d_out.cpu().numpy()
     for i in (0, batch // 2, batch - 1):
-        plain = oracle.compute(c.Gates, c.NumWires, c.num_inputs, bits[i])
+        plain = c.compute_bits(bits[i])  # plaintext evaluation (circuit/computer.go)
         ok = ok and bool((plain[c.NumWires - c.num_outputs:] == out[i]).all())
     g, e = float(np.mean(g_ms)), float(np.mean(e_ms))
     nonfree = info.n_and + info.n_or + info.n_inv

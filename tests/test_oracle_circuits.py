@@ -163,3 +163,15 @@ def test_synthetic_matches_plaintext():
         plain = oracle.compute(c.Gates, c.NumWires, 32, bits)
         out, _, _ = garble_eval_decode(c, drbg("sk", 24), "s%d" % t, bits)
         assert (out == plain[-c.num_outputs:]).all()
+
+
+def test_host_compute_bits_matches_oracle(aes_circ, add64_circ):
+    """mpc_amd.circuit.Circuit.compute_bits (host mirror of circuit/computer.go) against the oracle's restatement"""
+    import numpy as np
+    from mpc_amd.circuit import comparator64, synthetic_levelised
+    rng = np.random.default_rng(3)
+    for c in (aes_circ, add64_circ, comparator64(),
+              synthetic_levelised(6, 40, 0.3, seed=5, ninputs=32, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1)):
+        for _ in range(3):
+            b = rng.integers(0, 2, c.num_inputs).astype(np.uint8)
+            assert (c.compute_bits(b) == oracle.compute(c.Gates, c.NumWires, c.num_inputs, b)).all()
