@@ -1,0 +1,98 @@
+"""Differential fuzzing of the GPU schedules against the oracle on small random circuits that stress the planner:
+long XOR fan-in (term lists over 8 / 32 entries -> lane-split items, second XOR rounds), XOR of a wire with itself,
+dead gates, outputs that are input wires or produced by every gate type, re-used wire ids, circuits without any
+table-producing gate and without any gate at all."""
+import numpy as np
+import pytest
+
+import oracle
+from mpc_amd import engine
+from mpc_amd.circuit import AND, GATE, INV, OR, XNOR, XOR, Circuit
+from tests.test_gpu_garble_eval import check_garble_eval
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes(range(100, 132))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def random_circuit(rng, ninputs, ngates, p_xor, reuse, nout):
+    """gate i reads two earlier wires (biased to recent ones) and writes either a fresh wire or, with probability
+    `reuse`, an existing NON-input wire again (the reference allows re-assignment; the plan renames)."""
+    gates = np.zeros(ngates, GATE)
+    nw = ninputs
+    live = list(range(ninputs))
+    for i in range(ngates):
+        a = live[int(rng.integers(max(0, len(live) - 12), len(live)))] if rng.random() < 0.7 else live[int(rng.integers(0, len(live)))]
+        b = live[int(rng.integers(0, len(live)))]
+        u = rng.random()
+        if u < p_xor:
+            op = XOR if rng.random() < 0.8 else XNOR
+            if rng.random() < 0.03:
+                b = a  # x ^ x
+        else:
+            op = [AND, OR, INV][int(rng.integers(0, 3))]
+        if nw > ninputs and rng.random() < reuse:
+            out = int(rng.integers(ninputs, nw))
+        else:
+            out = nw
+            nw += 1
+            live.append(out)
+        gates[i] = (a, 0 if op == INV else b, out, op, 0)
+    # outputs are the LAST nout wires: append copies (XOR with a zero... not available) -> just make sure enough wires
+    nout = min(nout, nw)
+    return Circuit(nw, [ninputs // 2, ninputs - ninputs // 2], [nout], gates)
+
+
+def xor_tree(rng, ninputs, fan):
+    """outputs that are XORs of up to `fan` inputs through chains and trees (one chunk, several XOR rounds)"""
+    gates = []
+    nw = ninputs
+    acc = 0
+    for i in range(1, fan):  # chain: list length i+1
+        gates.append((acc, i % ninputs if i % ninputs != acc else (i + 1) % ninputs, nw, XNOR if i % 7 == 0 else XOR))
+        acc = nw
+        nw += 1
+    # a few ANDs consuming intermediate chain values so that they have to be materialised
+    for j in range(0, fan - 1, 5):
+        gates.append((ninputs + j, (j * 3) % ninputs, nw, AND))
+        nw += 1
+    g = np.zeros(len(gates), GATE)
+    for k, (a, b, o, op) in enumerate(gates):
+        g[k] = (a, b, o, op, 0)
+    return Circuit(nw, [ninputs // 2, ninputs - ninputs // 2], [min(8, nw)], g)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    ninputs = int(rng.integers(2, 40))
+    ngates = int(rng.integers(1, 400))
+    c = random_circuit(rng, ninputs, ngates, p_xor=float(rng.choice([0.0, 0.5, 0.8, 0.95, 1.0])),
+                       reuse=float(rng.choice([0.0, 0.05, 0.2])), nout=int(rng.integers(1, 12)))
+    batch = int(rng.choice([1, 3, 17, 70]))
+    for schedule in (0, 1, 2):
+        check_garble_eval(ctx, c, KEY, batch, "fuzz%d" % seed, schedule=schedule)
+
+
+@pytest.mark.parametrize("fan", [9, 17, 33, 70, 200])
+def test_long_xor_lists(ctx, fan):
+    c = xor_tree(np.random.default_rng(fan), 24, fan)
+    for schedule in (0, 1, 2):
+        check_garble_eval(ctx, c, KEY, 9, "xt%d" % fan, schedule=schedule)
+    # batches whose tiles hold 2 and 4 instances: the lane-split items join across TI-strided lanes
+    for batch in (520, 1030):
+        check_garble_eval(ctx, c, KEY, batch, "xtb%d" % fan, schedule=1, sample=[0, 1, 2, 3, 4, 5, batch // 2, batch - 2, batch - 1])
+
+
+def test_no_gates_and_outputs_are_inputs(ctx):
+    g = np.zeros(0, GATE)
+    c = Circuit(6, [3, 3], [2], g)  # outputs = input wires 4, 5
+    for schedule in (0, 1, 2):
+        check_garble_eval(ctx, c, KEY, 5, "nogates", schedule=schedule)
