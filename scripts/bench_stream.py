@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Config-5-shaped streaming garbler throughput (circuit/stream_garble.go path): a program of large per-step circuits
+(each step consumes the previous step's outputs through global wire ids) through gc_stream_garble.  A single serial
+instance: one launch sequence per step.  Prints one JSON line: gates/s, AND/s, stream bytes/s and the SHA-256 of the
+byte stream (tests/test_gpu_stream.py checks the same construction against the CPU restatement at a smaller size)."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from mpc_amd import engine
+from mpc_amd.circuit import synthetic_levelised
+
+
+def make_steps(nsteps, levels, width, and_frac, nin=256):
+    """step k reads global wires [k*nin, (k+1)*nin) and writes [(k+1)*nin, (k+2)*nin)"""
+    steps = []
+    for k in range(nsteps):
+        c = synthetic_levelised(levels, width, and_frac, seed=900 + (k % 4), ninputs=nin, inv_frac=0.05)
+        # the generator emits min(width, 128) outputs; chain them (repeated) into the next step's nin inputs
+        nout = c.num_outputs
+        in_ = [k * nin + i for i in range(nin)]
+        out_ = [(k + 1) * nin + i for i in range(nout)]
+        steps.append((c, in_, out_))
+    return steps
+
+
+def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(range(32)), ctx=None):
+    per = levels * width
+    nsteps = max(1, total_gates // per)
+    nin = 256
+    steps = make_steps(nsteps, levels, width, and_frac, nin)
+    prim = list(range(nin))
+    # later steps read wires the previous step did not write (nout < nin): declare those as primary inputs as well
+    for k in range(1, nsteps):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    rnd = hashlib.shake_256(b"stream-bench").digest(16 * (len(prim) + 1))
+    own = ctx is None
+    if own:
+        ctx = engine.Context(0)
+    g = engine.Stream(ctx, key, rnd, prim)
+    h = hashlib.sha256()
+    nbytes = 0
+    # warm: first use of a circuit builds and caches its plan
+    t0 = time.perf_counter()
+    for c, in_, out_ in steps:
+        data = g.garble(c.Gates, c.NumWires, in_, out_)
+        h.update(data)
+        nbytes += len(data)
+    t1 = time.perf_counter()
+    gates = sum(c.NumGates for c, _, _ in steps)
+    ands = sum(c.stats()["AND"] for c, _, _ in steps)
+    g.close()
+    if own:
+        ctx.close()
+    dt = t1 - t0
+    return {"steps": nsteps, "gates": gates, "and": ands, "seconds": dt, "gates_per_s": gates / dt,
+            "and_per_s": ands / dt, "stream_bytes": nbytes, "stream_MBps": nbytes / dt / 1e6, "sha256": h.hexdigest()}
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000)))

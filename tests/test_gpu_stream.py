@@ -79,3 +79,30 @@ def test_stream_evaluator_matches_oracle_and_plaintext(base, keylen):
         ge.circuit(steps[0][0].NumGates, steps[0][0].NumWires, 600, data[: len(data) // 2])
     assert e.value.code in (engine.GC_E_ROWS, engine.GC_E_GATE, engine.GC_E_ARG)
     gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_large_chained_program_matches_oracle():
+    """the construction of scripts/bench_stream.py (config 5 shape: large per-step circuits chained through global
+    wire ids) at a size the oracle restates in a second: byte streams equal, SHA-256 over the whole stream equal"""
+    import hashlib
+    from scripts.bench_stream import make_steps
+    ctx = engine.Context(0)
+    nin = 256
+    steps = make_steps(5, 16, 1024, 0.25, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("bigstream", 32)
+    rnd = drbg("bigstream-rnd", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    h0, h1 = hashlib.sha256(), hashlib.sha256()
+    for c, in_, out_ in steps:
+        want = og.garble(c.Gates, c.NumWires, in_, out_)
+        got = gg.garble(c.Gates, c.NumWires, in_, out_)
+        assert len(got) == len(want) and got == want
+        h0.update(want)
+        h1.update(got)
+    assert h0.digest() == h1.digest()
+    assert sum(c.NumGates for c, _, _ in steps) == 5 * 16 * 1024
+    gg.close()
+    ctx.close()
