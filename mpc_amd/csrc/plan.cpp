@@ -266,10 +266,10 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
                 }
                 const uint32_t per = (nt + P - 1) / P;
                 for (uint32_t part = 0; part < P; part++) {
-                    const uint32_t t0 = std::min(nt, per * part), t1 = std::min(nt, per * (part + 1));
+                    const uint32_t lo = std::min(nt, per * part), hi = std::min(nt, per * (part + 1));
                     XOut x = dummy;
-                    x.n = (uint16_t)(t1 - t0);
-                    for (uint32_t t = t0; t < t1; t++) x.t[t - t0] = (uint16_t)lds_of[ex[g][t]];
+                    x.n = (uint16_t)(hi - lo);
+                    for (uint32_t t = lo; t < hi; t++) x.t[t - lo] = (uint16_t)lds_of[ex[g][t]];
                     if (part == 0) {
                         x.out = (uint16_t)lds_of[pid];
                         x.flags = (uint16_t)((is_output[pid] ? kXoStore : 0) | (rpar[g] ? kXoRpar : 0) |
