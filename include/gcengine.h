@@ -269,6 +269,11 @@ int gc_batch_gather_outputs(gc_batch *, void *d_out);
 size_t gc_tables_wire_bytes(const gc_circ *);
 int gc_batch_egress_tables(gc_batch *, void *d_out, size_t stride);
 int gc_batch_ingest_tables(gc_batch *, const void *d_in, size_t stride, void *d_bad);
+/* sha2pc's encoding of the same tables (sha2pc/encoding.go:363-411 encodeGarbledTables / decodeGarbledTables): the
+ * rows of all gates back to back in gate order, BE(D0)||BE(D1) each, no headers: 16 * slab_rows bytes per instance
+ * (= garbledTableByteLen, sha2pc/params.go); stride = bytes between instances, a multiple of 16. */
+int gc_batch_egress_tables_dense(gc_batch *, void *d_out, size_t stride);
+int gc_batch_ingest_tables_dense(gc_batch *, const void *d_in, size_t stride);
 
 /* timing of the most recent garble / eval on this batch, measured with HIP events recorded on
  * the ctx stream around the gate kernels (the one fused launch, or the level launches; the few-microsecond

@@ -721,6 +721,26 @@ int gc_batch_ingest_tables(gc_batch *b, const void *d_in, size_t stride, void *d
     return GC_OK;
 }
 
+int gc_batch_egress_tables_dense(gc_batch *b, void *d_out, size_t stride) {
+    if (!b || !d_out || (stride & 15) || stride < (size_t)b->circ->plan.p.info.slab_rows * 16) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_slab_be(b->d_T, b->g.lt, b->circ->plan.p.info.slab_rows, b->g.batch, (uint8_t *)d_out, stride, false,
+                   ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_batch_ingest_tables_dense(gc_batch *b, const void *d_in, size_t stride) {
+    if (!b || !d_in || (stride & 15) || stride < (size_t)b->circ->plan.p.info.slab_rows * 16) return GC_E_ARG;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_slab_be(b->d_T, b->g.lt, b->circ->plan.p.info.slab_rows, b->g.batch, (uint8_t *)const_cast<void *>(d_in), stride,
+                   true, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
 float gc_batch_last_ms(gc_batch *b) {
     if (!b || !b->timed) return -1.0f;
     if (hipSetDevice(b->circ->ctx->device) != hipSuccess) return -1.0f;

@@ -464,53 +464,83 @@ __device__ __forceinline__ uint32_t rows_of_op(uint32_t op) { return op == GC_AN
 __global__ __launch_bounds__(256) void k_tables_egress(const uint4 *__restrict__ T, Layout lt,
                                                        const uint8_t *__restrict__ ops,
                                                        const uint32_t *__restrict__ row_of_gate, uint32_t ngates,
-                                                       uint8_t *__restrict__ out, size_t stride) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x, inst = blockIdx.y;
-    uint32_t *base = (uint32_t *)(out + (size_t)inst * stride);
-    if (g == 0) base[0] = bswap32(ngates);
-    if (g >= ngates) return;
-    const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
-    uint32_t *p = base + 1 + g + 4 * (size_t)row;  // byte offset 4 + 4g + 16 row
-    p[0] = bswap32(n);
-    for (uint32_t r = 0; r < n; r++) {
-        const uint4 v = T[lt.at(row + r, inst)];
-        p[1 + 4 * r] = bswap32(v.y);  // BE(D0) || BE(D1)
-        p[2 + 4 * r] = bswap32(v.x);
-        p[3 + 4 * r] = bswap32(v.w);
-        p[4 + 4 * r] = bswap32(v.z);
+                                                       uint32_t batch, uint8_t *__restrict__ out, size_t stride) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    for (uint32_t inst = blockIdx.y; inst < batch; inst += gridDim.y) {
+        uint32_t *base = (uint32_t *)(out + (size_t)inst * stride);
+        if (g == 0) base[0] = bswap32(ngates);
+        if (g >= ngates) continue;
+        const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
+        uint32_t *p = base + 1 + g + 4 * (size_t)row;  // byte offset 4 + 4g + 16 row
+        p[0] = bswap32(n);
+        for (uint32_t r = 0; r < n; r++) {
+            const uint4 v = T[lt.at(row + r, inst)];
+            p[1 + 4 * r] = bswap32(v.y);  // BE(D0) || BE(D1)
+            p[2 + 4 * r] = bswap32(v.x);
+            p[3 + 4 * r] = bswap32(v.w);
+            p[4 + 4 * r] = bswap32(v.z);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_tables_ingest(uint4 *__restrict__ T, Layout lt, const uint8_t *__restrict__ ops,
                                                        const uint32_t *__restrict__ row_of_gate, uint32_t ngates,
-                                                       const uint8_t *__restrict__ in, size_t stride,
+                                                       uint32_t batch, const uint8_t *__restrict__ in, size_t stride,
                                                        uint32_t *__restrict__ bad) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x, inst = blockIdx.y;
-    const uint32_t *base = (const uint32_t *)(in + (size_t)inst * stride);
-    if (g == 0 && bswap32(base[0]) != ngates) atomicAdd(bad, 1u);
-    if (g >= ngates) return;
-    const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
-    const uint32_t *p = base + 1 + g + 4 * (size_t)row;
-    if (bswap32(p[0]) != n) {
-        atomicAdd(bad, 1u);
-        return;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    for (uint32_t inst = blockIdx.y; inst < batch; inst += gridDim.y) {
+        const uint32_t *base = (const uint32_t *)(in + (size_t)inst * stride);
+        if (g == 0 && bswap32(base[0]) != ngates) atomicAdd(bad, 1u);
+        if (g >= ngates) continue;
+        const uint32_t row = row_of_gate[g], n = rows_of_op(ops[g]);
+        const uint32_t *p = base + 1 + g + 4 * (size_t)row;
+        if (bswap32(p[0]) != n) {
+            atomicAdd(bad, 1u);
+            continue;
+        }
+        for (uint32_t r = 0; r < n; r++)
+            T[lt.at(row + r, inst)] =
+                make_uint4(bswap32(p[2 + 4 * r]), bswap32(p[1 + 4 * r]), bswap32(p[4 + 4 * r]), bswap32(p[3 + 4 * r]));
     }
-    for (uint32_t r = 0; r < n; r++)
-        T[lt.at(row + r, inst)] =
-            make_uint4(bswap32(p[2 + 4 * r]), bswap32(p[1 + 4 * r]), bswap32(p[4 + 4 * r]), bswap32(p[3 + 4 * r]));
+}
+
+// sha2pc's table encoding (sha2pc/encoding.go:363-411 encodeGarbledTables / :413ff decodeGarbledTables): the rows of
+// all gates back to back in gate order, each label as BE(D0) || BE(D1), no headers (garbledTableByteLen =
+// 16 * rows).  thread = (row, instance)
+__global__ __launch_bounds__(256) void k_slab_be(uint4 *__restrict__ T, Layout lt, uint32_t rows, uint32_t batch,
+                                                 uint8_t *__restrict__ buf, size_t stride, bool ingest) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (uint32_t inst = blockIdx.y; inst < batch; inst += gridDim.y) {
+        uint4 *p = (uint4 *)(buf + (size_t)inst * stride) + r;
+        if (ingest) {
+            const uint4 v = *p;
+            T[lt.at(r, inst)] = make_uint4(bswap32(v.y), bswap32(v.x), bswap32(v.w), bswap32(v.z));
+        } else {
+            const uint4 v = T[lt.at(r, inst)];
+            *p = make_uint4(bswap32(v.y), bswap32(v.x), bswap32(v.w), bswap32(v.z));
+        }
+    }
 }
 
 void launch_tables_egress(const uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
                           uint32_t ngates, uint32_t batch, uint8_t *out, size_t stride, hipStream_t s) {
-    dim3 grid((ngates + 256) / 256, batch);
-    hipLaunchKernelGGL(k_tables_egress, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, out, stride);
+    dim3 grid((ngates + 256) / 256, batch < 32768 ? batch : 32768);
+    hipLaunchKernelGGL(k_tables_egress, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, batch, out, stride);
 }
 
 void launch_tables_ingest(uint4 *T, const Layout &lt, const uint8_t *ops, const uint32_t *row_of_gate,
                           uint32_t ngates, uint32_t batch, const uint8_t *in, size_t stride, uint32_t *bad,
                           hipStream_t s) {
-    dim3 grid((ngates + 256) / 256, batch);
-    hipLaunchKernelGGL(k_tables_ingest, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, in, stride, bad);
+    dim3 grid((ngates + 256) / 256, batch < 32768 ? batch : 32768);
+    hipLaunchKernelGGL(k_tables_ingest, grid, dim3(256), 0, s, T, lt, ops, row_of_gate, ngates, batch, in, stride, bad);
+}
+
+void launch_slab_be(uint4 *T, const Layout &lt, uint32_t rows, uint32_t batch, uint8_t *buf, size_t stride, bool ingest,
+                    hipStream_t s) {
+    if (rows == 0) return;
+    dim3 grid((rows + 255) / 256, batch < 32768 ? batch : 32768);
+    hipLaunchKernelGGL(k_slab_be, grid, dim3(256), 0, s, T, lt, rows, batch, buf, stride, ingest);
 }
 
 }  // namespace gc

@@ -145,6 +145,10 @@ void launch_tables_ingest(uint4 *T, const Layout &lt, const uint8_t *ops, const 
                           uint32_t ngates, uint32_t batch, const uint8_t *in, size_t stride, uint32_t *bad,
                           hipStream_t s);
 
+// sha2pc's headerless table encoding (sha2pc/encoding.go:363-411): rows in gate order, BE(D0)||BE(D1) each
+void launch_slab_be(uint4 *T, const Layout &lt, uint32_t rows, uint32_t batch, uint8_t *buf, size_t stride, bool ingest,
+                    hipStream_t s);
+
 // ---- OT kernels (ot_kernels.hip) -------------------------------------------------------------
 // IKNP OT extension, fused (iknp_fused_kernels.hip): column AES-128-CTR PRG + u-matrix / delta fold + createLabels.
 // rk0/rk1: [128][44] expanded column keys (big-endian words); pos0: bytes every column stream has already

@@ -119,6 +119,8 @@ def lib():
         "gc_tables_wire_bytes": (sz, [vp]),
         "gc_batch_egress_tables": (i32, [vp, vp, sz]),
         "gc_batch_ingest_tables": (i32, [vp, vp, sz, vp]),
+        "gc_batch_egress_tables_dense": (i32, [vp, vp, sz]),
+        "gc_batch_ingest_tables_dense": (i32, [vp, vp, sz]),
         "gc_batch_last_ms": (C.c_float, [vp]),
         "gc_batch_last_launches": (u32, [vp]),
         "gc_batch_debug_profile": (i32, [vp, i32, vp]),
@@ -388,6 +390,12 @@ class Batch:
 
     def egress_tables(self, d_out, stride):
         _check(lib().gc_batch_egress_tables(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables")
+
+    def egress_tables_dense(self, d_out, stride):
+        _check(lib().gc_batch_egress_tables_dense(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables_dense")
+
+    def ingest_tables_dense(self, d_in, stride):
+        _check(lib().gc_batch_ingest_tables_dense(self.h, C.c_void_p(d_in), stride), "gc_batch_ingest_tables_dense")
 
     def ingest_tables(self, d_in, stride, d_bad):
         _check(lib().gc_batch_ingest_tables(self.h, C.c_void_p(d_in), stride, C.c_void_p(d_bad)),

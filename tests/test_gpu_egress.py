@@ -72,3 +72,35 @@ def test_egress_ingest(schedule, aes_circ):
         assert int(d_bad.cpu()[0]) == 2
         gb.close(); ev.close(); dc.close()
     ctx.close()
+
+
+def test_dense_encoding_sha2pc(sha_circ):
+    """sha2pc/encoding.go:363-411: rows in gate order, BE(D0)||BE(D1) each, garbledTableByteLen = 16 * 42914"""
+    import torch
+    c = sha_circ
+    batch = 3
+    ctx = engine.Context(0)
+    dc = engine.DeviceCircuit(ctx, c)
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    key = bytes(range(32))
+    stride_rnd = 16 * (c.num_inputs + 1)
+    rnd = drbg("dense", stride_rnd * batch)
+    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    nbytes = 16 * c.slab_rows()
+    assert nbytes == 16 * 42914
+    d_wire = torch.zeros(batch * nbytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gb.garble(key, d_rnd.data_ptr())
+    gb.egress_tables_dense(d_wire.data_ptr(), nbytes)
+    ctx.sync()
+    wire = d_wire.cpu().numpy().reshape(batch, nbytes)
+    ref = oracle.garble(c.Gates, c.NumWires, c.num_inputs, key, rnd[:stride_rnd])
+    want = b"".join(oracle.label_to_bytes(l) for l in ref["slab"])
+    assert wire[0].tobytes() == want
+    slab = gb.read_slab()
+    for i in range(batch):
+        assert wire[i].tobytes() == b"".join(oracle.label_to_bytes(l) for l in slab[i])
+    ev.ingest_tables_dense(d_wire.data_ptr(), nbytes)
+    ctx.sync()
+    assert (ev.read_slab() == slab).all()
+    gb.close(); ev.close(); dc.close(); ctx.close()
