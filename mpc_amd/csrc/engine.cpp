@@ -249,7 +249,7 @@ static BatchGeom geom_for(const gc_batch *b) {
     const uint32_t nls = flat ? p.n_flat_slots : p.n_lds_slots;
     // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
     const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
-    return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat);
+    return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat, p.fl_unit_stride);
 }
 
 static hipError_t alloc_buffers(gc_batch *b) {
@@ -397,6 +397,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
         f.nunits = (uint32_t)p.fl_units.size();
         f.ninputs = p.info.ninputs;
         f.nls = p.n_flat_slots;
+        f.ustride = p.fl_unit_stride;
         f.W = b->d_W;
         f.R = b->d_R;
         f.T = const_cast<uint4 *>(T);

@@ -14,7 +14,8 @@
 // fused_lds_kernels.hip cost ~20 % of a pass in dependent LDS round trips with the AES pipe idle).
 // The next unit's image (descriptors + XOuts, <= 14.5 KiB) is fetched into one register per thread
 // while the current unit executes and committed to the other LDS buffer before the closing barrier.
-// LDS map: 64 KiB AES table | 2 x kUnit16 uint4 stage (29 KiB) | R[TI] | wires [slot][TI] (last slot = zero label).
+// LDS map: 64 KiB AES table | 2 x ustride uint4 stage (ustride = the circuit's largest unit, <= 14.5 KiB) | R[TI] |
+// wires [slot][TI] (last slot = zero label).
 #include "aes_device.h"
 #include "kernels.h"
 
@@ -43,7 +44,6 @@ __device__ __forceinline__ uint4 dpp128(uint4 v) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr uint32_t kStageOff = kTeDualBytes / 16;
-constexpr uint32_t kStageEnd = kStageOff + 2 * kUnit16;
 
 #define GC_FPROF(slot)                                               \
     if constexpr (PROF) {                                            \
@@ -66,6 +66,7 @@ struct FlArgs {
     const uint32_t *hgslot, *ogslot;
     const uint16_t *in_lds;
     uint32_t nunits, ninputs, ti_log2, zslot;
+    uint32_t ustride;  // uint4 per stage buffer
     size_t w_tile, t_tile;
     uint4 *W;
     const uint4 *R;
@@ -206,7 +207,8 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     uint32_t *te = (uint32_t *)smem;                                                                         \
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;                                    \
     uint4 *stage = smem + kStageOff;                                                                         \
-    uint4 *rl = smem + kStageEnd;                                                                            \
+    const uint32_t ustride = a.ustride;                                                                      \
+    uint4 *rl = smem + kStageOff + 2 * ustride;                                                              \
     uint4 *wl = rl + TI;                                                                                     \
     load_te_dual(te, a.te0);                                                                                 \
     uint32_t rkr[4 * (NR + 1)];                                                                              \
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     GC_FL_PROLOGUE(true)
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
-        const uint4 *buf = stage + (ui & 1u) * kUnit16;
+        const uint4 *buf = stage + (ui & 1u) * ustride;
         const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         GC_FPROF(2)
         if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
         GC_FPROF(4)
-        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre;
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     GC_FL_PROLOGUE(false)
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
-        const uint4 *buf = stage + (ui & 1u) * kUnit16;
+        const uint4 *buf = stage + (ui & 1u) * ustride;
         const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
         uint4 pre = make_uint4(0, 0, 0, 0);
         if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         GC_FPROF(2)
         if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
         GC_FPROF(4)
-        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * kUnit16 + threadIdx.x] = pre;
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre;
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     GC_FPROF_EPILOGUE()
 }
 
-size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2) {
-    return (size_t)kStageEnd * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
+size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride) {
+    return (size_t)(kStageOff + 2 * ustride) * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
 }
 
 template <typename K>
@@ -423,6 +425,7 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     a.ninputs = f.ninputs;
     a.ti_log2 = g.ti_log2;
     a.zslot = f.nls - 1;
+    a.ustride = f.ustride;
     a.w_tile = g.lw.tile_stride;
     a.t_tile = g.lt.tile_stride;
     a.W = f.W;
@@ -432,7 +435,7 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     a.te0 = f.te0;
     a.prof = f.prof;
     if (a.nunits == 0) return hipSuccess;
-    const size_t lds = fused_flat_bytes(f.nls, g.ti_log2);
+    const size_t lds = fused_flat_bytes(f.nls, g.ti_log2, f.ustride);
 #define GC_M3(KERN, NR) \
     (f.prof ? launch_fl(KERN<NR, true>, a, g.ntiles, lds, s) : launch_fl(KERN<NR, false>, a, g.ntiles, lds, s))
 #define GC_M2(KERN) (f.rounds == 10 ? GC_M3(KERN, 10) : f.rounds == 12 ? GC_M3(KERN, 12) : GC_M3(KERN, 14))

@@ -11,7 +11,7 @@
 namespace gc {
 
 BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls,
-                    uint32_t max_ti_log2, bool flat) {
+                    uint32_t max_ti_log2, bool flat, uint32_t ustride) {
     BatchGeom g{};
     g.batch = batch;
     if (batch >= 256) {
@@ -35,7 +35,7 @@ BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab
         while (t < max_ti_log2 && (batch >> (t + 1)) >= 256) t++;
         // LDS-resident wires: the tile's live labels (+R) must fit beside the 64 KiB AES table
         const size_t lds_budget = 160 * 1024;
-        auto need = [&](uint32_t tt) { return flat ? fused_flat_bytes(nls, tt) : fused_lds_bytes(nls, tt); };
+        auto need = [&](uint32_t tt) { return flat ? fused_flat_bytes(nls, tt, ustride) : fused_lds_bytes(nls, tt); };
         g.lds_wires = nls != 0xffffffffu && need(0) <= lds_budget;
         if (g.lds_wires)
             while (t > 0 && need(t) > lds_budget) t--;

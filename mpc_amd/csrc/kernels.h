@@ -44,7 +44,7 @@ struct BatchGeom {
 // nls: live-label high-water mark of the LDS schedule (0xffffffff: does not fit -> global-memory wires)
 // nls: live labels of the LDS plan that will run (0xffffffff: none); flat: size them for the flattened kernels
 BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab_rows, uint32_t nls,
-                    uint32_t max_ti_log2 = 6, bool flat = false);
+                    uint32_t max_ti_log2 = 6, bool flat = false, uint32_t ustride = 0);
 
 struct LevelArgs {
     const GateDesc *descs;  // device, already offset to the step
@@ -104,6 +104,7 @@ struct FusedFlatArgs {
     const uint32_t *hgslot, *ogslot;
     const uint16_t *in_lds;
     uint32_t nunits, ninputs, nls;  // nls = Plan::n_flat_slots (zero slot included)
+    uint32_t ustride;               // Plan::fl_unit_stride: uint4 per LDS stage buffer (largest unit of the circuit)
     uint4 *W;
     const uint4 *R;
     uint4 *T;
@@ -112,7 +113,7 @@ struct FusedFlatArgs {
     int rounds;
     uint64_t *prof;  // optional [ntiles][16] cycle breakdown (debug), nullptr in production
 };
-size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2);
+size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride);
 hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &a, const BatchGeom &g, hipStream_t s);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]

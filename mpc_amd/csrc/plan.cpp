@@ -224,6 +224,7 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
         p.fl_hgslot.insert(p.fl_hgslot.end(), uhg.begin(), uhg.end());
         p.fl_ogslot.insert(p.fl_ogslot.end(), uog.begin(), uog.end());
         p.fl_units.push_back(u);
+        p.fl_unit_stride = std::max(p.fl_unit_stride, (u.n16 + 3u) & ~3u);
         uh.clear(), uo.clear(), uhg.clear(), uog.clear();
         u = FUnit{};
         u.xparts = 1;

@@ -127,6 +127,7 @@ struct Plan {
     std::vector<uint16_t> fl_in_lds;    // LDS slot of every input wire (0xffff: never read)
     uint32_t n_flat_slots = 0xffffffffu;  // live labels incl. the zero slot (= slot n_flat_slots - 1)
     uint32_t n_flat_outs = 0, n_flat_terms = 0, n_flat_steps = 0;
+    uint32_t fl_unit_stride = 0;        // uint4 per LDS stage buffer = the largest unit (<= kUnit16)
     uint32_t fl_max_parts = 1;          // largest XOut part count: a tile may hold at most 16 / fl_max_parts instances
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
