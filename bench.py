@@ -23,9 +23,9 @@ sys.path.insert(0, ROOT)
 ALG_BYTES = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 # Secondary bound (SURVEY.md §8d "LDS bandwidth / VALU issue on AND-dense levels"): the fixed-key hash is a
-# T-table AES out of LDS.  tools/aes_ubench measures the production AES core alone at 10.67 cycles per block per
-# CU with 16 waves/CU (57.6 G blocks/s on 256 CUs; profiles/r01_aes_ubench.txt).
-AES_CORE_PEAK_BLOCKS = 57.6e9
+# T-table AES out of LDS.  tools/aes_ubench measures the production AES core alone at 10.28 cycles per block per
+# CU with 16 waves/CU (59.7 G blocks/s on 256 CUs; profiles/r01_aes_ubench.txt).
+AES_CORE_PEAK_BLOCKS = 59.7e9
 AES_BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}  # (garble, eval) distinct AES blocks per gate
 
 

@@ -180,12 +180,27 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
+// One round's sixteen lookups of a block, issued as ONE batch: all addresses, then all loads, then the combines.
+// Left to itself the compiler splits a round into two halves of eight lookups with a wait in between, i.e. two
+// LDS round trips per round: 340 vs 249 cycles per round for a lone wave, 686 vs 663 with 16 waves per CU
+// (tools/aes_model_ubench.hip, variants 1 / 8).  sched_barrier pins the three groups.
+__device__ __forceinline__ void te_round_addrs(const uint32_t (&a)[4], uint32_t lo0, uint32_t lo2, uint32_t (&ad)[16]) {
+    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        ad[4 * c + 0] = __builtin_amdgcn_perm(a[c], lo0, sel3);            // Te0[b3(a_c)]
+        ad[4 * c + 1] = __builtin_amdgcn_perm(a[(c + 2) & 3], lo2, sel1);  // Te2[b1(a_c+2)]
+        ad[4 * c + 2] = __builtin_amdgcn_perm(a[(c + 1) & 3], lo0, sel2);  // Te0[b2(a_c+1)]  (-> Te1 by rotr8)
+        ad[4 * c + 3] = __builtin_amdgcn_perm(a[(c + 3) & 3], lo2, sel0);  // Te2[b0(a_c+3)]  (-> Te3 by rotr8)
+    }
+}
+
 // rk: NR+1 round keys as big-endian words, expected in SGPRs (see load_round_keys)
 template <int NR, int N>
 __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint32_t (&rk)[4 * (NR + 1)],
                                                  const uint32_t *te, uint32_t lo0) {
+    (void)te;  // the table sits at LDS offset 0 (te_dual_check)
     const uint32_t lo2 = lo0 + 128u;
-    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
 #pragma unroll
     for (int k = 0; k < N; k++) {
         s[k][0] ^= rk[0];
@@ -195,31 +210,47 @@ __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint
     }
 #pragma unroll
     for (int r = 1; r < NR; r++) {
+        uint32_t ad[N][16], t[N][16];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
-#define GC_COL(c0, c1, c2, c3, key)                                                                   \
-    (xor3(te_dual(c0, sel3, lo0), te_dual(c2, sel1, lo2), (key)) ^                                    \
-     rotr32(te_dual(c1, sel2, lo0) ^ te_dual(c3, sel0, lo2), 8))
-            s[k][0] = GC_COL(a0, a1, a2, a3, rk[4 * r + 0]);
-            s[k][1] = GC_COL(a1, a2, a3, a0, rk[4 * r + 1]);
-            s[k][2] = GC_COL(a2, a3, a0, a1, rk[4 * r + 2]);
-            s[k][3] = GC_COL(a3, a0, a1, a2, rk[4 * r + 3]);
-#undef GC_COL
-        }
+        for (int k = 0; k < N; k++) te_round_addrs(s[k], lo0, lo2, ad[k]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) t[k][i] = *(lds_u32 *)(uintptr_t)ad[k][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                s[k][c] = xor3(t[k][4 * c], t[k][4 * c + 1], rk[4 * r + c]) ^ rotr32(t[k][4 * c + 2] ^ t[k][4 * c + 3], 8);
     }
-    // final round (no MixColumns): S[x] is bytes 2,1 of Te0[x] and bytes 3,0 of Te2[x]
+    // final round (no MixColumns): S[x] is bytes 2,1 of Te0[x] and bytes 3,0 of Te2[x]; same byte positions as above
+    // but the roles of the two table halves are swapped for the first and last byte
+    {
+        const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+        uint32_t ad[N][16], t[N][16];
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        const uint32_t a0 = s[k][0], a1 = s[k][1], a2 = s[k][2], a3 = s[k][3];
-#define GC_LAST(c0, c1, c2, c3, key)                                                                       \
-    (((te_dual(c0, sel3, lo2) & 0xff000000u) | (te_dual(c1, sel2, lo0) & 0x00ff0000u) |                   \
-      (te_dual(c2, sel1, lo0) & 0x0000ff00u) | (te_dual(c3, sel0, lo2) & 0x000000ffu)) ^ (key))
-        s[k][0] = GC_LAST(a0, a1, a2, a3, rk[4 * NR + 0]);
-        s[k][1] = GC_LAST(a1, a2, a3, a0, rk[4 * NR + 1]);
-        s[k][2] = GC_LAST(a2, a3, a0, a1, rk[4 * NR + 2]);
-        s[k][3] = GC_LAST(a3, a0, a1, a2, rk[4 * NR + 3]);
-#undef GC_LAST
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                ad[k][4 * c + 0] = __builtin_amdgcn_perm(s[k][c], lo2, sel3);
+                ad[k][4 * c + 1] = __builtin_amdgcn_perm(s[k][(c + 1) & 3], lo0, sel2);
+                ad[k][4 * c + 2] = __builtin_amdgcn_perm(s[k][(c + 2) & 3], lo0, sel1);
+                ad[k][4 * c + 3] = __builtin_amdgcn_perm(s[k][(c + 3) & 3], lo2, sel0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) t[k][i] = *(lds_u32 *)(uintptr_t)ad[k][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                s[k][c] = ((t[k][4 * c] & 0xff000000u) | (t[k][4 * c + 1] & 0x00ff0000u) | (t[k][4 * c + 2] & 0x0000ff00u) |
+                           (t[k][4 * c + 3] & 0x000000ffu)) ^ rk[4 * NR + c];
     }
 }
 

@@ -72,17 +72,21 @@ __device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t key
 #pragma unroll
     for (int r = 1; r < 10; r++) {
         k = lds_ld4(keyaddr + 16u * r);
+        const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+        uint32_t ad[N][16], t[N][16];  // one batch of lookups per round (see aes_encrypt_dual)
 #pragma unroll
-        for (int n = 0; n < N; n++) {
-            const uint32_t a0 = s[n][0], a1 = s[n][1], a2 = s[n][2], a3 = s[n][3];
-#define GC_COL(c0, c1, c2, c3, key) \
-    (xor3(te_dual(c0, sel3, lo0), te_dual(c2, sel1, lo2), (key)) ^ rotr32(te_dual(c1, sel2, lo0) ^ te_dual(c3, sel0, lo2), 8))
-            s[n][0] = GC_COL(a0, a1, a2, a3, k.x);
-            s[n][1] = GC_COL(a1, a2, a3, a0, k.y);
-            s[n][2] = GC_COL(a2, a3, a0, a1, k.z);
-            s[n][3] = GC_COL(a3, a0, a1, a2, k.w);
-#undef GC_COL
-        }
+        for (int n = 0; n < N; n++) te_round_addrs(s[n], lo0, lo2, ad[n]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) t[n][i] = *(lds_u32 *)(uintptr_t)ad[n][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                s[n][c] = xor3(t[n][4 * c], t[n][4 * c + 1], kk[c]) ^ rotr32(t[n][4 * c + 2] ^ t[n][4 * c + 3], 8);
     }
     k = lds_ld4(keyaddr + 160u);
 #pragma unroll

@@ -51,6 +51,31 @@ __device__ __forceinline__ uint32_t col(const uint32_t *te, uint32_t c0, uint32_
     return X3(X3(t0, t2, key), t1, t3);
 }
 
+// variant 8: production column formula, but all 16 addresses first, then all 16 loads, then the combines
+// (sched_barrier keeps the compiler from splitting the round into two 8-lookup halves with a wait in between)
+__device__ __forceinline__ void round_batched(const uint32_t *te, uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3,
+                                              const uint32_t *rk4, uint32_t lo0, uint32_t lo2) {
+    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+    const uint32_t s[4] = {a0, a1, a2, a3};
+    uint32_t ad[16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        ad[4 * c + 0] = __builtin_amdgcn_perm(s[c], lo0, sel3);
+        ad[4 * c + 1] = __builtin_amdgcn_perm(s[(c + 2) & 3], lo2, sel1);
+        ad[4 * c + 2] = __builtin_amdgcn_perm(s[(c + 1) & 3], lo0, sel2);
+        ad[4 * c + 3] = __builtin_amdgcn_perm(s[(c + 3) & 3], lo2, sel0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = *(lds_u32 *)(uintptr_t)ad[i];
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t n[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) n[c] = X3(t[4 * c], t[4 * c + 1], rk4[c]) ^ rotr32(t[4 * c + 2] ^ t[4 * c + 3], 8);
+    a0 = n[0], a1 = n[1], a2 = n[2], a3 = n[3];
+}
+
 template <int V>
 __global__ __launch_bounds__(1024) void k_bench(const uint32_t *rk, const uint32_t *te0, uint4 *out, int iters) {
     extern __shared__ uint4 smem[];
@@ -64,6 +89,10 @@ __global__ __launch_bounds__(1024) void k_bench(const uint32_t *rk, const uint32
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 1; r < 14; r++) {
+            if (V == 8) {
+                round_batched(te, a0, a1, a2, a3, &rkr[4 * r], lo0, lo2);
+                continue;
+            }
             const uint32_t n0 = col<V>(te, a0, a1, a2, a3, rkr[4 * r + 0], lo0, lo2);
             const uint32_t n1 = col<V>(te, a1, a2, a3, a0, rkr[4 * r + 1], lo0, lo2);
             const uint32_t n2 = col<V>(te, a2, a3, a0, a1, rkr[4 * r + 2], lo0, lo2);
@@ -107,7 +136,7 @@ int main() {
     hipMalloc(&d_out, 256 * 1024 * 16);
     hipMemcpy(d_rk, k.w, 240, hipMemcpyHostToDevice);
     hipMemcpy(d_te, aes_tables().te0, 1024, hipMemcpyHostToDevice);
-    for (int threads : {64, 256, 512, 1024}) {
+    for (int threads : {64, 128, 256, 512, 576, 1024}) {
         run<0>(threads, d_rk, d_te, d_out);
         run<1>(threads, d_rk, d_te, d_out);
         run<2>(threads, d_rk, d_te, d_out);
@@ -116,6 +145,7 @@ int main() {
         run<5>(threads, d_rk, d_te, d_out);
         run<6>(threads, d_rk, d_te, d_out);
         run<7>(threads, d_rk, d_te, d_out);
+        run<8>(threads, d_rk, d_te, d_out);
     }
     return 0;
 }
