@@ -173,7 +173,12 @@ def main():
     device_step()  # first call uploads the round keys (not capturable), and warms the allocator
     ctx.sync()
     if not args.no_graph and args.schedule != 0:
-        graphs = [ctx.capture(lambda k=k: device_step(k)) for k in range(nbuf)]
+        try:
+            graphs = [ctx.capture(lambda k=k: device_step(k)) for k in range(nbuf)]
+        except Exception as e:  # capture is an optimisation: fall back to direct launches of the same kernels
+            print("bench: hipGraph capture unavailable (%s); launching directly" % e, file=sys.stderr)
+            graphs = None
+            ctx.sync()
     for _ in range(args.warmup):
         step()
     fence()
