@@ -70,8 +70,8 @@ def cpu_baseline(circ, key, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--circuit", default=os.path.join(ROOT, "tests", "golden", "aes_128.gcf"))
     ap.add_argument("--key-bytes", type=int, default=32, choices=[16, 24, 32])
