@@ -94,6 +94,11 @@ int gc_plan_get_info(const gc_plan *, gc_plan_info *out);
  *  row_of_gate[ngates+1]  first slab row of the gate (== Garbled.Gates[i] offset into the slab)
  *  slot_of_gate[ngates]   device wire slot written by the gate
  * any pointer may be NULL */
+/* Host-side self-check of the flattened fused schedule (no GPU involved): evaluates the circuit on plaintext bits by
+ * walking the exact unit program, LDS slot assignment, part joins and global stores the fused kernels execute, with
+ * their parallel semantics.  in_bits[ninputs], out_bits[noutputs] (one byte per bit).  GC_E_WIRE: a slot was read
+ * before it was written; GC_E_ARG: no flattened schedule / malformed items. */
+int gc_plan_simulate(const gc_plan *, const uint8_t *in_bits, uint8_t *out_bits);
 int gc_plan_describe(const gc_plan *, uint32_t *level_of_gate, uint32_t *tweak_of_gate,
                      uint32_t *row_of_gate, uint32_t *slot_of_gate);
 

@@ -289,6 +289,71 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
     emit();
 }
 
+// Host-side self-check of the flattened schedule: evaluates the PLAINTEXT function by walking the exact unit
+// program, LDS slot assignment, part joins and global stores the kernels use, with the kernels' parallel semantics
+// (inside a hash part / an XOR part every read happens before any write).  A slot recycled too early, a missing
+// materialisation or a wrong term list shows up as a wrong output bit — without a GPU.
+int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits) {
+    if (p.n_flat_slots == 0xffffffffu) return GC_E_ARG;
+    const uint32_t nin = p.info.ninputs;
+    std::vector<uint8_t> lds(p.n_flat_slots, 0), glob(p.info.nslots, 0);
+    std::vector<uint8_t> poison(p.n_flat_slots, 0);  // 1 = holds a value, 0 = never written (reads of those are errors)
+    const uint32_t zslot = p.n_flat_slots - 1;
+    poison[zslot] = 1;
+    for (uint32_t w = 0; w < nin; w++) {
+        glob[w] = in_bits[w] & 1;
+        if (p.fl_in_lds[w] != 0xffff) lds[p.fl_in_lds[w]] = glob[w], poison[p.fl_in_lds[w]] = 1;
+    }
+    for (const FUnit &u : p.fl_units) {
+        const uint32_t *img = p.fl_prog.data() + (size_t)u.off16 * 4;
+        const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        std::vector<std::pair<uint32_t, uint8_t>> writes;
+        for (uint32_t g = 0; g < nh; g++) {
+            const uint32_t lin = img[4 * g], lout = img[4 * g + 1], op = img[4 * g + 3] >> kOpShift;
+            const uint32_t sa = lin & 0xffffu, sb = lin >> 16;
+            if (!poison[sa] || (op != GC_INV && !poison[sb])) return GC_E_WIRE;
+            if ((g < u.n_and) != (op == GC_AND) || (g >= u.n_and + u.n_or) != (op == GC_INV)) return GC_E_GATE;
+            const uint8_t a = lds[sa], b = lds[sb];
+            const uint8_t v = op == GC_AND ? (a & b) : op == GC_OR ? (a | b) : (uint8_t)(a ^ 1);
+            writes.emplace_back(lout & 0xffffu, v);
+            if (lout & kFStoreGlobal) glob[p.fl_hgslot[u.hfirst + g]] = v;
+        }
+        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
+        writes.clear();
+        const uint32_t *outs = img + (size_t)u.outs_off16 * 4;
+        std::vector<uint8_t> partial(u.nout, 0);
+        for (uint32_t o = 0; o < u.nout; o++) {
+            const uint32_t *x = outs + 6 * o;
+            const uint32_t n = x[5] & 0xffffu;
+            uint8_t acc = 0;
+            for (uint32_t k = 0; k < (n > 4 ? 8u : 4u); k++) {  // the kernel reads 4 or 8 slots, padding = zero slot
+                const uint32_t sl = (x[k / 2] >> (16 * (k & 1))) & 0xffffu;
+                if (k < n ? !poison[sl] : sl != zslot) return GC_E_WIRE;
+                acc ^= lds[sl];
+            }
+            partial[o] = acc;
+        }
+        for (uint32_t o = 0; o < u.nout; o++) {
+            const uint32_t *x = outs + 6 * o;
+            const uint32_t flags = x[4] >> 16, slot = x[4] & 0xffffu;
+            if (flags & kXoPart) continue;
+            uint8_t acc = partial[o];
+            const uint32_t parts = (flags & kXoJoin4) ? 4u : (flags & kXoJoin2) ? 2u : 1u;
+            if (parts > u.xparts || o % parts || o + parts > u.nout) return GC_E_ARG;
+            for (uint32_t k = 1; k < parts; k++) {
+                if (!((outs[6 * (o + k) + 4] >> 16) & kXoPart)) return GC_E_ARG;
+                acc ^= partial[o + k];
+            }
+            if (flags & kXoRpar) acc ^= 1;  // XNOR: the garbler's "XOR R once" is the plaintext complement
+            writes.emplace_back(slot, acc);
+            if (flags & kXoStore) glob[p.fl_ogslot[u.ofirst + o]] = acc;
+        }
+        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
+    }
+    for (uint32_t j = 0; j < p.info.noutputs; j++) out_bits[j] = glob[p.out_slots[j]];
+    return GC_OK;
+}
+
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
                Plan *out) {
     if ((!gates && ngates) || !out) return GC_E_ARG;
@@ -548,6 +613,11 @@ int gc_plan_get_info(const gc_plan *pl, gc_plan_info *out) {
     if (!pl || !out) return GC_E_ARG;
     *out = pl->p.info;
     return GC_OK;
+}
+
+int gc_plan_simulate(const gc_plan *pl, const uint8_t *in_bits, uint8_t *out_bits) {
+    if (!pl || (!in_bits && pl->p.info.ninputs) || (!out_bits && pl->p.info.noutputs)) return GC_E_ARG;
+    return gc::simulate_flat(pl->p, in_bits, out_bits);
 }
 
 int gc_plan_describe(const gc_plan *pl, uint32_t *level_of_gate, uint32_t *tweak_of_gate, uint32_t *row_of_gate,

@@ -138,6 +138,9 @@ struct Plan {
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
                Plan *out);
 
+// plaintext walk of the flattened unit program (host-side self-check, see plan.cpp)
+int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits);
+
 }  // namespace gc
 
 struct gc_plan {

@@ -67,6 +67,7 @@ def lib():
         "gc_plan_create": (vp, [vp, u32, u32, u32, u32, ip]),
         "gc_plan_free": (None, [vp]),
         "gc_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
+        "gc_plan_simulate": (i32, [vp, vp, vp]),
         "gc_plan_describe": (i32, [vp, vp, vp, vp, vp]),
         "gc_device_count": (i32, []),
         "gc_ctx_create": (vp, [i32, ip]),
@@ -192,6 +193,14 @@ class Plan:
         self.slot_of_gate = np.zeros(n, np.uint32)
         _check(L.gc_plan_describe(self.h, _p(self.level_of_gate), _p(self.tweak_of_gate), _p(self.row_of_gate),
                                   _p(self.slot_of_gate)), "gc_plan_describe")
+
+    def simulate(self, in_bits):
+        """plaintext walk of the flattened unit program (gc_plan_simulate): output bits"""
+        b = np.ascontiguousarray(in_bits, dtype=np.uint8)
+        assert len(b) == self.info.ninputs
+        out = np.zeros(max(self.info.noutputs, 1), np.uint8)
+        _check(lib().gc_plan_simulate(self.h, _p(b) if len(b) else None, _p(out)), "gc_plan_simulate")
+        return out[: self.info.noutputs]
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

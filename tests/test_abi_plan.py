@@ -111,3 +111,52 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(engine.EngineError) as e:
         engine.Context(0)
     assert e.value.code == engine.GC_E_HIP
+
+
+def _fuzz_circuit(rng, ninputs, ngates, p_xor, reuse):
+    import numpy as np
+    from mpc_amd.circuit import AND, GATE, INV, OR, XNOR, XOR, Circuit
+    gates = np.zeros(ngates, GATE)
+    nw = ninputs
+    live = list(range(ninputs))
+    for i in range(ngates):
+        a = live[int(rng.integers(max(0, len(live) - 12), len(live)))] if rng.random() < 0.7 else live[int(rng.integers(0, len(live)))]
+        b = live[int(rng.integers(0, len(live)))]
+        if rng.random() < p_xor:
+            op = XOR if rng.random() < 0.8 else XNOR
+            if rng.random() < 0.03:
+                b = a
+        else:
+            op = [AND, OR, INV][int(rng.integers(0, 3))]
+        if nw > ninputs and rng.random() < reuse:
+            out = int(rng.integers(ninputs, nw))
+        else:
+            out = nw
+            nw += 1
+            live.append(out)
+        gates[i] = (a, 0 if op == INV else b, out, op, 0)
+    nout = min(int(rng.integers(1, 12)), nw)
+    return Circuit(nw, [ninputs // 2, ninputs - ninputs // 2], [nout], gates)
+
+
+def test_flat_schedule_simulates_to_plaintext(aes_circ, sha_circ, add64_circ):
+    """gc_plan_simulate walks the flattened unit program (slots, parts, stores) on plaintext bits with the kernels'
+    read-before-write semantics: must equal plain evaluation — checks the planner (hash-phase order, XOR flattening,
+    LDS slot recycling, lane-split items) without a GPU."""
+    import numpy as np
+    from mpc_amd.circuit import and_chain, comparator64, synthetic_levelised
+    rng = np.random.default_rng(77)
+    circs = [aes_circ, sha_circ, add64_circ, comparator64(), and_chain(50),
+             synthetic_levelised(6, 300, 0.3, seed=3, ninputs=64, or_frac=0.1, inv_frac=0.1, xnor_frac=0.1),
+             synthetic_levelised(40, 20, 0.05, seed=4, ninputs=40, xnor_frac=0.3),   # long XOR lists, extra XOR rounds
+             synthetic_levelised(3, 2000, 0.0, seed=5, ninputs=128)]                  # no table-producing gate at all
+    for k in range(40):
+        circs.append(_fuzz_circuit(rng, int(rng.integers(2, 40)), int(rng.integers(1, 500)),
+                                   float(rng.choice([0.0, 0.5, 0.8, 0.95, 1.0])), float(rng.choice([0.0, 0.05, 0.2]))))
+    for c in circs:
+        pl = engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs)
+        assert pl.info.n_flat_slots != 0xffffffff
+        for _ in range(3):
+            b = rng.integers(0, 2, c.num_inputs).astype(np.uint8)
+            want = c.compute_bits(b)[c.NumWires - c.num_outputs:]
+            assert (pl.simulate(b) == want).all(), repr(c)
