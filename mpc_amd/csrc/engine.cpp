@@ -382,7 +382,13 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
     }
 }
 
-static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
+// does this batch run the flattened fused kernels?
+static bool uses_flat(const gc_batch *b) {
+    return b->schedule == 1 && b->g.lds_wires && !b->store_all && !b->single_phase &&
+           !b->circ->plan.p.fl_units.empty();
+}
+
+static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd = nullptr) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
     // fused, LDS-resident wires, flattened XOR (the production path).  The level-walking kernel below keeps
@@ -405,6 +411,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T) {
         f.te0 = b->circ->ctx->d_te0;
         f.rounds = b->rounds;
         f.prof = b->d_prof;
+        f.rnd = rnd;
         GC_HIP(launch_fused_flat(eval, f, b->g, s));
         b->last_launches = f.nunits ? 1 : 0;
         b->have_all_wires = false;
@@ -496,10 +503,12 @@ int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *
     int rc = set_key(b, key, keylen);
     if (rc != GC_OK) return rc;
     const Plan &p = b->circ->plan.p;
-    launch_init_garble((const uint4 *)d_rnd, p.info.ninputs, b->d_W, b->d_R, b->g, ctx->stream);
-    // the events bracket the gate kernels only (the label-initialisation kernel above is a few microseconds)
+    // the flattened fused kernel draws R and the input labels itself; the other schedules get them from a small
+    // initialisation kernel (outside the timed bracket)
+    const bool fused_init = uses_flat(b);
+    if (!fused_init) launch_init_garble((const uint4 *)d_rnd, p.info.ninputs, b->d_W, b->d_R, b->g, ctx->stream);
     if (!ctx->capturing) GC_HIP(hipEventRecord(b->ev0, ctx->stream));
-    rc = run_levels(b, false, b->d_T);
+    rc = run_levels(b, false, b->d_T, fused_init ? (const uint4 *)d_rnd : nullptr);
     if (rc != GC_OK) return rc;
     if (!ctx->capturing) GC_HIP(hipEventRecord(b->ev1, ctx->stream));
     b->timed = !ctx->capturing;

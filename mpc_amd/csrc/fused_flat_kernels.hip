@@ -74,6 +74,9 @@ struct FlArgs {
     const uint32_t *rk;
     const uint32_t *te0;
     uint64_t *prof;
+    const uint4 *rnd;  // garbler only: the caller's random stream (nullptr: R / input labels are already in place)
+    uint4 *Rout;       // garbler only: R of every instance, for the later passes of the pipeline
+    uint32_t batch;
 };
 
 // Unit header i.  Loaded with VECTOR loads on purpose (vz is a zero the compiler cannot see through): scalar loads
@@ -214,13 +217,34 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     uint32_t rkr[4 * (NR + 1)];                                                                              \
     load_round_keys<NR>(rkr, a.rk);                                                                          \
     uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
-    if (threadIdx.x < TI) {                                                                                  \
-        if (LOAD_R) rl[threadIdx.x] = a.R[(size_t)blockIdx.x * TI + threadIdx.x];                            \
-        wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                                     \
-    }                                                                                                        \
-    for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                    \
-        const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                                   \
-        if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                          \
+    if (threadIdx.x < TI) wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                   \
+    if (LOAD_R && a.rnd) {                                                                                   \
+        /* garbler: draw R and the input zero-labels of the tile straight from the caller's random stream   */ \
+        /* ([instance][1 + ninputs] big-endian labels; garble.go:253-258, 271-278) - no separate init kernel */ \
+        for (uint32_t i = threadIdx.x; i < ((a.ninputs + 1) << ti_log2); i += TF) {                          \
+            const uint32_t j = i >> ti_log2, inst = i & tim, gi = blockIdx.x * TI + inst;                    \
+            uint4 v = make_uint4(0, 0, 0, 0);                                                                \
+            if (gi < a.batch) {                                                                              \
+                const uint4 raw = a.rnd[(size_t)gi * (a.ninputs + 1) + j];                                   \
+                v = make_uint4(__builtin_bswap32(raw.y), __builtin_bswap32(raw.x), __builtin_bswap32(raw.w), \
+                               __builtin_bswap32(raw.z));                                                    \
+            }                                                                                                \
+            if (j == 0) {                                                                                    \
+                v.y |= 0x80000000u; /* R.SetS(true) */                                                       \
+                rl[inst] = v;                                                                                \
+                a.Rout[(size_t)blockIdx.x * TI + inst] = v;                                                  \
+            } else {                                                                                         \
+                const uint32_t ls = a.in_lds[j - 1];                                                         \
+                Wt[((j - 1) << ti_log2) + inst] = v;                                                         \
+                if (ls != 0xffffu) wl[(ls << ti_log2) + inst] = v;                                           \
+            }                                                                                                \
+        }                                                                                                    \
+    } else {                                                                                                 \
+        if (LOAD_R && threadIdx.x < TI) rl[threadIdx.x] = a.R[(size_t)blockIdx.x * TI + threadIdx.x];        \
+        for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                \
+            const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                               \
+            if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                      \
+        }                                                                                                    \
     }                                                                                                        \
     uint32_t vz;                                                                                             \
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
@@ -434,6 +458,9 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     a.rk = f.rk;
     a.te0 = f.te0;
     a.prof = f.prof;
+    a.rnd = eval ? nullptr : f.rnd;
+    a.Rout = const_cast<uint4 *>(f.R);
+    a.batch = g.batch;
     if (a.nunits == 0) return hipSuccess;
     const size_t lds = fused_flat_bytes(f.nls, g.ti_log2, f.ustride);
 #define GC_M3(KERN, NR) \
