@@ -412,6 +412,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
         f.rounds = b->rounds;
         f.prof = b->d_prof;
         f.rnd = rnd;
+        f.has_or = p.info.n_or != 0;
         GC_HIP(launch_fused_flat(eval, f, b->g, s));
         b->last_launches = f.nunits ? 1 : 0;
         b->have_all_wires = false;

@@ -114,18 +114,18 @@ __device__ __forceinline__ FUnit uniform_unit(const FUnit &v) {
 struct HP {
     uint32_t kind, g, inst, q;
 };
-template <int LQA, int LQO, int LQI>
+template <int LQA, int LQO, int LQI, bool HAS_OR = true>
 __device__ __forceinline__ HP hpos(uint32_t t, const FUnit &c, uint32_t ti_log2, uint32_t tim) {
     HP p{0, 0, 0, 0};
     const uint32_t e_and = (c.n_and << ti_log2) << LQA;
-    const uint32_t e_or = e_and + ((c.n_or << ti_log2) << LQO);
+    const uint32_t e_or = HAS_OR ? e_and + ((c.n_or << ti_log2) << LQO) : e_and;
     const uint32_t e_all = e_or + ((c.n_inv << ti_log2) << LQI);
     if (t < e_and) {
         p.kind = 1;
         p.g = t >> (ti_log2 + LQA);
         p.inst = (t >> LQA) & tim;
         p.q = t & ((1u << LQA) - 1);
-    } else if (t < e_or) {
+    } else if (HAS_OR && t < e_or) {
         const uint32_t u = t - e_and;
         p.kind = 2;
         p.g = c.n_and + (u >> (ti_log2 + LQO));
@@ -258,7 +258,8 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
 
 }  // namespace
 
-template <int NR, bool PROF>
+// HAS_OR = false: the circuit has no OR gate (the common case): the OR paths and their selects are compiled out
+template <int NR, bool PROF, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     GC_FL_PROLOGUE(true)
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         if (nh) {
             const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
-            const HP hp = hpos<2, 2, 1>(t0 + threadIdx.x, u, ti_log2, tim);
+            const HP hp = hpos<2, 2, 1, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
             const uint4 dv = buf[hp.g];
             const FDesc d{dv.x, dv.y, dv.z, dv.w};
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             const uint4 va = wl[((d.lin & 0xffffu) << ti_log2) + inst];
             uint4 base;
             uint32_t k[4];
-            if (hp.kind == 2) {  // OR: e[2u+v] = enc(a_u, b_v, 0, id)  (garble.go:74-83, 421-424)
+            if (HAS_OR && hp.kind == 2) {  // OR: e[2u+v] = enc(a_u, b_v, 0, id)  (garble.go:74-83, 421-424)
                 const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
                 const uint4 x = lxor(va, land(R, (q & 2) ? ~0u : 0u));
                 const uint4 y = lxor(vb, land(R, (q & 1) ? ~0u : 0u));
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 out_label = lxor(v, dpp128<DPP_XOR2>(v));
                 if (q == 0) row[0] = tab;
                 else if (q == 2) row[TI] = tab;
-            } else if (hp.kind == 3) {  // garble.go:446-474
+            } else if (!HAS_OR || hp.kind == 3) {  // garble.go:446-474
                 const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));       // E0 ^ E1
                 out_label = lbit_s(base) ? lxor(p, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
                 if (q == 0) row[0] = lxor(p, R);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     GC_FPROF_EPILOGUE()
 }
 
-template <int NR, bool PROF>
+template <int NR, bool PROF, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     GC_FL_PROLOGUE(false)
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         if (nh) {
             const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
         for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
-            const HP hp = hpos<1, 0, 0>(t0 + threadIdx.x, u, ti_log2, tim);
+            const HP hp = hpos<1, 0, 0, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
             const uint4 dv = buf[hp.g];
             const FDesc d{dv.x, dv.y, dv.z, dv.w};
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
                 if (q) x = wl[((d.lin >> 16) << ti_log2) + inst];
                 tab = row[q ? TI : 0];  // issued before the hash: arrives while the AES runs
                 make_k_half(x, d.tweak + q, k);
-            } else if (hp.kind == 3) {
+            } else if (!HAS_OR || hp.kind == 3) {
                 tab = row[0];
                 make_k_half(va, d.tweak, k);
             } else {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
                 else v = lxor(h, land(tab, smask(x)));              // WG = H(a) ^ (sa ? TG : 0)
                 out_label = lxor(v, dpp128<DPP_XOR1>(v));
                 writer = q == 0;
-            } else if (hp.kind == 3) {  // eval.go:96-109
+            } else if (!HAS_OR || hp.kind == 3) {  // eval.go:96-109
                 out_label = lxor(h, land(tab, smask(x)));
             } else {  // eval.go:80-94 (tab is zero for index 0)
                 out_label = lxor(h, tab);
@@ -463,8 +464,10 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     a.batch = g.batch;
     if (a.nunits == 0) return hipSuccess;
     const size_t lds = fused_flat_bytes(f.nls, g.ti_log2, f.ustride);
-#define GC_M3(KERN, NR) \
-    (f.prof ? launch_fl(KERN<NR, true>, a, g.ntiles, lds, s) : launch_fl(KERN<NR, false>, a, g.ntiles, lds, s))
+#define GC_M3(KERN, NR)                                                                      \
+    (f.prof ? launch_fl(KERN<NR, true, true>, a, g.ntiles, lds, s)                           \
+            : f.has_or ? launch_fl(KERN<NR, false, true>, a, g.ntiles, lds, s)              \
+                       : launch_fl(KERN<NR, false, false>, a, g.ntiles, lds, s))
 #define GC_M2(KERN) (f.rounds == 10 ? GC_M3(KERN, 10) : f.rounds == 12 ? GC_M3(KERN, 12) : GC_M3(KERN, 14))
     return eval ? GC_M2(k_eval_flat) : GC_M2(k_garble_flat);
 #undef GC_M2

@@ -113,6 +113,7 @@ struct FusedFlatArgs {
     int rounds;
     uint64_t *prof;  // optional [ntiles][16] cycle breakdown (debug), nullptr in production
     const uint4 *rnd;  // garble: draw R and the input labels from this stream inside the kernel (no init launch)
+    bool has_or;       // the circuit has OR gates (selects the kernel build with the OR paths)
 };
 size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride);
 hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &a, const BatchGeom &g, hipStream_t s);
