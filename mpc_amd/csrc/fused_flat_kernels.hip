@@ -265,9 +265,6 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
-        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
         if (nh) {
@@ -338,6 +335,13 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         }
         }
         GC_FPROF(1)
+        // Prefetch of the next unit's image and of the header after it, issued AFTER the hash part: vector-memory
+        // waits are in order, and the hash part's own waits (the evaluator's table rows; register re-use hazards the
+        // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
+        // during the barrier and the XOR part.
+        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
@@ -358,9 +362,6 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
-        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);  // lands during this unit
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
         if (nh) {
@@ -413,6 +414,13 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         }
         }
         GC_FPROF(1)
+        // Prefetch of the next unit's image and of the header after it, issued AFTER the hash part: vector-memory
+        // waits are in order, and the hash part's own waits (the evaluator's table rows; register re-use hazards the
+        // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
+        // during the barrier and the XOR part.
+        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
