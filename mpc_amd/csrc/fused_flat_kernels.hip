@@ -181,7 +181,11 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     const uint32_t nitems = u.nout << ti_log2;
     for (uint32_t t = threadIdx.x; t < nitems; t += TF) {
         const uint32_t o = t >> ti_log2, inst = t & tim;
-        const uint2 d0 = outs[3 * o], d1 = outs[3 * o + 1], d2 = outs[3 * o + 2];
+        const uint2 d0 = outs[3 * o], d2 = outs[3 * o + 2];
+        uint2 d1 = outs[3 * o + 1];
+        // keep the read of the second half of the item with the other two (one LDS round trip for the whole item);
+        // the compiler would otherwise sink it into the n > 4 branch: a third dependent round trip for long lists
+        asm volatile("" : "+v"(d1.x), "+v"(d1.y));
         const uint32_t flags = d2.x >> 16, n = d2.y & 0xffffu;
         const uint4 v0 = wl[((d0.x & 0xffffu) << ti_log2) + inst], v1 = wl[((d0.x >> 16) << ti_log2) + inst];
         const uint4 v2 = wl[((d0.y & 0xffffu) << ti_log2) + inst], v3 = wl[((d0.y >> 16) << ti_log2) + inst];
