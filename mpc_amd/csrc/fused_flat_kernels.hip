@@ -117,6 +117,18 @@ struct HP {
 template <int LQA, int LQO, int LQI, bool HAS_OR = true>
 __device__ __forceinline__ HP hpos(uint32_t t, const FUnit &c, uint32_t ti_log2, uint32_t tim) {
     HP p{0, 0, 0, 0};
+    if constexpr (!HAS_OR) {  // AND lanes, then INV lanes: branch-free (selects instead of exec-mask regions)
+        const uint32_t e_and = (c.n_and << ti_log2) << LQA;
+        const uint32_t e_all = e_and + ((c.n_inv << ti_log2) << LQI);
+        const bool is_and = t < e_and;
+        const uint32_t u = is_and ? t : t - e_and;
+        const uint32_t lq = is_and ? (uint32_t)LQA : (uint32_t)LQI;
+        p.kind = is_and ? 1u : t < e_all ? 3u : 0u;
+        p.g = (u >> (ti_log2 + lq)) + (is_and ? 0u : c.n_and);
+        p.inst = (u >> lq) & tim;
+        p.q = u & ((1u << lq) - 1);
+        return p;
+    }
     const uint32_t e_and = (c.n_and << ti_log2) << LQA;
     const uint32_t e_or = HAS_OR ? e_and + ((c.n_or << ti_log2) << LQO) : e_and;
     const uint32_t e_all = e_or + ((c.n_inv << ti_log2) << LQI);
