@@ -265,7 +265,9 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     uint32_t vz;                                                                                             \
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
     FUnit u = uniform_unit(load_unit(a.units, 0, a.nunits, vz));                                             \
-    FUnit un = uniform_unit(load_unit(a.units, 1, a.nunits, vz)); /* headers run two units ahead */          \
+    /* the next header stays in VGPRs (the kernels are short of SGPRs: 60 hold the AES-256 round keys) and is  */ \
+    /* only made wave-uniform when it becomes the current one; headers run two units ahead                   */ \
+    FUnit un = load_unit(a.units, 1, a.nunits, vz);                                                          \
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
     __syncthreads();                                                                                         \
     const uint32_t lo = te_lane_off();                                                                       \
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
-        u = un;
-        un = uniform_unit(unn_v);
+        u = uniform_unit(un);
+        un = unn_v;
     }
     GC_FPROF_EPILOGUE()
 }
@@ -445,8 +447,8 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
-        u = un;
-        un = uniform_unit(unn_v);
+        u = uniform_unit(un);
+        un = unn_v;
     }
     GC_FPROF_EPILOGUE()
 }
