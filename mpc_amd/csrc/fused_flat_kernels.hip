@@ -41,6 +41,16 @@ __device__ __forceinline__ uint4 dpp128(uint4 v) {
     return make_uint4(dpp32<CTRL>(v.x), dpp32<CTRL>(v.y), dpp32<CTRL>(v.z), dpp32<CTRL>(v.w));
 }
 
+// m ? a : b and h ^ (w & m) per bit: one v_bitop3_b32 each
+__device__ __forceinline__ uint4 bsel4(uint32_t m, uint4 a, uint4 b) {
+    return make_uint4(__builtin_amdgcn_bitop3_b32(m, a.x, b.x, 0xCA), __builtin_amdgcn_bitop3_b32(m, a.y, b.y, 0xCA),
+                      __builtin_amdgcn_bitop3_b32(m, a.z, b.z, 0xCA), __builtin_amdgcn_bitop3_b32(m, a.w, b.w, 0xCA));
+}
+__device__ __forceinline__ uint4 xand4(uint4 h, uint4 w, uint32_t m) {
+    return make_uint4(__builtin_amdgcn_bitop3_b32(h.x, w.x, m, 0x78), __builtin_amdgcn_bitop3_b32(h.y, w.y, m, 0x78),
+                      __builtin_amdgcn_bitop3_b32(h.z, w.z, m, 0x78), __builtin_amdgcn_bitop3_b32(h.w, w.w, m, 0x78));
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr uint32_t kStageOff = kTeDualBytes / 16;
@@ -314,22 +324,19 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             GC_FPROF(7)
             uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
             uint4 out_label;
-            if (hp.kind == 1) {  // garble.go:353-395
+            if (hp.kind == 1) {  // garble.go:353-395; branch-free over the four lanes of the gate (q): bit selects
+                const uint32_t m2 = (q & 2) ? ~0u : 0u;        // lanes 2,3 build TE / WE0, lanes 0,1 TG / WG0
                 const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));  // lanes 0,1: Ha0^Ha1 ; lanes 2,3: Hb0^Hb1
                 const uint4 a0 = dpp128<DPP_BC0>(base);
                 const uint32_t pa = smask(a0);
                 const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
-                uint4 v, tab;
-                if (q & 2) {
-                    tab = lxor(p, a0);                     // TE = Hb0^Hb1^a0
-                    v = lxor(h, land(lxor(tab, a0), pb));  // WE0 = Hb0 ^ (pb ? TE^a0 : 0)
-                } else {
-                    tab = lxor(p, land(R, pb));            // TG = Ha0^Ha1^(pb?R:0)
-                    v = lxor(h, land(tab, pa));            // WG0 = Ha0 ^ (pa ? TG : 0)
-                }
+                const uint32_t mk = m2 ? pb : pa;
+                // tab = p ^ (lanes 2,3: a0 | lanes 0,1: pb ? R : 0)      TE = Hb0^Hb1^a0, TG = Ha0^Ha1^(pb?R:0)
+                const uint4 tab = lxor(p, bsel4(m2, a0, land(R, pb)));
+                // v = h ^ (mk ? (lanes 2,3: TE^a0 = p | lanes 0,1: TG) : 0)   WE0 = Hb0^(pb?TE^a0:0), WG0 = Ha0^(pa?TG:0)
+                const uint4 v = xand4(h, bsel4(m2, p, tab), mk);
                 out_label = lxor(v, dpp128<DPP_XOR2>(v));
-                if (q == 0) row[0] = tab;
-                else if (q == 2) row[TI] = tab;
+                if (!(q & 1)) row[(q & 2) ? TI : 0] = tab;
             } else if (!HAS_OR || hp.kind == 3) {  // garble.go:446-474
                 const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));       // E0 ^ E1
                 out_label = lbit_s(base) ? lxor(p, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
