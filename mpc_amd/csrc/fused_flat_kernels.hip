@@ -398,17 +398,16 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             const FDesc d{dv.x, dv.y, dv.z, dv.w};
             const uint32_t inst = hp.inst, q = hp.q;
             const uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
-            const uint4 va = wl[((d.lin & 0xffffu) << ti_log2) + inst];
+            // AND: lane q hashes operand q (a, b) with tweak + q and needs table row q; INV: operand a, row 0
+            const uint32_t mq = q ? ~0u : 0u;  // q is 0 for INV / OR lanes
+            const uint32_t opslot = (HAS_OR && hp.kind == 2) ? (d.lin & 0xffffu) : q ? (d.lin >> 16) : (d.lin & 0xffffu);
+            const uint4 va = wl[(opslot << ti_log2) + inst];
             uint4 x = va, tab = make_uint4(0, 0, 0, 0);
             uint32_t k[4];
-            if (hp.kind == 1) {
-                if (q) x = wl[((d.lin >> 16) << ti_log2) + inst];
+            if (!HAS_OR || hp.kind != 2) {
                 tab = row[q ? TI : 0];  // issued before the hash: arrives while the AES runs
                 make_k_half(x, d.tweak + q, k);
-            } else if (!HAS_OR || hp.kind == 3) {
-                tab = row[0];
-                make_k_half(va, d.tweak, k);
-            } else {
+            } else {  // OR (eval.go:80-94): both operands, row index - 1 (index 0 has no row)
                 const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
                 const uint32_t index = (lbit_s(va) ? 2u : 0u) | (lbit_s(vb) ? 1u : 0u);
                 if (index > 0) tab = row[(size_t)(index - 1) << ti_log2];
@@ -421,9 +420,8 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             bool writer = true;
             if (hp.kind == 1) {  // eval.go:53-78
                 const uint4 av = dpp128<DPP_PAIR0>(x);
-                uint4 v;
-                if (q) v = lxor(h, land(lxor(tab, av), smask(x)));  // WE = H(b) ^ (sb ? TE^a : 0)
-                else v = lxor(h, land(tab, smask(x)));              // WG = H(a) ^ (sa ? TG : 0)
+                // lane 0: WG = H(a) ^ (sa ? TG : 0); lane 1: WE = H(b) ^ (sb ? TE^a : 0)
+                const uint4 v = xand4(h, xand4(tab, av, mq), smask(x));
                 out_label = lxor(v, dpp128<DPP_XOR1>(v));
                 writer = q == 0;
             } else if (!HAS_OR || hp.kind == 3) {  // eval.go:96-109
