@@ -304,7 +304,9 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             const FDesc d{dv.x, dv.y, dv.z, dv.w};
             const uint32_t inst = hp.inst, q = hp.q;
             const uint4 R = rl[inst];
-            const uint4 va = wl[((d.lin & 0xffffu) << ti_log2) + inst];
+            // AND q=0..3 hash a0,a1,b0,b1 (lanes 2,3 read operand b and use tweak + 1); INV q=0,1 hash a0,a1
+            const bool second = (hp.kind == 1) && (q & 2);
+            const uint4 va = wl[((second ? (d.lin >> 16) : (d.lin & 0xffffu)) << ti_log2) + inst];
             uint4 base;
             uint32_t k[4];
             if (HAS_OR && hp.kind == 2) {  // OR: e[2u+v] = enc(a_u, b_v, 0, id)  (garble.go:74-83, 421-424)
@@ -313,9 +315,8 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 y = lxor(vb, land(R, (q & 1) ? ~0u : 0u));
                 base = make_uint4(x.y, y.y, 0, 0);
                 make_k(x, y, d.tweak, k);
-            } else {  // AND q=0..3 -> a0,a1,b0,b1 ; INV q=0,1 -> a0,a1 ; K = 2x ^ tweak
-                const bool second = (hp.kind == 1) && (q & 2);
-                base = second ? wl[((d.lin >> 16) << ti_log2) + inst] : va;
+            } else {  // K = 2x ^ tweak, x = the operand's zero label (q even) or one label (q odd)
+                base = va;
                 const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
                 make_k_half(x, d.tweak + (second ? 1u : 0u), k);
             }
