@@ -497,7 +497,8 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     if (a.nunits == 0) return hipSuccess;
     const size_t lds = fused_flat_bytes(f.nls, g.ti_log2, f.ustride);
 #define GC_M3(KERN, NR)                                                                      \
-    (f.prof ? launch_fl(KERN<NR, true, true>, a, g.ntiles, lds, s)                           \
+    (f.prof ? (f.has_or ? launch_fl(KERN<NR, true, true>, a, g.ntiles, lds, s)               \
+                        : launch_fl(KERN<NR, true, false>, a, g.ntiles, lds, s))             \
             : f.has_or ? launch_fl(KERN<NR, false, true>, a, g.ntiles, lds, s)              \
                        : launch_fl(KERN<NR, false, false>, a, g.ntiles, lds, s))
 #define GC_M2(KERN) (f.rounds == 10 ? GC_M3(KERN, 10) : f.rounds == 12 ? GC_M3(KERN, 12) : GC_M3(KERN, 14))
