@@ -175,8 +175,16 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
         up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
         up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
-        up((void **)&c->d_fl_prog, p.fl_prog.data(), p.fl_prog.size() * sizeof(uint32_t));
-        up((void **)&c->d_fl_units, p.fl_units.data(), p.fl_units.size() * sizeof(FUnit));
+        {
+            // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
+            // stage buffer of zero padding behind the real data
+            std::vector<uint32_t> prog(p.fl_prog);
+            prog.resize(prog.size() + 4 * 1024, 0);
+            std::vector<FUnit> units(p.fl_units);
+            units.resize(units.size() + 2, FUnit{});
+            up((void **)&c->d_fl_prog, prog.data(), prog.size() * sizeof(uint32_t));
+            up((void **)&c->d_fl_units, units.data(), units.size() * sizeof(FUnit));
+        }
         up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
         up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
         up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));

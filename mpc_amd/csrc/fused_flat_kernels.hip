@@ -93,15 +93,16 @@ struct FlArgs {
 // share the lgkm counter with LDS and return out of order, so with a header in flight the first LDS read of the
 // next unit would have to wait for it (s_waitcnt lgkmcnt(0)); vector loads are tracked by vmcnt and cost nothing
 // until their values are used one unit later.
-__device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t n, uint32_t vz) {
-    FUnit u{};
-    if (i < n) {
-        const uint4 *p = (const uint4 *)(units + i) + vz;
-        const uint4 a = p[0], b = p[1], c = p[2];
-        u.off16 = a.x, u.n16 = a.y, u.n_and = a.z, u.n_or = a.w;
-        u.n_inv = b.x, u.nout = b.y, u.outs_off16 = b.z, u.xparts = b.w;
-        u.hfirst = c.x, u.ofirst = c.y;
-    }
+// The unit array ends with two all-zero records and the program with one stage buffer of padding (engine.cpp), so
+// headers and images two units past the end can be fetched without bounds checks (they describe empty units).
+__device__ __forceinline__ FUnit load_unit(const FUnit *units, uint32_t i, uint32_t vz) {
+    FUnit u;
+    const uint4 *p = (const uint4 *)(units + i) + vz;
+    const uint4 a = p[0], b = p[1], c = p[2];
+    u.off16 = a.x, u.n16 = a.y, u.n_and = a.z, u.n_or = a.w;
+    u.n_inv = b.x, u.nout = b.y, u.outs_off16 = b.z, u.xparts = b.w;
+    u.hfirst = c.x, u.ofirst = c.y;
+    u.pad_[0] = u.pad_[1] = 0;
     return u;
 }
 // wave-uniform copy in SGPRs (readfirstlane) of a header whose loads have landed
@@ -274,10 +275,10 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     }                                                                                                        \
     uint32_t vz;                                                                                             \
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
-    FUnit u = uniform_unit(load_unit(a.units, 0, a.nunits, vz));                                             \
+    FUnit u = uniform_unit(load_unit(a.units, 0, vz));                                             \
     /* the next header stays in VGPRs (the kernels are short of SGPRs: 60 hold the AES-256 round keys) and is  */ \
     /* only made wave-uniform when it becomes the current one; headers run two units ahead                   */ \
-    FUnit un = load_unit(a.units, 1, a.nunits, vz);                                                          \
+    FUnit un = load_unit(a.units, 1, vz);                                                          \
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
     __syncthreads();                                                                                         \
     const uint32_t lo = te_lane_off();                                                                       \
@@ -365,9 +366,8 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         // waits are in order, and the hash part's own waits (the evaluator's table rows; register re-use hazards the
         // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
         // during the barrier and the XOR part.
-        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
+        const FUnit unn_v = load_unit(a.units, ui + 2, vz);
+        const uint4 pre = a.prog[un.off16 + threadIdx.x];  // past the image's end: the next image or padding
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
@@ -442,9 +442,8 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         // waits are in order, and the hash part's own waits (the evaluator's table rows; register re-use hazards the
         // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
         // during the barrier and the XOR part.
-        const FUnit unn_v = load_unit(a.units, ui + 2, a.nunits, vz);
-        uint4 pre = make_uint4(0, 0, 0, 0);
-        if (threadIdx.x < un.n16) pre = a.prog[un.off16 + threadIdx.x];
+        const FUnit unn_v = load_unit(a.units, ui + 2, vz);
+        const uint4 pre = a.prog[un.off16 + threadIdx.x];  // past the image's end: the next image or padding
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
