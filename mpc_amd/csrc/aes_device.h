@@ -261,6 +261,18 @@ __device__ __forceinline__ void load_round_keys(uint32_t (&rk)[4 * (NR + 1)], co
     for (int i = 0; i < 4 * (NR + 1); i++) rk[i] = __builtin_amdgcn_readfirstlane(g_rk[i]);
 }
 
+// As above, but only the first NS words go to SGPRs; the rest is fetched with vector loads (vz: a zero in a VGPR that
+// the compiler cannot see through) and therefore lives in VGPRs.  The flat kernels have VGPRs to spare and are short
+// of SGPRs: with all 60 AES-256 key words in SGPRs 25-40 other scalars spill, and every reload is a v_readlane — a
+// VALU slot in kernels that are VALU-issue bound.
+template <int NR, int NS>
+__device__ __forceinline__ void load_round_keys_split(uint32_t (&rk)[4 * (NR + 1)], const uint32_t *__restrict__ g_rk,
+                                                      uint32_t vz) {
+#pragma unroll
+    for (int i = 0; i < 4 * (NR + 1); i++)
+        rk[i] = i < NS ? (uint32_t)__builtin_amdgcn_readfirstlane(g_rk[i]) : g_rk[i + vz];
+}
+
 // N hashes pi(K) ^ K in lock-step (N independent AES chains per lane hide the LDS latency)
 template <int NR, int N>
 __device__ __forceinline__ void hash_dual_n(const uint32_t (&k)[N][4], uint4 (&out)[N],

@@ -242,7 +242,9 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     uint4 *wl = rl + TI;                                                                                     \
     load_te_dual(te, a.te0);                                                                                 \
     uint32_t rkr[4 * (NR + 1)];                                                                              \
-    load_round_keys<NR>(rkr, a.rk);                                                                          \
+    uint32_t vz;                                                                                             \
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
+    load_round_keys_split<NR, (4 * (NR + 1) > 32 ? 4 * (NR + 1) - 32 : 4 * (NR + 1))>(rkr, a.rk, vz);        \
     uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
     if (threadIdx.x < TI) wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                   \
     if (LOAD_R && a.rnd) {                                                                                   \
@@ -273,8 +275,6 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
             if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                      \
         }                                                                                                    \
     }                                                                                                        \
-    uint32_t vz;                                                                                             \
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
     FUnit u = uniform_unit(load_unit(a.units, 0, vz));                                             \
     /* the next header stays in VGPRs (the kernels are short of SGPRs: 60 hold the AES-256 round keys) and is  */ \
     /* only made wave-uniform when it becomes the current one; headers run two units ahead                   */ \
