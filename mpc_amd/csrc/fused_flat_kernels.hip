@@ -325,7 +325,15 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             const uint4 h = hash_dual<NR>(k, rkr, te, lo);
             GC_FPROF(7)
             uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
-            uint4 out_label;
+            // the zero label of the output wire goes out from lane 0 of the gate (called inside every branch: merging
+            // the branches' results first costs a register copy per word)
+            auto put = [&](const uint4 &out_label) {
+                if (q == 0) {
+                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                    if (d.lout & kFStoreGlobal)
+                        Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+                }
+            };
             if (hp.kind == 1) {  // garble.go:353-395; branch-free over the four lanes of the gate (q): bit selects
                 const uint32_t m2 = (q & 2) ? ~0u : 0u;        // lanes 2,3 build TE / WE0, lanes 0,1 TG / WG0
                 const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));  // lanes 0,1: Ha0^Ha1 ; lanes 2,3: Hb0^Hb1
@@ -337,12 +345,12 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 tab = lxor(p, bsel4(m2, a0, land(R, pb)));
                 // v = h ^ (mk ? (lanes 2,3: TE^a0 = p | lanes 0,1: TG) : 0)   WE0 = Hb0^(pb?TE^a0:0), WG0 = Ha0^(pa?TG:0)
                 const uint4 v = xand4(h, bsel4(m2, p, tab), mk);
-                out_label = lxor(v, dpp128<DPP_XOR2>(v));
                 if (!(q & 1)) row[(q & 2) ? TI : 0] = tab;
+                put(lxor(v, dpp128<DPP_XOR2>(v)));
             } else if (!HAS_OR || hp.kind == 3) {  // garble.go:446-474
                 const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));       // E0 ^ E1
-                out_label = lbit_s(base) ? lxor(p, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
                 if (q == 0) row[0] = lxor(p, R);
+                put(lxor(h, sel4(lbit_s(base), p, R)));  // S(a0) ? E1 = E0 ^ (E0^E1) : E0 ^ R
             } else {  // OR: garble.go:412-444
                 const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
                 const uint32_t l0 = 2 * pa + pb;
@@ -351,13 +359,8 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 t0v = dpp128<DPP_BC0>(tk);
                 const uint32_t m0 = l0 == 0 ? ~0u : 0u;
                 const uint4 c0 = lxor(t0v, land(R, ~m0)), c1 = lxor(t0v, land(R, m0));
-                out_label = c0;
                 if (q != 0) row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
-            }
-            if (q == 0) {
-                wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
-                if (d.lout & kFStoreGlobal)
-                    Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+                put(c0);
             }
         }
         }
@@ -417,23 +420,22 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
             const uint4 h = hash_dual<NR>(k, rkr, te, lo);
             GC_FPROF(7)
-            uint4 out_label;
-            bool writer = true;
+            auto put = [&](const uint4 &out_label) {  // inside every branch: no result merge, no register copies
+                if (q == 0) {
+                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                    if (d.lout & kFStoreGlobal)
+                        Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+                }
+            };
             if (hp.kind == 1) {  // eval.go:53-78
                 const uint4 av = dpp128<DPP_PAIR0>(x);
                 // lane 0: WG = H(a) ^ (sa ? TG : 0); lane 1: WE = H(b) ^ (sb ? TE^a : 0)
                 const uint4 v = xand4(h, xand4(tab, av, mq), smask(x));
-                out_label = lxor(v, dpp128<DPP_XOR1>(v));
-                writer = q == 0;
+                put(lxor(v, dpp128<DPP_XOR1>(v)));
             } else if (!HAS_OR || hp.kind == 3) {  // eval.go:96-109
-                out_label = lxor(h, land(tab, smask(x)));
+                put(xand4(h, tab, smask(x)));
             } else {  // eval.go:80-94 (tab is zero for index 0)
-                out_label = lxor(h, tab);
-            }
-            if (writer) {
-                wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
-                if (d.lout & kFStoreGlobal)
-                    Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
+                put(lxor(h, tab));
             }
         }
         }
