@@ -251,9 +251,17 @@ static void free_buffers(gc_batch *b) {
 // (re)allocate the label / table / R arrays for the batch's schedule (= memory layout)
 // live labels the kernel of this batch keeps in LDS: the flattened plan normally, the level-walking plan when
 // every wire has to be materialised (store_all) or schedule 2 was asked for
+// The flattened kernels are the choice unless every wire has to be materialised (store_all), schedule 2 was asked
+// for, or the circuit has no flattened plan.  They address a tile's table rows with 32-bit element offsets:
+// slab_rows * 64 < 2^28 (a circuit with >= 4 Mi table rows does not fit an LDS plan anyway).
+static bool want_flat(const gc_batch *b) {
+    const Plan &p = b->circ->plan.p;
+    return !b->store_all && !b->single_phase && p.n_flat_slots != 0xffffffffu && p.info.slab_rows < (1u << 22);
+}
+
 static BatchGeom geom_for(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    const bool flat = !(b->store_all || b->single_phase);
+    const bool flat = want_flat(b);
     const uint32_t nls = flat ? p.n_flat_slots : p.n_lds_slots;
     // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
     const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
@@ -392,8 +400,7 @@ static void enqueue_levels(gc_batch *b, bool eval, const uint4 *T, hipStream_t s
 
 // does this batch run the flattened fused kernels?
 static bool uses_flat(const gc_batch *b) {
-    return b->schedule == 1 && b->g.lds_wires && !b->store_all && !b->single_phase &&
-           !b->circ->plan.p.fl_units.empty();
+    return b->schedule == 1 && b->g.lds_wires && want_flat(b) && !b->circ->plan.p.fl_units.empty();
 }
 
 static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd = nullptr) {
@@ -401,7 +408,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
     const Plan &p = b->circ->plan.p;
     // fused, LDS-resident wires, flattened XOR (the production path).  The level-walking kernel below keeps
     // every intermediate wire (store_all / Garbled.Wires).
-    if (b->schedule == 1 && b->g.lds_wires && !b->store_all && !b->single_phase) {
+    if (b->schedule == 1 && b->g.lds_wires && want_flat(b)) {
         FusedFlatArgs f{};
         f.prog = b->circ->d_fl_prog;
         f.units = b->circ->d_fl_units;
