@@ -282,6 +282,7 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
     __syncthreads();                                                                                         \
     const uint32_t lo = te_lane_off();                                                                       \
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);                           \
     uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = 0;                                                  \
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         GC_FPROF(0)
         if (nh) {
             const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
-        for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
+        for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<2, 2, 1, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
             const uint4 dv = buf[hp.g];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         GC_FPROF(0)
         if (nh) {
             const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
-        for (uint32_t t0 = 0; t0 < e_all; t0 += TF) {
+        for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<1, 0, 0, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
             const uint4 dv = buf[hp.g];
