@@ -249,8 +249,11 @@ __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint
         for (int k = 0; k < N; k++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                s[k][c] = ((t[k][4 * c] & 0xff000000u) | (t[k][4 * c + 1] & 0x00ff0000u) | (t[k][4 * c + 2] & 0x0000ff00u) |
-                           (t[k][4 * c + 3] & 0x000000ffu)) ^ rk[4 * NR + c];
+            {  // byte 3 of t0, byte 2 of t1, byte 1 of t2, byte 0 of t3: three bit-selects (v_bitop3 0xCA = m ? a : b)
+                const uint32_t hi = __builtin_amdgcn_bitop3_b32(0xff000000u, t[k][4 * c], t[k][4 * c + 1], 0xCA);
+                const uint32_t lo = __builtin_amdgcn_bitop3_b32(0x0000ff00u, t[k][4 * c + 2], t[k][4 * c + 3], 0xCA);
+                s[k][c] = __builtin_amdgcn_bitop3_b32(0xffff0000u, hi, lo, 0xCA) ^ rk[4 * NR + c];
+            }
     }
 }
 
