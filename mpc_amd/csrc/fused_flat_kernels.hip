@@ -319,7 +319,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 make_k(x, y, d.tweak, k);
             } else {  // K = 2x ^ tweak, x = the operand's zero label (q even) or one label (q odd)
                 base = va;
-                const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
+                const uint4 x = xand4(base, R, (q & 1) ? ~0u : 0u);  // base ^ (q odd ? R : 0): one v_bitop3 per word
                 make_k_half(x, d.tweak + (second ? 1u : 0u), k);
             }
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
