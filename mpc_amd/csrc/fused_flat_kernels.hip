@@ -341,11 +341,12 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 a0 = dpp128<DPP_BC0>(base);
                 const uint32_t pa = smask(a0);
                 const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
-                const uint32_t mk = m2 ? pb : pa;
-                // tab = p ^ (lanes 2,3: a0 | lanes 0,1: pb ? R : 0)      TE = Hb0^Hb1^a0, TG = Ha0^Ha1^(pb?R:0)
-                const uint4 tab = lxor(p, bsel4(m2, a0, land(R, pb)));
-                // v = h ^ (mk ? (lanes 2,3: TE^a0 = p | lanes 0,1: TG) : 0)   WE0 = Hb0^(pb?TE^a0:0), WG0 = Ha0^(pa?TG:0)
-                const uint4 v = xand4(h, bsel4(m2, p, tab), mk);
+                const uint32_t mk = m2 ? pb : pa, rm = pb & ~m2;
+                // w = lanes 0,1: TG = Ha0^Ha1^(pb ? R : 0) | lanes 2,3: Hb0^Hb1 (= TE ^ a0)
+                const uint4 w = xand4(p, R, rm);
+                const uint4 tab = xand4(w, a0, m2);  // lanes 0,1: TG | lanes 2,3: TE = Hb0^Hb1^a0
+                // v = lanes 0,1: WG0 = Ha0 ^ (pa ? TG : 0) | lanes 2,3: WE0 = Hb0 ^ (pb ? TE^a0 : 0)
+                const uint4 v = xand4(h, w, mk);
                 if (!(q & 1)) row[(q & 2) ? TI : 0] = tab;
                 put(lxor(v, dpp128<DPP_XOR2>(v)));
             } else if (!HAS_OR || hp.kind == 3) {  // garble.go:446-474
