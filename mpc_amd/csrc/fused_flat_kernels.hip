@@ -41,6 +41,9 @@ __device__ __forceinline__ uint4 dpp128(uint4 v) {
     return make_uint4(dpp32<CTRL>(v.x), dpp32<CTRL>(v.y), dpp32<CTRL>(v.z), dpp32<CTRL>(v.w));
 }
 
+typedef uint32_t lds_v4 __attribute__((ext_vector_type(4)));
+using lds_v4p = __attribute__((address_space(3))) const lds_v4 *;
+
 // m ? a : b and h ^ (w & m) per bit: one v_bitop3_b32 each
 __device__ __forceinline__ uint4 bsel4(uint32_t m, uint4 a, uint4 b) {
     return make_uint4(__builtin_amdgcn_bitop3_b32(m, a.x, b.x, 0xCA), __builtin_amdgcn_bitop3_b32(m, a.y, b.y, 0xCA),
@@ -210,12 +213,18 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
         // the compiler would otherwise sink it into the n > 4 branch: a third dependent round trip for long lists
         asm volatile("" : "+v"(d1.x), "+v"(d1.y));
         const uint32_t flags = d2.x >> 16, n = d2.y & 0xffffu;
-        const uint4 v0 = wl[((d0.x & 0xffffu) << ti_log2) + inst], v1 = wl[((d0.x >> 16) << ti_log2) + inst];
-        const uint4 v2 = wl[((d0.y & 0xffffu) << ti_log2) + inst], v3 = wl[((d0.y >> 16) << ti_log2) + inst];
+        // byte addressing by hand: label of slot s, instance inst = wl + (s << (ti_log2 + 4)) + 16 inst — one shift of
+        // the extracted half-word and one add per term
+        const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
+        auto lab = [&](uint32_t packed, bool high) {
+            const uint32_t s16 = high ? packed >> 16 : packed & 0xffffu;
+            const lds_v4 v = *(lds_v4p)(uintptr_t)((s16 << sh) + ib);
+            return make_uint4(v.x, v.y, v.z, v.w);
+        };
+        const uint4 v0 = lab(d0.x, false), v1 = lab(d0.x, true), v2 = lab(d0.y, false), v3 = lab(d0.y, true);
         uint4 acc = lxor(lxor(v0, v1), lxor(v2, v3));
         if (n > 4) {  // items are sorted by length: whole waves skip this
-            const uint4 v4 = wl[((d1.x & 0xffffu) << ti_log2) + inst], v5 = wl[((d1.x >> 16) << ti_log2) + inst];
-            const uint4 v6 = wl[((d1.y & 0xffffu) << ti_log2) + inst], v7 = wl[((d1.y >> 16) << ti_log2) + inst];
+            const uint4 v4 = lab(d1.x, false), v5 = lab(d1.x, true), v6 = lab(d1.y, false), v7 = lab(d1.y, true);
             acc = lxor(acc, lxor(lxor(v4, v5), lxor(v6, v7)));
         }
         if (u.xparts > 1) {  // unit-uniform: collect the partial sums of lists that were spread over 2 / 4 lanes
