@@ -262,6 +262,11 @@ void *gc_batch_dev_slab(gc_batch *);
 void *gc_batch_dev_r(gc_batch *);
 /* output-wire labels gathered into a dense device buffer gc_label [noutputs][bstride] */
 int gc_batch_gather_outputs(gc_batch *, void *d_out);
+/* Device-side hand-over of input labels through an OT (garbler.go:102-132): the garbler's {L0, L1} pairs of input
+ * wires [first, first+count) as gc_wire [batch][count] (what COT.Send consumes), and the evaluator's delivered
+ * labels gc_label [batch][count] back into its wire array.  Asynchronous on the ctx stream. */
+int gc_batch_gather_input_wires(gc_batch *garbler, uint32_t first, uint32_t count, void *d_wires_out);
+int gc_batch_set_input_range(gc_batch *evaluator, uint32_t first, uint32_t count, const void *d_labels);
 
 /* Table egress / ingest in the wire format of the 2-party driver, on the device:
  * replaces the per-gate SendUint32(len) + SendLabel loop of circuit.Garbler (circuit/garbler.go:69-82) and the
@@ -353,6 +358,13 @@ int gc_mitccrh_hash(gc_ctx *, const gc_label *seed, uint64_t gid0, gc_label *blk
 int gc_cot_send_pads(gc_ctx *, const gc_label *seed, const gc_label *delta, const gc_label *data,
                      const gc_wire *wires, size_t n, gc_label *out);
 /* Replaces the unpad loop of COT.Receive (cot.go:200-232): result[n] in = IKNP output, out = chosen labels */
+/* device-resident forms (device pointers, asynchronous on the ctx stream): d_data = the sender's IKNP labels
+ * (gc_iknp_send_dev), d_wires = gc_wire [n], d_out = gc_label [2n]; d_flags = u8 [n] choice bits, d_sent = the 2n
+ * labels received, d_result = the receiver's IKNP labels in, the chosen wire labels out */
+int gc_cot_send_pads_dev(gc_ctx *, const gc_label *seed, const gc_label *delta, const void *d_data,
+                         const void *d_wires, size_t n, void *d_out);
+int gc_cot_receive_unpad_dev(gc_ctx *, const gc_label *seed, const void *d_flags, const void *d_sent,
+                             void *d_result, size_t n);
 int gc_cot_receive_unpad(gc_ctx *, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
                          gc_label *result, size_t n);
 

@@ -696,6 +696,34 @@ int gc_batch_gather_outputs(gc_batch *b, void *d_out) {
     return GC_OK;
 }
 
+// garbler: both labels of input wires [first, first + count) of every instance, as gc_wire {L0, L0^R} in a dense
+// device buffer [batch][count] — what the OT sender (COT) consumes
+int gc_batch_gather_input_wires(gc_batch *b, uint32_t first, uint32_t count, void *d_wires_out) {
+    if (!b || (!d_wires_out && count)) return GC_E_ARG;
+    const uint32_t nin = b->circ->plan.p.info.ninputs;
+    if (first > nin || count > nin - first) return GC_E_ARG;
+    if (count == 0) return GC_OK;
+    gc_ctx *ctx = b->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_gather(b->d_W, b->g.lw, 0, nullptr, first, count, b->d_R, 1, (uint4 *)d_wires_out, 2 * (size_t)count,
+                  b->g.batch, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+// evaluator: active labels of input wires [first, first + count) from a dense device buffer gc_label [batch][count]
+int gc_batch_set_input_range(gc_batch *ev, uint32_t first, uint32_t count, const void *d_labels) {
+    if (!ev || (!d_labels && count)) return GC_E_ARG;
+    const uint32_t nin = ev->circ->plan.p.info.ninputs;
+    if (first > nin || count > nin - first) return GC_E_ARG;
+    if (count == 0) return GC_OK;
+    gc_ctx *ctx = ev->circ->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_scatter((const uint4 *)d_labels, count, count, nullptr, first, ev->d_W, ev->g.lw, 0, ev->g.batch, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
 int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
     if (!b) return GC_E_ARG;
     gc_ctx *ctx = b->circ->ctx;

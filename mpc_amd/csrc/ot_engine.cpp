@@ -402,4 +402,27 @@ int gc_cot_receive_unpad(gc_ctx *ctx, const gc_label *seed, const uint8_t *flags
     return GC_OK;
 }
 
+// device-resident forms of the two COT pad loops: device pointers, asynchronous on the ctx stream, no staging
+int gc_cot_send_pads_dev(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, const void *d_data,
+                         const void *d_wires, size_t n, void *d_out) {
+    if (!ctx || !seed || !delta || (n && (!d_data || !d_wires || !d_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_cot_send(to_u4(*seed), to_u4(*delta), (const uint4 *)d_data, (const uint4 *)d_wires, n, (uint4 *)d_out,
+                    ctx->d_te0, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_cot_receive_unpad_dev(gc_ctx *ctx, const gc_label *seed, const void *d_flags, const void *d_sent,
+                             void *d_result, size_t n) {
+    if (!ctx || !seed || (n && (!d_flags || !d_sent || !d_result))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_cot_recv(to_u4(*seed), (const uint8_t *)d_flags, (const uint4 *)d_sent, (uint4 *)d_result, n, ctx->d_te0,
+                    ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
 }  // extern "C"

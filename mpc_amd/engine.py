@@ -120,6 +120,10 @@ def lib():
         "gc_tables_wire_bytes": (sz, [vp]),
         "gc_batch_egress_tables": (i32, [vp, vp, sz]),
         "gc_batch_ingest_tables": (i32, [vp, vp, sz, vp]),
+        "gc_batch_gather_input_wires": (i32, [vp, u32, u32, vp]),
+        "gc_batch_set_input_range": (i32, [vp, u32, u32, vp]),
+        "gc_cot_send_pads_dev": (i32, [vp, vp, vp, vp, vp, sz, vp]),
+        "gc_cot_receive_unpad_dev": (i32, [vp, vp, vp, vp, vp, sz]),
         "gc_batch_egress_tables_dense": (i32, [vp, vp, sz]),
         "gc_batch_ingest_tables_dense": (i32, [vp, vp, sz]),
         "gc_batch_last_ms": (C.c_float, [vp]),
@@ -400,6 +404,12 @@ class Batch:
     def egress_tables(self, d_out, stride):
         _check(lib().gc_batch_egress_tables(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables")
 
+    def gather_input_wires(self, first, count, d_out):
+        _check(lib().gc_batch_gather_input_wires(self.h, first, count, C.c_void_p(d_out)), "gc_batch_gather_input_wires")
+
+    def set_input_range(self, first, count, d_labels):
+        _check(lib().gc_batch_set_input_range(self.h, first, count, C.c_void_p(d_labels)), "gc_batch_set_input_range")
+
     def egress_tables_dense(self, d_out, stride):
         _check(lib().gc_batch_egress_tables_dense(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables_dense")
 
@@ -597,6 +607,16 @@ def cot_send_pads(ctx, seed, delta, data, wires):
     _check(lib().gc_cot_send_pads(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), _p(d), _p(w), len(d), _p(out)),
            "gc_cot_send_pads")
     return out[: 2 * len(d)]
+
+
+def cot_send_pads_dev(ctx, seed, delta, d_data, d_wires, n, d_out):
+    _check(lib().gc_cot_send_pads_dev(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), C.c_void_p(d_data), C.c_void_p(d_wires),
+                                      n, C.c_void_p(d_out)), "gc_cot_send_pads_dev")
+
+
+def cot_receive_unpad_dev(ctx, seed, d_flags, d_sent, d_result, n):
+    _check(lib().gc_cot_receive_unpad_dev(ctx.h, _p(_lab1(seed)), C.c_void_p(d_flags), C.c_void_p(d_sent),
+                                          C.c_void_p(d_result), n), "gc_cot_receive_unpad_dev")
 
 
 def cot_receive_unpad(ctx, seed, flags, sent, result):
