@@ -227,7 +227,9 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
             const uint4 v4 = lab(d1.x, false), v5 = lab(d1.x, true), v6 = lab(d1.y, false), v7 = lab(d1.y, true);
             acc = lxor(acc, lxor(lxor(v4, v5), lxor(v6, v7)));
         }
-        if (u.xparts > 1) {  // unit-uniform: collect the partial sums of lists that were spread over 2 / 4 lanes
+        // collect the partial sums of lists that were spread over 2 / 4 lanes: only in units that have such lists, and
+        // there only in the waves that hold them (they come first in the length order) - a wave-uniform test
+        if (u.xparts > 1 && __ballot((flags & (kXoJoin2 | kXoJoin4 | kXoPart)) != 0) != 0) {
             const bool four = u.xparts > 2;
             if (ti_log2 == 0) acc = join_parts<1>(acc, flags, four);
             else if (ti_log2 == 1) acc = join_parts<2>(acc, flags, four);
