@@ -252,8 +252,8 @@ static void free_buffers(gc_batch *b) {
 // live labels the kernel of this batch keeps in LDS: the flattened plan normally, the level-walking plan when
 // every wire has to be materialised (store_all) or schedule 2 was asked for
 // The flattened kernels are the choice unless every wire has to be materialised (store_all), schedule 2 was asked
-// for, or the circuit has no flattened plan.  They address a tile's table rows with 32-bit element offsets:
-// slab_rows * 64 < 2^28 (a circuit with >= 4 Mi table rows does not fit an LDS plan anyway).
+// for, or the circuit has no flattened plan.  They address a tile's table rows with 32-bit BYTE offsets:
+// slab_rows * 64 instances * 16 B < 2^32 (a circuit with >= 4 Mi table rows does not fit an LDS plan anyway).
 static bool want_flat(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
     return !b->store_all && !b->single_phase && p.n_flat_slots != 0xffffffffu && p.info.slab_rows < (1u << 22);

@@ -34,21 +34,28 @@ constexpr int DPP_PAIR0 = 0xA0;  // [0,0,2,2]
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    // quad permutes have no invalid source lanes inside a full quad: no "old" value, so no register initialisation
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ uint4 dpp128(uint4 v) {
     return make_uint4(dpp32<CTRL>(v.x), dpp32<CTRL>(v.y), dpp32<CTRL>(v.z), dpp32<CTRL>(v.w));
 }
 
+// v ^ (v of the quad partner): computed by every lane of the quad so that it is four v_xor_b32_dpp; the opaque asm
+// keeps the compiler from sinking the XOR into the q == 0 branch that uses it (DPP cannot read from lanes that are
+// switched off, so there it becomes 4 DPP moves + 4 XORs)
+template <int CTRL>
+__device__ __forceinline__ uint4 quad_xor(uint4 v) {
+    uint4 o = make_uint4(v.x ^ dpp32<CTRL>(v.x), v.y ^ dpp32<CTRL>(v.y), v.z ^ dpp32<CTRL>(v.z), v.w ^ dpp32<CTRL>(v.w));
+    asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
+    return o;
+}
+
 typedef uint32_t lds_v4 __attribute__((ext_vector_type(4)));
 using lds_v4p = __attribute__((address_space(3))) const lds_v4 *;
 
-// m ? a : b and h ^ (w & m) per bit: one v_bitop3_b32 each
-__device__ __forceinline__ uint4 bsel4(uint32_t m, uint4 a, uint4 b) {
-    return make_uint4(__builtin_amdgcn_bitop3_b32(m, a.x, b.x, 0xCA), __builtin_amdgcn_bitop3_b32(m, a.y, b.y, 0xCA),
-                      __builtin_amdgcn_bitop3_b32(m, a.z, b.z, 0xCA), __builtin_amdgcn_bitop3_b32(m, a.w, b.w, 0xCA));
-}
+// h ^ (w & m) per bit: one v_bitop3_b32 per word
 __device__ __forceinline__ uint4 xand4(uint4 h, uint4 w, uint32_t m) {
     return make_uint4(__builtin_amdgcn_bitop3_b32(h.x, w.x, m, 0x78), __builtin_amdgcn_bitop3_b32(h.y, w.y, m, 0x78),
                       __builtin_amdgcn_bitop3_b32(h.z, w.z, m, 0x78), __builtin_amdgcn_bitop3_b32(h.w, w.w, m, 0x78));
@@ -336,7 +343,10 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
             const uint4 h = hash_dual<NR>(k, rkr, te, lo);
             GC_FPROF(7)
-            uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
+            // 32-bit byte offset into the tile's table rows (launch_fused_flat checks that a tile's rows stay below
+            // 4 GiB): scalar base + one VGPR offset instead of 64-bit address arithmetic per lane
+            const uint32_t rowb = (((d.row_op & kRowMask) << ti_log2) + inst) << 4;
+            auto row = [&](uint32_t r) -> uint4 & { return *(uint4 *)((char *)Tt + (rowb + (r << 4))); };
             // the zero label of the output wire goes out from lane 0 of the gate (called inside every branch: merging
             // the branches' results first costs a register copy per word)
             auto put = [&](const uint4 &out_label) {
@@ -358,11 +368,11 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 tab = xand4(w, a0, m2);  // lanes 0,1: TG | lanes 2,3: TE = Hb0^Hb1^a0
                 // v = lanes 0,1: WG0 = Ha0 ^ (pa ? TG : 0) | lanes 2,3: WE0 = Hb0 ^ (pb ? TE^a0 : 0)
                 const uint4 v = xand4(h, w, mk);
-                if (!(q & 1)) row[(q & 2) ? TI : 0] = tab;
-                put(lxor(v, dpp128<DPP_XOR2>(v)));
+                if (!(q & 1)) row((q & 2) ? TI : 0) = tab;
+                put(quad_xor<DPP_XOR2>(v));
             } else if (!HAS_OR || hp.kind == 3) {  // garble.go:446-474
-                const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));       // E0 ^ E1
-                if (q == 0) row[0] = lxor(p, R);
+                const uint4 p = quad_xor<DPP_XOR1>(h);              // E0 ^ E1
+                if (q == 0) row(0) = lxor(p, R);
                 put(lxor(h, sel4(lbit_s(base), p, R)));  // S(a0) ? E1 = E0 ^ (E0^E1) : E0 ^ R
             } else {  // OR: garble.go:412-444
                 const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 const uint4 t0v = dpp128<DPP_BC0>(tk);
                 const uint32_t m0 = l0 == 0 ? ~0u : 0u;
                 const uint4 c0 = lxor(t0v, land(R, ~m0)), c1 = lxor(t0v, land(R, m0));
-                if (q != 0) row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
+                if (q != 0) row((q - 1) << ti_log2) = lxor(tk, q == l0 ? c0 : c1);
                 put(c0);
             }
         }
@@ -414,7 +424,8 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             const uint4 dv = buf[hp.g];
             const FDesc d{dv.x, dv.y, dv.z, dv.w};
             const uint32_t inst = hp.inst, q = hp.q;
-            const uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
+            const uint32_t rowb = (((d.row_op & kRowMask) << ti_log2) + inst) << 4;  // 32-bit byte offset, as in the garbler
+            auto row = [&](uint32_t r) -> const uint4 & { return *(const uint4 *)((const char *)Tt + (rowb + (r << 4))); };
             // AND: lane q hashes operand q (a, b) with tweak + q and needs table row q; INV: operand a, row 0
             const uint32_t mq = q ? ~0u : 0u;  // q is 0 for INV / OR lanes
             const uint32_t opslot = (HAS_OR && hp.kind == 2) ? (d.lin & 0xffffu) : q ? (d.lin >> 16) : (d.lin & 0xffffu);
@@ -422,12 +433,12 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             uint4 x = va, tab = make_uint4(0, 0, 0, 0);
             uint32_t k[4];
             if (!HAS_OR || hp.kind != 2) {
-                tab = row[q ? TI : 0];  // issued before the hash: arrives while the AES runs
+                tab = row(q ? TI : 0);  // issued before the hash: arrives while the AES runs
                 make_k_half(x, d.tweak + q, k);
             } else {  // OR (eval.go:80-94): both operands, row index - 1 (index 0 has no row)
                 const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
                 const uint32_t index = (lbit_s(va) ? 2u : 0u) | (lbit_s(vb) ? 1u : 0u);
-                if (index > 0) tab = row[(size_t)(index - 1) << ti_log2];
+                if (index > 0) tab = row((index - 1) << ti_log2);
                 make_k(va, vb, d.tweak, k);
             }
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
                 const uint4 av = dpp128<DPP_PAIR0>(x);
                 // lane 0: WG = H(a) ^ (sa ? TG : 0); lane 1: WE = H(b) ^ (sb ? TE^a : 0)
                 const uint4 v = xand4(h, xand4(tab, av, mq), smask(x));
-                put(lxor(v, dpp128<DPP_XOR1>(v)));
+                put(quad_xor<DPP_XOR1>(v));
             } else if (!HAS_OR || hp.kind == 3) {  // eval.go:96-109
                 put(xand4(h, tab, smask(x)));
             } else {  // eval.go:80-94 (tab is zero for index 0)

@@ -7,7 +7,8 @@ from mpc_amd import engine, parse_file
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 keylen = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-c = parse_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "aes_128.gcf"))
+name = sys.argv[3] if len(sys.argv) > 3 else "aes_128.gcf"
+c = parse_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", name))
 ctx = engine.Context(0)
 dc = engine.DeviceCircuit(ctx, c)
 gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
