@@ -61,6 +61,10 @@ __device__ __forceinline__ uint4 xand4(uint4 h, uint4 w, uint32_t m) {
                       __builtin_amdgcn_bitop3_b32(h.z, w.z, m, 0x78), __builtin_amdgcn_bitop3_b32(h.w, w.w, m, 0x78));
 }
 
+__device__ __forceinline__ uint4 lxor3(uint4 a, uint4 b, uint4 c) {
+    return make_uint4(xor3(a.x, b.x, c.x), xor3(a.y, b.y, c.y), xor3(a.z, b.z, c.z), xor3(a.w, b.w, c.w));
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr uint32_t kStageOff = kTeDualBytes / 16;
@@ -229,10 +233,10 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
             return make_uint4(v.x, v.y, v.z, v.w);
         };
         const uint4 v0 = lab(d0.x, false), v1 = lab(d0.x, true), v2 = lab(d0.y, false), v3 = lab(d0.y, true);
-        uint4 acc = lxor(lxor(v0, v1), lxor(v2, v3));
+        uint4 acc = lxor(lxor3(v0, v1, v2), v3);  // three-input XORs (v_bitop3): 2 + 2 instead of 3 + 4 per word
         if (n > 4) {  // items are sorted by length: whole waves skip this
             const uint4 v4 = lab(d1.x, false), v5 = lab(d1.x, true), v6 = lab(d1.y, false), v7 = lab(d1.y, true);
-            acc = lxor(acc, lxor(lxor(v4, v5), lxor(v6, v7)));
+            acc = lxor3(lxor3(acc, v4, v5), v6, v7);
         }
         // collect the partial sums of lists that were spread over 2 / 4 lanes: only in units that have such lists, and
         // there only in the waves that hold them (they come first in the length order) - a wave-uniform test
