@@ -196,17 +196,29 @@ __device__ __forceinline__ void te_round_addrs(const uint32_t (&a)[4], uint32_t 
 }
 
 // rk: NR+1 round keys as big-endian words, expected in SGPRs (see load_round_keys)
-template <int NR, int N>
+// FEED = 1: the caller wants pi(K) ^ K (the fixed-key hash): the last AddRoundKey and the feed-forward of the input
+// block become one three-input XOR per word.  FEED = 2: as 1, and the input is already whitened (s = K ^ rk[0..3],
+// whiten_half / whiten_k) with the last round key folded (fold_last_round_key): pi(K) ^ K = SB ^ (rk_last ^ rk_0) ^ s.
+template <int NR, int N, int FEED = 0>
 __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint32_t (&rk)[4 * (NR + 1)],
                                                  const uint32_t *te, uint32_t lo0) {
+    uint32_t fin[FEED ? N : 1][4];
+    if constexpr (FEED) {
+#pragma unroll
+        for (int k = 0; k < N; k++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) fin[k][c] = s[k][c];
+    }
     (void)te;  // the table sits at LDS offset 0 (te_dual_check)
     const uint32_t lo2 = lo0 + 128u;
+    if constexpr (FEED != 2) {
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        s[k][0] ^= rk[0];
-        s[k][1] ^= rk[1];
-        s[k][2] ^= rk[2];
-        s[k][3] ^= rk[3];
+        for (int k = 0; k < N; k++) {
+            s[k][0] ^= rk[0];
+            s[k][1] ^= rk[1];
+            s[k][2] ^= rk[2];
+            s[k][3] ^= rk[3];
+        }
     }
 #pragma unroll
     for (int r = 1; r < NR; r++) {
@@ -252,7 +264,9 @@ __device__ __forceinline__ void aes_encrypt_dual(uint32_t (&s)[N][4], const uint
             {  // byte 3 of t0, byte 2 of t1, byte 1 of t2, byte 0 of t3: three bit-selects (v_bitop3 0xCA = m ? a : b)
                 const uint32_t hi = __builtin_amdgcn_bitop3_b32(0xff000000u, t[k][4 * c], t[k][4 * c + 1], 0xCA);
                 const uint32_t lo = __builtin_amdgcn_bitop3_b32(0x0000ff00u, t[k][4 * c + 2], t[k][4 * c + 3], 0xCA);
-                s[k][c] = __builtin_amdgcn_bitop3_b32(0xffff0000u, hi, lo, 0xCA) ^ rk[4 * NR + c];
+                const uint32_t sb = __builtin_amdgcn_bitop3_b32(0xffff0000u, hi, lo, 0xCA);
+                if constexpr (FEED) s[k][c] = xor3(sb, rk[4 * NR + c], fin[k][c]);
+                else s[k][c] = sb ^ rk[4 * NR + c];
             }
     }
 }
@@ -288,19 +302,17 @@ __device__ __forceinline__ void hash_dual_n(const uint32_t (&k)[N][4], uint4 (&o
         s[i][2] = k[i][2];
         s[i][3] = k[i][3];
     }
-    aes_encrypt_dual<NR, N>(s, rk, te, lo0);
+    aes_encrypt_dual<NR, N, 1>(s, rk, te, lo0);
 #pragma unroll
-    for (int i = 0; i < N; i++)
-        out[i] = make_uint4(s[i][1] ^ k[i][1], s[i][0] ^ k[i][0], s[i][3] ^ k[i][3], s[i][2] ^ k[i][2]);
+    for (int i = 0; i < N; i++) out[i] = make_uint4(s[i][1], s[i][0], s[i][3], s[i][2]);
 }
 
 template <int NR>
 __device__ __forceinline__ uint4 hash_dual(const uint32_t (&k)[4], const uint32_t (&rk)[4 * (NR + 1)],
                                            const uint32_t *te, uint32_t lo0) {
     uint32_t s[1][4] = {{k[0], k[1], k[2], k[3]}};
-    aes_encrypt_dual<NR, 1>(s, rk, te, lo0);
-    uint32_t o[4] = {s[0][0] ^ k[0], s[0][1] ^ k[1], s[0][2] ^ k[2], s[0][3] ^ k[3]};
-    return make_uint4(o[1], o[0], o[3], o[2]);
+    aes_encrypt_dual<NR, 1, 1>(s, rk, te, lo0);
+    return make_uint4(s[0][1], s[0][0], s[0][3], s[0][2]);
 }
 
 // ---- label arithmetic (ot/label.go) on the uint4 form --------------------------------------
@@ -325,6 +337,21 @@ __device__ __forceinline__ void label_shl_cols(uint4 v, uint32_t (&k)[4]) {
 
 __device__ __forceinline__ uint4 cols_to_label(const uint32_t (&s)[4]) { return make_uint4(s[1], s[0], s[3], s[2]); }
 
+// ---- the same hash with the key whitening folded into the key set-up (flat kernels) --------
+// rk_last ^= rk_0, once per kernel: the feed-forward then takes the whitened block instead of K
+template <int NR>
+__device__ __forceinline__ void fold_last_round_key(uint32_t (&rk)[4 * (NR + 1)]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) rk[4 * NR + c] ^= rk[c];
+}
+template <int NR>
+__device__ __forceinline__ uint4 hash_dual_whitened(const uint32_t (&s0)[4], const uint32_t (&rk)[4 * (NR + 1)],
+                                                    const uint32_t *te, uint32_t lo0) {
+    uint32_t s[1][4] = {{s0[0], s0[1], s0[2], s0[3]}};
+    aes_encrypt_dual<NR, 1, 2>(s, rk, te, lo0);
+    return make_uint4(s[0][1], s[0][0], s[0][3], s[0][2]);
+}
+
 // Hash inputs of encryptHalf (circuit/garble.go:104-136): K = 2x ^ i, i in the low 32 bits of D1
 __device__ __forceinline__ void make_k_half(uint4 x, uint32_t tweak, uint32_t (&k)[4]) {
     label_shl_cols<1>(x, k);
@@ -339,6 +366,25 @@ __device__ __forceinline__ void make_k(uint4 a, uint4 b, uint32_t tweak, uint32_
     k[1] ^= kb[1];
     k[2] ^= kb[2];
     k[3] ^= kb[3] ^ tweak;
+}
+
+// whitened forms for hash_dual_whitened: s0 = K ^ rk_0, the tweak joins the last column's XOR
+__device__ __forceinline__ void whiten_half(uint4 x, uint32_t tweak, const uint32_t *rk0, uint32_t (&s0)[4]) {
+    uint32_t k[4];
+    label_shl_cols<1>(x, k);
+    s0[0] = k[0] ^ rk0[0];
+    s0[1] = k[1] ^ rk0[1];
+    s0[2] = k[2] ^ rk0[2];
+    s0[3] = xor3(k[3], tweak, rk0[3]);
+}
+__device__ __forceinline__ void whiten_k(uint4 a, uint4 b, uint32_t tweak, const uint32_t *rk0, uint32_t (&s0)[4]) {
+    uint32_t ka[4], kb[4];
+    label_shl_cols<1>(a, ka);
+    label_shl_cols<2>(b, kb);
+    s0[0] = xor3(ka[0], kb[0], rk0[0]);
+    s0[1] = xor3(ka[1], kb[1], rk0[1]);
+    s0[2] = xor3(ka[2], kb[2], rk0[2]);
+    s0[3] = xor3(ka[3], kb[3], rk0[3]) ^ tweak;
 }
 
 // N hashes pi(K) ^ K in lock-step; k[][] in: hash inputs, out: hash values (as labels)

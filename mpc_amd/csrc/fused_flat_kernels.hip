@@ -54,6 +54,23 @@ __device__ __forceinline__ uint4 quad_xor(uint4 v) {
 
 typedef uint32_t lds_v4 __attribute__((ext_vector_type(4)));
 using lds_v4p = __attribute__((address_space(3))) const lds_v4 *;
+using lds_v4w = __attribute__((address_space(3))) lds_v4 *;
+
+// Wire labels in LDS by byte address: label of slot s, instance inst = ib + (s << sh) with ib = wl + 16 inst and
+// sh = ti_log2 + 4: one v_lshl_add_u32 per access (the indexed form costs two shifts and a three-input add)
+__device__ __forceinline__ uint4 lds_label(uint32_t ib, uint32_t slot, uint32_t sh) {
+    const lds_v4 v = *(lds_v4p)(uintptr_t)((slot << sh) + ib);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_label_put(uint32_t ib, uint32_t slot, uint32_t sh, uint4 v) {
+    lds_v4 o;
+    o.x = v.x, o.y = v.y, o.z = v.z, o.w = v.w;
+    *(lds_v4w)(uintptr_t)((slot << sh) + ib) = o;
+}
+// low (hi = false) or high half-word of a packed slot pair, chosen per lane: one v_perm_b32
+__device__ __forceinline__ uint32_t half_of(uint32_t packed, bool hi) {
+    return __builtin_amdgcn_perm(packed, packed, hi ? 0x0c0c0302u : 0x0c0c0100u);
+}
 
 // h ^ (w & m) per bit: one v_bitop3_b32 per word
 __device__ __forceinline__ uint4 xand4(uint4 h, uint4 w, uint32_t m) {
@@ -249,7 +266,7 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
         }
         if (flags & kXoPart) continue;
         if (GARBLE && (flags & kXoRpar)) acc = lxor(acc, rl[inst]);
-        wl[((d2.x & 0xffffu) << ti_log2) + inst] = acc;
+        lds_label_put(ib, d2.x & 0xffffu, sh, acc);
         if (flags & kXoStore) Wt[((size_t)ogslot[u.ofirst + o] << ti_log2) + inst] = acc;
     }
 }
@@ -267,6 +284,7 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     uint32_t vz;                                                                                             \
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
     load_round_keys_split<NR, (4 * (NR + 1) > 32 ? 4 * (NR + 1) - 32 : 4 * (NR + 1))>(rkr, a.rk, vz);        \
+    fold_last_round_key<NR>(rkr); /* the hashes run on whitened blocks (hash_dual_whitened) */              \
     uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
     if (threadIdx.x < TI) wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                   \
     if (LOAD_R && a.rnd) {                                                                                   \
@@ -329,23 +347,25 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             const uint32_t inst = hp.inst, q = hp.q;
             const uint4 R = rl[inst];
             // AND q=0..3 hash a0,a1,b0,b1 (lanes 2,3 read operand b and use tweak + 1); INV q=0,1 hash a0,a1
-            const bool second = (hp.kind == 1) && (q & 2);
-            const uint4 va = wl[((second ? (d.lin >> 16) : (d.lin & 0xffffu)) << ti_log2) + inst];
+            // (INV lanes have q < 2, so only the OR kind needs the test)
+            const bool second = (!HAS_OR || hp.kind == 1) && (q & 2);
+            const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
+            const uint4 va = lds_label(ib, half_of(d.lin, second), sh);
             uint4 base;
             uint32_t k[4];
             if (HAS_OR && hp.kind == 2) {  // OR: e[2u+v] = enc(a_u, b_v, 0, id)  (garble.go:74-83, 421-424)
-                const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
+                const uint4 vb = lds_label(ib, d.lin >> 16, sh);
                 const uint4 x = lxor(va, land(R, (q & 2) ? ~0u : 0u));
                 const uint4 y = lxor(vb, land(R, (q & 1) ? ~0u : 0u));
                 base = make_uint4(x.y, y.y, 0, 0);
-                make_k(x, y, d.tweak, k);
+                whiten_k(x, y, d.tweak, rkr, k);
             } else {  // K = 2x ^ tweak, x = the operand's zero label (q even) or one label (q odd)
                 base = va;
                 const uint4 x = xand4(base, R, (q & 1) ? ~0u : 0u);  // base ^ (q odd ? R : 0): one v_bitop3 per word
-                make_k_half(x, d.tweak + (second ? 1u : 0u), k);
+                whiten_half(x, d.tweak + (HAS_OR ? (second ? 1u : 0u) : (q >> 1)), rkr, k);
             }
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
-            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            const uint4 h = hash_dual_whitened<NR>(k, rkr, te, lo);
             GC_FPROF(7)
             // 32-bit byte offset into the tile's table rows (launch_fused_flat checks that a tile's rows stay below
             // 4 GiB): scalar base + one VGPR offset instead of 64-bit address arithmetic per lane
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             // the branches' results first costs a register copy per word)
             auto put = [&](const uint4 &out_label) {
                 if (q == 0) {
-                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                    lds_label_put(ib, d.lout & 0xffffu, sh, out_label);
                     if (d.lout & kFStoreGlobal)
                         Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
                 }
@@ -432,25 +452,25 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
             auto row = [&](uint32_t r) -> const uint4 & { return *(const uint4 *)((const char *)Tt + (rowb + (r << 4))); };
             // AND: lane q hashes operand q (a, b) with tweak + q and needs table row q; INV: operand a, row 0
             const uint32_t mq = q ? ~0u : 0u;  // q is 0 for INV / OR lanes
-            const uint32_t opslot = (HAS_OR && hp.kind == 2) ? (d.lin & 0xffffu) : q ? (d.lin >> 16) : (d.lin & 0xffffu);
-            const uint4 va = wl[(opslot << ti_log2) + inst];
+            const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
+            const uint4 va = lds_label(ib, half_of(d.lin, !(HAS_OR && hp.kind == 2) && q), sh);
             uint4 x = va, tab = make_uint4(0, 0, 0, 0);
             uint32_t k[4];
             if (!HAS_OR || hp.kind != 2) {
                 tab = row(q ? TI : 0);  // issued before the hash: arrives while the AES runs
-                make_k_half(x, d.tweak + q, k);
+                whiten_half(x, d.tweak + q, rkr, k);
             } else {  // OR (eval.go:80-94): both operands, row index - 1 (index 0 has no row)
-                const uint4 vb = wl[((d.lin >> 16) << ti_log2) + inst];
+                const uint4 vb = lds_label(ib, d.lin >> 16, sh);
                 const uint32_t index = (lbit_s(va) ? 2u : 0u) | (lbit_s(vb) ? 1u : 0u);
                 if (index > 0) tab = row((index - 1) << ti_log2);
-                make_k(va, vb, d.tweak, k);
+                whiten_k(va, vb, d.tweak, rkr, k);
             }
             GC_FPROF(6)  // debug profile: slot 6 = operand fetch + key set-up, slot 7 = AES, slot 1 = combine + stores
-            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+            const uint4 h = hash_dual_whitened<NR>(k, rkr, te, lo);
             GC_FPROF(7)
             auto put = [&](const uint4 &out_label) {  // inside every branch: no result merge, no register copies
                 if (q == 0) {
-                    wl[((d.lout & 0xffffu) << ti_log2) + inst] = out_label;
+                    lds_label_put(ib, d.lout & 0xffffu, sh, out_label);
                     if (d.lout & kFStoreGlobal)
                         Wt[((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst] = out_label;
                 }
