@@ -212,6 +212,7 @@ void gc_circ_free(gc_circ *c) {
     if (c->d_steps) (void)hipFree(c->d_steps);
     if (c->d_ops) (void)hipFree(c->d_ops);
     if (c->d_row_of_gate) (void)hipFree(c->d_row_of_gate);
+    if (c->d_gwires) (void)hipFree(c->d_gwires);
     if (c->d_fdescs) (void)hipFree(c->d_fdescs);
     if (c->d_fgslot) (void)hipFree(c->d_fgslot);
     if (c->d_fsteps) (void)hipFree(c->d_fsteps);
@@ -911,9 +912,14 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
     return rc;
 }
 
-int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
-                     gc_label *slab_out, gc_label *out_l0) {
-    if (!c || !r) return GC_E_ARG;
+}  // extern "C"
+
+// One instance garbled from explicit labels; the pooled batch is handed to the caller with the tables still in
+// b->d_T (the streaming garbler serialises them on the device) and goes back with gc_circ_release_batch.
+int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
+                          gc_label *out_l0, gc_batch **bout) {
+    if (!c || !r || !bout) return GC_E_ARG;
+    *bout = nullptr;
     const Plan &p = c->plan.p;
     if (p.info.ninputs && !inputs) return GC_E_ARG;
     int rc = GC_OK;
@@ -934,9 +940,31 @@ int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_lab
         if ((rc = set_key(b, key, keylen)) != GC_OK) break;
         b->store_all = false;
         if ((rc = run_levels(b, false, b->d_T)) != GC_OK) break;
-        if (slab_out && (rc = gc_batch_read_slab(b, slab_out)) != GC_OK) break;
         if (out_l0 && (rc = gc_batch_read_outputs(b, out_l0)) != GC_OK) break;
     } while (0);
+    if (rc != GC_OK) {
+        pool_put(c, b);
+        return rc;
+    }
+    *bout = b;
+    return GC_OK;
+}
+
+void gc_circ_release_batch(gc_circ *c, gc_batch *b) {
+    if (c && b) pool_put(c, b);
+}
+
+extern "C" {
+
+int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
+                     gc_label *slab_out, gc_label *out_l0) {
+    gc_batch *b = nullptr;
+    int rc = gc_garble_labels_keep(c, key, keylen, r, inputs, out_l0, &b);
+    if (rc != GC_OK) return rc;
+    if (slab_out) {
+        std::lock_guard<std::mutex> lk(c->ctx->mu);
+        rc = gc_batch_read_slab(b, slab_out);
+    }
     pool_put(c, b);
     return rc;
 }

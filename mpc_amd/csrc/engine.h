@@ -48,6 +48,7 @@ struct gc_circ {
     gc::Step *d_steps = nullptr;
     uint8_t *d_ops = nullptr;            // op of every gate, original order (table egress / ingest)
     uint32_t *d_row_of_gate = nullptr;   // first slab row of every gate, original order
+    uint32_t *d_gwires = nullptr;        // streaming garbler: {in0, in1, out} of every gate, original order (lazy)
     gc::FDesc *d_fdescs = nullptr;   // LDS schedule
     uint32_t *d_fgslot = nullptr;
     gc::Step *d_fsteps = nullptr;
@@ -91,3 +92,9 @@ struct gc_batch {
     bool timed = false;
     uint32_t last_launches = 0;
 };
+
+// internal (C++ linkage): one instance garbled from explicit labels, the pooled batch kept by the caller
+// (tables in b->d_T) until gc_circ_release_batch — used by the streaming garbler's device-side serialiser
+int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
+                          gc_label *out_l0, gc_batch **bout);
+void gc_circ_release_batch(gc_circ *c, gc_batch *b);

@@ -4,9 +4,12 @@
 // The persistent wire store (stream.wires) stays on the host — it is touched only at circuit
 // boundaries; each Garble call (i) resolves the circuit's input wires through in[] (:131-141),
 // (ii) garbles the circuit on the device with the SAME kernels as Circuit.Garble (the tweak restarts
-// at 0 per circuit, :174, exactly like a fresh Circuit.Garble) and (iii) serialises the gates into the
-// caller's buffer in the reference's wire format (:391-446), byte for byte.  Circuits are cached by
-// content, so an SSA instruction that repeats re-uses its levelised plan and device buffers.
+// at 0 per circuit, :174, exactly like a fresh Circuit.Garble) and (iii) serialises the gates in the
+// reference's wire format (:391-446), byte for byte — ON THE DEVICE: per-gate byte sizes, a two-level exclusive
+// scan and a writer kernel that places header and rows at the gate's byte offset; the host copies the finished
+// byte string into the caller's buffer (the per-gate host loop was 4 ms for a 131 072-gate step, ten times the
+// garbling itself).  Circuits are cached by content, so an SSA instruction that repeats re-uses its levelised
+// plan and device buffers.
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -23,38 +26,195 @@ struct gc_stream {
     std::vector<gc_label> l0;     // global wire -> L0 (L1 = L0 ^ R)
     std::vector<gc_label> tmp_l0; // stream.tmp (only outputs of the current circuit are meaningful)
     std::unordered_map<uint64_t, gc_circ *> cache;
+    uint32_t *d_io = nullptr;   // in[] then out[] of the current call
+    size_t io_cap = 0;
+    uint64_t *d_boff = nullptr; // per block of kSerGates gates: byte size, then exclusive offset; [nblocks] = total
+    size_t boff_cap = 0;
+    uint8_t *d_bytes = nullptr; // the serialised circuit
+    size_t bytes_cap = 0;
 };
 
 namespace {
+
+// ---- device-side serialiser (stream_garble.go:391-446) ---------------------------------------------------
+constexpr uint32_t kSerThreads = 256, kSerPer = 4, kSerGates = kSerThreads * kSerPer;
+
+struct SerArgs {
+    const uint32_t *gw;   // {in0, in1, out} per gate
+    const uint8_t *ops;
+    const uint32_t *row_of_gate;
+    const uint32_t *in, *out;  // wire maps of this call
+    uint32_t ngates, first_tmp, first_out;
+};
+struct SerGate {
+    uint32_t ai, bi, ci, size;
+    uint8_t op, wc, rows, shortf;
+};
+__device__ __forceinline__ SerGate ser_gate(const SerArgs &a, uint32_t i) {
+    SerGate g{};
+    const uint32_t op = a.ops[i];
+    const uint32_t w0 = a.gw[3 * i], w1 = a.gw[3 * i + 1], w2 = a.gw[3 * i + 2];
+    uint32_t flags = op;
+    auto get = [&](uint32_t w, uint32_t bit) -> uint32_t {  // Get/Set indirection (:131-157) + the tmp flag
+        if (w < a.first_tmp) return a.in[w];
+        if (w >= a.first_out) return a.out[w - a.first_out];
+        flags |= bit;
+        return w;
+    };
+    g.bi = op != GC_INV ? get(w1, 0x40) : 0;
+    g.ai = get(w0, 0x80);
+    g.ci = get(w2, 0x20);
+    g.wc = op == GC_INV ? 2 : 3;
+    g.rows = op == GC_AND ? 2 : op == GC_OR ? 3 : op == GC_INV ? 1 : 0;
+    g.shortf = g.ai <= 0xffff && g.bi <= 0xffff && g.ci <= 0xffff;
+    g.op = (uint8_t)(flags | (g.shortf ? 0x10 : 0));
+    g.size = 1 + (g.shortf ? 2u : 4u) * g.wc + 16u * g.rows;
+    return g;
+}
+
+// byte size of every block of kSerGates gates
+__global__ __launch_bounds__(kSerThreads) void k_ser_sizes(SerArgs a, uint64_t *boff) {
+    __shared__ uint32_t red[kSerThreads / 64];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kSerPer; k++) {
+        const uint32_t i = blockIdx.x * kSerGates + threadIdx.x * kSerPer + k;
+        if (i < a.ngates) sum += ser_gate(a, i).size;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < kSerThreads / 64; w++) t += red[w];
+        boff[blockIdx.x] = t;
+    }
+}
+// exclusive scan of the block sizes in place (one workgroup; a step has a few hundred to a few thousand blocks);
+// boff[nblocks] = total
+__global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblocks) {
+    __shared__ uint64_t part[1024];
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nblocks);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += boff[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < 1024; i++) {
+            const uint64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        boff[nblocks] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint64_t v = boff[i];
+        boff[i] = run;
+        run += v;
+    }
+}
+// every gate to its byte offset: op byte, 2-3 wire ids (BE u16 if all fit, else BE u32), rows as BE(D0)||BE(D1)
+__global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint64_t *boff, const uint4 *T, Layout lt,
+                                                           uint8_t *buf) {
+    __shared__ uint32_t wsum[kSerThreads / 64];
+    SerGate g[kSerPer];
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < kSerPer; k++) {
+        const uint32_t i = blockIdx.x * kSerGates + threadIdx.x * kSerPer + k;
+        g[k] = SerGate{};
+        if (i < a.ngates) g[k] = ser_gate(a, i);
+        mine += g[k].size;
+    }
+    // exclusive scan of the threads' sizes: inside the wave by shuffles, across the waves through LDS
+    uint32_t incl = mine;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
+    size_t pos = boff[blockIdx.x] + base + (incl - mine);
+    for (uint32_t k = 0; k < kSerPer; k++) {
+        const uint32_t i = blockIdx.x * kSerGates + threadIdx.x * kSerPer + k;
+        if (i >= a.ngates) break;
+        const SerGate &q = g[k];
+        uint8_t *p = buf + pos;
+        *p++ = q.op;
+        auto put = [&](uint32_t v) {
+            if (!q.shortf) {
+                *p++ = (uint8_t)(v >> 24);
+                *p++ = (uint8_t)(v >> 16);
+            }
+            *p++ = (uint8_t)(v >> 8);
+            *p++ = (uint8_t)v;
+        };
+        put(q.ai);
+        if (q.wc == 3) put(q.bi);
+        put(q.ci);
+        const uint32_t r0 = a.row_of_gate[i];
+        for (uint32_t r = 0; r < q.rows; r++) {
+            const uint4 v = T[lt.at(r0 + r, 0)];  // uint4 label: (x, y) = D0 low / high, (z, w) = D1 low / high
+            const uint32_t w4[4] = {v.y, v.x, v.w, v.z};
+            for (int j = 0; j < 4; j++) {
+                *p++ = (uint8_t)(w4[j] >> 24);
+                *p++ = (uint8_t)(w4[j] >> 16);
+                *p++ = (uint8_t)(w4[j] >> 8);
+                *p++ = (uint8_t)w4[j];
+            }
+        }
+        pos += q.size;
+    }
+}
+
+template <typename T>
+hipError_t grow(T **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 2 + 64;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e == hipSuccess) *cap = n;
+    return e;
+}
 
 inline uint64_t be64(const uint8_t *p) {
     uint64_t v = 0;
     for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
     return v;
 }
-inline void put_be64(uint8_t *p, uint64_t v) {
-    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (56 - 8 * i));
-}
 inline void ensure(gc_stream *s, uint32_t max) {  // ensureWires, 64 Ki-wire pages (:95-100)
     if (max < s->l0.size()) return;
     s->l0.resize(((size_t)max / 0x10000 + 1) * 0x10000, gc_label{0, 0});
 }
 
+// content hash of a circuit (cache key): four independent multiply-xor lanes over the gate words, so the
+// multiplies of consecutive gates overlap (one dependent chain was 0.2 ms per 131 072-gate step)
 uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout) {
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) {
-        h ^= v;
-        h *= 1099511628211ull;
+    constexpr uint64_t kPrime = 1099511628211ull;
+    uint64_t h[4] = {1469598103934665603ull ^ ngates, 0x9e3779b97f4a7c15ull ^ nwires, 0xc2b2ae3d27d4eb4full ^ nin,
+                     0x165667b19e3779f9ull ^ nout};
+    auto mix = [&](int l, const gc_gate &g) {
+        h[l] = (h[l] ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
+        h[l] = (h[l] ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
     };
-    mix(ngates);
-    mix(nwires);
-    mix(nin);
-    mix(nout);
-    for (uint32_t i = 0; i < ngates; i++) {
-        mix(((uint64_t)gates[i].in0 << 32) | gates[i].in1);
-        mix(((uint64_t)gates[i].out << 8) | gates[i].op);
+    uint32_t i = 0;
+    for (; i + 4 <= ngates; i += 4) {
+        mix(0, gates[i]);
+        mix(1, gates[i + 1]);
+        mix(2, gates[i + 2]);
+        mix(3, gates[i + 3]);
     }
-    return h;
+    for (; i < ngates; i++) mix(i & 3, gates[i]);
+    uint64_t r = 0;
+    for (int l = 0; l < 4; l++) r = (r ^ h[l]) * kPrime + (r >> 29);
+    return r;
 }
 
 }  // namespace
@@ -88,6 +248,9 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
 void gc_stream_free(gc_stream *s) {
     if (!s) return;
     for (auto &kv : s->cache) gc_circ_free(kv.second);
+    if (s->d_io) (void)hipFree(s->d_io);
+    if (s->d_boff) (void)hipFree(s->d_boff);
+    if (s->d_bytes) (void)hipFree(s->d_bytes);
     delete s;
 }
 
@@ -108,95 +271,90 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     for (uint32_t i = 0; i < nin; i++) mx = std::max(mx, in[i]);
     for (uint32_t i = 0; i < nout; i++) mx = std::max(mx, out[i]);
     ensure(s, mx);
-    // byte size of the serialised circuit is static: 1 + idx bytes + 16 per row
-    size_t need = 0;
-    for (uint32_t i = 0; i < ngates; i++) {
-        const gc_gate &g = gates[i];
-        if (g.op > GC_INV) return GC_E_GATE;
-        if (g.out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
-        auto index = [&](uint32_t w) { return w < first_tmp ? in[w] : w >= first_out ? out[w - first_out] : w; };
-        const uint32_t ai = index(g.in0), bi = g.op == GC_INV ? 0 : index(g.in1), ci = index(g.out);
-        const bool shortf = ai <= 0xffff && bi <= 0xffff && ci <= 0xffff;
-        const int wc = g.op == GC_INV ? 2 : 3, rows = g.op == GC_AND ? 2 : g.op == GC_OR ? 3 : g.op == GC_INV ? 1 : 0;
-        need += 1 + (size_t)(shortf ? 2 : 4) * wc + 16 * (size_t)rows;
-    }
-    *written = need;
-    if (need > cap) return GC_E_ARG;
+    *written = 0;
     if (ngates == 0) return GC_OK;
 
-    // device circuit (cached by content)
+    // device circuit (cached by content); a new circuit is validated once (garbleGate's checks, :195-210)
     const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
     gc_circ *circ = nullptr;
     auto it = s->cache.find(h);
     if (it != s->cache.end()) circ = it->second;
     else {
+        for (uint32_t i = 0; i < ngates; i++) {
+            if (gates[i].op > GC_INV) return GC_E_GATE;
+            if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
+        }
         int st = GC_OK;
         circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &st);
         if (!circ) return st;
+        std::vector<uint32_t> gw((size_t)3 * ngates);
+        for (uint32_t i = 0; i < ngates; i++) {
+            gw[3 * (size_t)i] = gates[i].in0;
+            gw[3 * (size_t)i + 1] = gates[i].in1;
+            gw[3 * (size_t)i + 2] = gates[i].out;
+        }
+        hipError_t e = hipMalloc((void **)&circ->d_gwires, gw.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(circ->d_gwires, gw.data(), gw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            gc_circ_free(circ);
+            return GC_E_HIP;
+        }
         s->cache.emplace(h, circ);
     }
-    const Plan &p = circ->plan.p;
-    // input labels through in[] (Get, :131-141)
-    std::vector<gc_label> inl(nin);
+    gc_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
+
+    // (1) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form)
+    SerArgs a{};
+    uint64_t need = 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = grow(&s->d_io, &s->io_cap, (size_t)nin + nout + 1);
+        if (e == hipSuccess) e = grow(&s->d_boff, &s->boff_cap, (size_t)nblocks + 1);
+        if (e == hipSuccess && nin) e = hipMemcpyAsync(s->d_io, in, nin * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && nout)
+            e = hipMemcpyAsync(s->d_io + nin, out, nout * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return GC_E_HIP;
+        a.gw = circ->d_gwires;
+        a.ops = circ->d_ops;
+        a.row_of_gate = circ->d_row_of_gate;
+        a.in = s->d_io;
+        a.out = s->d_io + nin;
+        a.ngates = ngates;
+        a.first_tmp = first_tmp;
+        a.first_out = first_out;
+        hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff);
+        hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, st, s->d_boff, nblocks);
+        e = hipMemcpyAsync(&need, s->d_boff + nblocks, sizeof(need), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return GC_E_HIP;
+    }
+    *written = (size_t)need;
+    if (need > cap) return GC_E_ARG;
+
+    // (2) input labels through in[] (Get, :131-141); garble; outputs into the global store (Set, :143-157)
+    std::vector<gc_label> inl(nin), outl(std::max<uint32_t>(nout, 1));
     for (uint32_t i = 0; i < nin; i++) inl[i] = s->l0[in[i]];
-    std::vector<gc_label> slab(std::max<uint32_t>(p.info.slab_rows, 1)), outl(std::max<uint32_t>(nout, 1));
-    int rc = gc_garble_labels(circ, s->key.data(), s->key.size(), &s->r, inl.data(), slab.data(), outl.data());
+    gc_batch *b = nullptr;
+    int rc = gc_garble_labels_keep(circ, s->key.data(), s->key.size(), &s->r, inl.data(), outl.data(), &b);
     if (rc != GC_OK) return rc;
-    // Set (:143-157): circuit outputs land in the global store
     for (uint32_t j = 0; j < nout; j++) s->l0[out[j]] = outl[j];
 
-    // wire format (:391-446)
-    size_t pos = 0;
-    for (uint32_t i = 0; i < ngates; i++) {
-        const gc_gate &g = gates[i];
-        uint32_t ai, bi = 0, ci;
-        bool at = false, bt = false, ct = false;
-        auto get = [&](uint32_t w, uint32_t &idx, bool &tmp) {
-            if (w < first_tmp) idx = in[w];
-            else if (w >= first_out) idx = out[w - first_out];
-            else {
-                idx = w;
-                tmp = true;
-            }
-        };
-        if (g.op != GC_INV) get(g.in1, bi, bt);
-        get(g.in0, ai, at);
-        get(g.out, ci, ct);
-        uint8_t op = g.op;
-        if (at) op |= 0x80;
-        if (bt) op |= 0x40;
-        if (ct) op |= 0x20;
-        const int wc = g.op == GC_INV ? 2 : 3;
-        if (ai <= 0xffff && bi <= 0xffff && ci <= 0xffff) {
-            buf[pos++] = op | 0x10;
-            buf[pos++] = (uint8_t)(ai >> 8);
-            buf[pos++] = (uint8_t)ai;
-            if (wc == 3) {
-                buf[pos++] = (uint8_t)(bi >> 8);
-                buf[pos++] = (uint8_t)bi;
-            }
-            buf[pos++] = (uint8_t)(ci >> 8);
-            buf[pos++] = (uint8_t)ci;
-        } else {
-            buf[pos++] = op;
-            auto p32 = [&](uint32_t v) {
-                buf[pos++] = (uint8_t)(v >> 24);
-                buf[pos++] = (uint8_t)(v >> 16);
-                buf[pos++] = (uint8_t)(v >> 8);
-                buf[pos++] = (uint8_t)v;
-            };
-            p32(ai);
-            if (wc == 3) p32(bi);
-            p32(ci);
+    // (3) wire format (:391-446) written by the device at the scanned offsets, one copy into the caller's buffer
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipError_t e = grow(&s->d_bytes, &s->bytes_cap, (size_t)need);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff, b->d_T, b->g.lt, s->d_bytes);
+            e = hipMemcpyAsync(buf, s->d_bytes, (size_t)need, hipMemcpyDeviceToHost, st);
         }
-        const uint32_t r0 = p.row_of_gate[i], r1 = p.row_of_gate[i + 1];
-        for (uint32_t r = r0; r < r1; r++) {  // Label.Bytes: BE(D0) || BE(D1)
-            put_be64(buf + pos, slab[r].d0);
-            put_be64(buf + pos + 8, slab[r].d1);
-            pos += 16;
-        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = GC_E_HIP;
     }
-    return pos == need ? GC_OK : GC_E_ARG;
+    gc_circ_release_batch(circ, b);
+    return rc;
 }
 
 // ---- streaming evaluator ----------------------------------------------------------------

@@ -462,7 +462,10 @@ class Stream:
         g = np.ascontiguousarray(gates, dtype=GATE)
         i = np.ascontiguousarray(in_, dtype=np.uint32)
         o = np.ascontiguousarray(out_, dtype=np.uint32)
-        buf = np.zeros(len(g) * 61 + 16, np.uint8)
+        need = len(g) * 61 + 16  # upper bound: 13 header bytes + 3 rows per gate
+        buf = getattr(self, "_buf", None)
+        if buf is None or len(buf) < need:  # reused across calls: a fresh 8 MB array per step costs more than the step
+            buf = self._buf = np.empty(need + need // 2, np.uint8)
         n = C.c_size_t(0)
         _check(lib().gc_stream_garble(self.h, _p(g), len(g), nwires, _p(i), len(i), _p(o), len(o), _p(buf), len(buf),
                                       C.byref(n)), "gc_stream_garble")
