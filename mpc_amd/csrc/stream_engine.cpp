@@ -365,8 +365,12 @@ struct gc_stream_eval {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
     std::vector<gc_label> wires;  // StreamEval.wires (global store)
-    std::vector<gc_label> tmp;    // StreamEval.tmp
     std::unordered_map<uint64_t, gc_circ *> cache;
+    // per-circuit scratch, kept across calls: last writer of every tmp / global wire with a generation stamp
+    std::vector<uint32_t> cur_t, stamp_t, cur_w, stamp_w;
+    uint32_t gen = 0;
+    std::vector<gc_gate> gates;
+    std::vector<gc_label> slab;
 };
 
 extern "C" {
@@ -409,17 +413,33 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                            size_t len, size_t *consumed) {
     if (!e || (!buf && len) || !consumed) return GC_E_ARG;
     if (e->wires.size() < nwires) e->wires.resize(nwires, gc_label{0, 0});  // InitCircuit(numWires, numTmpWires)
-    if (e->tmp.size() < ntmp) e->tmp.assign(ntmp, gc_label{0, 0});
     *consumed = 0;
     if (ngates == 0) return GC_OK;
-    // parse the gate stream (stream_evaluator.go:272-345) into an SSA gate list:
-    //   ids [0, nin) = wires read before this circuit writes them (in order of first use), nin + g = output of gate g
+    // Parse the gate stream (stream_evaluator.go:272-345) into an SSA gate list.  Wire ids of the device circuit:
+    //   [0, nin)            wires read before this circuit writes them, in order of first use
+    //   then one id per gate: first the gates that write a tmp wire, last the gates that write a global wire —
+    //   those are the circuit's outputs and the only labels that come back (streaming.Set, :346-432).
+    // "Who wrote (tmp, idx) last" is an array look-up with a generation stamp (no clearing between circuits).
+    // A tmp wire is private to its OpCircuit block (stream_garble.go:131-157 gives every non-input, non-output
+    // wire of the circuit a tmp id, written by a gate before any gate reads it): a block that reads a tmp it has
+    // not written is rejected instead of evaluated on a stale label.
     struct Ref { bool tmp; uint32_t idx; };
-    std::vector<gc_gate> gates(ngates);
+    if (e->stamp_t.size() < ntmp) {
+        e->stamp_t.resize(ntmp, 0);
+        e->cur_t.resize(ntmp, 0);
+    }
+    if (++e->gen == 0) {  // stamp wrap-around
+        std::fill(e->stamp_t.begin(), e->stamp_t.end(), 0);
+        std::fill(e->stamp_w.begin(), e->stamp_w.end(), 0);
+        e->gen = 1;
+    }
+    const uint32_t gen = e->gen;
+    std::vector<gc_gate> &gates = e->gates;
+    std::vector<gc_label> &slab = e->slab;
+    gates.resize(ngates);
+    slab.clear();
     std::vector<Ref> dst(ngates), inputs;
-    std::vector<gc_label> slab;
-    std::unordered_map<uint64_t, uint32_t> cur;  // (tmp, idx) -> current id; inputs get 0x80000000|k until numbered
-    auto keyof = [](bool t, uint32_t i) { return ((uint64_t)(t ? 1 : 0) << 32) | i; };
+    uint32_t n_global = 0;
     size_t pos = 0;
     for (uint32_t g = 0; g < ngates; g++) {
         if (pos + 1 > len) return GC_E_ROWS;
@@ -428,76 +448,98 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         gop &= 0x0f;
         if (gop > GC_INV) return GC_E_GATE;  // "invalid operation"
         const int nw = gop == GC_INV ? 2 : 3;
+        const size_t sz = shortf ? 2 : 4;
+        const uint32_t rows = gop == GC_AND ? 2 : gop == GC_OR ? 3 : gop == GC_INV ? 1 : 0;
+        if (pos + sz * nw + 16 * (size_t)rows > len) return GC_E_ROWS;
         uint32_t w[3] = {0, 0, 0};
         for (int i = 0; i < nw; i++) {
-            const size_t sz = shortf ? 2 : 4;
-            if (pos + sz > len) return GC_E_ROWS;
             for (size_t b = 0; b < sz; b++) w[i] = (w[i] << 8) | buf[pos + b];
             pos += sz;
         }
-        const uint32_t rows = gop == GC_AND ? 2 : gop == GC_OR ? 3 : gop == GC_INV ? 1 : 0;
         for (uint32_t r = 0; r < rows; r++) {
-            if (pos + 16 > len) return GC_E_ROWS;
             slab.push_back(gc_label{be64(buf + pos), be64(buf + pos + 8)});
             pos += 16;
         }
-        auto use = [&](bool t, uint32_t idx) -> uint32_t {
-            auto it = cur.find(keyof(t, idx));
-            if (it != cur.end()) return it->second;
+        int err = GC_OK;
+        auto use = [&](bool t, uint32_t idx) -> uint32_t {  // current id of a wire; bit 31: a circuit input
+            if (t) {
+                if (idx >= ntmp || e->stamp_t[idx] != gen) {
+                    err = GC_E_ARG;
+                    return 0;
+                }
+                return e->cur_t[idx];
+            }
+            if (idx >= e->stamp_w.size()) {
+                e->stamp_w.resize((size_t)idx + 1 + e->stamp_w.size() / 2, 0);
+                e->cur_w.resize(e->stamp_w.size(), 0);
+            }
+            if (e->stamp_w[idx] == gen) return e->cur_w[idx];
             const uint32_t id = 0x80000000u | (uint32_t)inputs.size();
-            inputs.push_back(Ref{t, idx});
-            cur.emplace(keyof(t, idx), id);
+            inputs.push_back(Ref{false, idx});
+            e->stamp_w[idx] = gen;
+            e->cur_w[idx] = id;
             return id;
         };
         gates[g].in0 = use(at, w[0]);
         gates[g].in1 = nw == 3 ? use(bt, w[1]) : gates[g].in0;
+        if (err != GC_OK) return err;
         gates[g].op = gop;
         gates[g].level = 0;
-        dst[g] = Ref{ct, w[nw - 1]};
-        cur[keyof(ct, w[nw - 1])] = g;  // gate index for now; renumbered below
-        gates[g].out = g;
+        const uint32_t ci = w[nw - 1];
+        dst[g] = Ref{ct, ci};
+        if (ct) {
+            if (ci >= ntmp) return GC_E_ARG;
+            e->stamp_t[ci] = gen;
+            e->cur_t[ci] = g;
+        } else {
+            if (ci >= e->stamp_w.size()) {
+                e->stamp_w.resize((size_t)ci + 1 + e->stamp_w.size() / 2, 0);
+                e->cur_w.resize(e->stamp_w.size(), 0);
+            }
+            e->stamp_w[ci] = gen;
+            e->cur_w[ci] = g;
+            n_global++;
+        }
+        gates[g].out = g;  // gate index for now; numbered below
     }
-    const uint32_t nin = (uint32_t)inputs.size();
-    for (uint32_t g = 0; g < ngates; g++) {
-        auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : nin + v; };
-        gates[g].in0 = fix(gates[g].in0);
-        gates[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
-        gates[g].out = nin + g;
+    const uint32_t nin = (uint32_t)inputs.size(), nout = n_global, n_tmp = ngates - n_global;
+    {
+        std::vector<uint32_t> id_of(ngates);
+        uint32_t kt = 0, kg = 0;
+        for (uint32_t g = 0; g < ngates; g++) id_of[g] = dst[g].tmp ? nin + kt++ : nin + n_tmp + kg++;
+        for (uint32_t g = 0; g < ngates; g++) {
+            auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : id_of[v]; };
+            gates[g].in0 = fix(gates[g].in0);
+            gates[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
+            gates[g].out = id_of[g];
+        }
     }
     const uint32_t cw = nin + ngates;
     // device circuit, cached by content
-    const uint64_t h = circuit_hash(gates.data(), ngates, cw, nin, 0);
+    const uint64_t h = circuit_hash(gates.data(), ngates, cw, nin, nout);
     gc_circ *circ = nullptr;
     auto it = e->cache.find(h);
     if (it != e->cache.end()) circ = it->second;
     else {
         int st = GC_OK;
-        circ = gc_circ_load(e->ctx, gates.data(), ngates, cw, nin, 0, &st);
+        circ = gc_circ_load(e->ctx, gates.data(), ngates, cw, nin, nout, &st);
         if (!circ) return st;
         e->cache.emplace(h, circ);
     }
-    std::vector<gc_label> wl(cw, gc_label{0, 0});
+    std::vector<gc_label> inl(std::max<uint32_t>(nin, 1)), outl(std::max<uint32_t>(nout, 1));
     for (uint32_t i = 0; i < nin; i++) {
         const Ref &r = inputs[i];
-        if (r.tmp) {
-            if (r.idx >= e->tmp.size()) return GC_E_ARG;
-            wl[i] = e->tmp[r.idx];
-        } else {
-            if (r.idx >= e->wires.size()) e->wires.resize((size_t)r.idx + 1, gc_label{0, 0});
-            wl[i] = e->wires[r.idx];
-        }
+        if (r.idx >= e->wires.size()) e->wires.resize((size_t)r.idx + 1, gc_label{0, 0});
+        inl[i] = e->wires[r.idx];
     }
-    int rc = gc_eval(circ, e->key.data(), e->key.size(), 1, wl.data(), nullptr, slab.data(), slab.size(), nullptr);
+    int rc = gc_eval(circ, e->key.data(), e->key.size(), 1, nullptr, inl.data(), slab.data(), slab.size(), outl.data());
     if (rc != GC_OK) return rc;
-    for (uint32_t g = 0; g < ngates; g++) {  // streaming.Set(cTmp, cIndex, output), in gate order
+    uint32_t k = 0;
+    for (uint32_t g = 0; g < ngates; g++) {  // streaming.Set(cTmp, cIndex, output) of the global wires, in gate order
         const Ref &d = dst[g];
-        if (d.tmp) {
-            if (d.idx >= e->tmp.size()) return GC_E_ARG;
-            e->tmp[d.idx] = wl[nin + g];
-        } else {
-            if (d.idx >= e->wires.size()) e->wires.resize((size_t)d.idx + 1, gc_label{0, 0});
-            e->wires[d.idx] = wl[nin + g];
-        }
+        if (d.tmp) continue;
+        if (d.idx >= e->wires.size()) e->wires.resize((size_t)d.idx + 1, gc_label{0, 0});
+        e->wires[d.idx] = outl[k++];
     }
     *consumed = pos;
     return GC_OK;

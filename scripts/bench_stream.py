@@ -29,7 +29,7 @@ def make_steps(nsteps, levels, width, and_frac, nin=256):
     return steps
 
 
-def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(range(32)), ctx=None):
+def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(range(32)), ctx=None, evaluate=True):
     per = levels * width
     nsteps = max(1, total_gates // per)
     nin = 256
@@ -43,6 +43,12 @@ def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(
     if own:
         ctx = engine.Context(0)
     g = engine.Stream(ctx, key, rnd, prim)
+    ev = engine.StreamEval(ctx, key) if evaluate else None
+    if ev is not None:  # the evaluator's input labels: all-zero inputs
+        for w in prim:
+            wire = g.get(w)
+            ev.set(w, (int(wire["l0"]["d0"]), int(wire["l0"]["d1"])))
+    etimes = []
     h = hashlib.sha256()
     nbytes = 0
     # the clock runs around the garble calls only (hashing the stream for the parity check is not part of the path);
@@ -55,6 +61,18 @@ def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(
         times.append(time.perf_counter() - t0)
         h.update(data)
         nbytes += len(data)
+        if ev is not None:
+            nw = max(max(in_), max(out_)) + 1
+            t0 = time.perf_counter()
+            used = ev.circuit(c.NumGates, c.NumWires, nw, data)
+            etimes.append(time.perf_counter() - t0)
+            assert used == len(data)
+    if ev is not None:  # the last step's outputs must be valid labels of the garbler's wires
+        for o in steps[-1][2][:8]:
+            wire = g.get(o)
+            got = ev.get(o)
+            assert got in ((int(wire["l0"]["d0"]), int(wire["l0"]["d1"])), (int(wire["l1"]["d0"]), int(wire["l1"]["d1"])))
+        ev.close()
     gates = sum(c.NumGates for c, _, _ in steps)
     ands = sum(c.stats()["AND"] for c, _, _ in steps)
     g.close()
@@ -71,6 +89,10 @@ def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(
         res["steady_ms_per_step"] = sdt / len(steady) * 1e3
         res["steady_gates_per_s"] = per_step_gates * len(steady) / sdt
         res["first_use_ms_per_circuit"] = sum(times[:ndistinct]) / ndistinct * 1e3
+    if etimes[ndistinct:]:
+        sdt = sum(etimes[ndistinct:])
+        res["eval_steady_ms_per_step"] = sdt / len(etimes[ndistinct:]) * 1e3
+        res["eval_steady_gates_per_s"] = per_step_gates * len(etimes[ndistinct:]) / sdt
     return res
 
 

@@ -41,6 +41,17 @@ def test_stream_errors():
     with pytest.raises(engine.EngineError) as e:
         engine.Stream(ctx, bytes(16), drbg("r", 16 * len(prim)), prim)
     assert e.value.code == engine.GC_E_RAND
+    # evaluator: a block that reads a tmp wire before writing it is rejected (a tmp is private to its OpCircuit
+    # block, stream_garble.go:131-157), and so is an unknown operation
+    ge = engine.StreamEval(ctx, bytes(16))
+    ge.set(0, (1, 2))
+    with pytest.raises(engine.EngineError) as e:
+        ge.circuit(1, 4, 4, bytes([0x90, 0, 0, 0, 0, 0, 1]))
+    assert e.value.code == engine.GC_E_ARG
+    with pytest.raises(engine.EngineError) as e:
+        ge.circuit(1, 4, 4, bytes([0x10 | 9, 0, 0, 0, 0, 0, 1]))
+    assert e.value.code == engine.GC_E_GATE
+    ge.close()
     ctx.close()
 
 
