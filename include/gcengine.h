@@ -195,7 +195,8 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *, const uint8_t *key, size_t keyle
 void gc_stream_eval_free(gc_stream_eval *);
 int gc_stream_eval_set_wire(gc_stream_eval *, uint32_t w, const gc_label *l); /* input labels (OT results etc.) */
 int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /* OpReturn / OpResult reads */
-/* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream */
+/* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream,
+ * GC_E_ARG a tmp wire read before this block wrote it (tmp wires are private to their OpCircuit block) */
 int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
                            size_t len, size_t *consumed);
 
