@@ -196,7 +196,7 @@ def main():
         elapsed = float(t.item())
 
     # per-pass device times (events on the engine stream) from a few extra, untimed-by-wall steps
-    for _ in range(min(5, max(1, args.steps))):
+    for _ in range(min(20, max(1, args.steps))):
         gb.garble(key, d_rnd.data_ptr())
         g_ms.append(gb.last_ms)
         ev.select_inputs(gb, d_bits.data_ptr())
