@@ -117,3 +117,36 @@ def test_stream_large_chained_program_matches_oracle():
     assert sum(c.NumGates for c, _, _ in steps) == 5 * 16 * 1024
     gg.close()
     ctx.close()
+
+
+def test_stream_million_gate_step_matches_oracle():
+    """one step of more than 2^20 gates: the device serialiser's block scan then runs more than one block per
+    thread (k_ser_scan), and the evaluator renames > 10^6 wires; wire ids above 0xffff (long form) and below mix"""
+    import hashlib
+    from scripts.bench_stream import make_steps
+    ctx = engine.Context(0)
+    nin = 256
+    steps = make_steps(1, 68, 16384, 0.2, nin)
+    c, in_, out_ = steps[0]
+    assert c.NumGates > (1 << 20)
+    in_ = [0x10000 - 128 + i for i in range(nin)]  # half of the input ids take the long form
+    prim = list(in_)
+    key = drbg("mstream", 16)
+    rnd = drbg("mstream-rnd", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = og.garble(c.Gates, c.NumWires, in_, out_)
+    got = gg.garble(c.Gates, c.NumWires, in_, out_)
+    assert len(got) == len(want)
+    assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+    # and the evaluator on that stream against the oracle's evaluator
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    for w in prim:
+        lab = gg.get(w)["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    nw = max(max(in_), max(out_)) + 1
+    assert ge.circuit(c.NumGates, c.NumWires, nw, got) == len(got)
+    assert oe.circuit(c.NumGates, c.NumWires, nw, want) == len(want)
+    for o in out_:
+        assert ge.get(o) == oe.get(o)
+    gg.close(); ge.close(); ctx.close()
