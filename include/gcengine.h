@@ -350,6 +350,14 @@ int gc_kos_receiver_tags(gc_ctx *, const gc_label *seed2, const gc_label *result
 int gc_kos_sender_check(gc_ctx *, const gc_label *seed2, const gc_label *result, size_t n,
                         const gc_label *choice_vec /*256*/, const gc_label *delta, const gc_label *x,
                         const gc_label *t0, const gc_label *t1, int *ok);
+/* the same two checks over labels (and the receiver's choice bytes) that are already in HBM — the outputs of
+ * gc_iknp_receive_dev / gc_iknp_send_dev; d_result [n] gc_label, d_b [n] bytes are DEVICE pointers (additive) */
+int gc_kos_receiver_tags_dev(gc_ctx *, const gc_label *seed2, const void *d_result, const void *d_b, size_t n,
+                             const gc_label *choice_vec, const uint8_t *bcv /*256*/, gc_label *x, gc_label *t0,
+                             gc_label *t1);
+int gc_kos_sender_check_dev(gc_ctx *, const gc_label *seed2, const void *d_result, size_t n,
+                            const gc_label *choice_vec /*256*/, const gc_label *delta, const gc_label *x,
+                            const gc_label *t0, const gc_label *t1, int *ok);
 
 /* Replaces (*MITCCRH).Hash over a whole COT/ROT run (mitccrh.go:93-128 as driven by cot.go:160-171,
  * 203-211): OT j (key index gid0+j, key = BE(Label{D0:gid,D1:0} ^ seed)) hashes its h consecutive

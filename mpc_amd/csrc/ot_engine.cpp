@@ -275,31 +275,87 @@ static void host_clmul128(const gc_label &a, const gc_label &b, uint64_t out[4])
 }
 
 // acc[6] <- sums over (result, b) then (choice_vec, bcv); shared by both roles
-static int kos_sums(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
-                    const gc_label *choice_vec, const uint8_t *bcv, uint64_t acc[6]) {
+// chi-PRG + inner products over labels that are ALREADY on the device (d_res [n], d_bits [n] or null) plus the 256-label
+// choice vector from the host: two launches into one accumulator — chi labels are consecutive in the stream, results
+// first (counter 0..n-1), then the choice vector (n..n+255) (iknp.go:159-174)
+static int kos_sums_dev(gc_ctx *ctx, const gc_label *seed2, const uint4 *d_res, const uint8_t *d_bits, size_t n,
+                        const gc_label *choice_vec, const uint8_t *bcv, uint64_t acc[6]) {
     GC_HIP(hipSetDevice(ctx->device));
     uint32_t rk[44];
     expand_label_key(*seed2, rk);  // newPrg(seed2) (iknp.go:150, 411)
-    DevBuf d_rk, d_v, d_b, d_acc;
-    const size_t m = n + 256;
+    DevBuf d_rk, d_cv, d_cb, d_zero, d_acc;
     GC_HIP(d_rk.alloc(sizeof rk));
-    GC_HIP(d_v.alloc(m * sizeof(uint4)));
-    GC_HIP(d_b.alloc(m));
+    GC_HIP(d_cv.alloc(256 * sizeof(uint4)));
+    GC_HIP(d_cb.alloc(256));
     GC_HIP(d_acc.alloc(6 * sizeof(uint64_t)));
     hipStream_t s = ctx->stream;
     GC_HIP(hipMemcpyAsync(d_rk.p, rk, sizeof rk, hipMemcpyHostToDevice, s));
-    if (n) GC_HIP(hipMemcpyAsync(d_v.p, result, n * sizeof(uint4), hipMemcpyHostToDevice, s));
-    GC_HIP(hipMemcpyAsync((uint4 *)d_v.p + n, choice_vec, 256 * sizeof(uint4), hipMemcpyHostToDevice, s));
-    GC_HIP(hipMemsetAsync(d_b.p, 0, m, s));
-    if (b && n) GC_HIP(hipMemcpyAsync(d_b.p, b, n, hipMemcpyHostToDevice, s));
-    if (bcv) GC_HIP(hipMemcpyAsync((uint8_t *)d_b.p + n, bcv, 256, hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemcpyAsync(d_cv.p, choice_vec, 256 * sizeof(uint4), hipMemcpyHostToDevice, s));
+    GC_HIP(hipMemsetAsync(d_cb.p, 0, 256, s));
+    if (bcv) GC_HIP(hipMemcpyAsync(d_cb.p, bcv, 256, hipMemcpyHostToDevice, s));
+    if (n && !d_bits) {  // the sender has no choice bits: x is not used, feed zeros
+        GC_HIP(d_zero.alloc(n));
+        GC_HIP(hipMemsetAsync(d_zero.p, 0, n, s));
+        d_bits = (const uint8_t *)d_zero.p;
+    }
     GC_HIP(hipMemsetAsync(d_acc.p, 0, 6 * sizeof(uint64_t), s));
-    // chi labels are consecutive in the stream: results first, then the choice vector (iknp.go:159-174)
-    launch_kos_accumulate((const uint32_t *)d_rk.p, 0, (const uint4 *)d_v.p, (const uint8_t *)d_b.p, m,
+    launch_kos_accumulate((const uint32_t *)d_rk.p, 0, d_res, d_bits, n, (unsigned long long *)d_acc.p, ctx->d_te0, s);
+    launch_kos_accumulate((const uint32_t *)d_rk.p, n, (const uint4 *)d_cv.p, (const uint8_t *)d_cb.p, 256,
                           (unsigned long long *)d_acc.p, ctx->d_te0, s);
     GC_HIP(hipGetLastError());
     GC_HIP(hipMemcpyAsync(acc, d_acc.p, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
+    return GC_OK;
+}
+
+// host-buffer form: stage the labels (and choice bits), then as above
+static int kos_sums(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
+                    const gc_label *choice_vec, const uint8_t *bcv, uint64_t acc[6]) {
+    GC_HIP(hipSetDevice(ctx->device));
+    DevBuf d_v, d_b;
+    hipStream_t s = ctx->stream;
+    if (n) {
+        GC_HIP(d_v.alloc(n * sizeof(uint4)));
+        GC_HIP(hipMemcpyAsync(d_v.p, result, n * sizeof(uint4), hipMemcpyHostToDevice, s));
+        if (b) {
+            GC_HIP(d_b.alloc(n));
+            GC_HIP(hipMemcpyAsync(d_b.p, b, n, hipMemcpyHostToDevice, s));
+        }
+    }
+    return kos_sums_dev(ctx, seed2, (const uint4 *)d_v.p, b ? (const uint8_t *)d_b.p : nullptr, n, choice_vec, bcv, acc);
+}
+
+static int kos_finish_sender(const uint64_t acc[6], const gc_label *delta, const gc_label *x, const gc_label *t0,
+                             const gc_label *t1) {
+    uint64_t r[4];
+    host_clmul128(*x, *delta, r);  // mul128(x, s.Delta) (iknp.go:186)
+    return (acc[0] ^ r[0]) == t0->d0 && (acc[1] ^ r[1]) == t0->d1 && (acc[2] ^ r[2]) == t1->d0 &&
+           (acc[3] ^ r[3]) == t1->d1;
+}
+
+// device-resident forms: the labels gc_iknp_receive_dev / gc_iknp_send_dev left in HBM are checked where they are
+int gc_kos_receiver_tags_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_result, const void *d_b, size_t n,
+                             const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) {
+    if (!ctx || !seed2 || !choice_vec || !bcv || !x || !t0 || !t1 || (n && (!d_result || !d_b))) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint64_t acc[6];
+    int rc = kos_sums_dev(ctx, seed2, (const uint4 *)d_result, (const uint8_t *)d_b, n, choice_vec, bcv, acc);
+    if (rc != GC_OK) return rc;
+    *t0 = gc_label{acc[0], acc[1]};
+    *t1 = gc_label{acc[2], acc[3]};
+    *x = gc_label{acc[4], acc[5]};
+    return GC_OK;
+}
+
+int gc_kos_sender_check_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_result, size_t n,
+                            const gc_label *choice_vec, const gc_label *delta, const gc_label *x, const gc_label *t0,
+                            const gc_label *t1, int *ok) {
+    if (!ctx || !seed2 || !choice_vec || !delta || !x || !t0 || !t1 || !ok || (n && !d_result)) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    uint64_t acc[6];
+    int rc = kos_sums_dev(ctx, seed2, (const uint4 *)d_result, nullptr, n, choice_vec, nullptr, acc);
+    if (rc != GC_OK) return rc;
+    *ok = kos_finish_sender(acc, delta, x, t0, t1);
     return GC_OK;
 }
 
@@ -324,10 +380,7 @@ int gc_kos_sender_check(gc_ctx *ctx, const gc_label *seed2, const gc_label *resu
     uint64_t acc[6];
     int rc = kos_sums(ctx, seed2, result, nullptr, n, choice_vec, nullptr, acc);
     if (rc != GC_OK) return rc;
-    uint64_t r[4];
-    host_clmul128(*x, *delta, r);  // mul128(x, s.Delta) (iknp.go:186)
-    *ok = (acc[0] ^ r[0]) == t0->d0 && (acc[1] ^ r[1]) == t0->d1 && (acc[2] ^ r[2]) == t1->d0 &&
-          (acc[3] ^ r[3]) == t1->d1;
+    *ok = kos_finish_sender(acc, delta, x, t0, t1);
     return GC_OK;
 }
 

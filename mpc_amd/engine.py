@@ -142,6 +142,8 @@ def lib():
         "gc_iknp_send_bits": (i32, [vp, vp, sz, sz, vp]),
         "gc_kos_receiver_tags": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "gc_kos_sender_check": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp, ip]),
+        "gc_kos_receiver_tags_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
+        "gc_kos_sender_check_dev": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp, ip]),
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
@@ -640,6 +642,25 @@ def kos_receiver_tags(ctx, seed2, result, b, choice_vec, bcv):
                                       len(r), _p(cv), _p(bc), _p(x), _p(t0), _p(t1)), "gc_kos_receiver_tags")
     f = lambda a: (int(a[0]["d0"]), int(a[0]["d1"]))
     return f(x), f(t0), f(t1)
+
+
+def kos_receiver_tags_dev(ctx, seed2, d_result, d_b, n, choice_vec, bcv):
+    """as kos_receiver_tags with the n labels / choice bytes in HBM (device pointers)"""
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    bc = np.ascontiguousarray(bcv, dtype=np.uint8)
+    x, t0, t1 = np.zeros(1, LABEL), np.zeros(1, LABEL), np.zeros(1, LABEL)
+    _check(lib().gc_kos_receiver_tags_dev(ctx.h, _p(_lab1(seed2)), C.c_void_p(d_result), C.c_void_p(d_b), n, _p(cv), _p(bc),
+                                          _p(x), _p(t0), _p(t1)), "gc_kos_receiver_tags_dev")
+    f = lambda a: (int(a[0]["d0"]), int(a[0]["d1"]))
+    return f(x), f(t0), f(t1)
+
+
+def kos_sender_check_dev(ctx, seed2, d_result, n, choice_vec, delta, x, t0, t1):
+    cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
+    ok = C.c_int(0)
+    _check(lib().gc_kos_sender_check_dev(ctx.h, _p(_lab1(seed2)), C.c_void_p(d_result), n, _p(cv), _p(_lab1(delta)),
+                                         _p(_lab1(x)), _p(_lab1(t0)), _p(_lab1(t1)), C.byref(ok)), "gc_kos_sender_check_dev")
+    return bool(ok.value)
 
 
 def kos_sender_check(ctx, seed2, result, choice_vec, delta, x, t0, t1):

@@ -144,6 +144,15 @@ def test_kos_check_matches_oracle(ctx, n):
         bad = sent.copy()
         bad[n // 2]["d1"] ^= 1 << 40
         assert not engine.kos_sender_check(ctx, seed2, bad, cvs, delta, x, t0, t1)
+    # the device-resident forms: labels and choice bytes stay in HBM (what gc_iknp_*_dev leave there)
+    import torch
+    d_got = torch.from_numpy(np.ascontiguousarray(got).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8)).cuda()
+    d_sent = torch.from_numpy(np.ascontiguousarray(sent).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8)).cuda()
+    d_b = torch.from_numpy(b.copy() if n else np.zeros(1, np.uint8)).cuda()
+    torch.cuda.synchronize()
+    assert engine.kos_receiver_tags_dev(ctx, seed2, d_got.data_ptr(), d_b.data_ptr(), n, cvr, bcv) == want
+    assert engine.kos_sender_check_dev(ctx, seed2, d_sent.data_ptr(), n, cvs, delta, x, t0, t1)
+    assert not engine.kos_sender_check_dev(ctx, seed2, d_sent.data_ptr(), n, cvs, delta, x, t0, (t1[0], t1[1] ^ 2))
 
 
 @pytest.mark.parametrize("n", [64, 1024, 1000, 70, 513])
