@@ -89,17 +89,32 @@ __device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t key
                 s[n][c] = xor3(t[n][4 * c], t[n][4 * c + 1], kk[c]) ^ rotr32(t[n][4 * c + 2] ^ t[n][4 * c + 3], 8);
     }
     k = lds_ld4(keyaddr + 160u);
+    {   // last round as in aes_encrypt_dual: one batch of 16 lookups per block, bytes merged with three bit-selects
+        const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
+        uint32_t ad[N][16], t[N][16];
 #pragma unroll
-    for (int n = 0; n < N; n++) {
-        const uint32_t a0 = s[n][0], a1 = s[n][1], a2 = s[n][2], a3 = s[n][3];
-#define GC_LAST(c0, c1, c2, c3, key)                                                               \
-    (((te_dual(c0, sel3, lo2) & 0xff000000u) | (te_dual(c1, sel2, lo0) & 0x00ff0000u) |           \
-      (te_dual(c2, sel1, lo0) & 0x0000ff00u) | (te_dual(c3, sel0, lo2) & 0x000000ffu)) ^ (key))
-        s[n][0] = GC_LAST(a0, a1, a2, a3, k.x);
-        s[n][1] = GC_LAST(a1, a2, a3, a0, k.y);
-        s[n][2] = GC_LAST(a2, a3, a0, a1, k.z);
-        s[n][3] = GC_LAST(a3, a0, a1, a2, k.w);
-#undef GC_LAST
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                ad[n][4 * c + 0] = __builtin_amdgcn_perm(s[n][c], lo2, sel3);
+                ad[n][4 * c + 1] = __builtin_amdgcn_perm(s[n][(c + 1) & 3], lo0, sel2);
+                ad[n][4 * c + 2] = __builtin_amdgcn_perm(s[n][(c + 2) & 3], lo0, sel1);
+                ad[n][4 * c + 3] = __builtin_amdgcn_perm(s[n][(c + 3) & 3], lo2, sel0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) t[n][i] = *(lds_u32 *)(uintptr_t)ad[n][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {  // byte 3 of t0, byte 2 of t1, byte 1 of t2, byte 0 of t3 (0xCA = m ? a : b)
+                const uint32_t hi = __builtin_amdgcn_bitop3_b32(0xff000000u, t[n][4 * c], t[n][4 * c + 1], 0xCA);
+                const uint32_t lo = __builtin_amdgcn_bitop3_b32(0x0000ff00u, t[n][4 * c + 2], t[n][4 * c + 3], 0xCA);
+                s[n][c] = __builtin_amdgcn_bitop3_b32(0xffff0000u, hi, lo, 0xCA) ^ kk[c];
+            }
     }
 }
 
