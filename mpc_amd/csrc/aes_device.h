@@ -352,6 +352,48 @@ __device__ __forceinline__ uint4 hash_dual_whitened(const uint32_t (&s0)[4], con
     return make_uint4(s[0][1], s[0][0], s[0][3], s[0][2]);
 }
 
+// ---- column-sliced form: the four lanes of a quad hold the four state columns of ONE block ----------------------
+// For hash phases with so little work that the phase IS the latency of a lone wave's AES (deep, narrow circuits:
+// sha256xor x 256 has ~13 ANDs per phase; a chain of ANDs has one): a lane looks up the four bytes of ITS column and
+// the quad exchanges the table values with DPP quad permutes (fused into the XORs) — 4 look-ups + 10 VALU per round
+// and lane instead of 16 + 32, four times the lanes.  Round keys come from LDS (keyaddr = byte address of word
+// [round 0][column of this lane], 16 bytes per round; the last round key is folded, fold_last_round_key).
+// s0 = the lane's column of K ^ rk_0; returns the lane's column of pi(K) ^ K.
+constexpr int GC_QROT1 = 0x39;  // quad_perm [1,2,3,0]: value of the next column's lane
+constexpr int GC_QROT2 = 0x4E;  // [2,3,0,1]
+constexpr int GC_QROT3 = 0x93;  // [3,0,1,2]
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_from(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+template <int NR>
+__device__ __forceinline__ uint32_t hash_col_whitened(uint32_t s0, uint32_t keyaddr, uint32_t lo0) {
+    const uint32_t lo2 = lo0 + 128u;
+    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+    uint32_t s = s0;
+#pragma unroll
+    for (int r = 1; r < NR; r++) {
+        // column c: Te0[b3(a_c)] ^ Te1[b2(a_c+1)] ^ Te2[b1(a_c+2)] ^ Te3[b0(a_c+3)], Te1/Te3 = rotr8(Te0/Te2)
+        const uint32_t a0 = __builtin_amdgcn_perm(s, lo0, sel3), a1 = __builtin_amdgcn_perm(s, lo0, sel2);
+        const uint32_t a2 = __builtin_amdgcn_perm(s, lo2, sel1), a3 = __builtin_amdgcn_perm(s, lo2, sel0);
+        const uint32_t A = *(lds_u32 *)(uintptr_t)a0, B = *(lds_u32 *)(uintptr_t)a1;
+        const uint32_t C = *(lds_u32 *)(uintptr_t)a2, D = *(lds_u32 *)(uintptr_t)a3;
+        const uint32_t k = *(lds_u32 *)(uintptr_t)(keyaddr + 16u * r);
+        const uint32_t x = (A ^ k) ^ quad_from<GC_QROT2>(C);
+        const uint32_t y = quad_from<GC_QROT1>(B) ^ quad_from<GC_QROT3>(D);
+        s = x ^ rotr32(y, 8);
+    }
+    // last round: byte 3 = S[b3(a_c)] (Te2), byte 2 = S[b2(a_c+1)] (Te0), byte 1 = S[b1(a_c+2)] (Te0), byte 0 (Te2)
+    const uint32_t a0 = __builtin_amdgcn_perm(s, lo2, sel3), a1 = __builtin_amdgcn_perm(s, lo0, sel2);
+    const uint32_t a2 = __builtin_amdgcn_perm(s, lo0, sel1), a3 = __builtin_amdgcn_perm(s, lo2, sel0);
+    const uint32_t A = *(lds_u32 *)(uintptr_t)a0, B = *(lds_u32 *)(uintptr_t)a1;
+    const uint32_t C = *(lds_u32 *)(uintptr_t)a2, D = *(lds_u32 *)(uintptr_t)a3;
+    const uint32_t k = *(lds_u32 *)(uintptr_t)(keyaddr + 16u * NR);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32(0xff000000u, A, quad_from<GC_QROT1>(B), 0xCA);
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32(0x0000ff00u, quad_from<GC_QROT2>(C), quad_from<GC_QROT3>(D), 0xCA);
+    return xor3(__builtin_amdgcn_bitop3_b32(0xffff0000u, hi, lo, 0xCA), k, s0);
+}
+
 // Hash inputs of encryptHalf (circuit/garble.go:104-136): K = 2x ^ i, i in the low 32 bits of D1
 __device__ __forceinline__ void make_k_half(uint4 x, uint32_t tweak, uint32_t (&k)[4]) {
     label_shl_cols<1>(x, k);

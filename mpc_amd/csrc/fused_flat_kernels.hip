@@ -84,7 +84,10 @@ __device__ __forceinline__ uint4 lxor3(uint4 a, uint4 b, uint4 c) {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr uint32_t kStageOff = kTeDualBytes / 16;
+// wide-form hash lanes up to which a unit takes the column-sliced form (4 x as many lanes: one pass of the workgroup)
+constexpr uint32_t kNarrowLanes = 256;
+constexpr uint32_t kKeyTab = kTeDualBytes;            // byte address of the round-key table of the column-sliced hashes
+constexpr uint32_t kStageOff = kTeDualBytes / 16 + 16;  // 256 bytes: 15 round keys x 4 columns
 
 #define GC_FPROF(slot)                                               \
     if constexpr (PROF) {                                            \
@@ -271,6 +274,116 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     }
 }
 
+// ---- hash part of a NARROW unit (no OR gate, at most 256 hash lanes): column-sliced ---------------------------
+// Every hash lane of the wide form becomes a quad (lane = 4 * wide lane + column): a lone wave's 14 AES rounds take
+// ~3.3 k cycles, the four quarter-waves of the column form ~2.2 k, and in such units that latency is the phase.  Same
+// arithmetic as the wide form, one 32-bit column per lane: label word W_c (big-endian column c) sits at dword c ^ 1.
+// Partner lanes of a gate are 4 (q ^ 1) and 8 (q ^ 2) lanes away: DPP row shifts / rotations inside the row of 16.
+__device__ __forceinline__ uint32_t lds_word(uint32_t addr) { return *(lds_u32 *)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_word_put(uint32_t addr, uint32_t v) {
+    *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)addr = v;
+}
+// value of the lane 4 further on (q even) / 4 back (q odd): the q ^ 1 partner
+__device__ __forceinline__ uint32_t pair4(uint32_t v) {
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);   // row_shl:4 -> banks 0, 2
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, 0x114, 0xf, 0xa, false);     // row_shr:4 -> banks 1, 3
+}
+// column c of K ^ rk_0 with K = 2x ^ tweak: (x_c << 1) | (x_c+1 >> 31), the tweak in column 3
+__device__ __forceinline__ uint32_t whiten_col(uint32_t xc, uint32_t xc1, uint32_t c, uint32_t tweak, uint32_t k0) {
+    const uint32_t kcol = __builtin_amdgcn_alignbit(xc, c == 3 ? 0u : xc1, 31);
+    return xor3(kcol, c == 3 ? tweak : 0u, k0);
+}
+
+template <int NR>
+__device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
+                                                   uint32_t tim, uint4 *wl, const uint4 *rl, uint4 *Tt, uint4 *Wt,
+                                                   uint32_t lo) {
+    const uint32_t TI = 1u << ti_log2;
+    const uint32_t e_all = hlanes<4, 4, 3>(u, ti_log2);
+    if (threadIdx.x >= e_all) return;
+    const HP hp = hpos<4, 4, 3, false>(threadIdx.x, u, ti_log2, tim);
+    const uint32_t c = hp.q & 3u, q = hp.q >> 2, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
+    const uint4 dv = buf[hp.g];
+    const FDesc d{dv.x, dv.y, dv.z, dv.w};
+    const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
+    const uint32_t ra = (uint32_t)(uintptr_t)rl + (inst << 4);
+    // the two operands' labels (an INV has one: its second slot field is not a slot)
+    const uint32_t sa = ((d.lin & 0xffffu) << sh) + ib, sb = hp.kind == 1 ? ((d.lin >> 16) << sh) + ib : sa;
+    const uint32_t so = (q & 2u) ? sb : sa;                                                // INV lanes have q < 2
+    const uint32_t keyaddr = kKeyTab + (c << 2);
+    // one LDS round trip: own operand (columns c, c+1), R (c, c+1), a0 column c, the two permute bits, round key 0
+    const uint32_t bc = lds_word(so + wo), bc1 = lds_word(so + (wo1 & 12u));
+    const uint32_t rc = lds_word(ra + wo), rc1 = lds_word(ra + (wo1 & 12u));
+    const uint32_t a0c = lds_word(sa + wo), a0y = lds_word(sa + 4), b0y = lds_word(sb + 4);
+    const uint32_t k0 = lds_word(keyaddr);
+    const uint32_t modd = (q & 1u) ? ~0u : 0u;
+    const uint32_t xc = __builtin_amdgcn_bitop3_b32(bc, rc, modd, 0x78), xc1 = __builtin_amdgcn_bitop3_b32(bc1, rc1, modd, 0x78);
+    const uint32_t h = hash_col_whitened<NR>(whiten_col(xc, xc1, c, d.tweak + (q >> 1), k0), keyaddr, lo);
+    const uint32_t rowb = ((((d.row_op & kRowMask) << ti_log2) + inst) << 4) + wo;
+    auto row = [&](uint32_t r) -> uint32_t & { return *(uint32_t *)((char *)Tt + (rowb + (r << 4))); };
+    auto put = [&](uint32_t v) {
+        if (q == 0) {
+            lds_word_put(((d.lout & 0xffffu) << sh) + ib + wo, v);
+            if (d.lout & kFStoreGlobal)
+                *(uint32_t *)((char *)(Wt + ((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst) + wo) = v;
+        }
+    };
+    const uint32_t p = h ^ pair4(h);
+    if (hp.kind == 1) {  // garble.go:353-395, one column
+        const uint32_t m2 = (q & 2u) ? ~0u : 0u;
+        const uint32_t pa = (uint32_t)((int32_t)a0y >> 31), pb = (uint32_t)((int32_t)b0y >> 31);
+        const uint32_t mk = m2 ? pb : pa, rm = pb & ~m2;
+        const uint32_t w = __builtin_amdgcn_bitop3_b32(p, rc, rm, 0x78);
+        const uint32_t tab = __builtin_amdgcn_bitop3_b32(w, a0c, m2, 0x78);
+        const uint32_t v = __builtin_amdgcn_bitop3_b32(h, w, mk, 0x78);
+        if (!(q & 1u)) row((q & 2u) ? TI : 0) = tab;
+        // the q ^ 2 partner is 8 lanes away: a rotation of the row by 8
+        uint32_t o = v ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);
+        asm volatile("" : "+v"(o));
+        put(o);
+    } else {  // INV, garble.go:446-474
+        if (q == 0) row(0) = p ^ rc;
+        put(h ^ (((int32_t)a0y < 0) ? p : rc));
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
+                                                 uint32_t tim, uint4 *wl, const uint4 *Tt, uint4 *Wt, uint32_t lo) {
+    const uint32_t TI = 1u << ti_log2;
+    const uint32_t e_all = hlanes<3, 2, 2>(u, ti_log2);
+    if (threadIdx.x >= e_all) return;
+    const HP hp = hpos<3, 2, 2, false>(threadIdx.x, u, ti_log2, tim);
+    const uint32_t c = hp.q & 3u, q = hp.q >> 2, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
+    const uint4 dv = buf[hp.g];
+    const FDesc d{dv.x, dv.y, dv.z, dv.w};
+    const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
+    const uint32_t sa = ((d.lin & 0xffffu) << sh) + ib, sb = hp.kind == 1 ? ((d.lin >> 16) << sh) + ib : sa;
+    const uint32_t so = q ? sb : sa;  // AND lane 1 hashes operand b (INV: q = 0)
+    const uint32_t keyaddr = kKeyTab + (c << 2);
+    const uint32_t rowb = ((((d.row_op & kRowMask) << ti_log2) + inst) << 4) + wo;
+    const uint32_t tab = *(const uint32_t *)((const char *)Tt + (rowb + ((q ? TI : 0u) << 4)));  // lands during the AES
+    const uint32_t xc = lds_word(so + wo), xc1 = lds_word(so + (wo1 & 12u)), xy = lds_word(so + 4);
+    const uint32_t ac = lds_word(sa + wo), k0 = lds_word(keyaddr);
+    const uint32_t h = hash_col_whitened<NR>(whiten_col(xc, xc1, c, d.tweak + q, k0), keyaddr, lo);
+    const uint32_t sm = (uint32_t)((int32_t)xy >> 31);
+    auto put = [&](uint32_t v) {
+        if (q == 0) {
+            lds_word_put(((d.lout & 0xffffu) << sh) + ib + wo, v);
+            if (d.lout & kFStoreGlobal)
+                *(uint32_t *)((char *)(Wt + ((size_t)a.hgslot[u.hfirst + hp.g] << ti_log2) + inst) + wo) = v;
+        }
+    };
+    if (hp.kind == 1) {  // eval.go:53-78: lane 0 WG = H(a) ^ (sa ? TG : 0), lane 1 WE = H(b) ^ (sb ? TE ^ a : 0)
+        const uint32_t v = __builtin_amdgcn_bitop3_b32(h, __builtin_amdgcn_bitop3_b32(tab, ac, q ? ~0u : 0u, 0x78), sm, 0x78);
+        uint32_t o = v ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x104, 0xf, 0xf, true);  // + the lane 4 further on (q = 1)
+        asm volatile("" : "+v"(o));
+        put(o);
+    } else {  // eval.go:96-109
+        put(__builtin_amdgcn_bitop3_b32(h, tab, sm, 0x78));
+    }
+}
+
 #define GC_FL_PROLOGUE(LOAD_R)                                                                               \
     extern __shared__ uint4 smem[];                                                                          \
     uint32_t *te = (uint32_t *)smem;                                                                         \
@@ -285,6 +398,11 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
     load_round_keys_split<NR, (4 * (NR + 1) > 32 ? 4 * (NR + 1) - 32 : 4 * (NR + 1))>(rkr, a.rk, vz);        \
     fold_last_round_key<NR>(rkr); /* the hashes run on whitened blocks (hash_dual_whitened) */              \
+    if (threadIdx.x < 4 * (NR + 1)) { /* the same keys, column-addressable, for hash_col_whitened */          \
+        uint32_t kv = a.rk[threadIdx.x];                                                                     \
+        if (threadIdx.x >= 4 * NR) kv ^= a.rk[threadIdx.x - 4 * NR];                                         \
+        ((uint32_t *)smem)[kKeyTab / 4 + threadIdx.x] = kv;                                                  \
+    }                                                                                                        \
     uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
     if (threadIdx.x < TI) wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                   \
     if (LOAD_R && a.rnd) {                                                                                   \
@@ -337,7 +455,11 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
-        if (nh) {
+        // narrow units (no OR, one wave-SIMD pass of the wide form at most): the column-sliced form
+        const bool narrow = u.n_or == 0 && hlanes<2, 2, 1>(u, ti_log2) <= kNarrowLanes;
+        if (nh && narrow) {
+            garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo);
+        } else if (nh) {
             const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
         for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<2, 2, 1, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
@@ -440,7 +562,10 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
-        if (nh) {
+        const bool narrow = u.n_or == 0 && hlanes<1, 0, 0>(u, ti_log2) <= kNarrowLanes;
+        if (nh && narrow) {
+            eval_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo);
+        } else if (nh) {
             const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
         for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<1, 0, 0, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
