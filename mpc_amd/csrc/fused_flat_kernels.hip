@@ -86,6 +86,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // wide-form hash lanes up to which a unit takes the column-sliced form (4 x as many lanes: one pass of the workgroup)
 constexpr uint32_t kNarrowLanes = 256;
+// largest column-sliced tail behind full sets of four wide waves (blocks): beyond it a fourth quarter-cost wave per
+// SIMD costs more than the one wide wave it replaces (measured: 128 and 192 are equal, 64 loses 1 %)
+constexpr uint32_t kTailMax = 192;
 constexpr uint32_t kKeyTab = kTeDualBytes;            // byte address of the round-key table of the column-sliced hashes
 constexpr uint32_t kStageOff = kTeDualBytes / 16 + 16;  // 256 bytes: 15 round keys x 4 columns
 
@@ -274,7 +277,33 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
     }
 }
 
-// ---- hash part of a NARROW unit (no OR gate, at most 256 hash lanes): column-sliced ---------------------------
+// How the hash lanes of a unit are split between the two forms.  The wide form costs one wave per 64 lanes and a hash
+// phase lasts as long as the busiest SIMD: with L lanes in the last pass of the workgroup, L = 256 k + r, the r lanes
+// past the last full set of four waves cost a whole extra wave on one SIMD.  Those r blocks go column-sliced instead
+// (4 r lanes on the waves the wide form leaves idle in that pass, ceil(r / 64) quarter-cost waves on EVERY SIMD) when
+// that is cheaper: always if the pass has no full set (k = 0: the former "narrow unit"), else for r <= 192 if the idle
+// waves suffice.  Units with an OR gate stay wide.
+struct HashSplit {
+    uint32_t wide_end;   // hash lanes [0, wide_end) run wide (a multiple of 256 when a tail exists)
+    uint32_t tail;       // number of blocks (wide lanes) in the column-sliced tail, 0: none
+    uint32_t tail_tid;   // first thread of the tail's column lanes
+};
+// branch-free on purpose (selects on SGPRs): it runs in every wave at the head of every unit, and as early-return code
+// it compiled to ~15 scalar branches — 200 cycles per unit
+__device__ __forceinline__ HashSplit split_hash_lanes(uint32_t e_all, bool has_or_gate) {
+    const uint32_t rem = e_all & (TF - 1u);  // lanes of the last, partial pass (0: the passes are all full)
+    const bool small = rem <= kNarrowLanes;
+    const uint32_t k = small ? 0u : rem >> 8, r = small ? rem : rem & 255u;
+    const bool fits = (k == 0) | ((r <= kTailMax) & (((r + 15u) >> 4) + 4u * k <= 16u));
+    const uint32_t tail = (!has_or_gate & fits) ? r : 0u;
+    HashSplit h;
+    h.tail = tail;
+    h.wide_end = e_all - tail;
+    h.tail_tid = h.wide_end & (TF - 1u);
+    return h;
+}
+
+// ---- column-sliced hash lanes (narrow units and the tails of wide ones) ----------------------------------------
 // Every hash lane of the wide form becomes a quad (lane = 4 * wide lane + column): a lone wave's 14 AES rounds take
 // ~3.3 k cycles, the four quarter-waves of the column form ~2.2 k, and in such units that latency is the phase.  Same
 // arithmetic as the wide form, one 32-bit column per lane: label word W_c (big-endian column c) sits at dword c ^ 1.
@@ -297,12 +326,12 @@ __device__ __forceinline__ uint32_t whiten_col(uint32_t xc, uint32_t xc1, uint32
 template <int NR>
 __device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
                                                    uint32_t tim, uint4 *wl, const uint4 *rl, uint4 *Tt, uint4 *Wt,
-                                                   uint32_t lo) {
+                                                   uint32_t lo, const HashSplit hs) {
     const uint32_t TI = 1u << ti_log2;
-    const uint32_t e_all = hlanes<4, 4, 3>(u, ti_log2);
-    if (threadIdx.x >= e_all) return;
-    const HP hp = hpos<4, 4, 3, false>(threadIdx.x, u, ti_log2, tim);
-    const uint32_t c = hp.q & 3u, q = hp.q >> 2, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
+    const uint32_t j = threadIdx.x - hs.tail_tid;  // column lane j = 4 * (block of the tail) + column
+    if (threadIdx.x < hs.tail_tid || j >= 4u * hs.tail) return;
+    const HP hp = hpos<2, 2, 1, false>(hs.wide_end + (j >> 2), u, ti_log2, tim);
+    const uint32_t c = j & 3u, q = hp.q, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
     const uint4 dv = buf[hp.g];
     const FDesc d{dv.x, dv.y, dv.z, dv.w};
     const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
@@ -349,12 +378,13 @@ __device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit
 
 template <int NR>
 __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
-                                                 uint32_t tim, uint4 *wl, const uint4 *Tt, uint4 *Wt, uint32_t lo) {
+                                                 uint32_t tim, uint4 *wl, const uint4 *Tt, uint4 *Wt, uint32_t lo,
+                                                 const HashSplit hs) {
     const uint32_t TI = 1u << ti_log2;
-    const uint32_t e_all = hlanes<3, 2, 2>(u, ti_log2);
-    if (threadIdx.x >= e_all) return;
-    const HP hp = hpos<3, 2, 2, false>(threadIdx.x, u, ti_log2, tim);
-    const uint32_t c = hp.q & 3u, q = hp.q >> 2, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
+    const uint32_t j = threadIdx.x - hs.tail_tid;
+    if (threadIdx.x < hs.tail_tid || j >= 4u * hs.tail) return;
+    const HP hp = hpos<1, 0, 0, false>(hs.wide_end + (j >> 2), u, ti_log2, tim);
+    const uint32_t c = j & 3u, q = hp.q, inst = hp.inst, wo = (c ^ 1u) << 2, wo1 = ((c + 1u) ^ 1u) << 2;
     const uint4 dv = buf[hp.g];
     const FDesc d{dv.x, dv.y, dv.z, dv.w};
     const uint32_t sh = ti_log2 + 4, ib = (uint32_t)(uintptr_t)wl + (inst << 4);
@@ -455,12 +485,13 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
-        // narrow units (no OR, one wave-SIMD pass of the wide form at most): the column-sliced form
-        const bool narrow = u.n_or == 0 && hlanes<2, 2, 1>(u, ti_log2) <= kNarrowLanes;
-        if (nh && narrow) {
-            garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo);
+        const uint32_t e_hash = hlanes<2, 2, 1>(u, ti_log2);
+        if (nh && u.n_or == 0 && e_hash <= kNarrowLanes) {  // a narrow unit: column-sliced as a whole
+            garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo, HashSplit{0, e_hash, 0});
         } else if (nh) {
-            const uint32_t e_all = hlanes<2, 2, 1>(u, ti_log2);
+            // wide form for whole sets of four waves, column-sliced form for what is left of the last pass
+            const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0);
+            const uint32_t e_all = hs.wide_end;
         for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<2, 2, 1, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
@@ -532,6 +563,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
                 put(c0);
             }
         }
+            if (hs.tail) garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo, hs);
         }
         GC_FPROF(1)
         // Prefetch of the next unit's image and of the header after it, issued AFTER the hash part: vector-memory
@@ -562,11 +594,13 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
         GC_FPROF(0)
-        const bool narrow = u.n_or == 0 && hlanes<1, 0, 0>(u, ti_log2) <= kNarrowLanes;
-        if (nh && narrow) {
-            eval_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo);
+        const uint32_t e_hash = hlanes<1, 0, 0>(u, ti_log2);
+        if (nh && u.n_or == 0 && e_hash <= kNarrowLanes) {  // a narrow unit: column-sliced as a whole
+            eval_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo, HashSplit{0, e_hash, 0});
         } else if (nh) {
-            const uint32_t e_all = hlanes<1, 0, 0>(u, ti_log2);
+            // wide form for whole sets of four waves, column-sliced form for what is left of the last pass
+            const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0);
+            const uint32_t e_all = hs.wide_end;
         for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<1, 0, 0, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
             if (hp.kind == 0) continue;
@@ -611,6 +645,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
                 put(lxor(h, tab));
             }
         }
+            if (hs.tail) eval_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo, hs);
         }
         GC_FPROF(1)
         // Prefetch of the next unit's image and of the header after it, issued AFTER the hash part: vector-memory
