@@ -31,3 +31,20 @@ def test_oracle_reproduces_golden(golden_dir):
         gold["circuits"]["aes_128"]["aes256"][:1]
     assert mk.golden_for("sha256xor", circs["sha256xor"], bytes.fromhex(mk.KEYS["aes128"]), 1) == \
         gold["circuits"]["sha256xor"]["aes128"][:1]
+
+
+def load_mk2(golden_dir):
+    spec = importlib.util.spec_from_file_location("make_golden_stream_ot", os.path.join(golden_dir, "make_golden_stream_ot.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_oracle_reproduces_stream_and_ot_golden(golden_dir):
+    """tests/golden/stream_ot_golden.json (streaming garbler bytes, IKNP messages and labels)"""
+    mk = load_mk2(golden_dir)
+    gold = json.load(open(os.path.join(golden_dir, "stream_ot_golden.json")))
+    for b, k in mk.STREAM_CASES:
+        assert mk.golden_stream(b, k) == gold["stream"]["%d/%d" % (b, k)]
+    for n in mk.IKNP_SIZES:
+        assert mk.golden_iknp(n) == gold["iknp"][str(n)]

@@ -201,3 +201,21 @@ def test_iknp_device_resident_api_matches_host_api(ctx):
         assert rx_d.last_ms > 0 and tx_d.last_ms > 0
     for o in (rx_h, tx_h, rx_d, tx_d):
         o.close()
+
+
+def test_iknp_matches_committed_golden(ctx, golden_dir):
+    """the committed digests of tests/golden/stream_ot_golden.json (made with the oracle by make_golden_stream_ot.py)"""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("mk2", os.path.join(golden_dir, "make_golden_stream_ot.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(golden_dir, "stream_ot_golden.json")))
+    for n in mk.IKNP_SIZES:
+        base, delta, k0, b = mk.iknp_inputs(n)
+        rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+        u, got = rcv.receive(b)
+        sent = snd.send(u, n)
+        assert mk.iknp_digest(u, got, sent) == gold["iknp"][str(n)]
+        rcv.close(); snd.close()

@@ -150,3 +150,21 @@ def test_stream_million_gate_step_matches_oracle():
     for o in out_:
         assert ge.get(o) == oe.get(o)
     gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_matches_committed_golden(golden_dir):
+    """the committed digests of tests/golden/stream_ot_golden.json (made with the oracle by make_golden_stream_ot.py)"""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("mk2", os.path.join(golden_dir, "make_golden_stream_ot.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(golden_dir, "stream_ot_golden.json")))
+    ctx = engine.Context(0)
+    for b, k in mk.STREAM_CASES:
+        steps, prim, key, rnd = mk.stream_inputs(b, k)
+        g = engine.Stream(ctx, key, rnd, prim)
+        assert mk.stream_digest(g, steps) == gold["stream"]["%d/%d" % (b, k)]
+        g.close()
+    ctx.close()
