@@ -39,7 +39,19 @@ def cpu_baseline(circ, key, seconds=12.0):
     host cores: one instance per thread-iteration, all cores.  Reported, never the target."""
     import oracle
 
-    threads = os.cpu_count() or 1
+    # threads = the CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes
+    # show 256 hardware threads and a quota of 16 CPUs: 256 threads there are throttled to a third of what 16 achieve)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    host_threads = threads
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            threads = max(1, min(threads, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
     probe = 40 * threads
     dt = oracle.bench_garble_eval(circ.Gates, circ.NumWires, circ.num_inputs, circ.num_outputs, key, probe, threads)
     reps = max(probe, int(probe * seconds / max(dt, 1e-3)))
@@ -50,8 +62,9 @@ def cpu_baseline(circ, key, seconds=12.0):
         "unit": "AND-gates/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d instances of %s garble+eval, oracle C loop (AES-NI=%s), %d threads, %.1f s" % (
-            reps, circ.name or "circuit", oracle.using_aesni(), threads, dt),
+        "sample": "%d instances of %s garble+eval, oracle C loop (AES-NI=%s), %d threads (CPU quota of the container; "
+                  "the host shows %d hardware threads), %.1f s" % (
+            reps, circ.name or "circuit", oracle.using_aesni(), threads, host_threads, dt),
         "published_reference": "155.1 ns/AND garble-only = 6.45 M AND/s, Go, i5-8257U 1 thread (benchmarks.md:726)",
     }
     ref = os.path.join(ROOT, "oracle", "_ref", "aesni_bench")
