@@ -57,6 +57,9 @@ def cpu_baseline(circ, key, seconds=12.0):
     reps = max(probe, int(probe * seconds / max(dt, 1e-3)))
     dt = oracle.bench_garble_eval(circ.Gates, circ.NumWires, circ.num_inputs, circ.num_outputs, key, reps, threads)
     ands = circ.stats()["AND"]
+    # one thread, the apples-to-apples counterpart of the reference's serial Go loop (~2 s sample)
+    r1 = max(8, int(2.0 * reps / max(dt, 1e-3) / threads))
+    dt1 = oracle.bench_garble_eval(circ.Gates, circ.NumWires, circ.num_inputs, circ.num_outputs, key, r1, 1)
     out = {
         "value": reps * ands / dt,
         "unit": "AND-gates/s",
@@ -65,6 +68,7 @@ def cpu_baseline(circ, key, seconds=12.0):
         "sample": "%d instances of %s garble+eval, oracle C loop (AES-NI=%s), %d threads (CPU quota of the container; "
                   "the host shows %d hardware threads), %.1f s" % (
             reps, circ.name or "circuit", oracle.using_aesni(), threads, host_threads, dt),
+        "single_thread_value": r1 * ands / dt1,
         "published_reference": "155.1 ns/AND garble-only = 6.45 M AND/s, Go, i5-8257U 1 thread (benchmarks.md:726)",
     }
     ref = os.path.join(ROOT, "oracle", "_ref", "aesni_bench")
