@@ -89,6 +89,9 @@ constexpr uint32_t kNarrowLanes = 256;
 // largest column-sliced tail behind full sets of four wide waves (blocks): beyond it a fourth quarter-cost wave per
 // SIMD costs more than the one wide wave it replaces (measured: 128 and 192 are equal, 64 loses 1 %)
 constexpr uint32_t kTailMax = 192;
+// the garbler's column lanes do more around the AES (R, both permute bits, two table rows): its optimum is lower
+// (measured 0.637 / 0.627 / 0.627 / 0.630 ms for 0 / 64 / 128 / 192)
+constexpr uint32_t kTailMaxGarble = 128;
 constexpr uint32_t kKeyTab = kTeDualBytes;            // byte address of the round-key table of the column-sliced hashes
 constexpr uint32_t kStageOff = kTeDualBytes / 16 + 16;  // 256 bytes: 15 round keys x 4 columns
 
@@ -290,11 +293,11 @@ struct HashSplit {
 };
 // branch-free on purpose (selects on SGPRs): it runs in every wave at the head of every unit, and as early-return code
 // it compiled to ~15 scalar branches — 200 cycles per unit
-__device__ __forceinline__ HashSplit split_hash_lanes(uint32_t e_all, bool has_or_gate) {
+__device__ __forceinline__ HashSplit split_hash_lanes(uint32_t e_all, bool has_or_gate, uint32_t tail_max = kTailMax) {
     const uint32_t rem = e_all & (TF - 1u);  // lanes of the last, partial pass (0: the passes are all full)
     const bool small = rem <= kNarrowLanes;
     const uint32_t k = small ? 0u : rem >> 8, r = small ? rem : rem & 255u;
-    const bool fits = (k == 0) | ((r <= kTailMax) & (((r + 15u) >> 4) + 4u * k <= 16u));
+    const bool fits = (k == 0) | ((r <= tail_max) & (((r + 15u) >> 4) + 4u * k <= 16u));
     const uint32_t tail = (!has_or_gate & fits) ? r : 0u;
     HashSplit h;
     h.tail = tail;
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
             garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo, HashSplit{0, e_hash, 0});
         } else if (nh) {
             // wide form for whole sets of four waves, column-sliced form for what is left of the last pass
-            const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0);
+            const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0, kTailMaxGarble);
             const uint32_t e_all = hs.wide_end;
         for (uint32_t t0 = 0; t0 + wave_base < e_all; t0 += TF) {  // scalar test: a wave without lanes leaves at once
             const HP hp = hpos<2, 2, 1, HAS_OR>(t0 + threadIdx.x, u, ti_log2, tim);
