@@ -258,11 +258,17 @@ __device__ __forceinline__ void xor_part(const uint4 *buf, const FUnit &u, const
             const lds_v4 v = *(lds_v4p)(uintptr_t)((s16 << sh) + ib);
             return make_uint4(v.x, v.y, v.z, v.w);
         };
-        const uint4 v0 = lab(d0.x, false), v1 = lab(d0.x, true), v2 = lab(d0.y, false), v3 = lab(d0.y, true);
-        uint4 acc = lxor(lxor3(v0, v1, v2), v3);  // three-input XORs (v_bitop3): 2 + 2 instead of 3 + 4 per word
-        if (n > 4) {  // items are sorted by length: whole waves skip this
+        // Items are sorted by length and padded with the zero slot: a wave that holds a list of more than four terms
+        // reads all eight labels in ONE batch (a wave-uniform branch; the short lists of that wave read zeros), the
+        // other waves read four.  Three-input XORs (v_bitop3): 2 / 4 per word.
+        uint4 acc;
+        if (__ballot(n > 4) != 0) {
+            const uint4 v0 = lab(d0.x, false), v1 = lab(d0.x, true), v2 = lab(d0.y, false), v3 = lab(d0.y, true);
             const uint4 v4 = lab(d1.x, false), v5 = lab(d1.x, true), v6 = lab(d1.y, false), v7 = lab(d1.y, true);
-            acc = lxor3(lxor3(acc, v4, v5), v6, v7);
+            acc = lxor(lxor3(lxor3(v0, v1, v2), v3, v4), lxor3(v5, v6, v7));
+        } else {
+            const uint4 v0 = lab(d0.x, false), v1 = lab(d0.x, true), v2 = lab(d0.y, false), v3 = lab(d0.y, true);
+            acc = lxor(lxor3(v0, v1, v2), v3);
         }
         // collect the partial sums of lists that were spread over 2 / 4 lanes: only in units that have such lists, and
         // there only in the waves that hold them (they come first in the length order) - a wave-uniform test
