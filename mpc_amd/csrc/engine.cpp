@@ -13,6 +13,9 @@ thread_local char tls_error[512] = "";
 
 void set_error(const char *what, hipError_t e) {
     std::snprintf(tls_error, sizeof tls_error, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    // a failed runtime call also leaves the thread's "last error" set: clear it, or the next launch's
+    // hipGetLastError() reports this failure again
+    (void)hipGetLastError();
 }
 
 }  // namespace gc
@@ -880,7 +883,10 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
             break;
         }
+        // a pooled batch keeps the geometry of its last use: keeping every wire runs the level-walking kernel, whose
+        // tile may be smaller than the flattened kernels' (relayout re-sizes the arrays if it is)
         b->store_all = wires_out != nullptr;
+        if ((rc = relayout(b)) != GC_OK) break;
         rc = gc_batch_garble(b, key, keylen, d_rnd.p);
         if (rc != GC_OK) break;
         if (r_out && (rc = gc_batch_read_r(b, r_out)) != GC_OK) break;
@@ -929,6 +935,8 @@ int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const g
     std::lock_guard<std::mutex> lk(ctx->mu);
     do {
         hipError_t e = hipSetDevice(ctx->device);
+        b->store_all = false;
+        if (e == hipSuccess && (rc = relayout(b)) != GC_OK) break;  // before anything is written into the arrays
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
             set_error("gc_garble_labels", e);
@@ -938,7 +946,6 @@ int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const g
         if (p.info.ninputs) rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         if (rc != GC_OK) break;
         if ((rc = set_key(b, key, keylen)) != GC_OK) break;
-        b->store_all = false;
         if ((rc = run_levels(b, false, b->d_T)) != GC_OK) break;
         if (out_l0 && (rc = gc_batch_read_outputs(b, out_l0)) != GC_OK) break;
     } while (0);
@@ -982,13 +989,14 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
     gc_ctx *ctx = c->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     do {
+        b->store_all = wires_inout != nullptr;
+        if ((rc = relayout(b)) != GC_OK) break;  // before the tables and labels go into the arrays
         if (p.info.slab_rows && (rc = gc_batch_write_slab(b, slab)) != GC_OK) break;
         if (wires_inout)
             rc = write_scatter(b, wires_inout, p.info.nwires, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         else
             rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         if (rc != GC_OK) break;
-        b->store_all = wires_inout != nullptr;
         rc = gc_batch_eval(b, key, keylen, b);
         if (rc != GC_OK) break;
         if (wires_inout && (rc = gc_batch_read_labels(b, wires_inout)) != GC_OK) break;

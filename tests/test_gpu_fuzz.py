@@ -81,6 +81,18 @@ def test_random_circuits(ctx, seed):
         check_garble_eval(ctx, c, KEY, batch, "fuzz%d" % seed, schedule=schedule)
 
 
+@pytest.mark.parametrize("batch", [2100, 4100, 16500])
+def test_host_api_large_batches_switch_layout(ctx, batch):
+    """gc_garble / gc_eval on pooled batches whose tile (8 - 64 instances per workgroup at these sizes) has to shrink
+    when a call keeps every wire (level-walking kernel, more LDS per instance than the flattened one): the arrays are
+    re-laid out before anything is written (a 400-circuit fuzz run found gc_eval launching with the other kernel's tile)"""
+    rng = np.random.default_rng(9100 + batch)
+    c = random_circuit(rng, 22, 2337, p_xor=0.8, reuse=0.02, nout=17)
+    sample = sorted(set(list(range(0, batch, 401)) + [batch - 1, batch - 2, 1]))
+    for schedule in (1, 2):
+        check_garble_eval(ctx, c, KEY, batch, "lb%d" % batch, check_all_wires=False, schedule=schedule, sample=sample)
+
+
 @pytest.mark.parametrize("fan", [9, 17, 33, 70, 200])
 def test_long_xor_lists(ctx, fan):
     c = xor_tree(np.random.default_rng(fan), 24, fan)
