@@ -182,7 +182,11 @@ void gc_stream_free(gc_stream *);
 int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
 /* Replaces (*Streaming).Garble(c, in, out)   stream_garble.go:161-192: garbles the circuit (tweak restarts
  * at 0, :174) and appends the serialised gates — op|flags, 16/32-bit wire indexes, table rows, exactly as
- * :391-446 writes them into conn.WriteBuf — to buf.  *written = bytes needed; GC_E_ARG if cap is smaller. */
+ * :391-446 writes them into conn.WriteBuf — to buf.  *written = bytes needed; GC_E_ARG if cap is smaller.
+ * in[] / out[] may overlap (output wires that are input wires are resolved through in[] and never set, as in
+ * :131-157).  Two deliberate differences, neither reachable from compiled programs: a gate that writes an
+ * input-mapped wire is rejected (GC_E_ARG), and a global wire that was never set reads as (L0, L1) = (0, R) —
+ * the reference's zero-initialised store gives (0, 0); the engine never stores L1 (always L0 ^ R). */
 int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
 

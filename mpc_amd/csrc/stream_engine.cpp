@@ -264,7 +264,9 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) {  // Streaming.G
 int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) {
     if (!s || (!gates && ngates) || (nin && !in) || (nout && !out) || !buf || !written) return GC_E_ARG;
-    if ((uint64_t)nin + nout > nwires) return GC_E_ARG;
+    // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
+    // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
+    if (nin > nwires || nout > nwires) return GC_E_ARG;
     const uint32_t first_tmp = nin, first_out = nwires - nout;
     // initCircuit (:102-114)
     uint32_t mx = 0;
@@ -340,7 +342,8 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     gc_batch *b = nullptr;
     int rc = gc_garble_labels_keep(circ, s->key.data(), s->key.size(), &s->r, inl.data(), outl.data(), &b);
     if (rc != GC_OK) return rc;
-    for (uint32_t j = 0; j < nout; j++) s->l0[out[j]] = outl[j];
+    for (uint32_t j = 0; j < nout; j++)
+        if (first_out + j >= first_tmp) s->l0[out[j]] = outl[j];  // an output wire that is an input wire has no gate: no Set
 
     // (3) wire format (:391-446) written by the device at the scanned offsets, one copy into the caller's buffer
     {

@@ -25,3 +25,98 @@ for seed in range(N):
         bad += 1
         print("FAIL seed", seed, "inputs", ninputs, "gates", ngates, "batch", batch, "schedule", schedule, str(e)[:160])
 print("done, failures:", bad)
+
+# ---- second pass: the device-resident pipeline (gc_batch_*: garble -> select -> eval -> decode) on random circuits, random
+# key sizes, batches up to 16 500: decoded bits against plaintext evaluation for every instance, tables and R of sampled
+# instances against the oracle
+from tests.test_gpu_garble_eval import oracle_instance, rnd_for
+from tests.util import drbg
+bad2 = 0
+for seed in range(N):
+    rng = np.random.default_rng(77000 + seed)
+    ninputs = int(rng.integers(2, 80))
+    ngates = int(rng.integers(1, 3000))
+    c = random_circuit(rng, ninputs, ngates, p_xor=float(rng.choice([0.0, 0.3, 0.6, 0.8, 0.9, 0.97, 1.0])),
+                       reuse=float(rng.choice([0.0, 0.02, 0.1, 0.3])), nout=int(rng.integers(1, 40)))
+    batch = int(rng.choice([1, 3, 64, 130, 520, 1030, 2100, 4100, 16500]))
+    key = drbg("xk%d" % seed, int(rng.choice([16, 24, 32])))
+    schedule = int(rng.choice([0, 1, 1, 2]))
+    try:
+        dc = engine.DeviceCircuit(ctx, c)
+        gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+        for b in (gb, ev):
+            b.set_schedule(schedule)
+        rnd = rnd_for(c, "xd%d" % seed, batch)
+        d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+        bits = (np.frombuffer(drbg("xb%d" % seed, c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
+        d_bits = torch.from_numpy(bits.copy()).cuda()
+        d_out = torch.zeros((batch, max(c.num_outputs, 1)), dtype=torch.uint8, device="cuda")
+        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        gb.garble(key, d_rnd.data_ptr())
+        ev.select_inputs(gb, d_bits.data_ptr())
+        ev.eval(key, gb)
+        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        ctx.sync()
+        assert int(d_mis.cpu()[0]) == 0, "decode mismatches"
+        out = d_out.cpu().numpy()
+        for i in sorted(set(list(range(0, batch, max(1, batch // 7))) + [batch - 1])):
+            plain = c.compute_bits(bits[i])
+            assert (plain[c.NumWires - c.num_outputs:] == out[i][: c.num_outputs]).all(), "decoded bits of instance %d" % i
+        slab, R = gb.read_slab(), gb.read_r()
+        for i in sorted(set([0, batch // 2, batch - 1])):
+            ref = oracle_instance(c, key, rnd, i)
+            assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all(), "tables of instance %d" % i
+        gb.close(); ev.close(); dc.close()
+    except (AssertionError, engine.EngineError) as e:
+        bad2 += 1
+        print("FAIL(device) seed", seed, "inputs", ninputs, "gates", ngates, "batch", batch, "schedule", schedule,
+              "key", len(key), str(e)[:160])
+print("device pipeline done, failures:", bad2)
+
+# ---- third pass: the streaming garbler / evaluator on random chained programs against the oracle's restatement
+import oracle
+bad3 = 0
+for seed in range(max(1, N // 4)):
+    rng = np.random.default_rng(91000 + seed)
+    base = int(rng.choice([0, 300, 0xff00, 0x10000, 70000]))
+    nsteps = int(rng.integers(1, 5))
+    key = drbg("sk%d" % seed, int(rng.choice([16, 24, 32])))
+    steps, prim, avail = [], [], []
+    nextid = base
+    for k in range(nsteps):
+        ninputs = int(rng.integers(2, 40))
+        c = random_circuit(rng, ninputs, int(rng.integers(1, 1500)), p_xor=float(rng.choice([0.3, 0.7, 0.9])),
+                           reuse=0.0, nout=int(rng.integers(1, 20)))
+        in_ = []
+        for i in range(c.num_inputs):  # earlier results or fresh primary inputs
+            if avail and rng.random() < 0.5:
+                in_.append(int(rng.choice(avail)))
+            else:
+                in_.append(nextid); prim.append(nextid); nextid += 1
+        out_ = list(range(nextid, nextid + c.num_outputs)); nextid += c.num_outputs
+        # only outputs a gate really writes: an output wire that is an input wire of the circuit is never Set, and a
+        # never-set global wire reads as (L0, L1) = (0, 0) in the reference but as (0, R) here (L1 is always L0 ^ R)
+        avail += [o for j, o in enumerate(out_) if c.NumWires - c.num_outputs + j >= c.num_inputs]
+        steps.append((c, in_, out_))
+    try:
+        rnd = drbg("sr%d" % seed, 16 * (len(prim) + 1))
+        og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+        oe, ge = oracle.StreamEval(key), engine.StreamEval(ctx, key)
+        for w in prim:
+            l = gg.get(w)["l0"]
+            ge.set(w, l); oe.set(w, l)
+        for c, in_, out_ in steps:
+            want = og.garble(c.Gates, c.NumWires, in_, out_)
+            got = gg.garble(c.Gates, c.NumWires, in_, out_)
+            assert got == want, "stream bytes"
+            nw = max(max(in_), max(out_)) + 1
+            assert ge.circuit(c.NumGates, c.NumWires, nw, got) == len(got)
+            assert oe.circuit(c.NumGates, c.NumWires, nw, want) == len(want)
+            for o in out_:
+                assert ge.get(o) == oe.get(o), "evaluated wire %d" % o
+        gg.close(); ge.close()
+    except (AssertionError, engine.EngineError) as e:
+        bad3 += 1
+        print("FAIL(stream) seed", seed, "base", base, "steps", nsteps, str(e)[:160])
+print("streaming done, failures:", bad3)

@@ -168,3 +168,24 @@ def test_stream_matches_committed_golden(golden_dir):
         assert mk.stream_digest(g, steps) == gold["stream"]["%d/%d" % (b, k)]
         g.close()
     ctx.close()
+
+
+def test_stream_outputs_that_are_input_wires():
+    """a circuit whose last wires are input wires (in[] and out[] overlap): Get / Set resolve through in[] first
+    (stream_garble.go:131-157), the overlapped output ids are never set; bytes equal to the oracle's"""
+    from mpc_amd.circuit import AND, GATE, XOR, Circuit
+    gates = np.zeros(2, GATE)
+    gates[0] = (0, 1, 4, XOR, 0)
+    gates[1] = (4, 2, 5, AND, 0)
+    c = Circuit(6, [4], [3], gates)  # inputs 0..3, outputs = wires 3, 4, 5: wire 3 is an input
+    in_, out_ = [10, 11, 12, 13], [20, 21, 22]
+    key = drbg("ovk", 16)
+    rnd = drbg("ovr", 16 * 5)
+    ctx = engine.Context(0)
+    og, gg = oracle.Stream(key, rnd, in_), engine.Stream(ctx, key, rnd, in_)
+    assert gg.garble(c.Gates, c.NumWires, in_, out_) == og.garble(c.Gates, c.NumWires, in_, out_)
+    for w in (21, 22):
+        assert gg.get(w)["l0"] == og.get(w)["l0"]
+    z = gg.get(20)["l0"]
+    assert int(z["d0"]) == 0 and int(z["d1"]) == 0  # never set
+    gg.close(); ctx.close()
