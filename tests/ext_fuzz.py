@@ -120,3 +120,48 @@ for seed in range(max(1, N // 4)):
         bad3 += 1
         print("FAIL(stream) seed", seed, "base", base, "steps", nsteps, str(e)[:160])
 print("streaming done, failures:", bad3)
+
+# ---- fourth pass: IKNP call sequences (stream positions that are not multiples of 16 bytes, ragged last chunks, the
+# device-resident and the host-buffer entry points mixed on one pair) + COT pads against the oracle
+from tests.test_gpu_ot import base_setup
+bad4 = 0
+for seed in range(max(1, N // 8)):
+    rng = np.random.default_rng(55000 + seed)
+    base, delta, k0 = base_setup("xot%d" % seed)
+    orcv, osnd = oracle.IKNPReceiver(base), oracle.IKNPSender(delta, k0)
+    grcv, gsnd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    try:
+        for call in range(int(rng.integers(1, 7))):
+            n = int(rng.choice([1, 3, 8, 9, 100, 511, 512, 513, 700, 1025, 4000, 20000]))
+            b = (np.frombuffer(drbg("xotb%d/%d" % (seed, call), n), np.uint8) & 1).astype(np.uint8)
+            wu, wgot = orcv.receive(b)
+            wsent = osnd.send(wu, n)
+            if rng.random() < 0.5:  # host buffers
+                u, got = grcv.receive(b)
+                sent = gsnd.send(u, n)
+            else:  # device-resident
+                chunks = (n + 511) // 512
+                packed = np.zeros(chunks * 64, np.uint8)
+                pk = np.packbits(b, bitorder="little")
+                packed[:len(pk)] = pk
+                d_choice = torch.from_numpy(packed).cuda()
+                d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
+                d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+                d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                grcv.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
+                gsnd.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+                ctx.sync()
+                u = d_u.cpu().numpy()[: len(wu)].tobytes()
+                got = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
+                sent = d_ls.cpu().numpy().view(np.uint64).reshape(n, 2)
+                got = np.rec.fromarrays([got[:, 0], got[:, 1]], names="d0,d1")
+                sent = np.rec.fromarrays([sent[:, 0], sent[:, 1]], names="d0,d1")
+            assert bytes(u) == bytes(wu), "u matrix, call %d n %d" % (call, n)
+            assert (np.asarray(got["d0"]) == wgot["d0"]).all() and (np.asarray(got["d1"]) == wgot["d1"]).all(), "receiver labels"
+            assert (np.asarray(sent["d0"]) == wsent["d0"]).all() and (np.asarray(sent["d1"]) == wsent["d1"]).all(), "sender labels"
+    except (AssertionError, engine.EngineError) as e:
+        bad4 += 1
+        print("FAIL(iknp) seed", seed, str(e)[:160])
+    grcv.close(); gsnd.close()
+print("iknp done, failures:", bad4)
