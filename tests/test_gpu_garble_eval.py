@@ -356,3 +356,44 @@ def test_pipeline_graph_replay(ctx, add64_circ):
             plain = oracle.compute(c.Gates, c.NumWires, c.num_inputs, bits[i])
             assert (out[i] == plain[c.NumWires - c.num_outputs:]).all()
     g.close(); gb.close(); ev.close(); dc.close()
+
+
+def test_concurrent_host_calls_on_one_circuit(ctx, add64_circ):
+    """Circuit.Garble may be called from several goroutines on one *Circuit (atomic scratch pool, garble.go:195-225);
+    here: eight threads on one gc_circ (pooled batches, calls serialised on the ctx's stream) and on a second ctx"""
+    import threading
+    c = add64_circ
+    dc = engine.DeviceCircuit(ctx, c)
+    ctx2 = engine.Context(0)
+    dc2 = engine.DeviceCircuit(ctx2, c)
+    errors = []
+
+    def worker(t):
+        try:
+            d = dc2 if t % 4 == 3 else dc
+            for it in range(6):
+                batch = [1, 3, 70, 300][(t + it) % 4]
+                rnd = rnd_for(c, "thr%d/%d" % (t, it), batch)
+                g = d.garble(KEY128, rnd, batch=batch, want_wires=(it % 2 == 0), want_io=True)
+                for i in (0, batch - 1):
+                    ref = oracle_instance(c, KEY128, rnd, i)
+                    assert g["R"][i] == ref["R"] and (g["slab"][i] == ref["slab"]).all()
+                    if it % 2 == 0:
+                        assert (g["wires"][i] == ref["wires"]).all()
+                inputs = np.ascontiguousarray(g["io"][:, : c.num_inputs]["l0"])
+                out = d.eval(KEY128, g["slab"], inputs=inputs, batch=batch)
+                plain = oracle.compute(c.Gates, c.NumWires, c.num_inputs, np.zeros(c.num_inputs, np.uint8))
+                for j in range(c.num_outputs):
+                    wi = c.NumWires - c.num_outputs + j
+                    want = g["io"][0][c.num_inputs + j]["l1"] if plain[wi] else g["io"][0][c.num_inputs + j]["l0"]
+                    assert out[0][j] == want
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dc.close(); dc2.close(); ctx2.close()
+    assert not errors, errors[:3]
