@@ -4,6 +4,7 @@ Run on a GPU box: python tests/ext_fuzz.py [N]"""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import oracle
 from mpc_amd import engine
 from tests.test_gpu_fuzz import random_circuit, xor_tree, KEY
 from tests.test_gpu_garble_eval import check_garble_eval
@@ -55,7 +56,30 @@ for seed in range(N):
         torch.cuda.synchronize()
         gb.garble(key, d_rnd.data_ptr())
         ev.select_inputs(gb, d_bits.data_ptr())
-        ev.eval(key, gb)
+        mode = int(rng.integers(0, 3)) if batch <= 4100 and c.slab_rows() else 0
+        if mode == 0:
+            ev.eval(key, gb)
+        else:  # tables leave the garbler in the driver's wire format (1) / sha2pc's dense form (2) and are ingested again
+            nbytes = dc.tables_wire_bytes if mode == 1 else 16 * c.slab_rows()
+            stride = (nbytes + 63) // 64 * 64
+            d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
+            d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            if mode == 1:
+                gb.egress_tables(d_wire.data_ptr(), stride)
+                ev.ingest_tables(d_wire.data_ptr(), stride, d_bad.data_ptr())
+            else:
+                gb.egress_tables_dense(d_wire.data_ptr(), stride)
+                ev.ingest_tables_dense(d_wire.data_ptr(), stride)
+            ev.eval(key, ev)
+            ctx.sync()
+            assert int(d_bad.cpu()[0]) == 0, "ingest flagged a header"
+            wire = d_wire.cpu().numpy().reshape(batch, stride)
+            sl = gb.read_slab()
+            for i in (0, batch - 1):
+                want = oracle.tables_serialize(c.Gates, sl[i]) if mode == 1 else \
+                    b"".join(int(x).to_bytes(8, "big") for row in sl[i] for x in (row["d0"], row["d1"]))
+                assert wire[i, :nbytes].tobytes() == want, "egress bytes of instance %d (mode %d)" % (i, mode)
         gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
         ctx.sync()
         assert int(d_mis.cpu()[0]) == 0, "decode mismatches"
