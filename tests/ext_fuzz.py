@@ -32,71 +32,22 @@ print("done, failures:", bad)
 # instances against the oracle
 from tests.test_gpu_garble_eval import oracle_instance, rnd_for
 from tests.util import drbg
-bad2 = 0
-for seed in range(N):
-    rng = np.random.default_rng(77000 + seed)
-    ninputs = int(rng.integers(2, 80))
-    ngates = int(rng.integers(1, 3000))
-    c = random_circuit(rng, ninputs, ngates, p_xor=float(rng.choice([0.0, 0.3, 0.6, 0.8, 0.9, 0.97, 1.0])),
-                       reuse=float(rng.choice([0.0, 0.02, 0.1, 0.3])), nout=int(rng.integers(1, 40)))
-    batch = int(rng.choice([1, 3, 64, 130, 520, 1030, 2100, 4100, 16500]))
-    key = drbg("xk%d" % seed, int(rng.choice([16, 24, 32])))
-    schedule = int(rng.choice([0, 1, 1, 2]))
-    try:
-        dc = engine.DeviceCircuit(ctx, c)
-        gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
-        for b in (gb, ev):
-            b.set_schedule(schedule)
-        rnd = rnd_for(c, "xd%d" % seed, batch)
-        d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
-        bits = (np.frombuffer(drbg("xb%d" % seed, c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
-        d_bits = torch.from_numpy(bits.copy()).cuda()
-        d_out = torch.zeros((batch, max(c.num_outputs, 1)), dtype=torch.uint8, device="cuda")
-        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        gb.garble(key, d_rnd.data_ptr())
-        ev.select_inputs(gb, d_bits.data_ptr())
-        mode = int(rng.integers(0, 3)) if batch <= 4100 and c.slab_rows() else 0
-        if mode == 0:
-            ev.eval(key, gb)
-        else:  # tables leave the garbler in the driver's wire format (1) / sha2pc's dense form (2) and are ingested again
-            nbytes = dc.tables_wire_bytes if mode == 1 else 16 * c.slab_rows()
-            stride = (nbytes + 63) // 64 * 64
-            d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
-            d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
-            torch.cuda.synchronize()
-            if mode == 1:
-                gb.egress_tables(d_wire.data_ptr(), stride)
-                ev.ingest_tables(d_wire.data_ptr(), stride, d_bad.data_ptr())
-            else:
-                gb.egress_tables_dense(d_wire.data_ptr(), stride)
-                ev.ingest_tables_dense(d_wire.data_ptr(), stride)
-            ev.eval(key, ev)
-            ctx.sync()
-            assert int(d_bad.cpu()[0]) == 0, "ingest flagged a header"
-            wire = d_wire.cpu().numpy().reshape(batch, stride)
-            sl = gb.read_slab()
-            for i in (0, batch - 1):
-                want = oracle.tables_serialize(c.Gates, sl[i]) if mode == 1 else \
-                    b"".join(int(x).to_bytes(8, "big") for row in sl[i] for x in (row["d0"], row["d1"]))
-                assert wire[i, :nbytes].tobytes() == want, "egress bytes of instance %d (mode %d)" % (i, mode)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
-        ctx.sync()
-        assert int(d_mis.cpu()[0]) == 0, "decode mismatches"
-        out = d_out.cpu().numpy()
-        for i in sorted(set(list(range(0, batch, max(1, batch // 7))) + [batch - 1])):
-            plain = c.compute_bits(bits[i])
-            assert (plain[c.NumWires - c.num_outputs:] == out[i][: c.num_outputs]).all(), "decoded bits of instance %d" % i
-        slab, R = gb.read_slab(), gb.read_r()
-        for i in sorted(set([0, batch // 2, batch - 1])):
-            ref = oracle_instance(c, key, rnd, i)
-            assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all(), "tables of instance %d" % i
-        gb.close(); ev.close(); dc.close()
-    except (AssertionError, engine.EngineError) as e:
-        bad2 += 1
-        print("FAIL(device) seed", seed, "inputs", ninputs, "gates", ngates, "batch", batch, "schedule", schedule,
-              "key", len(key), str(e)[:160])
-print("device pipeline done, failures:", bad2)
+from tests.test_gpu_fuzz import device_pipeline_case
+
+
+def run_device_pass(ctx, n):
+    bad = 0
+    for seed in range(n):
+        try:
+            device_pipeline_case(ctx, seed)
+        except (AssertionError, engine.EngineError) as e:
+            bad += 1
+            print("FAIL(device) seed", seed, str(e)[:200])
+    print("device pipeline done, failures:", bad)
+    return bad
+
+
+run_device_pass(ctx, N)
 
 # ---- third pass: the streaming garbler / evaluator on random chained programs against the oracle's restatement
 import oracle

@@ -108,3 +108,77 @@ def test_no_gates_and_outputs_are_inputs(ctx):
     c = Circuit(6, [3, 3], [2], g)  # outputs = input wires 4, 5
     for schedule in (0, 1, 2):
         check_garble_eval(ctx, c, KEY, 5, "nogates", schedule=schedule)
+
+
+def device_pipeline_case(ctx, seed):
+    """one random circuit, random key size, schedule and batch (1 - 16 500 instances) through the device-resident
+    pipeline: garble -> select -> (eval | table egress / ingest + eval) -> decode; decoded bits against plaintext
+    evaluation, tables of sampled instances against the oracle; raises on a mismatch (tests/ext_fuzz.py runs hundreds)"""
+    import torch
+    from tests.test_gpu_garble_eval import oracle_instance, rnd_for
+    from tests.util import drbg
+    rng = np.random.default_rng(77000 + seed)
+    ninputs = int(rng.integers(2, 80))
+    ngates = int(rng.integers(1, 3000))
+    c = random_circuit(rng, ninputs, ngates, p_xor=float(rng.choice([0.0, 0.3, 0.6, 0.8, 0.9, 0.97, 1.0])),
+                       reuse=float(rng.choice([0.0, 0.02, 0.1, 0.3])), nout=int(rng.integers(1, 40)))
+    batch = int(rng.choice([1, 3, 64, 130, 520, 1030, 2100, 4100, 16500]))
+    key = drbg("xk%d" % seed, int(rng.choice([16, 24, 32])))
+    schedule = int(rng.choice([0, 1, 1, 2]))
+    dc = engine.DeviceCircuit(ctx, c)
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    for b in (gb, ev):
+        b.set_schedule(schedule)
+    rnd = rnd_for(c, "xd%d" % seed, batch)
+    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    bits = (np.frombuffer(drbg("xb%d" % seed, c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
+    d_bits = torch.from_numpy(bits.copy()).cuda()
+    d_out = torch.zeros((batch, max(c.num_outputs, 1)), dtype=torch.uint8, device="cuda")
+    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gb.garble(key, d_rnd.data_ptr())
+    ev.select_inputs(gb, d_bits.data_ptr())
+    mode = int(rng.integers(0, 3)) if batch <= 4100 and c.slab_rows() else 0
+    if mode == 0:
+        ev.eval(key, gb)
+    else:  # tables leave the garbler in the driver's wire format (1) / sha2pc's dense form (2) and are ingested again
+        nbytes = dc.tables_wire_bytes if mode == 1 else 16 * c.slab_rows()
+        stride = (nbytes + 63) // 64 * 64
+        d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
+        d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if mode == 1:
+            gb.egress_tables(d_wire.data_ptr(), stride)
+            ev.ingest_tables(d_wire.data_ptr(), stride, d_bad.data_ptr())
+        else:
+            gb.egress_tables_dense(d_wire.data_ptr(), stride)
+            ev.ingest_tables_dense(d_wire.data_ptr(), stride)
+        ev.eval(key, ev)
+        ctx.sync()
+        assert int(d_bad.cpu()[0]) == 0, "ingest flagged a header"
+        wire = d_wire.cpu().numpy().reshape(batch, stride)
+        sl = gb.read_slab()
+        for i in (0, batch - 1):
+            want = oracle.tables_serialize(c.Gates, sl[i]) if mode == 1 else \
+                b"".join(int(x).to_bytes(8, "big") for row in sl[i] for x in (row["d0"], row["d1"]))
+            assert wire[i, :nbytes].tobytes() == want, "egress bytes of instance %d (mode %d)" % (i, mode)
+    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    ctx.sync()
+    assert int(d_mis.cpu()[0]) == 0, "decode mismatches"
+    out = d_out.cpu().numpy()
+    for i in sorted(set(list(range(0, batch, max(1, batch // 7))) + [batch - 1])):
+        plain = c.compute_bits(bits[i])
+        assert (plain[c.NumWires - c.num_outputs:] == out[i][: c.num_outputs]).all(), "decoded bits of instance %d" % i
+    slab, R = gb.read_slab(), gb.read_r()
+    for i in sorted(set([0, batch // 2, batch - 1])):
+        ref = oracle_instance(c, key, rnd, i)
+        assert R[i] == ref["R"] and (slab[i] == ref["slab"]).all(), "tables of instance %d" % i
+    gb.close(); ev.close(); dc.close()
+    return ninputs, ngates, batch, schedule, len(key)
+
+
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_device_pipeline_random(ctx, seed):
+    device_pipeline_case(ctx, seed)
