@@ -39,7 +39,8 @@ constexpr int DPP_PAIR0 = 0xA0;  // [0,0,2,2]
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t ldpp32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    // quad permutes have no invalid source lanes inside a full quad: no "old" value, so no register initialisation
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ uint4 ldpp128(uint4 v) {
