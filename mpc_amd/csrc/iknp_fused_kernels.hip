@@ -56,21 +56,62 @@ __device__ __forceinline__ uint32_t chunk_pos(uint32_t col, uint32_t rd) {
     return cg * kCgStride + k * 16u + (((rd >> 2) ^ ((k >> 1) & 3u)) << 2) + (rd & 3u);
 }
 
-// N AES-128 encryptions in lock-step with a per-lane key schedule in LDS (keyaddr = byte address of round key 0)
-template <int N>
-__device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t keyaddr, uint32_t lo0) {
+// What a lane (= one column key) keeps for the whole kernel: the counter blocks of a column are (0, 0, j_hi, j_lo), so
+// after the first AddRoundKey the state columns 0 and 1 are the key words themselves — half of round 1's sixteen
+// look-ups have constant inputs.  p[c] = rk_1[c] ^ (those two constant terms of column c); z, w = rk_0 words 2, 3.
+struct CtrKey {
+    uint32_t p[4], z, w;
+};
+__device__ __forceinline__ CtrKey ctr_key_setup(uint32_t keyaddr, uint32_t lo0) {
     const uint32_t lo2 = lo0 + 128u;
     const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
-    uint4 k = lds_ld4(keyaddr);
+    const uint4 k0 = lds_ld4(keyaddr), k1 = lds_ld4(keyaddr + 16u);
+    const uint32_t a0 = k0.x, a1 = k0.y;
+    CtrKey c;
+    // column c = Te0[b3(a_c)] ^ Te1[b2(a_c+1)] ^ Te2[b1(a_c+2)] ^ Te3[b0(a_c+3)], Te1 / Te3 = rotr8(Te0 / Te2)
+    c.p[0] = k1.x ^ te_dual(a0, sel3, lo0) ^ rotr32(te_dual(a1, sel2, lo0), 8);
+    c.p[1] = k1.y ^ te_dual(a1, sel3, lo0) ^ rotr32(te_dual(a0, sel0, lo2), 8);
+    c.p[2] = k1.z ^ te_dual(a0, sel1, lo2) ^ rotr32(te_dual(a1, sel0, lo2), 8);
+    c.p[3] = k1.w ^ te_dual(a1, sel1, lo2) ^ rotr32(te_dual(a0, sel2, lo0), 8);
+    c.z = k0.z;
+    c.w = k0.w;
+    return c;
+}
+
+// N AES-128-CTR blocks in lock-step with a per-lane key schedule in LDS (keyaddr = byte address of round key 0):
+// in: s[n][2], s[n][3] = the counter words j_hi, j_lo (words 0 and 1 of the block are zero); out: the four columns
+template <int N>
+__device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t keyaddr, uint32_t lo0, const CtrKey &ck) {
+    const uint32_t lo2 = lo0 + 128u;
+    const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
+    uint4 k;
+    {   // round 1: only the terms that depend on the counter (state columns 2 and 3): eight look-ups, not sixteen
+        uint32_t ad[N][8], t[N][8];
 #pragma unroll
-    for (int n = 0; n < N; n++) {
-        s[n][0] ^= k.x;
-        s[n][1] ^= k.y;
-        s[n][2] ^= k.z;
-        s[n][3] ^= k.w;
+        for (int n = 0; n < N; n++) {
+            const uint32_t a2 = s[n][2] ^ ck.z, a3 = s[n][3] ^ ck.w;
+            ad[n][0] = __builtin_amdgcn_perm(a2, lo2, sel1);  // col 0: Te2[b1(a2)]
+            ad[n][1] = __builtin_amdgcn_perm(a3, lo2, sel0);  //        Te3[b0(a3)] (rotr8)
+            ad[n][2] = __builtin_amdgcn_perm(a3, lo2, sel1);  // col 1: Te2[b1(a3)]
+            ad[n][3] = __builtin_amdgcn_perm(a2, lo0, sel2);  //        Te1[b2(a2)] (rotr8)
+            ad[n][4] = __builtin_amdgcn_perm(a2, lo0, sel3);  // col 2: Te0[b3(a2)]
+            ad[n][5] = __builtin_amdgcn_perm(a3, lo0, sel2);  //        Te1[b2(a3)] (rotr8)
+            ad[n][6] = __builtin_amdgcn_perm(a3, lo0, sel3);  // col 3: Te0[b3(a3)]
+            ad[n][7] = __builtin_amdgcn_perm(a2, lo2, sel0);  //        Te3[b0(a2)] (rotr8)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) t[n][i] = *(lds_u32 *)(uintptr_t)ad[n][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) s[n][c] = xor3(ck.p[c], t[n][2 * c], rotr32(t[n][2 * c + 1], 8));
     }
 #pragma unroll
-    for (int r = 1; r < 10; r++) {
+    for (int r = 2; r < 10; r++) {
         k = lds_ld4(keyaddr + 16u * r);
         const uint32_t kk[4] = {k.x, k.y, k.z, k.w};
         uint32_t ad[N][16], t[N][16];  // one batch of lookups per round (see aes_encrypt_dual)
@@ -121,7 +162,8 @@ __device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t key
 // 64 keystream bytes of one column starting at stream byte position p (p mod 16 == sh, launch-uniform):
 // t[0..15] little-endian dwords.  prg() of iknp.go:632-637 restated for a lane.
 template <bool MISALIGNED>
-__device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t keyaddr, uint32_t lo0, uint32_t (&t)[16]) {
+__device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t keyaddr, uint32_t lo0, const CtrKey &ck,
+                                              uint32_t (&t)[16]) {
     const uint64_t j0 = p >> 4;
     uint32_t w[20];
     // two blocks at a time: four in lock-step spill (1024-thread workgroups have 128 VGPRs per lane)
@@ -136,7 +178,7 @@ __device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t 
             s[n][2] = (uint32_t)(j >> 32);
             s[n][3] = (uint32_t)j;
         }
-        aes128_lanekey<2>(s, keyaddr, lo0);
+        aes128_lanekey<2>(s, keyaddr, lo0, ck);
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -153,7 +195,7 @@ __device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t 
     e[0][1] = 0;
     e[0][2] = (uint32_t)(j >> 32);
     e[0][3] = (uint32_t)j;
-    aes128_lanekey<1>(e, keyaddr, lo0);
+    aes128_lanekey<1>(e, keyaddr, lo0, ck);
 #pragma unroll
     for (int c = 0; c < 4; c++) w[16 + c] = __builtin_bswap32(e[0][c]);
     // bytes [sh, sh + 64) of the 80 bytes: sh is wave-uniform, 1..15
@@ -222,6 +264,7 @@ __global__ __launch_bounds__(IKT) void k_iknp_fused(const uint32_t *__restrict__
     const uint32_t stream = RECV ? (slice >> 2) : 0u;       // receiver: 0 = g0 (t), 1 = g1
     const uint32_t keyaddr = (stream ? kKey1 : kKey0) + col * 176u;
     const uint32_t bufaddr = kBuf + cig * kChunkBuf;
+    const CtrKey ck = ctr_key_setup(keyaddr, lo0);  // table and keys are in LDS (barrier above)
     const uint32_t sh = (uint32_t)(pos0 & 15u);
     const size_t chunks = (n + 511) / 512;
     const size_t groups = (chunks + NCH - 1) / NCH;
@@ -234,7 +277,7 @@ __global__ __launch_bounds__(IKT) void k_iknp_fused(const uint32_t *__restrict__
         const uint32_t rows = valid ? (uint32_t)((n - ofs) < 512 ? (n - ofs) : 512) : 0;
         const uint32_t byte_rows = (rows + 7) / 8;
         uint32_t t[16];
-        if (valid) column_stream<MISALIGNED>(pos0 + 64 * (uint64_t)chunk, sh, keyaddr, lo0, t);
+        if (valid) column_stream<MISALIGNED>(pos0 + 64 * (uint64_t)chunk, sh, keyaddr, lo0, ck, t);
         const size_t at = chunk * 8192 + (size_t)col * byte_rows;  // column-major message layout (iknp.go:490-499)
         if (RECV) {
             if (valid && stream == 1) {
