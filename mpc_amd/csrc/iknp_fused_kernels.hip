@@ -18,6 +18,7 @@
 // LDS: 64 KiB table | 22 KiB (44 KiB) round keys | 8 (4) chunk buffers of 8 448 bytes.
 #include "aes_device.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gc {
 
@@ -61,6 +62,7 @@ __device__ __forceinline__ uint32_t chunk_pos(uint32_t col, uint32_t rd) {
 // look-ups have constant inputs.  p[c] = rk_1[c] ^ (those two constant terms of column c); z, w = rk_0 words 2, 3.
 struct CtrKey {
     uint32_t p[4], z, w;
+    uint32_t q[4];  // p plus the terms of state column 2, valid while the counter's word 2 is zero (< 2^32 blocks)
 };
 __device__ __forceinline__ CtrKey ctr_key_setup(uint32_t keyaddr, uint32_t lo0) {
     const uint32_t lo2 = lo0 + 128u;
@@ -75,17 +77,46 @@ __device__ __forceinline__ CtrKey ctr_key_setup(uint32_t keyaddr, uint32_t lo0) 
     c.p[3] = k1.w ^ te_dual(a1, sel1, lo2) ^ rotr32(te_dual(a0, sel2, lo0), 8);
     c.z = k0.z;
     c.w = k0.w;
+    const uint32_t a2 = k0.z;  // j_hi = 0
+    c.q[0] = c.p[0] ^ te_dual(a2, sel1, lo2);
+    c.q[1] = c.p[1] ^ rotr32(te_dual(a2, sel2, lo0), 8);
+    c.q[2] = c.p[2] ^ te_dual(a2, sel3, lo0);
+    c.q[3] = c.p[3] ^ rotr32(te_dual(a2, sel0, lo2), 8);
     return c;
 }
 
 // N AES-128-CTR blocks in lock-step with a per-lane key schedule in LDS (keyaddr = byte address of round key 0):
 // in: s[n][2], s[n][3] = the counter words j_hi, j_lo (words 0 and 1 of the block are zero); out: the four columns
-template <int N>
+// HI0: every counter of the launch is below 2^32 (launch-uniform): column 2 is constant as well, four look-ups
+template <int N, bool HI0>
 __device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t keyaddr, uint32_t lo0, const CtrKey &ck) {
     const uint32_t lo2 = lo0 + 128u;
     const uint32_t sel0 = GC_PERM_SEL(0), sel1 = GC_PERM_SEL(1), sel2 = GC_PERM_SEL(2), sel3 = GC_PERM_SEL(3);
     uint4 k;
-    {   // round 1: only the terms that depend on the counter (state columns 2 and 3): eight look-ups, not sixteen
+    if constexpr (HI0) {  // round 1 from state column 3 alone
+        uint32_t ad[N][4], t[N][4];
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            const uint32_t a3 = s[n][3] ^ ck.w;
+            ad[n][0] = __builtin_amdgcn_perm(a3, lo2, sel0);  // col 0: Te3[b0(a3)] (rotr8)
+            ad[n][1] = __builtin_amdgcn_perm(a3, lo2, sel1);  // col 1: Te2[b1(a3)]
+            ad[n][2] = __builtin_amdgcn_perm(a3, lo0, sel2);  // col 2: Te1[b2(a3)] (rotr8)
+            ad[n][3] = __builtin_amdgcn_perm(a3, lo0, sel3);  // col 3: Te0[b3(a3)]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[n][i] = *(lds_u32 *)(uintptr_t)ad[n][i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < N; n++) {
+            s[n][0] = ck.q[0] ^ rotr32(t[n][0], 8);
+            s[n][1] = ck.q[1] ^ t[n][1];
+            s[n][2] = ck.q[2] ^ rotr32(t[n][2], 8);
+            s[n][3] = ck.q[3] ^ t[n][3];
+        }
+    } else {  // round 1: only the terms that depend on the counter (state columns 2 and 3): eight look-ups, not sixteen
         uint32_t ad[N][8], t[N][8];
 #pragma unroll
         for (int n = 0; n < N; n++) {
@@ -161,7 +192,7 @@ __device__ __forceinline__ void aes128_lanekey(uint32_t (&s)[N][4], uint32_t key
 
 // 64 keystream bytes of one column starting at stream byte position p (p mod 16 == sh, launch-uniform):
 // t[0..15] little-endian dwords.  prg() of iknp.go:632-637 restated for a lane.
-template <bool MISALIGNED>
+template <bool MISALIGNED, bool HI0>
 __device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t keyaddr, uint32_t lo0, const CtrKey &ck,
                                               uint32_t (&t)[16]) {
     const uint64_t j0 = p >> 4;
@@ -178,7 +209,7 @@ __device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t 
             s[n][2] = (uint32_t)(j >> 32);
             s[n][3] = (uint32_t)j;
         }
-        aes128_lanekey<2>(s, keyaddr, lo0, ck);
+        aes128_lanekey<2, HI0>(s, keyaddr, lo0, ck);
 #pragma unroll
         for (int n = 0; n < 2; n++)
 #pragma unroll
@@ -195,7 +226,7 @@ __device__ __forceinline__ void column_stream(uint64_t p, uint32_t sh, uint32_t 
     e[0][1] = 0;
     e[0][2] = (uint32_t)(j >> 32);
     e[0][3] = (uint32_t)j;
-    aes128_lanekey<1>(e, keyaddr, lo0, ck);
+    aes128_lanekey<1, HI0>(e, keyaddr, lo0, ck);
 #pragma unroll
     for (int c = 0; c < 4; c++) w[16 + c] = __builtin_bswap32(e[0][c]);
     // bytes [sh, sh + 64) of the 80 bytes: sh is wave-uniform, 1..15
@@ -242,7 +273,7 @@ __device__ __forceinline__ void store_quarter(uint8_t *dst, uint32_t byte_rows, 
             if (16u * q + 4u * i + b < byte_rows) dst[16 * q + 4 * i + b] = (uint8_t)(v[i] >> (8 * b));
 }
 
-template <bool RECV, bool MISALIGNED>
+template <bool RECV, bool MISALIGNED, bool HI0>
 __global__ __launch_bounds__(IKT) void k_iknp_fused(const uint32_t *__restrict__ rk0, const uint32_t *__restrict__ rk1,
                                                     uint64_t pos0, size_t n, const uint8_t *__restrict__ bbuf,
                                                     const uint8_t *__restrict__ u_in, uint4 delta,
@@ -277,7 +308,7 @@ __global__ __launch_bounds__(IKT) void k_iknp_fused(const uint32_t *__restrict__
         const uint32_t rows = valid ? (uint32_t)((n - ofs) < 512 ? (n - ofs) : 512) : 0;
         const uint32_t byte_rows = (rows + 7) / 8;
         uint32_t t[16];
-        if (valid) column_stream<MISALIGNED>(pos0 + 64 * (uint64_t)chunk, sh, keyaddr, lo0, ck, t);
+        if (valid) column_stream<MISALIGNED, HI0>(pos0 + 64 * (uint64_t)chunk, sh, keyaddr, lo0, ck, t);
         const size_t at = chunk * 8192 + (size_t)col * byte_rows;  // column-major message layout (iknp.go:490-499)
         if (RECV) {
             if (valid && stream == 1) {
@@ -368,22 +399,32 @@ hipError_t launch_iknp_fused(bool recv, const uint32_t *rk0, const uint32_t *rk1
     const unsigned grid = (unsigned)(groups < 256 ? groups : 256);
     const size_t lds = kTeDualBytes + (recv ? 2 : 1) * kKeyBytes + (size_t)nch * kChunkBuf;
     const bool mis = (pos0 & 15u) != 0;
+    // every counter this launch encrypts below 2^32 blocks (64 GiB of keystream per column): the cheaper first round
+    // (GC_IKNP_GENERIC=1 forces the general first round: the only way to exercise it short of 64 GiB of stream)
+    const char *gen = getenv("GC_IKNP_GENERIC");
+    const bool hi0 = ((pos0 >> 4) + 4 * (uint64_t)chunks + 8) < (1ull << 32) && !(gen && gen[0] == '1');
     hipError_t e = hipSuccess;
-#define GC_IK(R, M)                                                                                              \
-    do {                                                                                                         \
-        e = hipFuncSetAttribute((const void *)k_iknp_fused<R, M>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                (int)lds);                                                                       \
-        if (e == hipSuccess)                                                                                     \
-            hipLaunchKernelGGL((k_iknp_fused<R, M>), dim3(grid), dim3(IKT), lds, s, rk0, rk1, pos0, n, bbuf,     \
-                               u_in, delta, u_out, labels, te0);                                                 \
+#define GC_IK(R, M, H)                                                                                              \
+    do {                                                                                                            \
+        e = hipFuncSetAttribute((const void *)k_iknp_fused<R, M, H>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                          \
+        if (e == hipSuccess)                                                                                        \
+            hipLaunchKernelGGL((k_iknp_fused<R, M, H>), dim3(grid), dim3(IKT), lds, s, rk0, rk1, pos0, n, bbuf,     \
+                               u_in, delta, u_out, labels, te0);                                                    \
+    } while (0)
+#define GC_IK2(R, M)            \
+    do {                        \
+        if (hi0) GC_IK(R, M, true); \
+        else GC_IK(R, M, false);    \
     } while (0)
     if (recv) {
-        if (mis) GC_IK(true, true);
-        else GC_IK(true, false);
+        if (mis) GC_IK2(true, true);
+        else GC_IK2(true, false);
     } else {
-        if (mis) GC_IK(false, true);
-        else GC_IK(false, false);
+        if (mis) GC_IK2(false, true);
+        else GC_IK2(false, false);
     }
+#undef GC_IK2
 #undef GC_IK
     return e != hipSuccess ? e : hipGetLastError();
 }
