@@ -116,10 +116,11 @@ int gc_ctx_sync(gc_ctx *);
 void *gc_ctx_stream(gc_ctx *);
 
 /* Pipeline graphs (hipGraph): record a sequence of DEVICE-RESIDENT calls on this ctx (gc_batch_garble,
- * _select_inputs, _eval, _decode, _egress_tables, gc_iknp_*_dev, ...; same pointers every time) once, then replay it
+ * _select_inputs, _eval, _decode, _egress_tables, gc_cot_*_dev, ...; same pointers every time) once, then replay it
  * with a single launch — removes the host launch latency between the five-odd kernels of a step.
- * Between begin and end nothing executes; host-buffer calls (gc_garble, gc_eval, read_*, ...) and changes of key,
- * schedule or batch geometry are not allowed inside a capture; gc_batch_last_ms is not updated by replays. */
+ * Between begin and end nothing executes; host-buffer calls (gc_garble, gc_eval, read_*, ...), changes of key,
+ * schedule or batch geometry, and gc_iknp_*_dev (their column streams advance with every call: the position cannot be
+ * baked into a graph; they return GC_E_ARG) are not allowed inside a capture; gc_batch_last_ms is not updated by replays. */
 typedef struct gc_graph gc_graph;
 int gc_ctx_capture_begin(gc_ctx *);
 int gc_ctx_capture_end(gc_ctx *, gc_graph **out);

@@ -217,6 +217,8 @@ int gc_iknp_receive_dev(gc_iknp *k, const void *d_choice_packed, size_t n, void 
     if (!k || !k->receiver || (n && (!d_choice_packed || !d_u_out || !d_labels_out))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     gc_ctx *ctx = k->ctx;
+    // the stream position is a kernel argument and advances with every call: a replayed capture would reuse it
+    if (ctx->capturing) return GC_E_ARG;
     GC_HIP(hipSetDevice(ctx->device));
     int rc = iknp_ws(k, 0);
     if (rc != GC_OK) return rc;
@@ -234,6 +236,8 @@ int gc_iknp_send_dev(gc_iknp *k, const void *d_u_in, size_t n, void *d_labels_ou
     if (!k || k->receiver || (n && (!d_u_in || !d_labels_out))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     gc_ctx *ctx = k->ctx;
+    // the stream position is a kernel argument and advances with every call: a replayed capture would reuse it
+    if (ctx->capturing) return GC_E_ARG;
     GC_HIP(hipSetDevice(ctx->device));
     int rc = iknp_ws(k, 0);
     if (rc != GC_OK) return rc;

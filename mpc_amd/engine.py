@@ -235,12 +235,14 @@ class Context:
     def capture(self, fn):
         """record the device-resident calls fn() makes on this ctx into a Graph (gc_ctx_capture_*)"""
         _check(lib().gc_ctx_capture_begin(self.h), "gc_ctx_capture_begin")
+        g = C.c_void_p()
         try:
             fn()
-        finally:
-            g = C.c_void_p()
-            rc = lib().gc_ctx_capture_end(self.h, C.byref(g))
-        _check(rc, "gc_ctx_capture_end")
+        except BaseException:  # leave capture mode and drop the partial graph before the error travels on
+            if lib().gc_ctx_capture_end(self.h, C.byref(g)) == GC_OK and g:
+                lib().gc_graph_free(g)
+            raise
+        _check(lib().gc_ctx_capture_end(self.h, C.byref(g)), "gc_ctx_capture_end")
         return Graph(g)
 
     def close(self):

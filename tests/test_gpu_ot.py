@@ -228,3 +228,19 @@ def test_iknp_general_first_round(ctx, golden_dir, monkeypatch):
     test_iknp_matches_committed_golden(ctx, golden_dir)
     for n in (1, 513, 2049):
         test_iknp_matches_oracle_and_correlates(ctx, n)
+
+
+def test_iknp_refuses_graph_capture(ctx):
+    """the column streams advance with every call: inside gc_ctx_capture_* the device entry points return GC_E_ARG"""
+    import torch
+    base, delta, k0 = base_setup("cap")
+    rcv = engine.IKNPReceiver(ctx, base)
+    d = torch.zeros(8192 + 64 + 512 * 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(engine.EngineError) as e:
+        ctx.capture(lambda: rcv.receive_dev(d.data_ptr(), 512, d.data_ptr() + 64, d.data_ptr() + 64 + 8192))
+    assert e.value.code == engine.GC_E_ARG
+    u, got = rcv.receive(np.zeros(3, np.uint8))  # the pair is still usable and at position 0
+    wu, wgot = oracle.IKNPReceiver(base).receive(np.zeros(3, np.uint8))
+    assert bytes(u) == bytes(wu) and (got == wgot).all()
+    rcv.close()
