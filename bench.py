@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per gate per side (SURVEY.md §8d / DESIGN.md): 16-byte labels, L1 never stored
 ALG_BYTES = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}
+GATHER_EVERY = 8  # steps per all_gather of the decoded outputs (N > 1)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 # Secondary bound (SURVEY.md §8d "LDS bandwidth / VALU issue on AND-dense levels"): the fixed-key hash is a
 # T-table AES out of LDS.  tools/aes_ubench measures the production AES core alone at 10.28 cycles per block per
@@ -140,44 +141,58 @@ def main():
     d_rnd = torch.randint(0, 256, (batch, circ.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
     d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
     collective = world > 1 or args.force_collective
-    nbuf = 2 if collective else 1  # decoded outputs are double-buffered so that the gather of step i overlaps step i+1
-    d_outs = [torch.zeros((batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    d_out = d_outs[0]
+    # Decoded outputs of GATHER_EVERY steps are collected in one accumulator and gathered with ONE all_gather (fewer,
+    # larger collectives: a gather per step costs ~3 % even overlapped — its kernel shares the CUs with the next garble);
+    # two accumulators, so that the gather of one overlaps the steps that fill the other.
+    K = GATHER_EVERY if collective else 1
+    nacc = 2 if collective else 1
+    d_acc = [torch.zeros((K, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nacc)]
+    d_out = d_acc[0][0]
     d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d_all = [torch.zeros((world * batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nbuf)] \
+    d_all = [torch.zeros((world, K, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nacc)] \
         if collective else None
 
-    def device_step(k=0):
+    def device_step(a=0, j=0):
         gb.garble(key, d_rnd.data_ptr())
         ev.select_inputs(gb, d_bits.data_ptr())
         ev.eval(key, gb)
-        gb.decode(ev, d_outs[k].data_ptr(), d_mis.data_ptr())
+        gb.decode(ev, d_acc[a][j].data_ptr(), d_mis.data_ptr())
 
-    graphs = None  # the step's kernels recorded once in a hipGraph (gc_ctx_capture_*): one launch per step
+    graphs = None  # the step's kernels recorded once per output slot in a hipGraph (gc_ctx_capture_*): one launch per step
     # The only collective: all_gather of the decoded outputs over RCCL/xGMI, on torch's stream.  The engine runs on
-    # its own HIP stream; the two are chained with events (no host synchronisation inside the loop): the gather of
-    # step i waits for decode(i) and runs while step i+1 garbles; decode(i+2) waits for gather(i) (same buffer).
+    # its own HIP stream; the two are chained with events (no host synchronisation inside the loop): the gather of an
+    # accumulator waits for the decode that filled its last slot and runs while the next steps fill the other one; the
+    # first decode into an accumulator waits for its previous gather.
     eng_stream = torch.cuda.ExternalStream(ctx.stream) if collective else None
-    done_ev = [torch.cuda.Event() for _ in range(nbuf)]
-    gathered_ev = [None] * nbuf
+    done_ev = [torch.cuda.Event() for _ in range(nacc)]
+    gathered_ev = [None] * nacc
     counter = [0]
 
+    def gather(a):
+        done_ev[a].record(eng_stream)
+        torch.cuda.current_stream().wait_event(done_ev[a])
+        dist.all_gather_into_tensor(d_all[a].view(world * K * batch, -1), d_acc[a].view(K * batch, -1))
+        e = torch.cuda.Event()
+        e.record()
+        gathered_ev[a] = e
+
     def step():
-        k = counter[0] % nbuf
+        i = counter[0]
         counter[0] += 1
-        if collective and gathered_ev[k] is not None:
-            eng_stream.wait_event(gathered_ev[k])
+        a, j = (i // K) % nacc, i % K
+        if collective and j == 0 and gathered_ev[a] is not None:
+            eng_stream.wait_event(gathered_ev[a])
         if graphs is not None:
-            graphs[k].launch()
+            graphs[a][j].launch()
         else:
-            device_step(k)
-        if collective:
-            done_ev[k].record(eng_stream)
-            torch.cuda.current_stream().wait_event(done_ev[k])
-            dist.all_gather_into_tensor(d_all[k], d_outs[k])
-            e = torch.cuda.Event()
-            e.record()
-            gathered_ev[k] = e
+            device_step(a, j)
+        if collective and j == K - 1:
+            gather(a)
+
+    def flush():  # outputs of the steps since the last full accumulator
+        if collective and counter[0] % K:
+            gather((counter[0] // K) % nacc)
+            counter[0] += K - counter[0] % K
 
     def fence():
         ctx.sync()
@@ -191,19 +206,20 @@ def main():
     ctx.sync()
     if not args.no_graph and args.schedule != 0:
         try:
-            graphs = [ctx.capture(lambda k=k: device_step(k)) for k in range(nbuf)]
+            graphs = [[ctx.capture(lambda a=a, j=j: device_step(a, j)) for j in range(K)] for a in range(nacc)]
         except Exception as e:  # capture is an optimisation: fall back to direct launches of the same kernels
             print("bench: hipGraph capture unavailable (%s); launching directly" % e, file=sys.stderr)
             graphs = None
             ctx.sync()
     for _ in range(args.warmup):
         step()
+    flush()
     fence()
     g_ms, e_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP-event times of the passes, recorded on the engine's own stream (gc_batch_last_ms)
+    flush()  # every output of the timed steps is gathered inside the timed region
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -224,8 +240,8 @@ def main():
 
     ok = mismatches == 0
     if collective:  # the gathered tensor holds this rank's outputs at its offset
-        for k in range(nbuf):
-            ok = ok and bool(torch.equal(d_all[k][rank * batch:(rank + 1) * batch], d_outs[k]))
+        for a in range(nacc):
+            ok = ok and bool(torch.equal(d_all[a][rank], d_acc[a]))
     if args.check:
         bits = d_bits.cpu().numpy()
         out = d_out.cpu().numpy()
