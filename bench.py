@@ -3,7 +3,9 @@
 
 One "step" = one pass of the hot path over one batch of synthetic instances that are already
 resident in HBM: Circuit.Garble for `batch` instances, hand-over of the evaluator's input labels,
-Circuit.Eval, and BitFromLabel decoding (+ the RCCL gather of the decoded outputs when N > 1).
+Circuit.Eval, and BitFromLabel decoding (+ the RCCL all-gather of the decoded outputs when N > 1: gc_comm_allgather of
+libgcengine.so = ncclAllGather over xGMI called from the C ABI; torch.distributed only launches the ranks and carries
+the 128-byte communicator id over a gloo control group).
 Workload at N=1: BASELINE.json configs[1] — aes_128 (36 663 gates, 6 400 AND) x 1 024 instances,
 32-byte garbling key (AES-256, as circuit.Garbler uses).  N > 1: the same per-GPU batch on every
 rank (weak scaling, independent instances, no data-path collective except the output gather).
@@ -28,6 +30,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # CU with 16 waves/CU (59.7 G blocks/s on 256 CUs; profiles/r01_aes_ubench.txt).
 AES_CORE_PEAK_BLOCKS = 59.7e9
 AES_BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}  # (garble, eval) distinct AES blocks per gate
+# bytes READ per gate (garble, eval) of the same layout-independent model (393.4 B per AND for aes_128):
+# the north star's "HBM-read roofline"
+READ_BYTES = {"xor": (32, 32), "xnor": (32, 32), "and": (32, 64), "inv": (16, 32), "or": (32, 80)}
+# LDS array: a conflict-free wave64 ds_read_b32 takes 2 LDS cycles = 128 B/clk/CU, ~75 TB/s with every CU streaming
+# (MI355X_MICROARCH.md, LDS section) = 18.75 T table look-ups/s; one AES block is 16 look-ups per round.
+LDS_B32_PEAK_LOOKUPS = 75e12 / 4
 
 
 def alg_bytes_per_instance(info):
@@ -112,16 +120,13 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    from mpc_amd import engine, parse_file
+    from mpc_amd import dist as gdist, engine, parse_file
 
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_collective:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if "MASTER_ADDR" not in os.environ:  # --force-collective without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        gdist.init_control()  # gloo: rendezvous + the communicator id, no GPU collective goes through torch
 
     circ = parse_file(args.circuit)
     circ.name = os.path.splitext(os.path.basename(args.circuit))[0]
@@ -141,11 +146,13 @@ def main():
     d_rnd = torch.randint(0, 256, (batch, circ.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
     d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
     collective = world > 1 or args.force_collective
-    # Decoded outputs of GATHER_EVERY steps are collected in one accumulator and gathered with ONE all_gather (fewer,
-    # larger collectives: a gather per step costs ~3 % even overlapped — its kernel shares the CUs with the next garble);
-    # two accumulators, so that the gather of one overlaps the steps that fill the other.
+    comm = gdist.open_comm(ctx, rank, world) if collective else None  # gc_comm_init_rank: RCCL, one rank per GPU
+    # Decoded outputs of GATHER_EVERY steps are collected in one accumulator and gathered with ONE all-gather (fewer,
+    # larger collectives: 1 MiB per GPU per call at 1 024 instances; a gather per step cost ~3 %).  The gather is
+    # enqueued on the engine's stream right behind the decode that fills the last slot (stream order protects the
+    # accumulator; no host synchronisation inside the loop).
     K = GATHER_EVERY if collective else 1
-    nacc = 2 if collective else 1
+    nacc = 1
     d_acc = [torch.zeros((K, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nacc)]
     d_out = d_acc[0][0]
     d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -159,29 +166,15 @@ def main():
         gb.decode(ev, d_acc[a][j].data_ptr(), d_mis.data_ptr())
 
     graphs = None  # the step's kernels recorded once per output slot in a hipGraph (gc_ctx_capture_*): one launch per step
-    # The only collective: all_gather of the decoded outputs over RCCL/xGMI, on torch's stream.  The engine runs on
-    # its own HIP stream; the two are chained with events (no host synchronisation inside the loop): the gather of an
-    # accumulator waits for the decode that filled its last slot and runs while the next steps fill the other one; the
-    # first decode into an accumulator waits for its previous gather.
-    eng_stream = torch.cuda.ExternalStream(ctx.stream) if collective else None
-    done_ev = [torch.cuda.Event() for _ in range(nacc)]
-    gathered_ev = [None] * nacc
     counter = [0]
 
-    def gather(a):
-        done_ev[a].record(eng_stream)
-        torch.cuda.current_stream().wait_event(done_ev[a])
-        dist.all_gather_into_tensor(d_all[a].view(world * K * batch, -1), d_acc[a].view(K * batch, -1))
-        e = torch.cuda.Event()
-        e.record()
-        gathered_ev[a] = e
+    def gather(a):  # the only collective: ncclAllGather of the decoded outputs over RCCL/xGMI, behind the C ABI
+        comm.allgather(d_acc[a].data_ptr(), d_all[a].data_ptr(), d_acc[a].numel())
 
     def step():
         i = counter[0]
         counter[0] += 1
         a, j = (i // K) % nacc, i % K
-        if collective and j == 0 and gathered_ev[a] is not None:
-            eng_stream.wait_event(gathered_ev[a])
         if graphs is not None:
             graphs[a][j].launch()
         else:
@@ -197,8 +190,8 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()  # every rank's engine stream has drained (allreduce + stream sync)
             torch.cuda.synchronize()
 
     torch.cuda.synchronize()  # inputs were generated on torch's stream; the engine runs on its own
@@ -223,10 +216,8 @@ def main():
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)  # the job's step time is the slowest rank's
 
     # per-pass device times (events on the engine stream) from a few extra, untimed-by-wall steps
     for _ in range(min(20, max(1, args.steps))):
@@ -264,7 +255,10 @@ def main():
     sched_name = {0: "level-launch", 1: "fused-flat", 2: "fused-levels"}[args.schedule]
     blocks_g = sum(getattr(info, "n_" + k) * v[0] for k, v in AES_BLOCKS.items())
     blocks_e = sum(getattr(info, "n_" + k) * v[1] for k, v in AES_BLOCKS.items())
-    traffic = None
+    # HBM traffic of the garble launch: PMC counters cannot be read from inside the run; the figure is the one
+    # scripts/profile.sh measured with rocprofv3 --pmc for this batch / schedule / key size (profiles/latest_pmc.json,
+    # kernel named there) — null when the file does not describe this configuration.
+    traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
     if os.path.exists(pmc):
         try:
@@ -272,8 +266,12 @@ def main():
                 pj = json.load(f)
             if pj.get("batch") == batch and pj.get("schedule") == args.schedule and pj.get("key_bytes") == args.key_bytes:
                 traffic = pj.get("garble_hbm_bytes_per_launch")
+                traffic_src = "profiles/latest_pmc.json (rocprofv3 --pmc, %s)" % pj.get("source", "scripts/profile.sh")
         except Exception:
             traffic = None
+    read_b = sum(getattr(info, "n_" + k) * (v[0] + v[1]) for k, v in READ_BYTES.items())  # per instance, both passes
+    rounds = {16: 10, 24: 12, 32: 14}[args.key_bytes]
+    lookups_per_block = 16 * rounds
     res = {
         "metric": "AND-gates/sec (garble+eval), AES-128 circuit batch",
         "value": value,
@@ -312,8 +310,15 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "alg_bytes_per_launch": algb * batch / max(launches, 1),
             "avg_launch_us": g_avg * 1e3 / max(launches, 1),
+            # "achieved" prices the layout-independent byte model of SURVEY §8(d); the fused kernel keeps wires in LDS
+            # and really moves `traffic` bytes: the two honest views of the same launch follow.
+            "frac_read": value / world * (read_b / max(n_and, 1)) / 1e9 / HBM_PEAK_GBS,  # whole step, 393.4 B/AND model
+            "hbm_counter_GBs": (traffic / (g_avg * 1e-3) / 1e9) if traffic else None,  # what HBM really carried
+            "hbm_counter_frac": (traffic / (g_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "limiter": "LDS array + VALU issue of the T-table AES core (see aes_core); HBM is at hbm_counter_frac",
         },
         # what actually limits the kernels: AES blocks through the LDS T-table core (VALU issue + LDS address path)
         "aes_core": {
@@ -322,6 +327,11 @@ def main():
             "peak_blocks_per_s": AES_CORE_PEAK_BLOCKS,
             "frac_garble": blocks_g * batch / (g_avg * 1e-3) / AES_CORE_PEAK_BLOCKS,
             "frac_eval": blocks_e * batch / (e_avg * 1e-3) / AES_CORE_PEAK_BLOCKS,
+            "peak_source": "tools/aes_ubench: the production AES core alone, 16 waves/CU (own micro-benchmark)",
+            # against the hardware figure instead: table look-ups/s over the LDS array's ds_read_b32 rate
+            "lds_array_frac_garble": blocks_g * batch * lookups_per_block / (g_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS,
+            "lds_array_frac_eval": blocks_e * batch * lookups_per_block / (e_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS,
+            "lds_array_peak_lookups_per_s": LDS_B32_PEAK_LOOKUPS,
         },
     }
     if rank == 0:
@@ -334,8 +344,12 @@ def main():
     gb.close()
     ev.close()
     dc.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
-    if collective:
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line goes out LAST: flush whatever native libraries (RCCL banner) left in C stdio first

@@ -185,9 +185,12 @@ int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
  * at 0, :174) and appends the serialised gates — op|flags, 16/32-bit wire indexes, table rows, exactly as
  * :391-446 writes them into conn.WriteBuf — to buf.  *written = bytes needed; GC_E_ARG if cap is smaller.
  * in[] / out[] may overlap (output wires that are input wires are resolved through in[] and never set, as in
- * :131-157).  Two deliberate differences, neither reachable from compiled programs: a gate that writes an
- * input-mapped wire is rejected (GC_E_ARG), and a global wire that was never set reads as (L0, L1) = (0, R) —
- * the reference's zero-initialised store gives (0, 0); the engine never stores L1 (always L0 ^ R). */
+ * :131-157), and may name the same GLOBAL wire (in-place update): a gate that reads such an input after the gate that
+ * set the output sees the new label, as the reference's per-gate stream.wire() look-up does.  Deliberate differences,
+ * none reachable from compiled programs: a gate that writes an input-mapped wire is rejected (GC_E_ARG); a gate that
+ * reads an output-range wire before any gate of the circuit wrote it is rejected (GC_E_WIRE; the reference would read
+ * the global store's current label); a global wire that was never set reads as (L0, L1) = (0, R) — the reference's
+ * zero-initialised store gives (0, 0); the engine never stores L1 (always L0 ^ R). */
 int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
 
@@ -200,8 +203,10 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *, const uint8_t *key, size_t keyle
 void gc_stream_eval_free(gc_stream_eval *);
 int gc_stream_eval_set_wire(gc_stream_eval *, uint32_t w, const gc_label *l); /* input labels (OT results etc.) */
 int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /* OpReturn / OpResult reads */
-/* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream,
- * GC_E_ARG a tmp wire read before this block wrote it (tmp wires are private to their OpCircuit block) */
+/* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream (also:
+ * more gates announced than len / 5 bytes can hold), GC_E_ARG a tmp wire read before this block wrote it (tmp wires are
+ * private to their OpCircuit block), a tmp id >= ntmp or a global wire id >= nwires.  The block is the peer's data:
+ * nothing is sized by it before these checks, and allocation failures come back as GC_E_NOMEM. */
 int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
                            size_t len, size_t *consumed);
 
@@ -381,6 +386,39 @@ int gc_cot_receive_unpad_dev(gc_ctx *, const gc_label *seed, const void *d_flags
                              void *d_result, size_t n);
 int gc_cot_receive_unpad(gc_ctx *, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
                          gc_label *result, size_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (BASELINE config 4: 65 536 instances, 8 192 per GPU): instances are independent
+ * (fresh R and labels per Garble call, circuit/garble.go:253-278), so each device garbles / evaluates a contiguous
+ * instance range through its own gc_ctx and the ONLY exchange is the terminal all-gather of the decoded output
+ * bits (gc_batch_decode) or output labels (gc_batch_gather_outputs) — ncclAllGather of RCCL over xGMI, enqueued on
+ * the ctx stream behind the kernels that produce the data.  The reference has no counterpart (single device); a Go
+ * host (apps/garbled, circuit/garbler.go:53) calls these next to GarbleBatch / EvalBatch.  librccl is opened on first
+ * use; without it every call returns GC_E_HIP (gc_last_error() says why) and the single-GPU path is unaffected.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gc_comm gc_comm;
+#define GC_COMM_ID_BYTES 128
+int gc_comm_available(void); /* 1 if librccl could be opened and has every entry point used here */
+int gc_comm_version(void);   /* ncclGetVersion code (e.g. 22707), 0 if unavailable */
+/* One process (or OS thread) per GPU: rank 0 draws the id (ncclGetUniqueId), the host hands the 128 bytes to the other
+ * ranks over its own control channel, every rank joins with its ctx (ncclCommInitRank; collective, blocks until all
+ * nranks have called). */
+int gc_comm_get_unique_id(uint8_t *id, size_t len /* >= GC_COMM_ID_BYTES */);
+gc_comm *gc_comm_init_rank(gc_ctx *, const uint8_t *id, size_t idlen, int nranks, int rank, int *status);
+/* One process driving n devices (one gc_ctx each, distinct devices): ncclCommInitAll; out[n] */
+int gc_comm_init_all(gc_ctx *const *ctxs, int n, gc_comm **out);
+void gc_comm_destroy(gc_comm *);
+int gc_comm_rank(const gc_comm *);
+int gc_comm_nranks(const gc_comm *);
+/* d_recv[r * bytes .. (r+1) * bytes) = rank r's d_send[0 .. bytes): device pointers, `bytes` equal on all ranks
+ * (the host pads the last shard); asynchronous on the ctx stream */
+int gc_comm_allgather(gc_comm *, const void *d_send, void *d_recv, size_t bytes);
+/* the same for the n communicators of gc_comm_init_all from ONE host thread (ncclGroupStart / ncclGroupEnd) */
+int gc_comm_allgather_all(gc_comm *const *comms, int n, const void *const *d_send, void *const *d_recv, size_t bytes);
+/* host-side helpers for drivers and the benchmark: *value = max over ranks (synchronous); barrier = every rank's ctx
+ * stream has drained */
+int gc_comm_allreduce_max(gc_comm *, double *value);
+int gc_comm_barrier(gc_comm *);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 
 namespace gc {
 
@@ -16,6 +17,24 @@ void set_error(const char *what, hipError_t e) {
     // a failed runtime call also leaves the thread's "last error" set: clear it, or the next launch's
     // hipGetLastError() reports this failure again
     (void)hipGetLastError();
+}
+
+int on_exception() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        std::snprintf(tls_error, sizeof tls_error, "host allocation failed (std::bad_alloc)");
+        return GC_E_NOMEM;
+    } catch (const std::length_error &e) {
+        std::snprintf(tls_error, sizeof tls_error, "host allocation failed (%s)", e.what());
+        return GC_E_NOMEM;
+    } catch (const std::exception &e) {
+        std::snprintf(tls_error, sizeof tls_error, "internal error: %s", e.what());
+        return GC_E_HIP;
+    } catch (...) {
+        std::snprintf(tls_error, sizeof tls_error, "internal error (unknown exception)");
+        return GC_E_HIP;
+    }
 }
 
 }  // namespace gc
@@ -50,7 +69,7 @@ int gc_device_count(void) {
 
 // ---- context ---------------------------------------------------------------------------------
 
-gc_ctx *gc_ctx_create(int device, int *status) {
+gc_ctx *gc_ctx_create(int device, int *status) try {
     int rc = GC_OK;
     gc_ctx *c = new (std::nothrow) gc_ctx;
     if (!c) rc = GC_E_NOMEM;
@@ -72,6 +91,10 @@ gc_ctx *gc_ctx_create(int device, int *status) {
     }
     if (status) *status = rc;
     return c;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_ctx_destroy(gc_ctx *c) {
@@ -103,7 +126,7 @@ int gc_ctx_capture_begin(gc_ctx *c) {
     return GC_OK;
 }
 
-int gc_ctx_capture_end(gc_ctx *c, gc_graph **out) {
+int gc_ctx_capture_end(gc_ctx *c, gc_graph **out) try {
     if (!c || !c->capturing || !out) return GC_E_ARG;
     *out = nullptr;
     c->capturing = false;
@@ -125,6 +148,8 @@ int gc_ctx_capture_end(gc_ctx *c, gc_graph **out) {
     g->exec = exec;
     *out = g;
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_graph_launch(gc_graph *g) {
@@ -143,7 +168,7 @@ void gc_graph_free(gc_graph *g) {
 // ---- circuit ---------------------------------------------------------------------------------
 
 gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
-                      uint32_t noutputs, int *status) {
+                      uint32_t noutputs, int *status) try {
     int rc = GC_OK;
     gc_circ *c = nullptr;
     if (!ctx) rc = GC_E_ARG;
@@ -202,6 +227,10 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
     }
     if (status) *status = rc;
     return c;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_circ_free(gc_circ *c) {
@@ -285,7 +314,7 @@ static hipError_t alloc_buffers(gc_batch *b) {
     return e;
 }
 
-gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) {
+gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) try {
     int rc = GC_OK;
     gc_batch *b = nullptr;
     if (!circ || batch == 0) rc = GC_E_ARG;
@@ -312,6 +341,10 @@ gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) {
     }
     if (status) *status = rc;
     return b;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 static void drop_graphs(gc_batch *b) {
@@ -358,11 +391,13 @@ static int relayout(gc_batch *b) {
     return GC_OK;
 }
 
-int gc_batch_set_schedule(gc_batch *b, int schedule) {
+int gc_batch_set_schedule(gc_batch *b, int schedule) try {
     if (!b || schedule < 0 || schedule > 2) return GC_E_ARG;
     b->single_phase = schedule == 2;  // 1 and 2 share the tiled layout; the kernel (and maybe the tile) differs
     b->schedule = schedule ? 1 : 0;
     return relayout(b);
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_batch_set_graph(gc_batch *b, int on) {
@@ -637,10 +672,12 @@ int gc_batch_read_slab(gc_batch *b, gc_label *slab_out) {
     return read_gather(b, b->d_T, b->g.lt, nullptr, 0, b->circ->plan.p.info.slab_rows, 0, slab_out);
 }
 
-int gc_batch_set_store_all(gc_batch *b, int on) {
+int gc_batch_set_store_all(gc_batch *b, int on) try {
     if (!b) return GC_E_ARG;
     b->store_all = on != 0;
     return relayout(b);
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_batch_read_wires(gc_batch *b, gc_wire *wires_out) {
@@ -728,7 +765,7 @@ int gc_batch_set_input_range(gc_batch *ev, uint32_t first, uint32_t count, const
     return GC_OK;
 }
 
-int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
+int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) try {
     if (!b) return GC_E_ARG;
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
@@ -751,6 +788,8 @@ int gc_batch_debug_profile(gc_batch *b, int enable, uint64_t *out8) {
         b->d_prof = nullptr;
     }
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 size_t gc_tables_wire_bytes(const gc_circ *c) {
@@ -857,7 +896,7 @@ static void pool_put(gc_circ *c, gc_batch *b) {
 }
 
 int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen, uint32_t batch,
-              gc_label *r_out, gc_wire *wires_out, gc_wire *io_out, gc_label *slab_out) {
+              gc_label *r_out, gc_wire *wires_out, gc_wire *io_out, gc_label *slab_out) try {
     if (!c || !rnd || batch == 0) return GC_E_ARG;
     const Plan &p = c->plan.p;
     // error order of the reference: R is read first (garble.go:253), then aes.NewCipher (:260),
@@ -916,6 +955,8 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
     } while (0);
     pool_put(c, b);
     return rc;
+} catch (...) {
+    return gc::on_exception();
 }
 
 }  // extern "C"
@@ -964,7 +1005,7 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b) {
 extern "C" {
 
 int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
-                     gc_label *slab_out, gc_label *out_l0) {
+                     gc_label *slab_out, gc_label *out_l0) try {
     gc_batch *b = nullptr;
     int rc = gc_garble_labels_keep(c, key, keylen, r, inputs, out_l0, &b);
     if (rc != GC_OK) return rc;
@@ -974,10 +1015,12 @@ int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_lab
     }
     pool_put(c, b);
     return rc;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
-            const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels) {
+            const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels) try {
     if (!c || batch == 0 || (!wires_inout && !inputs)) return GC_E_ARG;
     const Plan &p = c->plan.p;
     AesKey k;
@@ -1009,6 +1052,8 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
     } while (0);
     pool_put(c, b);
     return rc;
+} catch (...) {
+    return gc::on_exception();
 }
 
 }  // extern "C"

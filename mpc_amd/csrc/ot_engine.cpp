@@ -57,7 +57,7 @@ int upload_keys(gc_ctx *ctx, const std::vector<uint32_t> &host, uint32_t **dptr)
 
 extern "C" {
 
-gc_iknp *gc_iknp_receiver_create(gc_ctx *ctx, const gc_wire *base, int *status) {
+gc_iknp *gc_iknp_receiver_create(gc_ctx *ctx, const gc_wire *base, int *status) try {
     int rc = (ctx && base) ? GC_OK : GC_E_ARG;
     gc_iknp *k = nullptr;
     if (rc == GC_OK && !(k = new (std::nothrow) gc_iknp)) rc = GC_E_NOMEM;
@@ -79,9 +79,13 @@ gc_iknp *gc_iknp_receiver_create(gc_ctx *ctx, const gc_wire *base, int *status) 
     }
     if (status) *status = rc;
     return k;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
-gc_iknp *gc_iknp_sender_create(gc_ctx *ctx, const gc_label *delta, const gc_label *k0, int *status) {
+gc_iknp *gc_iknp_sender_create(gc_ctx *ctx, const gc_label *delta, const gc_label *k0, int *status) try {
     int rc = (ctx && delta && k0) ? GC_OK : GC_E_ARG;
     gc_iknp *k = nullptr;
     if (rc == GC_OK && !(k = new (std::nothrow) gc_iknp)) rc = GC_E_NOMEM;
@@ -100,6 +104,10 @@ gc_iknp *gc_iknp_sender_create(gc_ctx *ctx, const gc_label *delta, const gc_labe
     }
     if (status) *status = rc;
     return k;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_iknp_free(gc_iknp *k) {
@@ -144,19 +152,21 @@ static int iknp_receive_packed(gc_iknp *k, const std::vector<uint8_t> &bbuf, siz
     return GC_OK;
 }
 
-int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out) {
+int gc_iknp_receive(gc_iknp *k, const uint8_t *choice, size_t n, uint8_t *u_out, gc_label *labels_out) try {
     if (!k || !k->receiver || (n && (!choice || !u_out || !labels_out))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     std::vector<uint8_t> bbuf(((n + 511) / 512) * 64, 0);  // iknp.go:472-477
     for (size_t i = 0; i < n; i++)
         if (choice[i]) bbuf[i / 8] |= (uint8_t)(1u << (i % 8));
     return iknp_receive_packed(k, bbuf, n, u_out, labels_out);
+} catch (...) {
+    return gc::on_exception();
 }
 
 // (*IKNPReceiver).ReceiveBits (iknp.go:554-620): same matrix, result = bit 0 of every label.  The reference
 // folds the choice vector in as whole little-endian 64-bit words only (words = byteRows/8, :583-597): the
 // choice bits of a trailing partial word do NOT enter u — reproduced here bit for bit.
-int gc_iknp_receive_bits(gc_iknp *k, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result) {
+int gc_iknp_receive_bits(gc_iknp *k, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result) try {
     if (!k || !k->receiver || (n && (!choices || !u_out || !result))) return GC_E_ARG;
     for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
     if (n == 0) return GC_OK;
@@ -173,9 +183,11 @@ int gc_iknp_receive_bits(gc_iknp *k, const uint64_t *choices, size_t n, uint8_t 
     for (size_t i = 0; i < n; i++)
         if (labels[i].d0 & 1) result[i / 64] |= (uint64_t)1 << (i % 64);  // labelsBuf[row].Bit(0) (:609-614)
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
-int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out) {
+int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_label *labels_out) try {
     if (!k || k->receiver || (n && (!u_in || !labels_out))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     if (u_len != gc_iknp_u_bytes(n)) return GC_E_ARG;  // "invalid chunk size" (iknp.go:207-209)
@@ -194,6 +206,8 @@ int gc_iknp_send(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, gc_lab
     GC_HIP(hipStreamSynchronize(s));
     k->pos += stream_advance(n);
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 // ---- device-resident entry points: no host staging, no allocation after the first call, asynchronous on the
@@ -339,7 +353,7 @@ static int kos_finish_sender(const uint64_t acc[6], const gc_label *delta, const
 
 // device-resident forms: the labels gc_iknp_receive_dev / gc_iknp_send_dev left in HBM are checked where they are
 int gc_kos_receiver_tags_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_result, const void *d_b, size_t n,
-                             const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) {
+                             const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) try {
     if (!ctx || !seed2 || !choice_vec || !bcv || !x || !t0 || !t1 || (n && (!d_result || !d_b))) return GC_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     uint64_t acc[6];
@@ -349,11 +363,13 @@ int gc_kos_receiver_tags_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_r
     *t1 = gc_label{acc[2], acc[3]};
     *x = gc_label{acc[4], acc[5]};
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_kos_sender_check_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_result, size_t n,
                             const gc_label *choice_vec, const gc_label *delta, const gc_label *x, const gc_label *t0,
-                            const gc_label *t1, int *ok) {
+                            const gc_label *t1, int *ok) try {
     if (!ctx || !seed2 || !choice_vec || !delta || !x || !t0 || !t1 || !ok || (n && !d_result)) return GC_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     uint64_t acc[6];
@@ -361,10 +377,12 @@ int gc_kos_sender_check_dev(gc_ctx *ctx, const gc_label *seed2, const void *d_re
     if (rc != GC_OK) return rc;
     *ok = kos_finish_sender(acc, delta, x, t0, t1);
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_kos_receiver_tags(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, const uint8_t *b, size_t n,
-                         const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) {
+                         const gc_label *choice_vec, const uint8_t *bcv, gc_label *x, gc_label *t0, gc_label *t1) try {
     if (!ctx || !seed2 || !choice_vec || !bcv || !x || !t0 || !t1 || (n && (!result || !b))) return GC_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     uint64_t acc[6];
@@ -374,11 +392,13 @@ int gc_kos_receiver_tags(gc_ctx *ctx, const gc_label *seed2, const gc_label *res
     *t1 = gc_label{acc[2], acc[3]};
     *x = gc_label{acc[4], acc[5]};
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_kos_sender_check(gc_ctx *ctx, const gc_label *seed2, const gc_label *result, size_t n,
                         const gc_label *choice_vec, const gc_label *delta, const gc_label *x, const gc_label *t0,
-                        const gc_label *t1, int *ok) {
+                        const gc_label *t1, int *ok) try {
     if (!ctx || !seed2 || !choice_vec || !delta || !x || !t0 || !t1 || !ok || (n && !result)) return GC_E_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     uint64_t acc[6];
@@ -386,10 +406,12 @@ int gc_kos_sender_check(gc_ctx *ctx, const gc_label *seed2, const gc_label *resu
     if (rc != GC_OK) return rc;
     *ok = kos_finish_sender(acc, delta, x, t0, t1);
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 // (*IKNPSender).SendBits (iknp.go:259-310): column 0 of the q-matrix == bit 0 of every label of send()
-int gc_iknp_send_bits(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, uint64_t *result) {
+int gc_iknp_send_bits(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, uint64_t *result) try {
     if (!k || k->receiver || (n && (!u_in || !result))) return GC_E_ARG;
     for (size_t i = 0; i < (n + 63) / 64; i++) result[i] = 0;
     if (n == 0) return GC_OK;
@@ -399,9 +421,11 @@ int gc_iknp_send_bits(gc_iknp *k, const uint8_t *u_in, size_t u_len, size_t n, u
     for (size_t i = 0; i < n; i++)
         if (labels[i].d0 & 1) result[i / 64] |= (uint64_t)1 << (i % 64);
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
-int gc_mitccrh_hash(gc_ctx *ctx, const gc_label *seed, uint64_t gid0, gc_label *blks, size_t n, uint32_t h) {
+int gc_mitccrh_hash(gc_ctx *ctx, const gc_label *seed, uint64_t gid0, gc_label *blks, size_t n, uint32_t h) try {
     if (!ctx || !seed || (n && !blks)) return GC_E_ARG;
     if (n == 0 || h == 0) return GC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -415,10 +439,12 @@ int gc_mitccrh_hash(gc_ctx *ctx, const gc_label *seed, uint64_t gid0, gc_label *
     GC_HIP(hipMemcpyAsync(blks, d.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     GC_HIP(hipStreamSynchronize(ctx->stream));
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_cot_send_pads(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, const gc_label *data,
-                     const gc_wire *wires, size_t n, gc_label *out) {
+                     const gc_wire *wires, size_t n, gc_label *out) try {
     if (!ctx || !seed || !delta || (n && (!data || !wires || !out))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -436,10 +462,12 @@ int gc_cot_send_pads(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, c
     GC_HIP(hipMemcpyAsync(out, d_out.p, n * 32, hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_cot_receive_unpad(gc_ctx *ctx, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
-                         gc_label *result, size_t n) {
+                         gc_label *result, size_t n) try {
     if (!ctx || !seed || (n && (!flags || !sent || !result))) return GC_E_ARG;
     if (n == 0) return GC_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -457,6 +485,8 @@ int gc_cot_receive_unpad(gc_ctx *ctx, const gc_label *seed, const uint8_t *flags
     GC_HIP(hipMemcpyAsync(result, d_r.p, n * 16, hipMemcpyDeviceToHost, s));
     GC_HIP(hipStreamSynchronize(s));
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 // device-resident forms of the two COT pad loops: device pointers, asynchronous on the ctx stream, no staging

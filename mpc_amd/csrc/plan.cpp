@@ -596,7 +596,7 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
 extern "C" {
 
 gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
-                        uint32_t noutputs, int *status) {
+                        uint32_t noutputs, int *status) try {
     gc_plan *pl = new (std::nothrow) gc_plan;
     int rc = pl ? gc::build_plan(gates, ngates, nwires, ninputs, noutputs, &pl->p) : GC_E_NOMEM;
     if (rc != GC_OK) {
@@ -605,6 +605,10 @@ gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, 
     }
     if (status) *status = rc;
     return pl;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_plan_free(gc_plan *pl) { delete pl; }
@@ -615,13 +619,15 @@ int gc_plan_get_info(const gc_plan *pl, gc_plan_info *out) {
     return GC_OK;
 }
 
-int gc_plan_simulate(const gc_plan *pl, const uint8_t *in_bits, uint8_t *out_bits) {
+int gc_plan_simulate(const gc_plan *pl, const uint8_t *in_bits, uint8_t *out_bits) try {
     if (!pl || (!in_bits && pl->p.info.ninputs) || (!out_bits && pl->p.info.noutputs)) return GC_E_ARG;
     return gc::simulate_flat(pl->p, in_bits, out_bits);
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_plan_describe(const gc_plan *pl, uint32_t *level_of_gate, uint32_t *tweak_of_gate, uint32_t *row_of_gate,
-                     uint32_t *slot_of_gate) {
+                     uint32_t *slot_of_gate) try {
     if (!pl) return GC_E_ARG;
     const gc::Plan &p = pl->p;
     if (level_of_gate) std::copy(p.level_of_gate.begin(), p.level_of_gate.end(), level_of_gate);
@@ -629,6 +635,8 @@ int gc_plan_describe(const gc_plan *pl, uint32_t *level_of_gate, uint32_t *tweak
     if (row_of_gate) std::copy(p.row_of_gate.begin(), p.row_of_gate.end(), row_of_gate);
     if (slot_of_gate) std::copy(p.slot_of_gate.begin(), p.slot_of_gate.end(), slot_of_gate);
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 }  // extern "C"

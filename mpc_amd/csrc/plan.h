@@ -15,6 +15,11 @@
 
 namespace gc {
 
+// status of the exception in flight (called from the catch (...) of an extern "C" entry point: no C++ exception may
+// cross the C ABI — under cgo it would end in std::terminate): std::bad_alloc / length_error -> GC_E_NOMEM, anything
+// else GC_E_HIP; the text goes to gc_last_error().  Defined in engine.cpp.
+int on_exception() noexcept;
+
 // One gate as the kernels see it (16 bytes, one s_load_dwordx4 when wave-uniform).
 struct GateDesc {
     uint32_t in0;     // wire slot of input 0

@@ -19,13 +19,29 @@
 
 using namespace gc;
 
+// A cached device circuit with the gate list it was built from.  The key is a 64-bit non-cryptographic hash: a hit is
+// only taken after the gates compare equal (an accidental — or, on the evaluator side, peer-crafted — collision would
+// otherwise select a plan with other input / output counts: wrong results or out-of-bounds label arrays).
+struct CircKey {
+    uint32_t in0, in1, out, op;
+};
+struct CircEntry {
+    gc_circ *circ = nullptr;
+    std::vector<CircKey> gates;
+    uint32_t nwires = 0, nin = 0, nout = 0;
+};
+using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
+
 struct gc_stream {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
     gc_label r{};
     std::vector<gc_label> l0;     // global wire -> L0 (L1 = L0 ^ R)
     std::vector<gc_label> tmp_l0; // stream.tmp (only outputs of the current circuit are meaningful)
-    std::unordered_map<uint64_t, gc_circ *> cache;
+    CircCache cache;
+    std::vector<uint32_t> alias_gen, alias_j;  // in[] / out[] aliasing check: stamp + index in out[] per global wire
+    uint32_t gen = 0;
+    std::vector<gc_gate> rewritten;            // gate list with aliased reads redirected (rare)
     uint32_t *d_io = nullptr;   // in[] then out[] of the current call
     size_t io_cap = 0;
     uint64_t *d_boff = nullptr; // per block of kSerGates gates: byte size, then exclusive offset; [nblocks] = total
@@ -217,12 +233,37 @@ uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, ui
     return r;
 }
 
+gc_circ *cache_find(const CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+                    uint32_t nin, uint32_t nout) {
+    auto range = cache.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        const CircEntry &e = it->second;
+        if (e.gates.size() != ngates || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
+        bool same = true;
+        for (uint32_t i = 0; i < ngates && same; i++)
+            same = e.gates[i].in0 == gates[i].in0 && e.gates[i].in1 == gates[i].in1 && e.gates[i].out == gates[i].out &&
+                   e.gates[i].op == gates[i].op;
+        if (same) return e.circ;
+    }
+    return nullptr;
+}
+
+void cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+               uint32_t nin, uint32_t nout) {
+    CircEntry e;
+    e.circ = circ;
+    e.nwires = nwires, e.nin = nin, e.nout = nout;
+    e.gates.resize(ngates);
+    for (uint32_t i = 0; i < ngates; i++) e.gates[i] = CircKey{gates[i].in0, gates[i].in1, gates[i].out, gates[i].op};
+    cache.emplace(h, std::move(e));
+}
+
 }  // namespace
 
 extern "C" {
 
 gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen,
-                            const uint32_t *inputs, uint32_t ninputs, int *status) {
+                            const uint32_t *inputs, uint32_t ninputs, int *status) try {
     int rc = GC_OK;
     gc_stream *s = nullptr;
     AesKey k;
@@ -243,11 +284,15 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
     }
     if (status) *status = rc;
     return s;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_stream_free(gc_stream *s) {
     if (!s) return;
-    for (auto &kv : s->cache) gc_circ_free(kv.second);
+    for (auto &kv : s->cache) gc_circ_free(kv.second.circ);
     if (s->d_io) (void)hipFree(s->d_io);
     if (s->d_boff) (void)hipFree(s->d_boff);
     if (s->d_bytes) (void)hipFree(s->d_bytes);
@@ -262,7 +307,7 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) {  // Streaming.G
 }
 
 int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
-                     uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) {
+                     uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) try {
     if (!s || (!gates && ngates) || (nin && !in) || (nout && !out) || !buf || !written) return GC_E_ARG;
     // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
     // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
@@ -276,12 +321,47 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     *written = 0;
     if (ngates == 0) return GC_OK;
 
+    // in[] / out[] naming the same GLOBAL wire (wire-id re-use, in-place update): the reference resolves
+    // stream.wire(index) per gate (:131-157), so a gate that reads the input-mapped wire after the gate that Set the
+    // output-mapped one sees the NEW label.  The device garbles from a snapshot of the inputs: redirect such reads to
+    // the producing circuit wire (same global id and flags on the wire, so the serialised bytes do not change).
+    {
+        if (s->alias_gen.size() < s->l0.size()) {
+            s->alias_gen.resize(s->l0.size(), 0);
+            s->alias_j.resize(s->l0.size(), 0);
+        }
+        if (++s->gen == 0) {
+            std::fill(s->alias_gen.begin(), s->alias_gen.end(), 0);
+            s->gen = 1;
+        }
+        for (uint32_t j = 0; j < nout; j++)
+            if (first_out + j >= first_tmp) {
+                s->alias_gen[out[j]] = s->gen;
+                s->alias_j[out[j]] = j;
+            }
+        bool aliased = false;
+        for (uint32_t i = 0; i < nin && !aliased; i++) aliased = s->alias_gen[in[i]] == s->gen;
+        if (aliased) {
+            std::vector<uint8_t> set(nout, 0);
+            s->rewritten.assign(gates, gates + ngates);
+            for (uint32_t g = 0; g < ngates; g++) {
+                gc_gate &q = s->rewritten[g];
+                auto redirect = [&](uint32_t w) {
+                    if (w < nin && s->alias_gen[in[w]] == s->gen && set[s->alias_j[in[w]]]) return first_out + s->alias_j[in[w]];
+                    return w;
+                };
+                q.in0 = redirect(q.in0);
+                if (q.op != GC_INV) q.in1 = redirect(q.in1);
+                if (q.out >= first_out && q.out < nwires) set[q.out - first_out] = 1;
+            }
+            gates = s->rewritten.data();
+        }
+    }
+
     // device circuit (cached by content); a new circuit is validated once (garbleGate's checks, :195-210)
     const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
-    gc_circ *circ = nullptr;
-    auto it = s->cache.find(h);
-    if (it != s->cache.end()) circ = it->second;
-    else {
+    gc_circ *circ = cache_find(s->cache, h, gates, ngates, nwires, nin, nout);
+    if (!circ) {
         for (uint32_t i = 0; i < ngates; i++) {
             if (gates[i].op > GC_INV) return GC_E_GATE;
             if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
@@ -301,7 +381,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
             gc_circ_free(circ);
             return GC_E_HIP;
         }
-        s->cache.emplace(h, circ);
+        cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
     }
     gc_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
@@ -358,6 +438,8 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     }
     gc_circ_release_batch(circ, b);
     return rc;
+} catch (...) {
+    return gc::on_exception();
 }
 
 // ---- streaming evaluator ----------------------------------------------------------------
@@ -368,7 +450,7 @@ struct gc_stream_eval {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
     std::vector<gc_label> wires;  // StreamEval.wires (global store)
-    std::unordered_map<uint64_t, gc_circ *> cache;
+    CircCache cache;
     // per-circuit scratch, kept across calls: last writer of every tmp / global wire with a generation stamp
     std::vector<uint32_t> cur_t, stamp_t, cur_w, stamp_w;
     uint32_t gen = 0;
@@ -378,7 +460,7 @@ struct gc_stream_eval {
 
 extern "C" {
 
-gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, int *status) {
+gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, int *status) try {
     int rc = GC_OK;
     AesKey k;
     gc_stream_eval *e = nullptr;
@@ -391,19 +473,25 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
     }
     if (status) *status = rc;
     return e;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
 void gc_stream_eval_free(gc_stream_eval *e) {
     if (!e) return;
-    for (auto &kv : e->cache) gc_circ_free(kv.second);
+    for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
     delete e;
 }
 
-int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) {
+int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) try {
     if (!e || !l) return GC_E_ARG;
     if (w >= e->wires.size()) e->wires.resize((size_t)w + 1, gc_label{0, 0});
     e->wires[w] = *l;
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
@@ -413,10 +501,15 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
 }
 
 int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
-                           size_t len, size_t *consumed) {
+                           size_t len, size_t *consumed) try {
     if (!e || (!buf && len) || !consumed) return GC_E_ARG;
-    if (e->wires.size() < nwires) e->wires.resize(nwires, gc_label{0, 0});  // InitCircuit(numWires, numTmpWires)
     *consumed = 0;
+    // The block comes from the peer: bound it before anything is sized by it.  A gate is at least 5 bytes (op + two
+    // 16-bit ids), so a header that announces more gates than the bytes can hold is a truncated stream; global wire
+    // ids must stay below the numWires of the block's own header (the reference indexes its store with them,
+    // stream_evaluator.go:29-96: an id beyond it panics there) and tmp ids below numTmpWires.
+    if ((size_t)ngates > len / 5) return GC_E_ROWS;
+    if (e->wires.size() < nwires) e->wires.resize(nwires, gc_label{0, 0});  // InitCircuit(numWires, numTmpWires)
     if (ngates == 0) return GC_OK;
     // Parse the gate stream (stream_evaluator.go:272-345) into an SSA gate list.  Wire ids of the device circuit:
     //   [0, nin)            wires read before this circuit writes them, in order of first use
@@ -472,6 +565,10 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                 }
                 return e->cur_t[idx];
             }
+            if (idx >= nwires) {
+                err = GC_E_ARG;
+                return 0;
+            }
             if (idx >= e->stamp_w.size()) {
                 e->stamp_w.resize((size_t)idx + 1 + e->stamp_w.size() / 2, 0);
                 e->cur_w.resize(e->stamp_w.size(), 0);
@@ -495,6 +592,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             e->stamp_t[ci] = gen;
             e->cur_t[ci] = g;
         } else {
+            if (ci >= nwires) return GC_E_ARG;
             if (ci >= e->stamp_w.size()) {
                 e->stamp_w.resize((size_t)ci + 1 + e->stamp_w.size() / 2, 0);
                 e->cur_w.resize(e->stamp_w.size(), 0);
@@ -520,14 +618,12 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     const uint32_t cw = nin + ngates;
     // device circuit, cached by content
     const uint64_t h = circuit_hash(gates.data(), ngates, cw, nin, nout);
-    gc_circ *circ = nullptr;
-    auto it = e->cache.find(h);
-    if (it != e->cache.end()) circ = it->second;
-    else {
+    gc_circ *circ = cache_find(e->cache, h, gates.data(), ngates, cw, nin, nout);
+    if (!circ) {
         int st = GC_OK;
         circ = gc_circ_load(e->ctx, gates.data(), ngates, cw, nin, nout, &st);
         if (!circ) return st;
-        e->cache.emplace(h, circ);
+        cache_put(e->cache, h, circ, gates.data(), ngates, cw, nin, nout);
     }
     std::vector<gc_label> inl(std::max<uint32_t>(nin, 1)), outl(std::max<uint32_t>(nout, 1));
     for (uint32_t i = 0; i < nin; i++) {
@@ -546,6 +642,8 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }
     *consumed = pos;
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
 }  // extern "C"

@@ -147,6 +147,18 @@ def lib():
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
+        "gc_comm_available": (i32, []),
+        "gc_comm_version": (i32, []),
+        "gc_comm_get_unique_id": (i32, [vp, sz]),
+        "gc_comm_init_rank": (vp, [vp, vp, sz, i32, i32, ip]),
+        "gc_comm_init_all": (i32, [vp, i32, vp]),
+        "gc_comm_destroy": (None, [vp]),
+        "gc_comm_rank": (i32, [vp]),
+        "gc_comm_nranks": (i32, [vp]),
+        "gc_comm_allgather": (i32, [vp, vp, vp, sz]),
+        "gc_comm_allgather_all": (i32, [vp, i32, vp, vp, sz]),
+        "gc_comm_allreduce_max": (i32, [vp, C.POINTER(C.c_double)]),
+        "gc_comm_barrier": (i32, [vp]),
     }
     for name, (res, args) in sigs.items():
         f = getattr(L, name)
@@ -509,6 +521,83 @@ class StreamEval:
     def close(self):
         if self.h:
             lib().gc_stream_eval_free(self.h)
+            self.h = None
+
+
+# ---- multi-GPU (gc_comm_*: RCCL all-gather of the shards' outputs) ----------------------------
+
+COMM_ID_BYTES = 128
+
+
+def comm_available():
+    return bool(lib().gc_comm_available())
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte ncclUniqueId the host hands to the other ranks"""
+    buf = np.zeros(COMM_ID_BYTES, np.uint8)
+    _check(lib().gc_comm_get_unique_id(_p(buf), len(buf)), "gc_comm_get_unique_id")
+    return buf.tobytes()
+
+
+class Comm:
+    """gc_comm: one rank of the output gather (one ctx = one device)"""
+
+    def __init__(self, ctx, uid, nranks, rank, _h=None):
+        self.ctx = ctx
+        if _h is not None:
+            self.h = _h
+        else:
+            u = _u8(uid)
+            st = C.c_int(0)
+            self.h = lib().gc_comm_init_rank(ctx.h, _p(u), len(u), nranks, rank, C.byref(st))
+            if not self.h:
+                raise EngineError(st.value, "gc_comm_init_rank")
+        self.rank = lib().gc_comm_rank(self.h)
+        self.nranks = lib().gc_comm_nranks(self.h)
+
+    @classmethod
+    def init_all(cls, ctxs):
+        """one process driving len(ctxs) devices (gc_comm_init_all)"""
+        n = len(ctxs)
+        hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        _check(lib().gc_comm_init_all(hs, n, out), "gc_comm_init_all")
+        return [cls(ctxs[i], None, n, i, _h=out[i]) for i in range(n)]
+
+    def allgather(self, d_send, d_recv, nbytes):
+        _check(lib().gc_comm_allgather(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), nbytes), "gc_comm_allgather")
+
+    @staticmethod
+    def allgather_all(comms, d_sends, d_recvs, nbytes):
+        n = len(comms)
+        hs = (C.c_void_p * n)(*[c.h for c in comms])
+        ss = (C.c_void_p * n)(*d_sends)
+        rs = (C.c_void_p * n)(*d_recvs)
+        _check(lib().gc_comm_allgather_all(hs, n, ss, rs, nbytes), "gc_comm_allgather_all")
+
+    def allgather_host(self, local):
+        """host array [rows, ...] -> [nranks, rows, ...]; staged through device buffers (torch as plumbing)"""
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(local)).to("cuda:%d" % self.ctx.device)
+        out = torch.empty((self.nranks,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        torch.cuda.synchronize(t.device)
+        self.allgather(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size())
+        self.ctx.sync()
+        return out.cpu().numpy()
+
+    def allreduce_max(self, value):
+        v = C.c_double(value)
+        _check(lib().gc_comm_allreduce_max(self.h, C.byref(v)), "gc_comm_allreduce_max")
+        return v.value
+
+    def barrier(self):
+        _check(lib().gc_comm_barrier(self.h), "gc_comm_barrier")
+
+    def close(self):
+        if self.h:
+            lib().gc_comm_destroy(self.h)
             self.h = None
 
 

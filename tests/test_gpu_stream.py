@@ -51,7 +51,42 @@ def test_stream_errors():
     with pytest.raises(engine.EngineError) as e:
         ge.circuit(1, 4, 4, bytes([0x10 | 9, 0, 0, 0, 0, 0, 1]))
     assert e.value.code == engine.GC_E_GATE
+    # the block is the peer's data: more gates announced than the bytes can hold, or a global wire id beyond the
+    # block's own numWires, are rejected before anything is sized by them (no std::bad_alloc across the C ABI)
+    with pytest.raises(engine.EngineError) as e:
+        ge.circuit(0x7fffffff, 4, 4, bytes([0x10, 0, 0, 0, 0, 0, 1]))
+    assert e.value.code == engine.GC_E_ROWS
+    with pytest.raises(engine.EngineError) as e:  # XOR 0, 0 -> global wire 0xffff of a 4-wire block
+        ge.circuit(1, 4, 4, bytes([0x10, 0, 0, 0, 0, 0xff, 0xff]))
+    assert e.value.code == engine.GC_E_ARG
+    with pytest.raises(engine.EngineError) as e:  # long form, reads global wire 0xfffffff0
+        ge.circuit(1, 4, 4, bytes([0x00, 0xff, 0xff, 0xff, 0xf0, 0, 0, 0, 0, 0, 0, 0, 1]))
+    assert e.value.code == engine.GC_E_ARG
     ge.close()
+    ctx.close()
+
+
+def test_stream_in_out_alias_the_same_global_wire():
+    """in[] and out[] naming the same global wire (in-place update): a gate reading that input AFTER the gate that set
+    the output sees the new label, as the reference's per-gate stream.wire() look-up does (stream_garble.go:131-157)"""
+    from mpc_amd.circuit import GATE
+    ctx = engine.Context(0)
+    key, prim = drbg("alias", 32), [0, 1, 2]
+    rnd = drbg("alias-rnd", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    # circuit wires: 0, 1 inputs; 2 tmp; 3, 4 outputs.  global: in = [0, 1], out = [0, 2]  (wire 3 updates global 0)
+    gates = np.zeros(4, GATE)
+    gates[0] = (0, 1, 2, 2, 0)   # tmp = AND(w0, w1)       reads the OLD global 0
+    gates[1] = (2, 1, 3, 0, 0)   # w3 (global 0) = tmp ^ w1
+    gates[2] = (0, 1, 4, 2, 0)   # w4 (global 2) = AND(w0, w1): w0 now resolves to the NEW global 0
+    gates[3] = (4, 0, 4, 0, 0)   # w4 ^= w0 (a re-written wire, new global 0 again)
+    for rep in range(2):
+        want = og.garble(gates, 5, [0, 1], [0, 2])
+        got = gg.garble(gates, 5, [0, 1], [0, 2])
+        assert got == want
+        for w in (0, 1, 2):
+            assert gg.get(w) == og.get(w)
+    gg.close()
     ctx.close()
 
 
