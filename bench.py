@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--key-bytes", type=int, default=32, choices=[16, 24, 32])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
@@ -339,6 +340,10 @@ def main():
             # second kernel pair of the path (ot/iknp.go): OT extension on the device-resident API, 4 Mi OTs
             from scripts.bench_iknp import run as iknp_run
             res["iknp"] = iknp_run(1 << 22, 5, ctx=ctx)
+        if world == 1 and not args.no_host_api and args.circuit.endswith("aes_128.gcf"):
+            # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
+            from scripts.bench_host_api import run as host_api_run
+            res["host_api"] = host_api_run(batch, 3, key)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
     gb.close()

@@ -163,6 +163,20 @@ int gc_garble(gc_circ *, const uint8_t *key, size_t keylen, const uint8_t *rnd, 
 int gc_eval(gc_circ *, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
             const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels);
 
+/* Pinned host memory for the two calls above (additive; the reference pools its scratch on the Go heap,
+ * garble.go:195-225 — the shim backs that pool with gc_host_alloc instead).  When slab_out / wires_out / io_out /
+ * slab / wires_inout point into pinned memory the calls DMA straight from / into the caller's pages (~57 GB/s instead
+ * of 37 / 46 GB/s through the runtime's bounce buffers) and overlap the DMA of one chunk of instances with the
+ * layout transpose of the next.  Pageable pointers keep working unchanged.
+ *  gc_host_alloc      hipHostMalloc (portable: usable with every device); NULL on failure
+ *  gc_host_register   pins an existing range (page-aligned ranges register fastest); undo with gc_host_unregister
+ *                     before the memory is freed */
+void *gc_host_alloc(size_t bytes);
+void gc_host_free(void *);
+int gc_host_register(void *p, size_t bytes);
+int gc_host_unregister(void *p);
+int gc_host_is_pinned(const void *p);
+
 /* Garble ONE instance whose R and input-wire L0 labels are given instead of drawn from a random
  * stream (what Streaming.Garble needs: the inputs of an SSA-step circuit are wires garbled earlier).
  *  r        the stream's R (S bit already set)        inputs   [ninputs] L0 labels

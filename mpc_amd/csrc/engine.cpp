@@ -3,6 +3,8 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -40,6 +42,30 @@ int on_exception() noexcept {
 }  // namespace gc
 
 using namespace gc;
+
+namespace {
+// developer aid: GC_TRACE=1 prints the wall-clock laps of the host-buffer calls to stderr
+struct Trace {
+    bool on;
+    const char *name;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit Trace(const char *n) : on(std::getenv("GC_TRACE") != nullptr), name(n) {
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gc trace] %s: %-18s %8.3f ms\n", name, what,
+                     std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+    ~Trace() {
+        if (on)
+            std::fprintf(stderr, "[gc trace] %s: total              %8.3f ms\n", name,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -105,7 +131,53 @@ void gc_ctx_destroy(gc_ctx *c) {
         (void)hipStreamDestroy(c->stream);
     }
     if (c->d_te0) (void)hipFree(c->d_te0);
+    for (int b = 0; b < 2; b++) {
+        if (c->stage[b]) (void)hipFree(c->stage[b]);
+        if (c->ev_k[b]) (void)hipEventDestroy(c->ev_k[b]);
+        if (c->ev_c[b]) (void)hipEventDestroy(c->ev_c[b]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
+}
+
+// ---- pinned host memory for the host-buffer API --------------------------------------------------------------
+// The literal drop-in calls move 238 KB of tables per aes_128 instance across PCIe.  From pageable memory the runtime
+// stages every copy through its own bounce buffers (37 / 46 GB/s measured); from pinned memory the DMA engine reads /
+// writes the caller's pages directly (~57 GB/s) and gc_garble / gc_eval pipeline it against their transpose kernels.
+// The Go shim backs its pooled scratch (Garbled.Wires / the slab, cf. garble.go:195-225) with gc_host_alloc.
+void *gc_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void gc_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int gc_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return GC_E_ARG;
+    GC_HIP(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return GC_OK;
+}
+
+int gc_host_unregister(void *p) {
+    if (!p) return GC_E_ARG;
+    GC_HIP(hipHostUnregister(p));
+    return GC_OK;
+}
+
+int gc_host_is_pinned(const void *p) {
+    if (!p) return 0;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a.type == hipMemoryTypeHost ? 1 : 0;
 }
 
 int gc_ctx_sync(gc_ctx *c) {
@@ -644,23 +716,77 @@ int gc_batch_read_r(gc_batch *b, gc_label *r_out) {
     return GC_OK;
 }
 
+// lazily: the copy stream, its events and two device staging buffers of at least `bytes` each
+static int ensure_pipeline(gc_ctx *ctx, size_t bytes) {
+    if (!ctx->copy_stream) GC_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        if (!ctx->ev_k[b]) GC_HIP(hipEventCreateWithFlags(&ctx->ev_k[b], hipEventDisableTiming));
+        if (!ctx->ev_c[b]) GC_HIP(hipEventCreateWithFlags(&ctx->ev_c[b], hipEventDisableTiming));
+    }
+    if (bytes > ctx->stage_cap) {
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+        GC_HIP(hipStreamSynchronize(ctx->copy_stream));
+        for (int b = 0; b < 2; b++) {
+            if (ctx->stage[b]) (void)hipFree(ctx->stage[b]);
+            ctx->stage[b] = nullptr;
+        }
+        ctx->stage_cap = 0;
+        for (int b = 0; b < 2; b++) GC_HIP(hipMalloc(&ctx->stage[b], bytes));
+        ctx->stage_cap = bytes;
+    }
+    return GC_OK;
+}
+
+constexpr size_t kPipeChunkBytes = (size_t)32 << 20;  // per staging buffer: long enough for full PCIe rate, short
+                                                      // enough that the first chunk's transpose hides nothing big
+
+// device [row][instance] array -> PINNED host [instance][n]: transpose kernel of chunk k + 1 on the ctx stream while the
+// DMA of chunk k runs on the copy stream
+static int read_gather_pinned(gc_batch *b, const uint4 *src, const Layout &lay, const uint32_t *slots, uint32_t slot0,
+                              uint32_t n, int mode, void *host_out) {
+    gc_ctx *ctx = b->circ->ctx;
+    const size_t elems = (size_t)n * (mode ? 2 : 1), per_inst = elems * sizeof(uint4);
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, kPipeChunkBytes / per_inst));
+    chunk = (chunk + 31u) & ~31u;
+    int rc = ensure_pipeline(ctx, (size_t)std::min<uint32_t>(chunk, (b->g.batch + 31u) & ~31u) * per_inst);
+    if (rc != GC_OK) return rc;
+    uint32_t k = 0;
+    for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk, k++) {
+        const int sb = (int)(k & 1);
+        const uint32_t cnt = std::min(chunk, b->g.batch - i0);
+        if (k >= 2) GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_c[sb], 0));  // the buffer's previous DMA is done
+        launch_gather(src, lay, i0, slots, slot0, n, b->d_R, mode, (uint4 *)ctx->stage[sb], elems, cnt, ctx->stream);
+        GC_HIP(hipGetLastError());
+        GC_HIP(hipEventRecord(ctx->ev_k[sb], ctx->stream));
+        GC_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_k[sb], 0));
+        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, ctx->stage[sb], (size_t)cnt * per_inst,
+                              hipMemcpyDeviceToHost, ctx->copy_stream));
+        GC_HIP(hipEventRecord(ctx->ev_c[sb], ctx->copy_stream));
+    }
+    GC_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return GC_OK;
+}
+
 static int read_gather(gc_batch *b, const uint4 *src, const Layout &lay, const uint32_t *slots, uint32_t slot0,
                        uint32_t n, int mode, void *host_out) {
     if (n == 0) return GC_OK;
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     const size_t elems = (size_t)n * (mode ? 2 : 1);
-    // bounded staging: move at most ~256 MiB per pass
+    if (elems * sizeof(uint4) * b->g.batch >= ((size_t)1 << 20) && gc_host_is_pinned(host_out))
+        return read_gather_pinned(b, src, lay, slots, slot0, n, mode, host_out);
+    // bounded staging in the ctx's persistent buffer (no hipMalloc / hipFree per call): at most 64 MiB per pass
     const size_t per_inst = elems * sizeof(uint4);
-    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)256 << 20) / per_inst));
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)64 << 20) / per_inst));
     chunk = (chunk + 31u) & ~31u;
-    DevBuf tmp;
-    GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
+    int rcp = ensure_pipeline(ctx, (size_t)std::min<uint32_t>(chunk, (b->g.batch + 31u) & ~31u) * per_inst);
+    if (rcp != GC_OK) return rcp;
+    void *tmp = ctx->stage[0];
     for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
         const uint32_t cnt = std::min(chunk, b->g.batch - i0);
-        launch_gather(src, lay, i0, slots, slot0, n, b->d_R, mode, (uint4 *)tmp.p, elems, cnt, ctx->stream);
+        launch_gather(src, lay, i0, slots, slot0, n, b->d_R, mode, (uint4 *)tmp, elems, cnt, ctx->stream);
         GC_HIP(hipGetLastError());
-        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, tmp.p, (size_t)cnt * per_inst,
+        GC_HIP(hipMemcpyAsync((uint8_t *)host_out + (size_t)i0 * per_inst, tmp, (size_t)cnt * per_inst,
                               hipMemcpyDeviceToHost, ctx->stream));
         GC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -695,22 +821,62 @@ int gc_batch_read_outputs(gc_batch *b, gc_label *out) {
     return read_gather(b, b->d_W, b->g.lw, b->circ->d_out_slots, 0, b->circ->plan.p.info.noutputs, 0, out);
 }
 
+// PINNED host [instance][src_stride] -> device [row][instance]: DMA of chunk k + 1 on the copy stream while the
+// scatter kernel of chunk k runs on the ctx stream
+static int write_scatter_pinned(gc_batch *b, const void *host_src, size_t src_stride_elems, size_t col0, uint32_t n,
+                                const uint32_t *slots, uint32_t slot0, uint4 *dst, const Layout &lay) {
+    gc_ctx *ctx = b->circ->ctx;
+    const size_t per_inst = (size_t)n * sizeof(uint4);
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, kPipeChunkBytes / per_inst));
+    chunk = (chunk + 31u) & ~31u;
+    int rc = ensure_pipeline(ctx, (size_t)std::min<uint32_t>(chunk, (b->g.batch + 31u) & ~31u) * per_inst);
+    if (rc != GC_OK) return rc;
+    // what is already queued on the ctx stream may still read the staging buffers (an earlier pipelined call)
+    GC_HIP(hipEventRecord(ctx->ev_k[0], ctx->stream));
+    GC_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_k[0], 0));
+    uint32_t k = 0;
+    for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk, k++) {
+        const int sb = (int)(k & 1);
+        const uint32_t cnt = std::min(chunk, b->g.batch - i0);
+        const uint8_t *src = (const uint8_t *)host_src + ((size_t)i0 * src_stride_elems + col0) * sizeof(uint4);
+        if (k >= 2) GC_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_k[sb], 0));  // its previous scatter is done
+        if (src_stride_elems == n)
+            GC_HIP(hipMemcpyAsync(ctx->stage[sb], src, (size_t)cnt * per_inst, hipMemcpyHostToDevice, ctx->copy_stream));
+        else
+            GC_HIP(hipMemcpy2DAsync(ctx->stage[sb], per_inst, src, src_stride_elems * sizeof(uint4), per_inst, cnt,
+                                    hipMemcpyHostToDevice, ctx->copy_stream));
+        GC_HIP(hipEventRecord(ctx->ev_c[sb], ctx->copy_stream));
+        GC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_c[sb], 0));
+        launch_scatter((const uint4 *)ctx->stage[sb], n, n, slots, slot0, dst, lay, i0, cnt, ctx->stream);
+        GC_HIP(hipGetLastError());
+        GC_HIP(hipEventRecord(ctx->ev_k[sb], ctx->stream));
+    }
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+}
+
 static int write_scatter(gc_batch *b, const void *host_src, size_t src_stride_elems, size_t col0, uint32_t n,
                          const uint32_t *slots, uint32_t slot0, uint4 *dst, const Layout &lay) {
     if (n == 0) return GC_OK;
     gc_ctx *ctx = b->circ->ctx;
     GC_HIP(hipSetDevice(ctx->device));
     const size_t per_inst = (size_t)n * sizeof(uint4);
-    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)256 << 20) / per_inst));
+    if (per_inst * b->g.batch >= ((size_t)1 << 20) && gc_host_is_pinned(host_src))
+        return write_scatter_pinned(b, host_src, src_stride_elems, col0, n, slots, slot0, dst, lay);
+    uint32_t chunk = (uint32_t)std::max<size_t>(32, std::min<size_t>(b->g.batch, ((size_t)64 << 20) / per_inst));
     chunk = (chunk + 31u) & ~31u;
-    DevBuf tmp;
-    GC_HIP(tmp.alloc((size_t)std::min<uint32_t>(chunk, b->g.batch) * per_inst));
+    int rcp = ensure_pipeline(ctx, (size_t)std::min<uint32_t>(chunk, (b->g.batch + 31u) & ~31u) * per_inst);
+    if (rcp != GC_OK) return rcp;
+    void *tmp = ctx->stage[0];
     for (uint32_t i0 = 0; i0 < b->g.batch; i0 += chunk) {
         const uint32_t cnt = std::min(chunk, b->g.batch - i0);
         const uint8_t *src = (const uint8_t *)host_src + ((size_t)i0 * src_stride_elems + col0) * sizeof(uint4);
-        GC_HIP(hipMemcpy2DAsync(tmp.p, per_inst, src, src_stride_elems * sizeof(uint4), per_inst, cnt,
-                                hipMemcpyHostToDevice, ctx->stream));
-        launch_scatter((const uint4 *)tmp.p, n, n, slots, slot0, dst, lay, i0, cnt, ctx->stream);
+        if (src_stride_elems == n)
+            GC_HIP(hipMemcpyAsync(tmp, src, (size_t)cnt * per_inst, hipMemcpyHostToDevice, ctx->stream));
+        else
+            GC_HIP(hipMemcpy2DAsync(tmp, per_inst, src, src_stride_elems * sizeof(uint4), per_inst, cnt,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        launch_scatter((const uint4 *)tmp, n, n, slots, slot0, dst, lay, i0, cnt, ctx->stream);
         GC_HIP(hipGetLastError());
         GC_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -907,11 +1073,13 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
     const size_t stride = 16 * ((size_t)p.info.ninputs + 1);
     if (rndlen < stride * batch) return GC_E_RAND;
     int rc = GC_OK;
+    Trace tr("gc_garble");
     gc_batch *b = pool_get(c, batch, &rc);
     if (!b) return rc;
     gc_ctx *ctx = c->ctx;
     // one HIP stream per ctx: serialise host-buffer calls that share the ctx
     std::lock_guard<std::mutex> lk(ctx->mu);
+    tr.lap("pool + lock");
     do {
         DevBuf d_rnd;
         hipError_t e = hipSetDevice(ctx->device);
@@ -926,33 +1094,42 @@ int gc_garble(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd,
         // tile may be smaller than the flattened kernels' (relayout re-sizes the arrays if it is)
         b->store_all = wires_out != nullptr;
         if ((rc = relayout(b)) != GC_OK) break;
+        tr.lap("rnd h2d + layout");
         rc = gc_batch_garble(b, key, keylen, d_rnd.p);
         if (rc != GC_OK) break;
         if (r_out && (rc = gc_batch_read_r(b, r_out)) != GC_OK) break;
+        tr.lap("garble + R");
         if (slab_out && (rc = gc_batch_read_slab(b, slab_out)) != GC_OK) break;
+        tr.lap("slab d2h");
         if (wires_out && (rc = gc_batch_read_wires(b, wires_out)) != GC_OK) break;
         if (io_out) {
-            // Wires[0:ninputs] then Wires[nwires-noutputs:]
+            // Wires[0:ninputs] then Wires[nwires-noutputs:]: both ranges gathered on the device into one dense
+            // [batch][ninputs + noutputs] wire array (two launches, column offset), one copy to the caller
             const uint32_t nio = p.info.ninputs + p.info.noutputs;
-            // gather the two ranges separately into a strided host buffer
-            std::vector<gc_wire> in((size_t)batch * p.info.ninputs), out((size_t)batch * p.info.noutputs);
-            rc = read_gather(b, b->d_W, b->g.lw, nullptr, 0, p.info.ninputs, 1, in.data());
-            if (rc != GC_OK) break;
-            rc = read_gather(b, b->d_W, b->g.lw, c->d_out_slots, 0, p.info.noutputs, 1, out.data());
-            if (rc != GC_OK) break;
-            for (uint32_t i = 0; i < batch; i++) {
-                std::copy(in.begin() + (size_t)i * p.info.ninputs, in.begin() + (size_t)(i + 1) * p.info.ninputs,
-                          io_out + (size_t)i * nio);
-                std::copy(out.begin() + (size_t)i * p.info.noutputs, out.begin() + (size_t)(i + 1) * p.info.noutputs,
-                          io_out + (size_t)i * nio + p.info.ninputs);
+            const size_t bytes = (size_t)batch * nio * sizeof(gc_wire);
+            if ((rc = ensure_pipeline(ctx, std::max(bytes, (size_t)1 << 20))) != GC_OK) break;
+            uint4 *st = (uint4 *)ctx->stage[0];
+            // a wire = 2 labels: row stride 2 * nio elements, the output range starts 2 * ninputs elements in
+            launch_gather(b->d_W, b->g.lw, 0, nullptr, 0, p.info.ninputs, b->d_R, 1, st, 2 * (size_t)nio, batch, ctx->stream);
+            launch_gather(b->d_W, b->g.lw, 0, c->d_out_slots, 0, p.info.noutputs, b->d_R, 1, st + 2 * (size_t)p.info.ninputs,
+                          2 * (size_t)nio, batch, ctx->stream);
+            hipError_t eg = hipGetLastError();
+            if (eg == hipSuccess) eg = hipMemcpyAsync(io_out, st, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (eg == hipSuccess) eg = hipStreamSynchronize(ctx->stream);
+            if (eg != hipSuccess) {
+                set_error("gc_garble (io wires)", eg);
+                rc = GC_E_HIP;
+                break;
             }
         }
+        tr.lap("wires / io d2h");
         hipError_t es = hipStreamSynchronize(ctx->stream);
         if (es != hipSuccess) {
             set_error("gc_garble", es);
             rc = GC_E_HIP;
         }
     } while (0);
+    tr.lap("sync + frees");
     pool_put(c, b);
     return rc;
 } catch (...) {
@@ -1027,6 +1204,7 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
     if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
     if (slab_rows_given != p.info.slab_rows || (!slab && p.info.slab_rows)) return GC_E_ROWS;
     int rc = GC_OK;
+    Trace tr("gc_eval");
     gc_batch *b = pool_get(c, batch, &rc);
     if (!b) return rc;
     gc_ctx *ctx = c->ctx;
@@ -1035,16 +1213,19 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
         b->store_all = wires_inout != nullptr;
         if ((rc = relayout(b)) != GC_OK) break;  // before the tables and labels go into the arrays
         if (p.info.slab_rows && (rc = gc_batch_write_slab(b, slab)) != GC_OK) break;
+        tr.lap("slab h2d");
         if (wires_inout)
             rc = write_scatter(b, wires_inout, p.info.nwires, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         else
             rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw);
         if (rc != GC_OK) break;
+        tr.lap("inputs h2d");
         rc = gc_batch_eval(b, key, keylen, b);
         if (rc != GC_OK) break;
         if (wires_inout && (rc = gc_batch_read_labels(b, wires_inout)) != GC_OK) break;
         if (out_labels && (rc = gc_batch_read_outputs(b, out_labels)) != GC_OK) break;
         hipError_t es = hipStreamSynchronize(ctx->stream);
+        tr.lap("eval + outputs");
         if (es != hipSuccess) {
             set_error("gc_eval", es);
             rc = GC_E_HIP;

@@ -32,6 +32,13 @@ struct gc_ctx {
     uint32_t *d_te0 = nullptr;  // Te0 (1 KiB), L2-resident source of the LDS tables
     std::mutex mu;              // serialises host-buffer calls sharing this ctx's stream
     bool capturing = false;     // between gc_ctx_capture_begin / _end: launches are recorded, not run
+    // host-buffer calls on PINNED caller memory (gc_host_alloc / gc_host_register): the DMA runs on its own stream,
+    // chunk k in flight while the transpose kernel of chunk k + 1 fills the other staging buffer (lazily created)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_k[2] = {nullptr, nullptr};  // kernel on stage[b] done
+    hipEvent_t ev_c[2] = {nullptr, nullptr};  // copy from / to stage[b] done
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_cap = 0;
 };
 
 struct gc_graph {

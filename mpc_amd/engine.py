@@ -147,6 +147,11 @@ def lib():
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
+        "gc_host_alloc": (vp, [sz]),
+        "gc_host_free": (None, [vp]),
+        "gc_host_register": (i32, [vp, sz]),
+        "gc_host_unregister": (i32, [vp]),
+        "gc_host_is_pinned": (i32, [vp]),
         "gc_comm_available": (i32, []),
         "gc_comm_version": (i32, []),
         "gc_comm_get_unique_id": (i32, [vp, sz]),
@@ -187,6 +192,32 @@ def _check(rc, what):
 
 def device_count():
     return lib().gc_device_count()
+
+
+class PinnedArray:
+    """numpy array backed by gc_host_alloc (pinned, DMA-able host memory): what the Go shim's scratch pool hands to
+    gc_garble / gc_eval.  Keep the object alive as long as views of .a are in use."""
+
+    def __init__(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self.ptr = lib().gc_host_alloc(max(n, 16))
+        if not self.ptr:
+            raise EngineError(GC_E_NOMEM, "gc_host_alloc(%d)" % n)
+        buf = (C.c_uint8 * max(n, 1)).from_address(self.ptr)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.a = None
+            lib().gc_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- plan (host only) ---------------------------------------------------------------------

@@ -1,11 +1,20 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the literal drop-in calls (gc_garble / gc_eval with HOST buffers): every call moves
 the caller's random stream in and R, the input/output wires and the table slab out (garble), the slab and input labels in
-and the output labels out (eval).  Reported next to the HBM-resident rate of bench.py, never instead of it."""
+and the output labels out (eval).  Reported next to the HBM-resident rate of bench.py, never instead of it.
+
+Three figures per batch size:
+  pageable   the caller's buffers are ordinary heap memory (what an unmodified Go caller passes)
+  pinned     the buffers come from gc_host_alloc (the shim's scratch pool): direct DMA, chunk-pipelined
+  duplex     pinned, garbler and evaluator as two threads with their own gc_ctx: garble of batch k+1 (tables device ->
+             host) overlaps eval of batch k (tables host -> device) — the two directions of the PCIe link; in the real
+             protocol the two passes run on two machines and each party sees its own direction only
+"""
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,45 +23,153 @@ import numpy as np
 from mpc_amd import engine, parse_file
 from mpc_amd.circuit import LABEL, WIRE
 
+p = lambda a: a.ctypes.data_as(C.c_void_p)
 
-def run(batch=1024, reps=5, key=bytes(range(32))):
-    c = parse_file(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "aes_128.gcf"))
-    ctx = engine.Context(0)
-    dc = engine.DeviceCircuit(ctx, c)
+
+class Party:
+    def __init__(self, c, batch, pinned, nslabs=1):
+        self.c, self.batch = c, batch
+        self.ctx = engine.Context(0)
+        self.dc = engine.DeviceCircuit(self.ctx, c)
+        rows, nin, nout = self.dc.info.slab_rows, c.num_inputs, c.num_outputs
+        self.rows, self.nin, self.nout = rows, nin, nout
+        self._keep = []
+
+        def arr(shape, dtype):
+            if not pinned:
+                return np.zeros(shape, dtype)
+            pa = engine.PinnedArray(shape, dtype)
+            pa.a[...] = np.zeros((), dtype)
+            self._keep.append(pa)
+            return pa.a
+
+        self.R = arr((batch,), LABEL)
+        self.slabs = [arr((batch, rows), LABEL) for _ in range(nslabs)]
+        self.io = arr((batch, nin + nout), WIRE)
+        self.inputs = arr((batch, nin), LABEL)
+        self.outl = arr((batch, nout), LABEL)
+
+    def close(self):
+        self.dc.close()
+        self.ctx.close()
+        for pa in self._keep:
+            pa.close()
+
+
+def run(batch=1024, reps=4, key=bytes(range(32)), circuit=None):
+    c = parse_file(circuit or os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "aes_128.gcf"))
     L = engine.lib()
-    rows, nin, nout = dc.info.slab_rows, c.num_inputs, c.num_outputs
+    nin = c.num_inputs
     rnd = np.frombuffer(np.random.default_rng(1).bytes(batch * 16 * (nin + 1)), np.uint8).copy()
     k = np.frombuffer(key, np.uint8).copy()
-    R = np.zeros(batch, LABEL)
-    slab = np.zeros((batch, rows), LABEL)
-    io = np.zeros((batch, nin + nout), WIRE)
-    outl = np.zeros((batch, nout), LABEL)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    tg, te = [], []
-    for r in range(reps + 1):
-        t0 = time.perf_counter()
-        rc = L.gc_garble(dc.h, p(k), len(k), p(rnd), len(rnd), batch, p(R), None, p(io), p(slab))
-        t1 = time.perf_counter()
-        assert rc == 0
-        inputs = np.ascontiguousarray(io[:, :nin]["l0"])  # all-zero inputs: the L0 labels
-        t2 = time.perf_counter()
-        rc = L.gc_eval(dc.h, p(k), len(k), batch, None, p(inputs), p(slab), rows, p(outl))
-        t3 = time.perf_counter()
-        assert rc == 0
-        if r:  # the first round warms allocations
-            tg.append(t1 - t0)
-            te.append(t3 - t2)
-    bits = c.compute_bits(np.zeros(nin, np.uint8))[c.NumWires - nout:].astype(bool)  # plaintext result for zero inputs
-    want = np.where(bits[None, :], io[:, nin:]["l1"], io[:, nin:]["l0"])
-    assert (outl == want).all()
-    g, e = min(tg), min(te)
-    n_and = dc.info.n_and * batch
-    res = {"batch": batch, "garble_ms": g * 1e3, "eval_ms": e * 1e3, "and_gates_per_s": n_and / (g + e),
-           "slab_MB": slab.nbytes / 1e6, "garble_GBs_out": (slab.nbytes + io.nbytes) / g / 1e9,
-           "eval_GBs_in": (slab.nbytes + inputs.nbytes) / e / 1e9}
-    dc.close()
-    ctx.close()
+    res = {"batch": batch}
+
+    def garble(P, slab):
+        rc = L.gc_garble(P.dc.h, p(k), len(k), p(rnd), len(rnd), batch, p(P.R), None, p(P.io), p(slab))
+        assert rc == 0, rc
+
+    def evaluate(P, slab, inputs):
+        rc = L.gc_eval(P.dc.h, p(k), len(k), batch, None, p(inputs), p(slab), P.rows, p(P.outl))
+        assert rc == 0, rc
+
+    bits = c.compute_bits(np.zeros(nin, np.uint8))[c.NumWires - c.num_outputs:].astype(bool)  # zero inputs
+
+    for mode in ("pageable", "pinned"):
+        P = Party(c, batch, mode == "pinned")
+        tg, te = [], []
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            garble(P, P.slabs[0])
+            t1 = time.perf_counter()
+            P.inputs[...] = P.io[:, :nin]["l0"]  # all-zero inputs: the L0 labels
+            t2 = time.perf_counter()
+            evaluate(P, P.slabs[0], P.inputs)
+            t3 = time.perf_counter()
+            if r:  # the first round warms allocations
+                tg.append(t1 - t0)
+                te.append(t3 - t2)
+        want = np.where(bits[None, :], P.io[:, nin:]["l1"], P.io[:, nin:]["l0"])
+        assert (P.outl == want).all()
+        g, e = min(tg), min(te)
+        n_and = P.dc.info.n_and * batch
+        nbytes = P.slabs[0].nbytes
+        res[mode] = {"garble_ms": g * 1e3, "eval_ms": e * 1e3, "and_gates_per_s": n_and / (g + e),
+                     "garble_GBs_out": (nbytes + P.io.nbytes) / g / 1e9, "eval_GBs_in": (nbytes + P.inputs.nbytes) / e / 1e9}
+        res["slab_MB"] = nbytes / 1e6
+        P.close()
+
+    # duplex: garbler thread and evaluator thread, two slabs in flight
+    G, E = Party(c, batch, True, nslabs=2), Party(c, batch, True, nslabs=0)
+    nrep = 2 * reps + 2
+    full = [threading.Semaphore(0), threading.Semaphore(0)]
+    free = [threading.Semaphore(1), threading.Semaphore(1)]
+    inputs = [np.zeros((batch, nin), LABEL), np.zeros((batch, nin), LABEL)]
+    ok = [True]
+    stamps = []
+
+    def garbler():
+        for r in range(nrep):
+            s = r & 1
+            free[s].acquire()
+            garble(G, G.slabs[s])
+            inputs[s][...] = G.io[:, :nin]["l0"]
+            full[s].release()
+
+    def evaluator():
+        for r in range(nrep):
+            s = r & 1
+            full[s].acquire()
+            E.inputs[...] = inputs[s]
+            evaluate(E, G.slabs[s], E.inputs)
+            stamps.append(time.perf_counter())
+            free[s].release()
+
+    tg_, te_ = threading.Thread(target=garbler), threading.Thread(target=evaluator)
+    tg_.start(); te_.start(); tg_.join(); te_.join()
+    want = np.where(bits[None, :], G.io[:, nin:]["l1"], G.io[:, nin:]["l0"])
+    ok[0] = bool((E.outl == want).all())
+    assert ok[0]
+    per = (stamps[-1] - stamps[1]) / (len(stamps) - 2)  # steady state: skip the warm-up batch
+    res["duplex"] = {"ms_per_batch": per * 1e3, "and_gates_per_s": G.dc.info.n_and * batch / per,
+                     "GBs_each_way": G.slabs[0].nbytes / per / 1e9}
+    G.close(); E.close()
+    res["link"] = link_probe()
     return res
+
+
+def link_probe(n=256 << 20):
+    """what the box's host link does for plain pinned-memory DMA (each direction alone, both at once): the bound the
+    figures above are to be read against"""
+    try:
+        import torch
+    except Exception:
+        return None
+    h_out = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    h_in = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    h_in.fill_(3)
+    d_a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def timed(fn, reps=4):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def d2h():
+        with torch.cuda.stream(s1):
+            h_out.copy_(d_a, non_blocking=True)
+
+    def h2d():
+        with torch.cuda.stream(s2):
+            d_b.copy_(h_in, non_blocking=True)
+
+    return {"d2h_GBs": n / timed(d2h) / 1e9, "h2d_GBs": n / timed(h2d) / 1e9,
+            "both_at_once_GBs_each": n / timed(lambda: (d2h(), h2d())) / 1e9}
 
 
 if __name__ == "__main__":

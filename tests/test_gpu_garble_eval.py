@@ -397,3 +397,48 @@ def test_concurrent_host_calls_on_one_circuit(ctx, add64_circ):
         t.join()
     dc.close(); dc2.close(); ctx2.close()
     assert not errors, errors[:3]
+
+
+def test_host_api_pinned_buffers_pipeline(ctx, aes_circ):
+    """gc_garble / gc_eval on PINNED caller memory (gc_host_alloc): direct DMA, chunk-pipelined against the layout
+    transposes (several chunks at this size) — same bytes as the pageable path and as the oracle"""
+    import ctypes as C
+    c = aes_circ
+    batch = 300
+    dc = engine.DeviceCircuit(ctx, c)
+    L = engine.lib()
+    rows, nin, nout = dc.info.slab_rows, c.num_inputs, c.num_outputs
+    rnd = np.frombuffer(rnd_for(c, "pinned", batch), np.uint8).copy()
+    k = np.frombuffer(KEY256, np.uint8).copy()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    keep = [engine.PinnedArray((batch,), LABEL), engine.PinnedArray((batch, rows), LABEL),
+            engine.PinnedArray((batch, nin + nout), engine.WIRE), engine.PinnedArray((batch, c.NumWires), LABEL),
+            engine.PinnedArray((batch, nout), LABEL)]
+    R, slab, io, wires, outl = [x.a for x in keep]
+    assert L.gc_host_is_pinned(ptr(slab)) == 1 and L.gc_host_is_pinned(ptr(rnd)) == 0
+    assert L.gc_garble(dc.h, ptr(k), len(k), ptr(rnd), len(rnd), batch, ptr(R), None, ptr(io), ptr(slab)) == 0
+    ref = dc.garble(KEY256, rnd.tobytes(), batch=batch, want_wires=False, want_io=True)  # pageable
+    assert (R == ref["R"]).all() and (slab == ref["slab"]).all() and (io == ref["io"]).all()
+    for i in (0, 159, 160, 299):  # chunk boundaries
+        o = oracle_instance(c, KEY256, rnd.tobytes(), i)
+        assert R[i] == o["R"] and (slab[i] == o["slab"]).all()
+    # eval: pinned slab + pinned full wire array (strided 2-D input copy, every wire read back)
+    wires[...] = np.zeros((), LABEL)
+    wires[:, :nin] = io[:, :nin]["l0"]
+    assert L.gc_eval(dc.h, ptr(k), len(k), batch, ptr(wires), None, ptr(slab), rows, ptr(outl)) == 0
+    out_ref = dc.eval(KEY256, ref["slab"], inputs=np.ascontiguousarray(ref["io"][:, :nin]["l0"]), batch=batch)
+    assert (outl == out_ref).all() and (wires[:, c.NumWires - nout:] == out_ref).all()
+    for i in (0, 160, 299):
+        w = np.zeros(c.NumWires, LABEL)
+        w[:nin] = io[i, :nin]["l0"]
+        oracle.eval_(c.Gates, c.NumWires, KEY256, w, slab[i])
+        assert (wires[i] == w).all()
+    # a registered (not allocated) range works the same
+    own = np.zeros((batch, rows), LABEL)
+    assert L.gc_host_register(ptr(own), own.nbytes) == 0 and L.gc_host_is_pinned(ptr(own)) == 1
+    assert L.gc_garble(dc.h, ptr(k), len(k), ptr(rnd), len(rnd), batch, ptr(R), None, None, ptr(own)) == 0
+    assert (own == slab).all()
+    assert L.gc_host_unregister(ptr(own)) == 0
+    dc.close()
+    for x in keep:
+        x.close()

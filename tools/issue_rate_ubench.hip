@@ -59,6 +59,10 @@
 #define I_ANDOR(A) "v_and_or_b32 " A ", " A ", %8, %9\n"
 #define I_BFE(A) "v_bfe_u32 " A ", " A ", 8, 8\n"
 #define I_LSHL(A) "v_lshlrev_b32 " A ", 1, " A "\n"
+#define I_LSHL_V(A) "v_lshlrev_b32 " A ", %9, " A "\n"
+#define I_AND(A) "v_and_b32 " A ", " A ", %8\n"
+#define I_OR(A) "v_or_b32 " A ", " A ", %8\n"
+#define I_XOR_C(A) "v_xor_b32 " A ", 0x55, " A "\n"
 #define I_MOVDPP(A) "v_mov_b32_dpp " A ", " A " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 #define I_XORDPP(A) "v_xor_b32_dpp " A ", " A ", " A " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 #define I_FMA(A) "v_fma_f32 " A ", " A ", %8, %9\n"
@@ -78,6 +82,10 @@ VALU_KERNEL(k_lshladd, I_LSHLADD)
 VALU_KERNEL(k_andor, I_ANDOR)
 VALU_KERNEL(k_bfe, I_BFE)
 VALU_KERNEL(k_lshl, I_LSHL)
+VALU_KERNEL(k_lshl_v, I_LSHL_V)
+VALU_KERNEL(k_and, I_AND)
+VALU_KERNEL(k_or, I_OR)
+VALU_KERNEL(k_xor_c, I_XOR_C)
 VALU_KERNEL(k_movdpp, I_MOVDPP)
 VALU_KERNEL(k_xordpp, I_XORDPP)
 VALU_KERNEL(k_fma, I_FMA)
@@ -159,36 +167,67 @@ __global__ __launch_bounds__(1024) void k_lds(uint32_t *out, int iters, uint64_t
     if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+// ---- vector-memory gathers from a small table that stays in the CU's L1: is the texture path a second look-up engine?
+// TABLE_BYTES = 1024 (compact Te0) or 65536 (the LDS layout); 16 loads per batch
+template <int SHIFT>
+__global__ __launch_bounds__(1024) void k_vmem(const uint32_t *tab, uint32_t *out, int iters, uint64_t *ticks) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t off[16], t[16];
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t idx = (x >> 24) & 0xffu;
+        off[i] = SHIFT == 2 ? idx * 4 : ((idx << 8) | ((lane & 31) * 4));
+    }
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(t[i]) : "v"(off[i]), "s"(tab) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        x ^= t[0];
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 static uint32_t *d_out;
 static uint64_t *d_ticks;
 static double g_clock_hz = 2.4e9;
 
+static int g_grid = 256;
 template <typename K>
 static double run(K kern, int threads, size_t lds, int iters, double *tick_cycles) {
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     if (lds) HIPCHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), lds, 0, d_out, 4, d_ticks);
+    hipLaunchKernelGGL(kern, dim3(g_grid), dim3(threads), lds, 0, d_out, 4, d_ticks);
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), lds, 0, d_out, iters, d_ticks);
+    hipLaunchKernelGGL(kern, dim3(g_grid), dim3(threads), lds, 0, d_out, iters, d_ticks);
     HIPCHECK(hipEventRecord(e1));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<uint64_t> h(256);
-    HIPCHECK(hipMemcpy(h.data(), d_ticks, 256 * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> h(g_grid);
+    HIPCHECK(hipMemcpy(h.data(), d_ticks, g_grid * 8, hipMemcpyDeviceToHost));
     double avg = 0;
     for (auto v : h) avg += (double)v;
-    *tick_cycles = avg / 256;
+    *tick_cycles = avg / g_grid;
     return ms * 1e-3;
 }
 
 int main() {
-    HIPCHECK(hipMalloc(&d_out, 256 * 1024 * 4));
-    HIPCHECK(hipMalloc(&d_ticks, 256 * 8));
-    // (4) clock: ticks of s_memtime per wall second on a long VALU kernel
+    HIPCHECK(hipMalloc(&d_out, 512 * 1024 * 4));
+    HIPCHECK(hipMalloc(&d_ticks, 512 * 8));
+    {  // warm the clocks up before anything is measured
+        double ticks;
+        for (int i = 0; i < 5; i++) run(k_xor, 1024, 0, 20000, &ticks);
+    }
+    // (4) clock: ticks of s_memtime per wall second on a long VALU kernel (after the warm-up above)
     {
         double ticks;
         const double s = run(k_xor, 1024, 0, 20000, &ticks);
@@ -202,29 +241,57 @@ int main() {
     } vs[] = {{"v_xor_b32 (vgpr,vgpr)", k_xor},   {"v_xor_b32 (sgpr,vgpr)", k_xor_s}, {"v_add_u32", k_add},
               {"v_perm_b32", k_perm},             {"v_alignbit_b32", k_align},        {"v_bitop3_b32 (3 vgpr)", k_bitop3},
               {"v_bitop3_b32 (sgpr src)", k_bitop3_s}, {"v_lshl_add_u32", k_lshladd},
-              {"v_and_or_b32", k_andor},          {"v_bfe_u32", k_bfe},               {"v_lshlrev_b32", k_lshl},
+              {"v_and_or_b32", k_andor},          {"v_bfe_u32", k_bfe},               {"v_lshlrev_b32 (const shift)", k_lshl}, {"v_lshlrev_b32 (vgpr shift)", k_lshl_v}, {"v_and_b32", k_and},
+              {"v_or_b32", k_or}, {"v_xor_b32 (literal)", k_xor_c},
               {"v_mov_b32_dpp quad_perm", k_movdpp}, {"v_xor_b32_dpp quad_perm", k_xordpp}, {"v_fma_f32", k_fma},
               {"v_add_f32", k_addf},              {"v_pk_add_u16", k_pkadd16},        {"v_mov_b32", k_mov},
               {"v_lshlrev_b32_sdwa BYTE_1", k_sdwa}};
     const int iters = 2000;
+    // ns = wall clock of the launch / instructions per SIMD (launch overhead included: ~10 us of ~0.1-1 ms)
     for (auto &v : vs) {
         printf("VALU %-28s", v.name);
-        for (int threads : {256, 512, 1024}) {
+        for (int wps : {1, 2, 4, 8}) {  // waves per SIMD; 8 = two workgroups of 1024 threads per CU
             double ticks;
-            run(v.k, threads, 0, iters, &ticks);
-            const double wps = threads / 256.0;  // waves per SIMD
-            printf("  %dw/SIMD: %.2f cyc/instr/SIMD", (int)wps, ticks / (iters * 64.0 * wps));
+            g_grid = wps == 8 ? 512 : 256;
+            const int threads = wps == 8 ? 1024 : 256 * wps;
+            const double sec = run(v.k, threads, 0, iters, &ticks);
+            g_grid = 256;
+            printf("  %dw: %.2f tick %.3f ns", wps, ticks / (iters * 64.0 * (wps == 8 ? 4 : wps)) / (wps == 8 ? 2 : 1),
+                   sec * 1e9 / (iters * 64.0 * wps));
         }
-        printf("\n");
+        printf("  (per wave-instr per SIMD)\n");
+    }
+    {  // VMEM gathers
+        uint32_t *d_tab;
+        HIPCHECK(hipMalloc(&d_tab, 65536));
+        HIPCHECK(hipMemset(d_tab, 1, 65536));
+        for (int threads : {256, 1024}) {
+            hipEvent_t e0, e1;
+            HIPCHECK(hipEventCreate(&e0));
+            HIPCHECK(hipEventCreate(&e1));
+            for (int shift : {2, 8}) {
+                auto kern = shift == 2 ? k_vmem<2> : k_vmem<8>;
+                hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, d_tab, d_out, 4, d_ticks);
+                HIPCHECK(hipDeviceSynchronize());
+                HIPCHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, d_tab, d_out, 500, d_ticks);
+                HIPCHECK(hipEventRecord(e1));
+                HIPCHECK(hipEventSynchronize(e1));
+                float ms = 0;
+                HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+                printf("VMEM global_load_dword gather, %s table, %2d waves/CU: %.3f ns per wave-load per CU\n",
+                       shift == 2 ? "1 KiB compact" : "64 KiB replicated", threads / 64, ms * 1e6 / (500.0 * 16 * (threads / 64)));
+            }
+        }
     }
     // (2) LDS shapes, 16 waves per CU, no VALU
     const size_t L = 65536 + 256;
 #define LDSRUN(MODE, NV, PR, LABEL)                                                                             \
     {                                                                                                           \
         double ticks;                                                                                           \
-        run(k_lds<MODE, NV, PR>, 1024, L, 1000, &ticks);                                                        \
-        printf("LDS  %-44s nvalu=%2d prio=%d: %.2f cyc per wave-load per CU, %.1f cyc per iteration (16 waves)\n", LABEL, NV, \
-               PR, ticks / (1000.0 * 16 * 16), ticks / 1000.0);                                                 \
+        const double sec = run(k_lds<MODE, NV, PR>, 1024, L, 1000, &ticks);                                     \
+        printf("LDS  %-44s nvalu=%2d prio=%d: %.2f tick %.3f ns per wave-load per CU; %.1f tick %.1f ns per iteration (16 waves)\n", \
+               LABEL, NV, PR, ticks / (1000.0 * 16 * 16), sec * 1e9 / (1000.0 * 16 * 16), ticks / 1000.0, sec * 1e9 / 1000.0); \
     }
     LDSRUN(0, 0, 0, "ds_read_b32 linear (bank = lane)")
     LDSRUN(1, 0, 0, "ds_read_b32 replicated row (production)")
