@@ -26,6 +26,12 @@ import (
 	"github.com/markkurossi/mpc/ot"
 )
 
+// HipAllWires makes Garble fill every element of Garbled.Wires (debug / parity runs).  Off by default: the
+// reference's callers read only the input range Wires[0:Inputs.Size()) and the output range
+// Wires[NumWires-Outputs.Size():] (circuit/garbler.go:87,132,153; sha2pc/garbler.go:115-126), and asking the
+// device for all 36 919 wires of aes_128 selects the slower kernel that materialises them.
+var HipAllWires = false
+
 // hipCircuit is the device twin of a *Circuit: created on first use, shared by all goroutines
 // (gc_circ is immutable; gc_garble / gc_eval are re-entrant).
 type hipCircuit struct {
@@ -101,14 +107,25 @@ func (c *Circuit) Garble(rand io.Reader, key []byte) (*Garbled, error) {
 	if len(scratch.slab) > 0 {
 		slabPtr = (*C.gc_label)(unsafe.Pointer(&scratch.slab[0]))
 	}
+	nout := c.Outputs.Size()
+	var wiresPtr, ioPtr *C.gc_wire
+	var io []ot.Wire
+	if HipAllWires {
+		wiresPtr = (*C.gc_wire)(unsafe.Pointer(&scratch.wires[0])) // Garbled.Wires: all wires, both labels
+	} else {
+		io = make([]ot.Wire, nin+nout)
+		ioPtr = (*C.gc_wire)(unsafe.Pointer(&io[0]))
+	}
 	st := C.gc_garble(h.circ, (*C.uint8_t)(unsafe.Pointer(&key[0])), C.size_t(len(key)),
 		(*C.uint8_t)(unsafe.Pointer(&rnd[0])), C.size_t(len(rnd)), 1,
-		(*C.gc_label)(unsafe.Pointer(&g.R)),
-		(*C.gc_wire)(unsafe.Pointer(&scratch.wires[0])), // Garbled.Wires: all wires, both labels
-		nil, slabPtr)
+		(*C.gc_label)(unsafe.Pointer(&g.R)), wiresPtr, ioPtr, slabPtr)
 	if st != C.GC_OK {
 		pool.Put(scratch)
 		return nil, statusError(st)
+	}
+	if !HipAllWires { // the two ranges the callers read; the rest of the pooled slice keeps stale scratch
+		copy(scratch.wires[:nin], io[:nin])
+		copy(scratch.wires[c.NumWires-nout:], io[nin:])
 	}
 	// Garbled.Gates[i] = sub-slice of the dense slab (nil for XOR/XNOR), garble.go:290-298
 	off := 0
@@ -161,6 +178,13 @@ func (c *Circuit) Eval(key []byte, wires []ot.Label, garbled [][]ot.Label) error
 		default:
 			continue
 		}
+		// exactly the rows Eval indexes (row[index-1], eval.go:86-104): a longer row must not shift the next gate's
+		switch c.Gates[i].Op {
+		case OR:
+			row = row[:3]
+		case INV:
+			row = row[:1]
+		}
 		slab = append(slab, row...)
 	}
 	var slabPtr *C.gc_label
@@ -195,3 +219,27 @@ func (c *Circuit) GarbleBatch(rnd []byte, key []byte, batch int) (R []ot.Label, 
 	}
 	return R, io, slab, nil
 }
+
+// EvalBatch is the counterpart of GarbleBatch: inputs holds batch x Inputs.Size() active labels, slab the tables as
+// GarbleBatch returned them; the result is batch x Outputs.Size() output labels (Wires[NumWires-Outputs.Size():]).
+func (c *Circuit) EvalBatch(key []byte, inputs []ot.Label, slab []ot.Label, batch int) ([]ot.Label, error) {
+	h, err := c.hip()
+	if err != nil {
+		return nil, err
+	}
+	if len(inputs) != batch*c.Inputs.Size() || len(slab) != batch*h.rows {
+		return nil, fmt.Errorf("EvalBatch: %d inputs / %d table labels for batch %d", len(inputs), len(slab), batch)
+	}
+	out := make([]ot.Label, batch*c.Outputs.Size())
+	var slabPtr *C.gc_label
+	if len(slab) > 0 {
+		slabPtr = (*C.gc_label)(unsafe.Pointer(&slab[0]))
+	}
+	st := C.gc_eval(h.circ, (*C.uint8_t)(unsafe.Pointer(&key[0])), C.size_t(len(key)), C.uint32_t(batch), nil,
+		(*C.gc_label)(unsafe.Pointer(&inputs[0])), slabPtr, C.size_t(h.rows), (*C.gc_label)(unsafe.Pointer(&out[0])))
+	if st != C.GC_OK {
+		return nil, statusError(st)
+	}
+	return out, nil
+}
+

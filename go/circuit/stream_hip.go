@@ -1,0 +1,134 @@
+//go:build gchip
+
+package circuit
+
+/*
+#include "gcengine.h"
+*/
+import "C"
+
+import (
+	"crypto/aes"
+	"fmt"
+	"io"
+	"time"
+	"unsafe"
+
+	"github.com/markkurossi/mpc/env"
+	"github.com/markkurossi/mpc/ot"
+	"github.com/markkurossi/mpc/p2p"
+)
+
+// SOURCE ONLY (no Go toolchain in the build image).  Drop-in bodies for the streaming garbler,
+// circuit/stream_garble.go:41-192: the Streaming type keeps its exported methods (NewStreaming, GetInput,
+// GetInputs, Garble) so compiler/ssa.Program.Stream (streamer.go:74-117,568,694) compiles unchanged; the wire
+// store and the per-gate loop live behind gc_stream_*.
+
+// Streaming is a streaming garbled circuit garbler (device twin of stream_garble.go:27-38).
+type Streaming struct {
+	conn *p2p.Conn
+	ctx  *C.gc_ctx
+	h    *C.gc_stream
+	buf  []byte // serialised gates of one Garble call
+}
+
+// NewStreaming creates a new streaming garbled circuit garbler (stream_garble.go:41-75).  The random stream is
+// consumed in the reference's order: R (16 bytes; :46), aes.NewCipher(key) (:52), one L0 per entry of inputs (:67-73).
+func NewStreaming(cfg *env.Config, key []byte, inputs []Wire, conn *p2p.Conn) (*Streaming, error) {
+	rand := cfg.GetRandom()
+	rnd := make([]byte, 16*(len(inputs)+1))
+	if _, err := io.ReadFull(rand, rnd[:16]); err != nil {
+		return nil, err
+	}
+	if _, err := aes.NewCipher(key); err != nil {
+		return nil, err
+	}
+	if _, err := io.ReadFull(rand, rnd[16:]); err != nil {
+		return nil, err
+	}
+	var st C.int
+	ctx := C.gc_ctx_create(0, &st)
+	if ctx == nil {
+		return nil, statusError(st)
+	}
+	var inPtr *C.uint32_t
+	if len(inputs) > 0 {
+		inPtr = (*C.uint32_t)(unsafe.Pointer(&inputs[0])) // circuit.Wire is uint32 (circuit.go:285)
+	}
+	h := C.gc_stream_create(ctx, (*C.uint8_t)(unsafe.Pointer(&key[0])), C.size_t(len(key)),
+		(*C.uint8_t)(unsafe.Pointer(&rnd[0])), C.size_t(len(rnd)), inPtr, C.uint32_t(len(inputs)), &st)
+	if h == nil {
+		C.gc_ctx_destroy(ctx)
+		return nil, statusError(st)
+	}
+	return &Streaming{conn: conn, ctx: ctx, h: h}, nil
+}
+
+// GetInput gets the value of the input wire (stream_garble.go:117-119).
+func (stream *Streaming) GetInput(w Wire) ot.Wire {
+	var out ot.Wire
+	if C.gc_stream_get_wire(stream.h, C.uint32_t(w), (*C.gc_wire)(unsafe.Pointer(&out))) != C.GC_OK {
+		panic(fmt.Sprintf("Streaming.GetInput: wire %d out of range", w)) // the reference indexes out of range
+	}
+	return out
+}
+
+// GetInputs gets the specified input wire range (stream_garble.go:122-128).
+func (stream *Streaming) GetInputs(offset, count int) []ot.Wire {
+	result := make([]ot.Wire, count)
+	for i := 0; i < count; i++ {
+		result[i] = stream.GetInput(Wire(offset + i))
+	}
+	return result
+}
+
+// Garble garbles the circuit and streams the garbled tables into the stream (stream_garble.go:161-192): the
+// gates' bytes — op|flags, 16/32-bit wire ids, table rows, exactly as garbleGate writes them (:391-446) — come
+// back from the device in one piece and go through conn.WriteBuf / NeedSpace like the per-gate loop's output.
+func (stream *Streaming) Garble(c *Circuit, in, out []Wire) (time.Duration, time.Duration, error) {
+	start := time.Now()
+	need := 61*len(c.Gates) + 16 // upper bound: 13 header bytes + 3 rows per gate
+	if len(stream.buf) < need {
+		stream.buf = make([]byte, need+need/2)
+	}
+	mid := time.Now()
+	if len(c.Gates) == 0 {
+		return mid.Sub(start), time.Since(mid), nil
+	}
+	var inPtr, outPtr *C.uint32_t
+	if len(in) > 0 {
+		inPtr = (*C.uint32_t)(unsafe.Pointer(&in[0]))
+	}
+	if len(out) > 0 {
+		outPtr = (*C.uint32_t)(unsafe.Pointer(&out[0]))
+	}
+	var written C.size_t
+	st := C.gc_stream_garble(stream.h, (*C.gc_gate)(unsafe.Pointer(&c.Gates[0])), C.uint32_t(len(c.Gates)),
+		C.uint32_t(c.NumWires), inPtr, C.uint32_t(len(in)), outPtr, C.uint32_t(len(out)),
+		(*C.uint8_t)(unsafe.Pointer(&stream.buf[0])), C.size_t(len(stream.buf)), &written)
+	if st != C.GC_OK {
+		if st == C.GC_E_GATE {
+			return 0, 0, fmt.Errorf("invalid operation") // garbleGate's default case
+		}
+		return 0, 0, statusError(st)
+	}
+	data := stream.buf[:int(written)]
+	for len(data) > 0 { // conn.NeedSpace(512) + direct writes into conn.WriteBuf in the reference (:177-185)
+		if err := stream.conn.NeedSpace(512); err != nil {
+			return 0, 0, err
+		}
+		k := copy(stream.conn.WriteBuf[stream.conn.WritePos:], data)
+		stream.conn.WritePos += k
+		data = data[k:]
+	}
+	return mid.Sub(start), time.Since(mid), nil
+}
+
+// Close releases the device state (additive: the reference's Streaming is garbage collected).
+func (stream *Streaming) Close() {
+	if stream.h != nil {
+		C.gc_stream_free(stream.h)
+		C.gc_ctx_destroy(stream.ctx)
+		stream.h, stream.ctx = nil, nil
+	}
+}

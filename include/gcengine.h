@@ -163,6 +163,19 @@ int gc_garble(gc_circ *, const uint8_t *key, size_t keylen, const uint8_t *rnd, 
 int gc_eval(gc_circ *, const uint8_t *key, size_t keylen, uint32_t batch, gc_label *wires_inout,
             const gc_label *inputs, const gc_label *slab, size_t slab_rows_given, gc_label *out_labels);
 
+/* The same two calls speaking the wire format of the 2-party driver (SURVEY §8f row 1 on the host-buffer API):
+ * gc_garble_wire = Circuit.Garble + the table send loop of circuit.Garbler (circuit/garbler.go:53-82) — wire_out
+ * receives, per instance and `stride` bytes apart (multiple of 4, >= gc_tables_wire_bytes()),
+ *   BE32(#gates) | per gate BE32(#rows) rows x BE(D0)||BE(D1)
+ * i.e. exactly what the SendUint32 / SendLabel loop would put on the connection: the shim hands it to conn in one
+ * piece.  gc_eval_wire = the receive loop of circuit.Evaluator (circuit/evaluator.go:40-66) + Circuit.Eval; *bad
+ * counts headers that do not match the circuit ("wrong number of gates", evaluator.go:44-47; row counts that Eval
+ * rejects, eval.go:54-56,86-89): non-zero returns GC_E_ROWS and nothing is evaluated. */
+int gc_garble_wire(gc_circ *, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen, uint32_t batch,
+                   gc_label *r_out, gc_wire *io_out, uint8_t *wire_out, size_t stride);
+int gc_eval_wire(gc_circ *, const uint8_t *key, size_t keylen, uint32_t batch, const gc_label *inputs,
+                 const uint8_t *wire_in, size_t stride, gc_label *out_labels, uint32_t *bad);
+
 /* Pinned host memory for the two calls above (additive; the reference pools its scratch on the Go heap,
  * garble.go:195-225 — the shim backs that pool with gc_host_alloc instead).  When slab_out / wires_out / io_out /
  * slab / wires_inout point into pinned memory the calls DMA straight from / into the caller's pages (~57 GB/s instead

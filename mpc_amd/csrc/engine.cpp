@@ -1237,4 +1237,130 @@ int gc_eval(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, gc_la
     return gc::on_exception();
 }
 
+
+// ---- host-buffer calls that speak the 2-party driver's wire format (SURVEY §8f row 1 on the host API) ------------
+// gc_garble_wire = Circuit.Garble + the table send loop of circuit.Garbler (garbler.go:53-82): the tables leave the
+// device already serialised (k_tables_egress), so the host does ONE conn.Write per instance instead of a
+// SendUint32 + SendLabel loop over 36 663 gates.  gc_eval_wire = the receive loop of circuit.Evaluator
+// (evaluator.go:40-66) + Circuit.Eval.
+
+int gc_garble_wire(gc_circ *c, const uint8_t *key, size_t keylen, const uint8_t *rnd, size_t rndlen, uint32_t batch,
+                   gc_label *r_out, gc_wire *io_out, uint8_t *wire_out, size_t stride) try {
+    if (!c || !rnd || batch == 0 || !wire_out) return GC_E_ARG;
+    const Plan &p = c->plan.p;
+    const size_t need = gc_tables_wire_bytes(c);
+    if (stride < need || (stride & 3)) return GC_E_ARG;
+    if (rndlen < 16) return GC_E_RAND;
+    AesKey k;
+    if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
+    const size_t rstride = 16 * ((size_t)p.info.ninputs + 1);
+    if (rndlen < rstride * batch) return GC_E_RAND;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, batch, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        DevBuf d_rnd, d_wire;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = d_rnd.alloc(rstride * batch);
+        if (e == hipSuccess) e = d_wire.alloc(stride * batch);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_rnd.p, rnd, rstride * batch, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_garble_wire", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            break;
+        }
+        b->store_all = false;
+        if ((rc = relayout(b)) != GC_OK) break;
+        if ((rc = gc_batch_garble(b, key, keylen, d_rnd.p)) != GC_OK) break;
+        if ((rc = gc_batch_egress_tables(b, d_wire.p, stride)) != GC_OK) break;
+        e = hipMemcpyAsync(wire_out, d_wire.p, stride * batch, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_garble_wire", e);
+            rc = GC_E_HIP;
+            break;
+        }
+        if (r_out && (rc = gc_batch_read_r(b, r_out)) != GC_OK) break;
+        if (io_out) {
+            const uint32_t nio = p.info.ninputs + p.info.noutputs;
+            const size_t bytes = (size_t)batch * nio * sizeof(gc_wire);
+            if ((rc = ensure_pipeline(ctx, std::max(bytes, (size_t)1 << 20))) != GC_OK) break;
+            uint4 *st = (uint4 *)ctx->stage[0];
+            launch_gather(b->d_W, b->g.lw, 0, nullptr, 0, p.info.ninputs, b->d_R, 1, st, 2 * (size_t)nio, batch, ctx->stream);
+            launch_gather(b->d_W, b->g.lw, 0, c->d_out_slots, 0, p.info.noutputs, b->d_R, 1, st + 2 * (size_t)p.info.ninputs,
+                          2 * (size_t)nio, batch, ctx->stream);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(io_out, st, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) {
+                set_error("gc_garble_wire (io wires)", e);
+                rc = GC_E_HIP;
+                break;
+            }
+        }
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_garble_wire", e);
+            rc = GC_E_HIP;
+        }
+    } while (0);
+    pool_put(c, b);
+    return rc;
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_eval_wire(gc_circ *c, const uint8_t *key, size_t keylen, uint32_t batch, const gc_label *inputs,
+                 const uint8_t *wire_in, size_t stride, gc_label *out_labels, uint32_t *bad) try {
+    if (!c || batch == 0 || !inputs || !wire_in || !bad) return GC_E_ARG;
+    const Plan &p = c->plan.p;
+    if (stride < gc_tables_wire_bytes(c) || (stride & 3)) return GC_E_ARG;
+    AesKey k;
+    if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, batch, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        DevBuf d_wire, d_bad;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = d_wire.alloc(stride * batch);
+        if (e == hipSuccess) e = d_bad.alloc(sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad.p, 0, sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_wire.p, wire_in, stride * batch, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_eval_wire", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            break;
+        }
+        b->store_all = false;
+        if ((rc = relayout(b)) != GC_OK) break;
+        if ((rc = gc_batch_ingest_tables(b, d_wire.p, stride, d_bad.p)) != GC_OK) break;
+        e = hipMemcpyAsync(bad, d_bad.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_eval_wire", e);
+            rc = GC_E_HIP;
+            break;
+        }
+        if (*bad) {  // "wrong number of gates" (evaluator.go:44-47) / a row count Eval would reject (eval.go:54-56,86-89)
+            rc = GC_E_ROWS;
+            break;
+        }
+        if ((rc = write_scatter(b, inputs, p.info.ninputs, 0, p.info.ninputs, nullptr, 0, b->d_W, b->g.lw)) != GC_OK) break;
+        if ((rc = gc_batch_eval(b, key, keylen, b)) != GC_OK) break;
+        if (out_labels && (rc = gc_batch_read_outputs(b, out_labels)) != GC_OK) break;
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_eval_wire", e);
+            rc = GC_E_HIP;
+        }
+    } while (0);
+    pool_put(c, b);
+    return rc;
+} catch (...) {
+    return gc::on_exception();
+}
+
 }  // extern "C"

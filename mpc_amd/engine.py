@@ -147,6 +147,8 @@ def lib():
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
+        "gc_garble_wire": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, sz]),
+        "gc_eval_wire": (i32, [vp, vp, sz, u32, vp, vp, sz, vp, vp]),
         "gc_host_alloc": (vp, [sz]),
         "gc_host_free": (None, [vp]),
         "gc_host_register": (i32, [vp, sz]),
@@ -363,6 +365,28 @@ class DeviceCircuit:
         rc = lib().gc_eval(self.h, _p(k), len(k), batch, _p(wires), _p(inputs), _p(slab) if slab.size else None,
                            rows, _p(out))
         _check(rc, "gc_eval")
+        return out[:, : self.c.num_outputs]
+
+    def garble_wire(self, key, rnd, batch=1):
+        """gc_garble_wire: dict(R, io, wire[batch, tables_wire_bytes] as uint8)"""
+        k, r = _u8(key), _u8(rnd)
+        stride = (self.tables_wire_bytes + 3) & ~3
+        R = np.zeros(batch, LABEL)
+        io = np.zeros((batch, self.c.num_inputs + self.c.num_outputs), WIRE)
+        wire = np.zeros((batch, stride), np.uint8)
+        _check(lib().gc_garble_wire(self.h, _p(k), len(k), _p(r), len(r), batch, _p(R), _p(io), _p(wire), stride),
+               "gc_garble_wire")
+        return {"R": R, "io": io, "wire": wire}
+
+    def eval_wire(self, key, wire, inputs, batch=1):
+        """gc_eval_wire: output labels [batch, noutputs]; raises GC_E_ROWS on malformed headers"""
+        k = _u8(key)
+        w = np.ascontiguousarray(wire, dtype=np.uint8).reshape(batch, -1)
+        inp = np.ascontiguousarray(inputs, dtype=LABEL)
+        out = np.zeros((batch, max(self.c.num_outputs, 1)), LABEL)
+        bad = C.c_uint32(0)
+        _check(lib().gc_eval_wire(self.h, _p(k), len(k), batch, _p(inp), _p(w), w.shape[1], _p(out), C.byref(bad)),
+               "gc_eval_wire")
         return out[:, : self.c.num_outputs]
 
     def close(self):

@@ -160,3 +160,47 @@ def test_flat_schedule_simulates_to_plaintext(aes_circ, sha_circ, add64_circ):
             b = rng.integers(0, 2, c.num_inputs).astype(np.uint8)
             want = c.compute_bits(b)[c.NumWires - c.num_outputs:]
             assert (pl.simulate(b) == want).all(), repr(c)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gcengine.h is what cgo compiles: it must be valid, warning-free plain C (C99, pedantic), not just C++;
+    every declared function can be referenced from C and the Go-layout structs have the documented sizes"""
+    import subprocess
+    names = declared_functions()
+    src = tmp_path / "abi_check.c"
+    body = ['#include "gcengine.h"',
+            "typedef char label_is_16[(sizeof(gc_label) == 16) ? 1 : -1];",
+            "typedef char wire_is_32[(sizeof(gc_wire) == 32) ? 1 : -1];",
+            "typedef char gate_is_20[(sizeof(gc_gate) == 20) ? 1 : -1];",
+            "typedef void (*fn)(void);", "fn table[] = {"]
+    body += ["    (fn)%s," % n for n in names]
+    body += ["};", "int main(void) { return sizeof table == 0; }"]
+    src.write_text("\n".join(body) + "\n")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type",
+                        "-I", inc, "-c", str(src), "-o", str(tmp_path / "abi_check.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_go_shim_names_only_declared_entry_points_and_covers_the_table():
+    """go/ is source only (no Go toolchain here): at least every C.gc_* it calls must exist in the header with that
+    spelling, and every host-facing entry point of the header must be bound by some Go stub (the device-resident
+    batch API and developer aids are reached from Go only through the additive batch wrappers)"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set(declared_functions())
+    used = set()
+    for path in glob.glob(os.path.join(root, "go", "*", "*.go")):
+        text = open(path).read()
+        assert text.startswith("//go:build gchip"), path
+        assert "\n    " not in text.replace("\n    //", ""), "%s: indent with tabs (gofmt)" % path
+        used |= set(re.findall(r"\bC\.(gc_[a-z0-9_]+)\(", text))
+    assert used and used <= names, sorted(used - names)
+    must = {"gc_ctx_create", "gc_circ_load", "gc_garble", "gc_eval", "gc_garble_wire", "gc_eval_wire", "gc_stream_create",
+            "gc_stream_get_wire", "gc_stream_garble", "gc_stream_eval_create", "gc_stream_eval_set_wire",
+            "gc_stream_eval_get_wire", "gc_stream_eval_circuit", "gc_iknp_receiver_create", "gc_iknp_sender_create",
+            "gc_iknp_receive", "gc_iknp_send", "gc_iknp_receive_bits", "gc_iknp_send_bits", "gc_kos_receiver_tags",
+            "gc_kos_sender_check", "gc_mitccrh_hash", "gc_cot_send_pads", "gc_cot_receive_unpad", "gc_host_alloc",
+            "gc_comm_init_all", "gc_comm_init_rank", "gc_comm_get_unique_id", "gc_comm_allgather_all"}
+    assert must <= used, sorted(must - used)

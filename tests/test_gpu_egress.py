@@ -104,3 +104,38 @@ def test_dense_encoding_sha2pc(sha_circ):
     ctx.sync()
     assert (ev.read_slab() == slab).all()
     gb.close(); ev.close(); dc.close(); ctx.close()
+
+
+def test_host_wire_calls_match_oracle(aes_circ):
+    """gc_garble_wire / gc_eval_wire (host buffers): the bytes circuit.Garbler's send loop would put on the connection
+    (garbler.go:69-82) == the oracle's serialiser over the oracle's slab; ingest + eval of them == oracle Eval;
+    a corrupted header is refused (evaluator.go:44-47, eval.go:54-56)"""
+    ctx = engine.Context(0)
+    key = bytes(range(32))
+    for c, batch in ((synthetic_levelised(8, 50, 0.3, seed=43, ninputs=32, or_frac=0.1, inv_frac=0.1, xnor_frac=0.05), 21),
+                     (aes_circ, 3)):
+        dc = engine.DeviceCircuit(ctx, c)
+        nin, nout = c.num_inputs, c.num_outputs
+        srnd = 16 * (nin + 1)
+        rnd = drbg("hw%d" % batch, srnd * batch)
+        g = dc.garble_wire(key, rnd, batch=batch)
+        nbytes = dc.tables_wire_bytes
+        bits = (np.frombuffer(drbg("hwb", batch * nin), np.uint8) & 1).reshape(batch, -1).astype(bool)
+        inputs = np.where(bits, g["io"][:, :nin]["l1"], g["io"][:, :nin]["l0"])
+        out = dc.eval_wire(key, g["wire"], inputs, batch=batch)
+        for i in range(batch):
+            ref = oracle.garble(c.Gates, c.NumWires, nin, key, rnd[i * srnd:(i + 1) * srnd])
+            assert g["R"][i] == ref["R"]
+            assert g["wire"][i, :nbytes].tobytes() == oracle.tables_serialize(c.Gates, ref["slab"])
+            assert (g["io"][i][:nin] == ref["wires"][:nin]).all() and (g["io"][i][nin:] == ref["wires"][c.NumWires - nout:]).all()
+            w = np.zeros(c.NumWires, engine.LABEL)
+            w[:nin] = inputs[i]
+            oracle.eval_(c.Gates, c.NumWires, key, w, ref["slab"])
+            assert (out[i] == w[c.NumWires - nout:]).all()
+        bad = g["wire"].copy()
+        bad[batch - 1, 3] ^= 1  # gate count of the last instance
+        with pytest.raises(engine.EngineError) as e:
+            dc.eval_wire(key, bad, inputs, batch=batch)
+        assert e.value.code == engine.GC_E_ROWS
+        dc.close()
+    ctx.close()
