@@ -337,9 +337,12 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_iknp:
-            # second kernel pair of the path (ot/iknp.go): OT extension on the device-resident API, 4 Mi OTs
-            from scripts.bench_iknp import run as iknp_run
-            res["iknp"] = iknp_run(1 << 22, 5, ctx=ctx)
+            # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):
+            # device-resident API, 4 Mi OTs
+            from scripts.bench_ot import run as ot_run
+            ot = ot_run(1 << 22, 5, ctx=ctx)
+            res["iknp"] = ot.pop("iknp")
+            res["ot"] = ot
         if world == 1 and not args.no_host_api and args.circuit.endswith("aes_128.gcf"):
             # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
             from scripts.bench_host_api import run as host_api_run

@@ -374,6 +374,11 @@ float gc_iknp_last_ms(gc_iknp *);
 int gc_iknp_receive_bits(gc_iknp *, const uint64_t *choices, size_t n, uint8_t *u_out, uint64_t *result);
 int gc_iknp_send_bits(gc_iknp *, const uint8_t *u_in, size_t u_len, size_t n, uint64_t *result);
 
+/* the same two bodies with the choice words, the u-matrix and the result words in HBM (device pointers, asynchronous on
+ * the ctx stream; the labels stay in the handle's device workspace) */
+int gc_iknp_receive_bits_dev(gc_iknp *, const void *d_choices, size_t n, void *d_u_out, void *d_result);
+int gc_iknp_send_bits_dev(gc_iknp *, const void *d_u_in, size_t n, void *d_result);
+
 /* KOS consistency check of the malicious variant: the chi-PRG + GF(2^128) inner products of
  * (*IKNPReceiver).Receive (ot/iknp.go:405-465) and (*IKNPSender).Send (ot/iknp.go:138-194; gf128.go:14-27,
  * mul128_generic.go).  chi_i = label i of the AES-128-CTR stream keyed by seed2: 0..n-1 for `result`,

@@ -163,6 +163,9 @@ hipError_t launch_iknp_fused(bool recv, const uint32_t *rk0, const uint32_t *rk1
                              const uint8_t *bbuf, const uint8_t *u_in, uint4 delta, uint8_t *u_out, uint4 *labels,
                              const uint32_t *te0, hipStream_t s);
 void launch_pack_bits(const uint8_t *b, size_t n, uint8_t *out, hipStream_t s);
+// bit-COT helpers: choice words -> per-chunk choice bytes (whole 64-bit words only, iknp.go:583-597); bit 0 of every label
+void launch_fold_choice_words(const uint64_t *choices, size_t n, uint64_t *bbuf, hipStream_t s);
+void launch_pack_label_bit0(const uint4 *labels, size_t n, uint64_t *result, hipStream_t s);
 // KOS check accumulators: acc[0..3] ^= XOR chi_i * v_i (256 bit), acc[4..5] ^= XOR_{bits_i} chi_i
 void launch_kos_accumulate(const uint32_t *rk, uint64_t idx0, const uint4 *v, const uint8_t *bits, size_t n,
                            unsigned long long *acc, const uint32_t *te0, hipStream_t s);

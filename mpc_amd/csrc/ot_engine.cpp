@@ -265,6 +265,54 @@ int gc_iknp_send_dev(gc_iknp *k, const void *d_u_in, size_t n, void *d_labels_ou
     return GC_OK;
 }
 
+// bit-COT with everything in HBM (additive): choices / result are packed little-endian u64 DEVICE
+// vectors of (n + 63) / 64 words, d_u the u-matrix as in gc_iknp_*_dev.  The labels go through the handle's
+// workspace and never leave the device.
+int gc_iknp_receive_bits_dev(gc_iknp *k, const void *d_choices, size_t n, void *d_u_out, void *d_result) {
+    if (!k || !k->receiver || (n && (!d_choices || !d_u_out || !d_result))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = k->ctx;
+    if (ctx->capturing) return GC_E_ARG;
+    GC_HIP(hipSetDevice(ctx->device));
+    const size_t chunks = (n + 511) / 512;
+    int rc = iknp_ws(k, n * sizeof(uint4) + chunks * 64);
+    if (rc != GC_OK) return rc;
+    uint4 *lab = (uint4 *)k->d_ws;
+    uint64_t *bbuf = (uint64_t *)((uint8_t *)k->d_ws + n * sizeof(uint4));
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipEventRecord(k->ev0, s));
+    launch_fold_choice_words((const uint64_t *)d_choices, n, bbuf, s);
+    GC_HIP(launch_iknp_fused(true, k->d_rk0, k->d_rk1, k->pos, n, (const uint8_t *)bbuf, nullptr, k->delta,
+                             (uint8_t *)d_u_out, lab, ctx->d_te0, s));
+    launch_pack_label_bit0(lab, n, (uint64_t *)d_result, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipEventRecord(k->ev1, s));
+    k->timed = true;
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
+int gc_iknp_send_bits_dev(gc_iknp *k, const void *d_u_in, size_t n, void *d_result) {
+    if (!k || k->receiver || (n && (!d_u_in || !d_result))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    gc_ctx *ctx = k->ctx;
+    if (ctx->capturing) return GC_E_ARG;
+    GC_HIP(hipSetDevice(ctx->device));
+    int rc = iknp_ws(k, n * sizeof(uint4));
+    if (rc != GC_OK) return rc;
+    uint4 *lab = (uint4 *)k->d_ws;
+    hipStream_t s = ctx->stream;
+    GC_HIP(hipEventRecord(k->ev0, s));
+    GC_HIP(launch_iknp_fused(false, k->d_rk0, nullptr, k->pos, n, nullptr, (const uint8_t *)d_u_in, k->delta, nullptr, lab,
+                             ctx->d_te0, s));
+    launch_pack_label_bit0(lab, n, (uint64_t *)d_result, s);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipEventRecord(k->ev1, s));
+    k->timed = true;
+    k->pos += stream_advance(n);
+    return GC_OK;
+}
+
 float gc_iknp_last_ms(gc_iknp *k) {
     if (!k || !k->timed) return -1.0f;
     if (hipSetDevice(k->ctx->device) != hipSuccess) return -1.0f;

@@ -140,6 +140,8 @@ def lib():
         "gc_iknp_last_ms": (C.c_float, [vp]),
         "gc_iknp_receive_bits": (i32, [vp, vp, sz, vp, vp]),
         "gc_iknp_send_bits": (i32, [vp, vp, sz, sz, vp]),
+        "gc_iknp_receive_bits_dev": (i32, [vp, vp, sz, vp, vp]),
+        "gc_iknp_send_bits_dev": (i32, [vp, vp, sz, vp]),
         "gc_kos_receiver_tags": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "gc_kos_sender_check": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp, ip]),
         "gc_kos_receiver_tags_dev": (i32, [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
@@ -692,6 +694,9 @@ class IKNPReceiver:
     def last_ms(self):
         return float(lib().gc_iknp_last_ms(self.h))
 
+    def receive_bits_dev(self, d_choices, n, d_u_out, d_result):
+        _check(lib().gc_iknp_receive_bits_dev(self.h, d_choices, n, d_u_out, d_result), "gc_iknp_receive_bits_dev")
+
     def receive_bits(self, choices, n):
         ch = np.ascontiguousarray(choices, dtype=np.uint64)
         u = np.zeros(max(lib().gc_iknp_u_bytes(n), 1), np.uint8)
@@ -730,6 +735,9 @@ class IKNPSender:
     @property
     def last_ms(self):
         return float(lib().gc_iknp_last_ms(self.h))
+
+    def send_bits_dev(self, d_u_in, n, d_result):
+        _check(lib().gc_iknp_send_bits_dev(self.h, d_u_in, n, d_result), "gc_iknp_send_bits_dev")
 
     def send_bits(self, u, n):
         ub = np.frombuffer(bytes(u), np.uint8) if len(u) else np.zeros(1, np.uint8)

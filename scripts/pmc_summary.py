@@ -17,7 +17,7 @@ for tag, counter in (("pmc_r", "FETCH_SIZE"), ("pmc_w", "WRITE_SIZE")):
     for f in files:
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") == counter:
-                k = row["Kernel_Name"].split("(")[0][:80]
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:80]
                 tot[k] += float(row["Counter_Value"])
                 cnt[k] += 1
     print("== %s (KiB, summed over dispatches) ==" % counter)

@@ -244,3 +244,46 @@ def test_iknp_refuses_graph_capture(ctx):
     wu, wgot = oracle.IKNPReceiver(base).receive(np.zeros(3, np.uint8))
     assert bytes(u) == bytes(wu) and (got == wgot).all()
     rcv.close()
+
+
+@pytest.mark.parametrize("n", [64, 1024, 1000, 70, 513, 4096 + 37])
+def test_bitcot_device_resident_matches_host(ctx, n):
+    """gc_iknp_*_bits_dev: choice words, u-matrix and result words stay in HBM; same bytes as the host calls (and so as
+    the oracle's ReceiveBits / SendBits, incl. the whole-word-only choice fold), stream position persisting"""
+    import torch
+    base, delta, k0 = base_setup("bitdev%d" % n)
+    rx_h, tx_h = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    rx_d, tx_d = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
+    words = (n + 63) // 64
+    for rep in range(2):
+        choices = np.frombuffer(drbg("bcd%d/%d" % (n, rep), 8 * words), "<u8").copy()
+        u, r = rx_h.receive_bits(choices, n)
+        s = tx_h.send_bits(u, n)
+        d_c = torch.from_numpy(choices.view(np.uint8).copy()).cuda()
+        d_u = torch.zeros(((n + 511) // 512) * 8192, dtype=torch.uint8, device="cuda")
+        d_r = torch.zeros(words * 8, dtype=torch.uint8, device="cuda")
+        d_s = torch.zeros(words * 8, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rx_d.receive_bits_dev(d_c.data_ptr(), n, d_u.data_ptr(), d_r.data_ptr())
+        tx_d.send_bits_dev(d_u.data_ptr(), n, d_s.data_ptr())
+        ctx.sync()
+        assert d_u.cpu().numpy()[:len(u)].tobytes() == u
+        assert (d_r.cpu().numpy().view("<u8") == r).all()
+        assert (d_s.cpu().numpy().view("<u8") == s).all()
+    for h in (rx_h, tx_h, rx_d, tx_d):
+        h.close()
+
+
+def test_cot_tuned_and_classic_kernels_agree(ctx, monkeypatch):
+    """the dual-table persistent COT kernels (default) and the first, 4 KiB-table form (GC_COT_CLASSIC) are both the
+    MITCCRH of ot/mitccrh.go: the reference's own vectors on each, ragged sizes"""
+    import subprocess, sys, os
+    code = ("import numpy as np, oracle; from mpc_amd import engine; from tests.test_gpu_ot import labels; from tests.util import drbg;"
+            "ctx = engine.Context(0); seed = oracle.label_from_bytes(drbg('cls', 16)); x = labels('clsx', 3001);"
+            "out = engine.mitccrh_hash(ctx, seed, 5, x, 1); m = oracle.MITCCRH(seed, 1);"
+            "import hashlib; print(hashlib.sha256(out.tobytes()).hexdigest())")
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    a = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    b = subprocess.run([sys.executable, "-c", code], env=dict(env, GC_COT_CLASSIC="1"), capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1]
