@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
     ap.add_argument("--check", action="store_true", help="verify decoded outputs against plaintext evaluation")
+    ap.add_argument("--sweep", action="store_true", help="synthetic levelised circuits (SURVEY §8d): W x AND-fraction grid + "
+                    "AND chain, AND/s and roofline fractions per circuit, one JSON line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +135,26 @@ def main():
     circ.name = os.path.splitext(os.path.basename(args.circuit))[0]
     key = bytes(range(args.key_bytes))
     ctx = engine.Context(local_rank)
+    if args.sweep:  # every rank sweeps its own GPU (independent instances); rank 0 reports the job
+        from scripts.sweep_synthetic import run as sweep_run
+        t0 = time.perf_counter()
+        rows = sweep_run(args.batch, 131072, key, ctx=ctx)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            for r in rows:
+                for k in ("and_gates_per_s", "nonfree_gates_per_s", "gates_per_s", "hbm_alg_GBs"):
+                    r[k + "_job"] = r[k] * world  # weak scaling: the same sweep on every GPU
+            print(json.dumps({"metric": "AND-gates/sec (garble+eval), synthetic levelised circuits", "unit": "AND-gates/s",
+                              "n_gpus": world, "scaling": "weak", "data": "synthetic", "dtype": "u32 (AES T-table / label XOR)",
+                              "config": {"workload": "SURVEY §8d grid W in {64,1024,16384} x f in {0,0.17,0.5,1} + AND chain, "
+                                         "131072 gates, batch=%d per GPU, %d-byte key" % (args.batch, args.key_bytes)},
+                              "sweep_wall_s": dt, "sweep": rows}), flush=True)
+        ctx.close()
+        return
     dc = engine.DeviceCircuit(ctx, circ)
     info = dc.info
     batch = args.batch

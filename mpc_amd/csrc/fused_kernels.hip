@@ -22,6 +22,7 @@
 namespace gc {
 
 constexpr int kFusedThreads = 1024;
+constexpr int kGroup = 4;  // passes of a level whose loads are issued together (see k_garble_fused)
 
 // quad_perm DPP controls
 constexpr int DPP_XOR1 = 0xB1;   // [1,0,3,2]
@@ -100,6 +101,182 @@ enum LaneKind { K_NONE = 0, K_AND = 1, K_OR = 2, K_INV = 3, K_FREE = 4 };
         plast = now__;                                                 \
     }
 
+template <int NR, bool PROF, int G>
+__device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
+                                             const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
+                                             const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
+                                             uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
+                                             uint4 *Tt, const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)],
+                                             const uint32_t *te, uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast) {
+    LanePos lp[G];
+    GateDesc d[G];
+    uint4 va[G], vb[G];
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        if (t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
+            lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
+            d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
+        } else {
+            lp[p] = classify<2, 2, 1>(st, t0 + p * kFusedThreads + threadIdx.x, ti_log2, tim);
+            d[p] = lp[p].kind ? descs[st.first + lp[p].g] : GateDesc{0, 0, 0, 0};
+        }
+    }
+    GC_PROF_MARK(0)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        va[p] = vb[p] = make_uint4(0, 0, 0, 0);
+        if (lp[p].kind == K_NONE) continue;
+        // AND lanes 2,3 hash operand b; OR and XOR lanes need both operands
+        const bool second = lp[p].kind == K_AND && (lp[p].q & 2);
+        va[p] = Wt[((size_t)(second ? d[p].in1 : d[p].in0) << ti_log2) + lp[p].inst];
+        if (lp[p].kind == K_FREE || lp[p].kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + lp[p].inst];
+    }
+    GC_PROF_MARK(1)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        const int kind = lp[p].kind;
+        const uint32_t g = lp[p].g, inst = lp[p].inst, q = lp[p].q;
+        if (kind == K_NONE) continue;
+        const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
+        if (kind == K_FREE) {
+            uint4 v = lxor(va[p], vb[p]);
+            if ((d[p].row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
+            Wt[o_out] = v;
+            continue;
+        }
+        // ---- hash lanes ----
+        const uint4 R = Rt[inst];
+        uint4 base;  // the L0 label this lane hashes (before the optional ^R)
+        uint32_t k[4];
+        if (kind == K_OR) {  // e[2u+v] = enc(a_u, b_v, 0, id): K = 2a ^ 4b ^ id  (garble.go:74-83)
+            const uint4 a = lxor(va[p], land(R, (q & 2) ? ~0u : 0u));
+            const uint4 b = lxor(vb[p], land(R, (q & 1) ? ~0u : 0u));
+            base = make_uint4(a.y, b.y, 0, 0);  // only the S bits are needed afterwards
+            make_k(a, b, d[p].tweak, k);
+        } else {  // AND: q = 0..3 -> a0,a1,b0,b1 ; INV: q = 0,1 -> a0,a1.  K = 2x ^ tweak
+            const bool second = (kind == K_AND) && (q & 2);
+            base = va[p];
+            const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
+            make_k_half(x, d[p].tweak + (second ? 1u : 0u), k);
+        }
+        const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+        uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
+
+        if (kind == K_AND) {  // garble.go:353-395
+            const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));   // lanes 0,1: Ha0^Ha1   lanes 2,3: Hb0^Hb1
+            const uint4 a0 = dpp128<DPP_BC0>(base);
+            const uint32_t pa = smask(a0);
+            const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
+            uint4 v;  // lane 0: WG0, lane 2: WE0
+            uint4 tab;
+            if (q & 2) {
+                tab = lxor(pp, a0);                                    // TE = Hb0^Hb1^a0
+                v = lxor(h, land(lxor(tab, a0), pb));                  // WE0 = Hb0 ^ (pb ? TE^a0 : 0)
+            } else {
+                tab = lxor(pp, land(R, pb));                           // TG = Ha0^Ha1^(pb?R:0)
+                v = lxor(h, land(tab, pa));                            // WG0 = Ha0 ^ (pa ? TG : 0)
+            }
+            const uint4 other = dpp128<DPP_XOR2>(v);
+            if (q == 0) {
+                Wt[o_out] = lxor(v, other);
+                row[0] = tab;
+            } else if (q == 2) {
+                row[TI] = tab;
+            }
+        } else if (kind == K_INV) {  // garble.go:446-474 (see gc_kernels.hip for the algebra)
+            const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));  // E0 ^ E1
+            if (q == 0) {
+                const bool sbit = lbit_s(base);
+                Wt[o_out] = sbit ? lxor(pp, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
+                row[0] = lxor(pp, R);
+            }
+        } else {  // K_OR: garble.go:412-444
+            // lane q holds e[q]; pa = S(a_u)^u, pb = S(b_v)^v recover the permute bits of (a0,b0)
+            const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
+            const uint32_t l0 = 2 * pa + pb;
+            // table[k] = e[k ^ l0]: lane k fetches lane k^l0
+            const uint4 x1 = dpp128<DPP_XOR1>(h), x2 = dpp128<DPP_XOR2>(h), x3 = dpp128<DPP_XOR3>(h);
+            const uint4 tk = l0 == 0 ? h : l0 == 1 ? x1 : l0 == 2 ? x2 : x3;
+            const uint4 tz = dpp128<DPP_BC0>(tk);
+            const uint32_t m0 = l0 == 0 ? ~0u : 0u;
+            const uint4 c0 = lxor(tz, land(R, ~m0)), c1 = lxor(tz, land(R, m0));
+            if (q == 0) Wt[o_out] = c0;
+            else row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
+        }
+    }
+    GC_PROF_MARK(2)
+}
+
+template <int NR, bool PROF, int G>
+__device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
+                                           const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
+                                           const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
+                                           uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
+                                           const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
+                                           uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast) {
+    LanePos lp[G];
+    GateDesc d[G];
+    uint4 va[G], vb[G], tab[G];
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        if (t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
+            lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
+            d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
+        } else {
+            lp[p] = classify<1, 0, 0>(st, t0 + p * kFusedThreads + threadIdx.x, ti_log2, tim);
+            d[p] = lp[p].kind ? descs[st.first + lp[p].g] : GateDesc{0, 0, 0, 0};
+        }
+    }
+    GC_PROF_MARK(0)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        va[p] = vb[p] = tab[p] = make_uint4(0, 0, 0, 0);
+        const int kind = lp[p].kind;
+        if (kind == K_NONE) continue;
+        const uint32_t inst = lp[p].inst, q = lp[p].q;
+        // AND lane 1 hashes operand b; OR and XOR lanes need both operands
+        va[p] = Wt[((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << ti_log2) + inst];
+        if (kind == K_FREE || kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + inst];
+        const uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
+        if (kind == K_AND) tab[p] = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
+        else if (kind == K_INV) tab[p] = row[0];
+    }
+    GC_PROF_MARK(1)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+        const int kind = lp[p].kind;
+        const uint32_t g = lp[p].g, inst = lp[p].inst, q = lp[p].q;
+        if (kind == K_NONE) continue;
+        const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
+        if (kind == K_FREE) {  // eval.go:49-51
+            Wt[o_out] = lxor(va[p], vb[p]);
+            continue;
+        }
+        uint32_t k[4];
+        const uint4 x = va[p];  // label hashed by this lane
+        if (kind == K_AND) make_k_half(x, d[p].tweak + q, k);
+        else if (kind == K_INV) make_k_half(x, d[p].tweak, k);
+        else make_k(va[p], vb[p], d[p].tweak, k);
+        const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+        if (kind == K_AND) {  // eval.go:53-78
+            const uint4 a = dpp128<DPP_PAIR0>(x);
+            uint4 v;
+            if (q) v = lxor(h, land(lxor(tab[p], a), smask(x)));  // WE = H(b) ^ (sb ? TE^a : 0)
+            else v = lxor(h, land(tab[p], smask(x)));             // WG = H(a) ^ (sa ? TG : 0)
+            const uint4 other = dpp128<DPP_XOR1>(v);
+            if (q == 0) Wt[o_out] = lxor(v, other);
+        } else if (kind == K_INV) {  // eval.go:96-109
+            Wt[o_out] = lxor(h, land(tab[p], smask(x)));
+        } else {  // eval.go:80-94: the row index depends on the labels themselves
+            const uint32_t index = (lbit_s(va[p]) ? 2u : 0u) | (lbit_s(vb[p]) ? 1u : 0u);
+            uint4 c = make_uint4(0, 0, 0, 0);
+            if (index > 0) c = (Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst)[(size_t)(index - 1) << ti_log2];
+            Wt[o_out] = lxor(h, c);
+        }
+    }
+    GC_PROF_MARK(2)
+}
+
 template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *__restrict__ descs,
                                                                 const Step *__restrict__ steps, uint32_t nsteps,
@@ -122,97 +299,31 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
-    // software pipeline: the descriptor of this thread's first lane of the NEXT level is fetched
-    // before the barrier of the current one (it does not depend on anything the level computes)
+    // Passes of a level (1024 lanes each) run in GROUPS of kGroup: first the descriptors of all passes of the group, then
+    // all their operand labels, then hash / combine / stores pass by pass.  On gfx9 loads and stores share vmcnt and
+    // complete out of order with each other, so the first load after a store waits for EVERY store before it
+    // (vmcnt(0)): with one pass at a time that drain (1-2 us) was paid per pass — 60-80 % of the kernel on wide levels
+    // (scripts/prof_fused_synth.py).  Now it is paid once per group, overlapped with the next group's loads.
+    // the next level's step record and the descriptors of its first group are fetched before the barrier of the current
+    // level (they do not depend on anything the level computes): narrow, deep circuits pay one load latency per level
+    // instead of three
     Step st_next = steps[0];
     LanePos lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t e_all = level_lanes<2, 2, 1>(st, ti_log2);
-        for (uint32_t t0 = 0; t0 < e_all; t0 += kFusedThreads) {
-            const LanePos lp = t0 == 0 ? lp_next : classify<2, 2, 1>(st, t0 + threadIdx.x, ti_log2, tim);
-            const int kind = lp.kind;
-            const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
-            if (kind == K_NONE) continue;
-            const GateDesc d = t0 == 0 ? d_next : descs[st.first + g];
-            GC_PROF_MARK(0)
-            const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
-            const uint4 va = Wt[((size_t)d.in0 << ti_log2) + inst];
-            if (kind == K_FREE) {
-                uint4 v = lxor(va, Wt[((size_t)d.in1 << ti_log2) + inst]);
-                if ((d.row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
-                Wt[o_out] = v;
-                continue;
-            }
-            // ---- hash lanes ----
-            const uint4 R = Rt[inst];
-            uint4 base;         // the L0 label this lane hashes (before the optional ^R)
-            uint32_t k[4];
-            if (kind == K_OR) {  // e[2u+v] = enc(a_u, b_v, 0, id): K = 2a ^ 4b ^ id  (garble.go:74-83)
-                const uint4 vb = Wt[((size_t)d.in1 << ti_log2) + inst];
-                const uint4 a = lxor(va, land(R, (q & 2) ? ~0u : 0u));
-                const uint4 b = lxor(vb, land(R, (q & 1) ? ~0u : 0u));
-                base = make_uint4(a.y, b.y, 0, 0);  // only the S bits are needed afterwards
-                make_k(a, b, d.tweak, k);
-            } else {  // AND: q = 0..3 -> a0,a1,b0,b1 ; INV: q = 0,1 -> a0,a1.  K = 2x ^ tweak
-                const bool second = (kind == K_AND) && (q & 2);
-                base = second ? Wt[((size_t)d.in1 << ti_log2) + inst] : va;
-                const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
-                make_k_half(x, d.tweak + (second ? 1u : 0u), k);
-            }
-            GC_PROF_MARK(1)
-            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
-            uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
-
-            if (kind == K_AND) {  // garble.go:353-395
-                const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));   // lanes 0,1: Ha0^Ha1   lanes 2,3: Hb0^Hb1
-                const uint4 a0 = dpp128<DPP_BC0>(base);
-                const uint32_t pa = smask(a0);
-                const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
-                uint4 v;  // lane 0: WG0, lane 2: WE0
-                uint4 tab;
-                if (q & 2) {
-                    tab = lxor(p, a0);                                     // TE = Hb0^Hb1^a0
-                    v = lxor(h, land(lxor(tab, a0), pb));                  // WE0 = Hb0 ^ (pb ? TE^a0 : 0)
-                } else {
-                    tab = lxor(p, land(R, pb));                            // TG = Ha0^Ha1^(pb?R:0)
-                    v = lxor(h, land(tab, pa));                            // WG0 = Ha0 ^ (pa ? TG : 0)
-                }
-                const uint4 other = dpp128<DPP_XOR2>(v);
-                if (q == 0) {
-                    Wt[o_out] = lxor(v, other);
-                    row[0] = tab;
-                } else if (q == 2) {
-                    row[TI] = tab;
-                }
-            } else if (kind == K_INV) {  // garble.go:446-474 (see gc_kernels.hip for the algebra)
-                const uint4 p = lxor(h, dpp128<DPP_XOR1>(h));  // E0 ^ E1
-                if (q == 0) {
-                    const bool s = lbit_s(base);
-                    Wt[o_out] = s ? lxor(p, h) : lxor(h, R);  // S(a0) ? E1 : E0^R
-                    row[0] = lxor(p, R);
-                }
-            } else {  // K_OR: garble.go:412-444
-                // lane q holds e[q]; pa = S(a_u)^u, pb = S(b_v)^v recover the permute bits of (a0,b0)
-                const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
-                const uint32_t l0 = 2 * pa + pb;
-                // table[k] = e[k ^ l0]: lane k fetches lane k^l0
-                const uint4 x1 = dpp128<DPP_XOR1>(h), x2 = dpp128<DPP_XOR2>(h), x3 = dpp128<DPP_XOR3>(h);
-                const uint4 tk = l0 == 0 ? h : l0 == 1 ? x1 : l0 == 2 ? x2 : x3;
-                const uint4 t0 = dpp128<DPP_BC0>(tk);
-                const uint32_t m0 = l0 == 0 ? ~0u : 0u;
-                const uint4 c0 = lxor(t0, land(R, ~m0)), c1 = lxor(t0, land(R, m0));
-                if (q == 0) Wt[o_out] = c0;
-                else row[(size_t)(q - 1) << ti_log2] = lxor(tk, q == l0 ? c0 : c1);
-            }
-        }
-        if (lv + 1 < nsteps) {  // prefetch the next level's step + this thread's first descriptor
+        // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
+        // zero-fill of empty passes on its critical path
+        if (e_all <= (uint32_t)kFusedThreads) garble_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
+        else
+            for (uint32_t t0 = 0; t0 < e_all; t0 += kGroup * kFusedThreads)
+                garble_group<NR, PROF, kGroup>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
+        if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
         }
-        GC_PROF_MARK(2)
         __syncthreads();
         GC_PROF_MARK(3)
     }
@@ -243,63 +354,27 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
+    // groups of kGroup passes: descriptors, then operand labels and table rows, then hashes and stores (see the garbler)
+    // the next level's step record and the descriptors of its first group are fetched before the barrier of the current
+    // level (they do not depend on anything the level computes): narrow, deep circuits pay one load latency per level
+    // instead of three
     Step st_next = steps[0];
     LanePos lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t e_all = level_lanes<1, 0, 0>(st, ti_log2);
-        for (uint32_t t0 = 0; t0 < e_all; t0 += kFusedThreads) {
-            const LanePos lp = t0 == 0 ? lp_next : classify<1, 0, 0>(st, t0 + threadIdx.x, ti_log2, tim);
-            const int kind = lp.kind;
-            const uint32_t g = lp.g, inst = lp.inst, q = lp.q;
-            if (kind == K_NONE) continue;
-            const GateDesc d = t0 == 0 ? d_next : descs[st.first + g];
-            GC_PROF_MARK(0)
-            const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
-            const uint4 va = Wt[((size_t)d.in0 << ti_log2) + inst];
-            if (kind == K_FREE) {  // eval.go:49-51
-                Wt[o_out] = lxor(va, Wt[((size_t)d.in1 << ti_log2) + inst]);
-                continue;
-            }
-            const uint4 *row = Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst;
-            uint32_t k[4];
-            uint4 x = va;  // label hashed by this lane
-            uint4 vb = make_uint4(0, 0, 0, 0);
-            if (kind == K_AND) {
-                if (q) x = Wt[((size_t)d.in1 << ti_log2) + inst];
-                make_k_half(x, d.tweak + q, k);
-            } else if (kind == K_INV) {
-                make_k_half(x, d.tweak, k);
-            } else {
-                vb = Wt[((size_t)d.in1 << ti_log2) + inst];
-                make_k(va, vb, d.tweak, k);
-            }
-            GC_PROF_MARK(1)
-            const uint4 h = hash_dual<NR>(k, rkr, te, lo);
-            if (kind == K_AND) {  // eval.go:53-78
-                const uint4 tab = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
-                const uint4 a = dpp128<DPP_PAIR0>(x);
-                uint4 v;
-                if (q) v = lxor(h, land(lxor(tab, a), smask(x)));  // WE = H(b) ^ (sb ? TE^a : 0)
-                else v = lxor(h, land(tab, smask(x)));             // WG = H(a) ^ (sa ? TG : 0)
-                const uint4 other = dpp128<DPP_XOR1>(v);
-                if (q == 0) Wt[o_out] = lxor(v, other);
-            } else if (kind == K_INV) {  // eval.go:96-109
-                Wt[o_out] = lxor(h, land(row[0], smask(x)));
-            } else {  // eval.go:80-94
-                const uint32_t index = (lbit_s(va) ? 2u : 0u) | (lbit_s(vb) ? 1u : 0u);
-                uint4 c = make_uint4(0, 0, 0, 0);
-                if (index > 0) c = row[(size_t)(index - 1) << ti_log2];
-                Wt[o_out] = lxor(h, c);
-            }
-        }
-        if (lv + 1 < nsteps) {  // prefetch the next level's step + this thread's first descriptor
+        // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
+        // zero-fill of empty passes on its critical path
+        if (e_all <= (uint32_t)kFusedThreads) eval_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
+        else
+            for (uint32_t t0 = 0; t0 < e_all; t0 += kGroup * kFusedThreads)
+                eval_group<NR, PROF, kGroup>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
+        if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
         }
-        GC_PROF_MARK(2)
         __syncthreads();
         GC_PROF_MARK(3)
     }

@@ -14,7 +14,7 @@ from .circuit import GATE, LABEL, WIRE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgcengine.so")
+LIB_PATH = os.environ.get("GC_LIB") or os.path.join(CSRC, "libgcengine.so")  # GC_LIB: developer builds
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gcengine.h")
 
 GC_OK, GC_E_KEYSIZE, GC_E_RAND, GC_E_GATE, GC_E_ROWS, GC_E_ARG, GC_E_HIP, GC_E_NOMEM, GC_E_WIRE = (

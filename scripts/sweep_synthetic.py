@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """SURVEY.md §8d synthetic levelised circuits: generator(levels, width, AND fraction, seed), gate at level l
 picks its inputs from levels < l; W in {64, 1024, 16384}, f in {0, 0.17, 0.5, 1}; plus buildANDChain(n)
-(circuit/garble_bench_test.go:19) as the worst case (depth n, width 1).  One JSON object per line:
-AND-gates/s and gates/s (garble+eval, device-resident), which kernels ran, and an output check against
-plaintext evaluation."""
+(circuit/garble_bench_test.go:19) as the worst case (depth n, width 1).  One JSON object per circuit:
+AND-gates/s and gates/s (garble+eval, device-resident), the same as fractions of the HBM roofline (algorithmic bytes
+of SURVEY §8d, and the read-only variant the north star names) and of the LDS array's look-up rate (what really bounds
+the hash), which kernels ran, and an output check against plaintext evaluation.  `python bench.py --sweep` prints the
+rows as one JSON line."""
 import json
 import os
 import sys
@@ -15,48 +17,76 @@ import torch
 from mpc_amd import engine
 from mpc_amd.circuit import and_chain, synthetic_levelised
 
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-gates_target = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
-key = bytes(range(32))
-ctx = engine.Context(0)
-cases = [(w, f) for w in (64, 1024, 16384) for f in (0.0, 0.17, 0.5, 1.0)]
-circs = [synthetic_levelised(max(2, gates_target // w), w, f, seed=100 + i, ninputs=256) for i, (w, f) in enumerate(cases)]
-circs.append(and_chain(4096))
-for c in circs:
-    dc = engine.DeviceCircuit(ctx, c)
-    info = dc.info
-    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(5)
-    d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
-    d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
-    d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    g_ms, e_ms = [], []
-    for it in range(4):
-        gb.garble(key, d_rnd.data_ptr())
-        ev.select_inputs(gb, d_bits.data_ptr())
-        ev.eval(key, gb)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
-        ctx.sync()
-        if it:
-            g_ms.append(gb.last_ms)
-            e_ms.append(ev.last_ms)
-    ok = int(d_mis.cpu()[0]) == 0
-    bits, out = d_bits.cpu().numpy(), d_out.cpu().numpy()
-    for i in (0, batch // 2, batch - 1):
-        plain = c.compute_bits(bits[i])  # plaintext evaluation (circuit/computer.go)
-        ok = ok and bool((plain[c.NumWires - c.num_outputs:] == out[i]).all())
-    g, e = float(np.mean(g_ms)), float(np.mean(e_ms))
-    nonfree = info.n_and + info.n_or + info.n_inv
-    print(json.dumps({
-        "circuit": c.name, "gates": int(info.ngates), "and": int(info.n_and), "levels": int(info.nlevels),
-        "hash_phases": int(info.n_hash_phases), "batch": batch, "tile_instances": gb.tile_instances,
-        "wires_in_lds": bool(gb.lds_wires), "live_labels": int(info.n_flat_slots) if info.n_flat_slots != 0xffffffff else None,
-        "garble_ms": round(g, 4), "eval_ms": round(e, 4),
-        "and_gates_per_s": info.n_and * batch / ((g + e) * 1e-3),
-        "nonfree_gates_per_s": nonfree * batch / ((g + e) * 1e-3),
-        "gates_per_s": info.ngates * batch / ((g + e) * 1e-3),
-        "outputs_ok": ok}), flush=True)
-    gb.close(); ev.close(); dc.close()
+ALG = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}                      # bytes per gate per side
+READ = {"xor": (32, 32), "xnor": (32, 32), "and": (32, 64), "inv": (16, 32), "or": (32, 80)}  # (garble, eval)
+BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}
+HBM_PEAK, LDS_LOOKUPS = 8000e9, 75e12 / 4
+
+
+def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4096):
+    own = ctx is None
+    if own:
+        ctx = engine.Context(0)
+    rounds = {16: 10, 24: 12, 32: 14}[len(key)]
+    cases = [(w, f) for w in (64, 1024, 16384) for f in (0.0, 0.17, 0.5, 1.0)]
+    circs = [synthetic_levelised(max(2, gates_target // w), w, f, seed=100 + i, ninputs=256) for i, (w, f) in enumerate(cases)]
+    circs.append(and_chain(chain))
+    rows = []
+    for c in circs:
+        dc = engine.DeviceCircuit(ctx, c)
+        info = dc.info
+        gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(5)
+        d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
+        d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
+        d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
+        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g_ms, e_ms = [], []
+        for it in range(4):
+            gb.garble(key, d_rnd.data_ptr())
+            ev.select_inputs(gb, d_bits.data_ptr())
+            ev.eval(key, gb)
+            gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+            ctx.sync()
+            if it:
+                g_ms.append(gb.last_ms)
+                e_ms.append(ev.last_ms)
+        ok = int(d_mis.cpu()[0]) == 0
+        bits, out = d_bits.cpu().numpy(), d_out.cpu().numpy()
+        for i in (0, batch // 2, batch - 1):
+            plain = c.compute_bits(bits[i])  # plaintext evaluation (circuit/computer.go)
+            ok = ok and bool((plain[c.NumWires - c.num_outputs:] == out[i]).all())
+        g, e = float(np.mean(g_ms)), float(np.mean(e_ms))
+        t = (g + e) * 1e-3
+        cnt = {k: int(getattr(info, "n_" + k)) for k in ALG}
+        nonfree = cnt["and"] + cnt["or"] + cnt["inv"]
+        alg = sum(cnt[k] * ALG[k] for k in ALG)                      # per instance per side
+        rd = sum(cnt[k] * (READ[k][0] + READ[k][1]) for k in ALG)    # per instance, both sides
+        lookups = sum(cnt[k] * (BLOCKS[k][0] + BLOCKS[k][1]) for k in BLOCKS) * 16 * rounds
+        rows.append({
+            "circuit": c.name, "gates": int(info.ngates), "and": cnt["and"], "levels": int(info.nlevels),
+            "hash_phases": int(info.n_hash_phases), "batch": batch, "tile_instances": gb.tile_instances,
+            "wires_in_lds": bool(gb.lds_wires),
+            "live_labels": int(info.n_flat_slots) if info.n_flat_slots != 0xffffffff else None,
+            "garble_ms": round(g, 4), "eval_ms": round(e, 4),
+            "and_gates_per_s": cnt["and"] * batch / t,
+            "nonfree_gates_per_s": nonfree * batch / t,
+            "gates_per_s": info.ngates * batch / t,
+            # fractions of the two rooflines: HBM at 8 TB/s over the layout-independent byte model (all bytes / reads
+            # only), and the LDS array's ds_read_b32 rate over the T-table look-ups of the hashes
+            "hbm_alg_GBs": 2 * alg * batch / t / 1e9,
+            "hbm_roofline_frac": 2 * alg * batch / t / HBM_PEAK,
+            "hbm_read_roofline_frac": rd * batch / t / HBM_PEAK,
+            "lds_array_frac": lookups * batch / t / LDS_LOOKUPS,
+            "outputs_ok": ok})
+        gb.close(); ev.close(); dc.close()
+    if own:
+        ctx.close()
+    return rows
+
+
+if __name__ == "__main__":
+    for r in run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 131072):
+        print(json.dumps(r), flush=True)

@@ -442,3 +442,29 @@ def test_host_api_pinned_buffers_pipeline(ctx, aes_circ):
     dc.close()
     for x in keep:
         x.close()
+
+
+@pytest.mark.parametrize("batch", [3, 70, 1030])
+def test_global_wire_kernels_on_a_circuit_that_exceeds_lds(ctx, batch):
+    """a circuit whose live labels do not fit the LDS plans runs the fused kernels with wires in HBM (passes of a level
+    grouped: descriptors, operands, hashes); every gate type, levels of several passes, all wires compared"""
+    c = synthetic_levelised(14, 2500, 0.3, seed=77, ninputs=64, or_frac=0.05, inv_frac=0.08, xnor_frac=0.1)
+    dc = engine.DeviceCircuit(ctx, c)
+    b = engine.Batch(dc, batch)
+    assert not b.lds_wires, "expected the HBM-wire kernels (live labels %d)" % dc.info.n_flat_slots
+    b.close(); dc.close()
+    sample = None if batch < 10 else sorted(set(list(range(0, batch, 97)) + [batch - 1, batch - 2]))
+    check_garble_eval(ctx, c, KEY256, batch, "glob%d" % batch, check_all_wires=(batch <= 70), schedule=1, sample=sample)
+
+
+@pytest.mark.parametrize("batch", [2, 520])
+def test_global_wire_kernels_narrow_deep_circuit(ctx, batch):
+    """the same kernels on levels of a single pass (their single-pass instantiation with the descriptor prefetched
+    across the level barrier): 900 levels x 64 gates, live labels beyond the LDS plans"""
+    c = synthetic_levelised(900, 64, 0.3, seed=78, ninputs=64, or_frac=0.05, inv_frac=0.08, xnor_frac=0.1)
+    dc = engine.DeviceCircuit(ctx, c)
+    b = engine.Batch(dc, batch)
+    assert not b.lds_wires, "expected the HBM-wire kernels (live labels %d)" % dc.info.n_flat_slots
+    b.close(); dc.close()
+    sample = None if batch < 10 else [0, 1, 255, 256, 519]
+    check_garble_eval(ctx, c, KEY128, batch, "globn%d" % batch, check_all_wires=(batch < 10), schedule=1, sample=sample)
