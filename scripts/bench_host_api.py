@@ -20,6 +20,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+try:  # torch bundles its own ROCm runtime: load it before libgcengine.so pulls in the system one (tests/conftest.py)
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
 from mpc_amd import engine, parse_file
 from mpc_amd.circuit import LABEL, WIRE
 
