@@ -121,13 +121,13 @@ def main():
             sys.exit(2)
         args.gpus = world
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes); before the runtime starts
     import numpy as np
     import torch
 
     from mpc_amd import dist as gdist, engine, parse_file
 
     torch.cuda.set_device(local_rank)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
         gdist.init_control()  # gloo: rendezvous + the communicator id, no GPU collective goes through torch
 

@@ -582,6 +582,46 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
         a.te0 = b->circ->ctx->d_te0;
         a.rounds = b->rounds;
         a.prof = b->d_prof;
+        // ONE instance of a wide circuit (a streamed SSA-step circuit): a single workgroup on one CU would walk it alone.
+        // When the levels average >= 2.5 passes of 1024 lanes, spread every level's passes over workgroups, one launch
+        // per level, recorded once in a hipGraph per (pass, key size, table pointer) and replayed.
+        if (b->g.batch == 1 && !b->d_prof && a.nsteps >= 2) {
+            uint64_t passes = 0;
+            for (const Step &st : p.levels) passes += level1_passes(st, eval);
+            if (passes * 2 >= (uint64_t)a.nsteps * 5) {
+                b->last_launches = a.nsteps;
+                const int kGraphKey = 3;  // distinct from the schedule-0 graphs of this batch
+                if (!b->use_graph || b->circ->ctx->capturing) {
+                    launch_levels1(eval, a, p.levels.data(), s);
+                    GC_HIP(hipGetLastError());
+                    return GC_OK;
+                }
+                for (auto &ge : b->graphs)
+                    if (ge.eval == eval && ge.rounds == b->rounds && ge.T == T && ge.schedule == kGraphKey) {
+                        GC_HIP(hipGraphLaunch(ge.exec, s));
+                        return GC_OK;
+                    }
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+                if (e == hipSuccess) {
+                    launch_levels1(eval, a, p.levels.data(), s);
+                    e = hipStreamEndCapture(s, &graph);
+                }
+                if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                if (graph) (void)hipGraphDestroy(graph);
+                if (e != hipSuccess) {  // capture unavailable: direct launches of the same kernels
+                    (void)hipGetLastError();
+                    b->use_graph = false;
+                    launch_levels1(eval, a, p.levels.data(), s);
+                    GC_HIP(hipGetLastError());
+                    return GC_OK;
+                }
+                b->graphs.push_back({eval, b->rounds, kGraphKey, T, exec});
+                GC_HIP(hipGraphLaunch(exec, s));
+                return GC_OK;
+            }
+        }
         if (eval) launch_eval_fused(a, b->g, s);
         else launch_garble_fused(a, b->g, s);
         GC_HIP(hipGetLastError());

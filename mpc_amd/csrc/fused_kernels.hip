@@ -101,7 +101,7 @@ enum LaneKind { K_NONE = 0, K_AND = 1, K_OR = 2, K_INV = 3, K_FREE = 4 };
         plast = now__;                                                 \
     }
 
-template <int NR, bool PROF, int G>
+template <int NR, bool PROF, int G, bool PRE = true>
 __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                              const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
                                              const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
@@ -113,7 +113,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
     uint4 va[G], vb[G];
 #pragma unroll
     for (int p = 0; p < G; p++) {
-        if (t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
+        if (PRE && t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
             lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
             d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
         } else {
@@ -207,7 +207,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
     GC_PROF_MARK(2)
 }
 
-template <int NR, bool PROF, int G>
+template <int NR, bool PROF, int G, bool PRE = true>
 __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                            const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
                                            const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
@@ -219,7 +219,7 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
     uint4 va[G], vb[G], tab[G];
 #pragma unroll
     for (int p = 0; p < G; p++) {
-        if (t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
+        if (PRE && t0 == 0 && p == 0) {  // prefetched across the previous level's barrier
             lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
             d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
         } else {
@@ -381,6 +381,81 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
     if constexpr (PROF) {
         if (threadIdx.x == 0 || threadIdx.x == kFusedThreads - 64)
             for (int i = 0; i < 4; i++) prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
+    }
+}
+
+// ---- ONE instance, one launch per level, lanes along the gates -------------------------------------------------------
+// A single instance on the fused kernels is one workgroup on one CU: a streamed SSA-step circuit of 131 072 gates spends
+// 0.78 ms there, AES-bound on that CU.  When a level has several passes of work, the level's lanes are spread over
+// workgroups instead — pass k of the level is workgroup k — and the levels become launches (the kernel boundary is
+// the inter-workgroup barrier; the launches are recorded once in a hipGraph per circuit and replayed).  Same lane
+// decomposition and the same code as a pass of the fused kernels (garble_group / eval_group with one pass, TI = 1).
+template <int NR>
+__global__ __launch_bounds__(kFusedThreads) void k_garble_level1(const GateDesc *__restrict__ descs, Step st, uint32_t ninputs,
+                                                                 uint4 *__restrict__ W, const uint4 *__restrict__ Rv,
+                                                                 uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
+                                                                 const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    uint32_t rkr[4 * (NR + 1)];
+    if (blockIdx.x * kFusedThreads < ((st.n_and + st.n_or) << 2) + (st.n_inv << 1)) {  // this pass has hash lanes
+        load_te_dual(te, g_te0);
+        load_round_keys<NR>(rkr, rk);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 * (NR + 1); i++) rkr[i] = 0;
+    }
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    garble_group<NR, false, 1, false>(st, blockIdx.x * kFusedThreads, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W,
+                                      T, Rv, rkr, te, te_lane_off(), pacc, plast);
+}
+
+template <int NR>
+__global__ __launch_bounds__(kFusedThreads) void k_eval_level1(const GateDesc *__restrict__ descs, Step st, uint32_t ninputs,
+                                                               uint4 *__restrict__ W, const uint4 *__restrict__ T,
+                                                               const uint32_t *__restrict__ rk,
+                                                               const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    uint32_t rkr[4 * (NR + 1)];
+    if (blockIdx.x * kFusedThreads < (st.n_and << 1) + st.n_or + st.n_inv) {
+        load_te_dual(te, g_te0);
+        load_round_keys<NR>(rkr, rk);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 * (NR + 1); i++) rkr[i] = 0;
+    }
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    eval_group<NR, false, 1, false>(st, blockIdx.x * kFusedThreads, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
+                                    rkr, te, te_lane_off(), pacc, plast);
+}
+
+// passes (1024-lane workgroups) of a level for one instance
+uint32_t level1_passes(const Step &st, bool eval) {
+    const uint32_t lanes = eval ? (st.n_and << 1) + st.n_or + st.n_inv + (st.count - st.nonfree)
+                                : ((st.n_and + st.n_or) << 2) + (st.n_inv << 1) + (st.count - st.nonfree);
+    return (lanes + kFusedThreads - 1) / kFusedThreads;
+}
+
+// one launch per level of `levels` (host copy of the device step array a.steps)
+void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream_t s) {
+    for (uint32_t lv = 0; lv < a.nsteps; lv++) {
+        const Step &st = levels[lv];
+        const uint32_t grid = level1_passes(st, eval);
+        if (grid == 0) continue;
+#define GC_L1(NR)                                                                                                      \
+    if (eval)                                                                                                          \
+        hipLaunchKernelGGL((k_eval_level1<NR>), dim3(grid), dim3(kFusedThreads), 0, s, a.descs, st, a.ninputs, a.W,    \
+                           (const uint4 *)a.T, a.rk, a.te0);                                                           \
+    else                                                                                                               \
+        hipLaunchKernelGGL((k_garble_level1<NR>), dim3(grid), dim3(kFusedThreads), 0, s, a.descs, st, a.ninputs, a.W,  \
+                           a.R, a.T, a.rk, a.te0)
+        switch (a.rounds) {
+        case 10: GC_L1(10); break;
+        case 12: GC_L1(12); break;
+        default: GC_L1(14); break;
+        }
+#undef GC_L1
     }
 }
 

@@ -76,6 +76,10 @@ struct FusedArgs {
 };
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
+// ONE instance with wires in HBM: one launch per level, pass k of the level = workgroup k (lanes along the gates);
+// levels = host copy of the step array
+uint32_t level1_passes(const Step &st, bool eval);
+void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream_t s);
 
 // Fused schedule with LDS-resident wires (fused_lds_kernels.hip)
 struct FusedLdsArgs {

@@ -2,6 +2,8 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 namespace gc {
@@ -158,6 +160,25 @@ static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, u
             const uint32_t s = take();
             lds_of[pid] = s;
             expire[std::max(last_use[pid], si + 1)].push_back(s);
+        }
+    }
+    if (std::getenv("GC_PLAN_DEBUG")) {  // developer aid: live labels after every step of the flattened schedule
+        std::vector<int32_t> delta((size_t)nsteps + 2, 0);
+        uint32_t nin_live = 0;
+        for (uint32_t w = 0; w < ninputs; w++)
+            if (last_use[w]) nin_live++, delta[last_use[w]]--;
+        for (uint32_t si = 0; si < nsteps; si++)
+            for (uint32_t k = step_first[si]; k < step_first[si + 1]; k++) {
+                const uint32_t pid = ninputs + gl[k];
+                delta[si]++;
+                delta[std::max(last_use[pid], si + 1)]--;
+            }
+        int32_t live = (int32_t)nin_live;
+        std::fprintf(stderr, "[plan] %u steps, %u inputs live at start, high-water %u\n", nsteps, nin_live, high);
+        for (uint32_t si = 0; si < nsteps; si++) {
+            live += delta[si];
+            std::fprintf(stderr, "[plan] step %u %s n=%u live=%d\n", si, is_free[ninputs + gl[step_first[si]]] ? "xor " : "hash",
+                         step_first[si + 1] - step_first[si], live);
         }
     }
     const uint32_t zslot = high;  // holds the zero label (padding of term lists)

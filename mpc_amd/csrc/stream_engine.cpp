@@ -15,9 +15,30 @@
 #include <new>
 #include <unordered_map>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "engine.h"
 
 using namespace gc;
+
+namespace {
+// developer aid: GC_TRACE=1 prints the wall-clock laps of a streaming step to stderr
+struct StreamTrace {
+    bool on;
+    std::chrono::steady_clock::time_point last;
+    StreamTrace() : on(std::getenv("GC_TRACE") != nullptr) {
+        if (on) last = std::chrono::steady_clock::now();
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gc trace] stream: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+}  // namespace
 
 // A cached device circuit with the gate list it was built from.  The key is a 64-bit non-cryptographic hash: a hit is
 // only taken after the gates compare equal (an accidental — or, on the evaluator side, peer-crafted — collision would
@@ -320,6 +341,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     ensure(s, mx);
     *written = 0;
     if (ngates == 0) return GC_OK;
+    StreamTrace tr;
 
     // in[] / out[] naming the same GLOBAL wire (wire-id re-use, in-place update): the reference resolves
     // stream.wire(index) per gate (:131-157), so a gate that reads the input-mapped wire after the gate that Set the
@@ -383,6 +405,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
         }
         cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
     }
+    tr.lap("alias + hash + cache");
     gc_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
@@ -415,6 +438,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     }
     *written = (size_t)need;
     if (need > cap) return GC_E_ARG;
+    tr.lap("sizes + scan + sync");
 
     // (2) input labels through in[] (Get, :131-141); garble; outputs into the global store (Set, :143-157)
     std::vector<gc_label> inl(nin), outl(std::max<uint32_t>(nout, 1));
@@ -422,6 +446,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     gc_batch *b = nullptr;
     int rc = gc_garble_labels_keep(circ, s->key.data(), s->key.size(), &s->r, inl.data(), outl.data(), &b);
     if (rc != GC_OK) return rc;
+    tr.lap("inputs + garble + outs");
     for (uint32_t j = 0; j < nout; j++)
         if (first_out + j >= first_tmp) s->l0[out[j]] = outl[j];  // an output wire that is an input wire has no gate: no Set
 
@@ -436,6 +461,7 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = GC_E_HIP;
     }
+    tr.lap("serialise + d2h");
     gc_circ_release_batch(circ, b);
     return rc;
 } catch (...) {

@@ -140,3 +140,24 @@ for seed in range(max(1, N // 8)):
         print("FAIL(iknp) seed", seed, str(e)[:160])
     grcv.close(); gsnd.close()
 print("iknp done, failures:", bad4)
+
+# ---- fifth pass: circuits whose live labels exceed every LDS plan (HBM-wire kernels: grouped passes, single-pass levels)
+# on random level shapes, every gate type, batches that give tiles of 1 to 8 instances; sampled instances byte for byte
+from mpc_amd.circuit import synthetic_levelised
+bad5 = 0
+for seed in range(max(2, N // 12)):
+    rng = np.random.default_rng(77000 + seed)
+    width = int(rng.choice([48, 64, 300, 1500, 2600, 5000]))
+    levels = int(max(2, rng.integers(20000, 45000) // width))
+    c = synthetic_levelised(levels, width, float(rng.choice([0.1, 0.3, 0.6])), seed=int(rng.integers(1, 1 << 30)),
+                            ninputs=int(rng.choice([16, 64, 200])), or_frac=float(rng.choice([0.0, 0.05])),
+                            inv_frac=float(rng.choice([0.0, 0.1])), xnor_frac=float(rng.choice([0.0, 0.1])))
+    batch = int(rng.choice([1, 3, 70, 300, 1030, 2100]))
+    sample = None if batch <= 3 else sorted(set([0, 1, batch // 2, batch - 2, batch - 1]))
+    try:
+        check_garble_eval(ctx, c, drbg("hk%d" % seed, int(rng.choice([16, 24, 32]))), batch, "xh%d" % seed,
+                          check_all_wires=(batch <= 3), schedule=1, sample=sample)
+    except (AssertionError, engine.EngineError) as e:
+        bad5 += 1
+        print("FAIL(hbm wires) seed", seed, "levels", levels, "width", width, "batch", batch, str(e)[:160])
+print("hbm-wire circuits done, failures:", bad5)

@@ -444,10 +444,11 @@ def test_host_api_pinned_buffers_pipeline(ctx, aes_circ):
         x.close()
 
 
-@pytest.mark.parametrize("batch", [3, 70, 1030])
+@pytest.mark.parametrize("batch", [1, 3, 70, 1030])
 def test_global_wire_kernels_on_a_circuit_that_exceeds_lds(ctx, batch):
     """a circuit whose live labels do not fit the LDS plans runs the fused kernels with wires in HBM (passes of a level
-    grouped: descriptors, operands, hashes); every gate type, levels of several passes, all wires compared"""
+    grouped: descriptors, operands, hashes); every gate type, levels of several passes, all wires compared.  batch = 1
+    takes the gate-parallel form: one launch per level, pass k of the level = workgroup k, replayed as a hipGraph."""
     c = synthetic_levelised(14, 2500, 0.3, seed=77, ninputs=64, or_frac=0.05, inv_frac=0.08, xnor_frac=0.1)
     dc = engine.DeviceCircuit(ctx, c)
     b = engine.Batch(dc, batch)
@@ -455,6 +456,9 @@ def test_global_wire_kernels_on_a_circuit_that_exceeds_lds(ctx, batch):
     b.close(); dc.close()
     sample = None if batch < 10 else sorted(set(list(range(0, batch, 97)) + [batch - 1, batch - 2]))
     check_garble_eval(ctx, c, KEY256, batch, "glob%d" % batch, check_all_wires=(batch <= 70), schedule=1, sample=sample)
+    if batch == 1:  # again: the second call replays the recorded graph; another key size records its own
+        check_garble_eval(ctx, c, KEY256, batch, "glob1b", check_all_wires=True, schedule=1)
+        check_garble_eval(ctx, c, KEY128, batch, "glob1c", check_all_wires=False, schedule=1)
 
 
 @pytest.mark.parametrize("batch", [2, 520])
