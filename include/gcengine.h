@@ -221,10 +221,24 @@ int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
 int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
 
+/* The same call in two halves (additive): _begin enqueues one circuit — input labels gathered from the stream's wire store
+ * (which lives in HBM), garbling, output labels scattered back, serialisation — and returns without waiting for the GPU;
+ * _finish hands out the bytes of the OLDEST circuit in flight.  Calling begin(k + 1) before finish(k) overlaps the host's
+ * share of a step (content hash, plan look-up, launches) with the GPU's share of the step before; the bytes still leave in
+ * order, so a driver writes them to the connection exactly as before.  At most two circuits in flight (a third _begin
+ * returns GC_E_ARG); gc_stream_garble is _begin + _finish and needs nothing in flight; gc_stream_get_wire waits for the
+ * circuits in flight.  If cap is too small _finish returns GC_E_ARG with *written = the size needed; that circuit has been
+ * garbled (its outputs are set) and its bytes are dropped. */
+int gc_stream_garble_begin(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                           uint32_t nin, const uint32_t *out, uint32_t nout);
+int gc_stream_garble_finish(gc_stream *, uint8_t *buf, size_t cap, size_t *written);
+
 /* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
  * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
  * reading the framing (OpCircuit header: step, numGates, numTmpWires, numWires) and hands the gate bytes over;
- * the gates are parsed back into a circuit, levelised and evaluated with the same kernels as Circuit.Eval. */
+ * the gates are parsed back into a circuit, levelised and evaluated with the same kernels as Circuit.Eval.  The wire
+ * store lives in HBM: gc_stream_eval_circuit returns once the block is parsed and its kernels are enqueued (the parsing of
+ * the next block overlaps them); gc_stream_eval_get_wire waits for them. */
 typedef struct gc_stream_eval gc_stream_eval;
 gc_stream_eval *gc_stream_eval_create(gc_ctx *, const uint8_t *key, size_t keylen, int *status);
 void gc_stream_eval_free(gc_stream_eval *);

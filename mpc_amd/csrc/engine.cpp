@@ -1219,6 +1219,49 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b) {
     if (c && b) pool_put(c, b);
 }
 
+int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
+                const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
+                gc_batch **bout) {
+    if (!c || !bout || !d_store || (!eval && !r)) return GC_E_ARG;
+    *bout = nullptr;
+    const Plan &p = c->plan.p;
+    if (eval && (slab_rows != p.info.slab_rows || (!slab_host && slab_rows))) return GC_E_ROWS;
+    int rc = GC_OK;
+    gc_batch *b = pool_get(c, 1, &rc);
+    if (!b) return rc;
+    gc_ctx *ctx = c->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    do {
+        hipError_t e = hipSetDevice(ctx->device);
+        b->store_all = false;
+        if (e == hipSuccess && (rc = relayout(b)) != GC_OK) break;
+        if (e == hipSuccess && !eval) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
+        // one instance: a tile of one, the table array is the dense slab [row] and wire slot w is element w
+        if (e == hipSuccess && eval && slab_rows)
+            e = hipMemcpyAsync(b->d_T, slab_host, slab_rows * sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            set_error("gc_pass_dev", e);
+            rc = GC_E_HIP;
+            break;
+        }
+        launch_store_gather(b->d_W, (const uint4 *)d_store, d_in_idx, p.info.ninputs, ctx->stream);
+        if ((rc = set_key(b, key, keylen)) != GC_OK) break;
+        if ((rc = run_levels(b, eval, b->d_T)) != GC_OK) break;
+        launch_store_scatter((uint4 *)const_cast<void *>(d_store), b->d_W, c->d_out_slots, d_out_idx, p.info.noutputs, ctx->stream);
+        e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("gc_pass_dev", e);
+            rc = GC_E_HIP;
+        }
+    } while (0);
+    if (rc != GC_OK) {
+        pool_put(c, b);
+        return rc;
+    }
+    *bout = b;
+    return GC_OK;
+}
+
 extern "C" {
 
 int gc_garble_labels(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,

@@ -105,3 +105,11 @@ struct gc_batch {
 int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,
                           gc_label *out_l0, gc_batch **bout);
 void gc_circ_release_batch(gc_circ *c, gc_batch *b);
+// internal: ONE instance whose input labels come from, and whose output labels go to, a DEVICE-resident wire store
+// (the streaming garbler / evaluator): W[i] = d_store[d_in_idx[i]], pass, d_store[d_out_idx[j]] = W[out_slot[j]]
+// (index 0xffffffff: not stored).  eval: the tables come from the host slab (slab_rows labels).  Everything is
+// enqueued on the ctx stream; nothing is waited for.  The pooled batch comes back in *bout (tables in b->d_T for the
+// garbler's serialiser; later passes on the same stream may reuse it at once).
+int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
+                const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
+                gc_batch **bout);

@@ -543,4 +543,23 @@ void launch_slab_be(uint4 *T, const Layout &lt, uint32_t rows, uint32_t batch, u
     hipLaunchKernelGGL(k_slab_be, grid, dim3(256), 0, s, T, lt, rows, batch, buf, stride, ingest);
 }
 
+// ---- label exchange between a one-instance batch and a device-resident wire store (streaming) ----------------------
+// W[slot0 + i] = store[idx[i]]
+__global__ void k_store_gather(uint4 *__restrict__ W, const uint4 *__restrict__ store, const uint32_t *__restrict__ idx, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) W[i] = store[idx[i]];
+}
+// store[idx[j]] = W[slots[j]]; idx 0xffffffff = no store (an output wire that is an input wire is never set)
+__global__ void k_store_scatter(uint4 *__restrict__ store, const uint4 *__restrict__ W, const uint32_t *__restrict__ slots,
+                                const uint32_t *__restrict__ idx, uint32_t n) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && idx[j] != 0xffffffffu) store[idx[j]] = W[slots[j]];
+}
+void launch_store_gather(uint4 *W, const uint4 *store, const uint32_t *idx, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_store_gather, dim3((n + 255) / 256), dim3(256), 0, s, W, store, idx, n);
+}
+void launch_store_scatter(uint4 *store, const uint4 *W, const uint32_t *slots, const uint32_t *idx, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_store_scatter, dim3((n + 255) / 256), dim3(256), 0, s, store, W, slots, idx, n);
+}
+
 }  // namespace gc

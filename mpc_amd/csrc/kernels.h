@@ -134,6 +134,11 @@ void launch_gather(const uint4 *W, const Layout &lay, uint32_t inst0, const uint
 void launch_scatter(const uint4 *src, size_t src_stride_elems, uint32_t n, const uint32_t *slots, uint32_t slot0,
                     uint4 *W, const Layout &lay, uint32_t inst0, uint32_t count, hipStream_t s);
 
+// one-instance batch <-> device-resident wire store (streaming): W[i] = store[idx[i]];  store[idx[j]] = W[slots[j]]
+// (idx 0xffffffff: skip)
+void launch_store_gather(uint4 *W, const uint4 *store, const uint32_t *idx, uint32_t n, hipStream_t s);
+void launch_store_scatter(uint4 *store, const uint4 *W, const uint32_t *slots, const uint32_t *idx, uint32_t n, hipStream_t s);
+
 void launch_select_inputs(uint4 *We, const uint4 *Wg, const uint4 *R, const uint8_t *bits, uint32_t ninputs,
                           const BatchGeom &g, hipStream_t s);
 void launch_decode(const uint4 *Wg, const uint4 *R, const uint4 *We, const uint32_t *out_slots, uint32_t noutputs,

@@ -53,22 +53,102 @@ struct CircEntry {
 };
 using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
 
+// Global wire store of a stream (Streaming.wires / StreamEval.wires, stream_garble.go:27-38, stream_evaluator.go:29-34) in
+// HBM: the circuits of consecutive steps hand labels to each other on the device (gather before / scatter after every
+// pass), so a step does not wait for the GPU at all and the host work of step k + 1 (hashing, cache look-up, parsing)
+// overlaps the kernels of step k.  Labels the HOST sets (the stream's inputs) live in a host shadow until the next pass
+// uploads them; labels a circuit wrote are read back on demand (GetInput / OpReturn are rare).
+struct DevStore {
+    std::vector<gc_label> host;   // valid where !on_dev
+    std::vector<uint8_t> on_dev;  // 1: the current label was written by a circuit on the device
+    std::vector<uint32_t> dirty;  // host-set wires not uploaded yet
+    uint4 *d = nullptr;
+    size_t cap = 0;
+
+    void ensure(size_t n) {
+        if (host.size() < n) {
+            host.resize(n, gc_label{0, 0});
+            on_dev.resize(n, 0);
+        }
+    }
+    void set(uint32_t w, const gc_label &l) {
+        ensure((size_t)w + 1);
+        host[w] = l;
+        on_dev[w] = 0;
+        dirty.push_back(w);
+    }
+    // device array covers every wire, host-set labels are uploaded (runs of consecutive indices as one copy)
+    int flush(gc_ctx *ctx) {
+        hipStream_t st = ctx->stream;
+        if (host.size() > cap) {
+            const size_t ncap = std::max(host.size(), cap * 2);
+            uint4 *nd = nullptr;
+            GC_HIP(hipMalloc((void **)&nd, ncap * sizeof(uint4)));
+            GC_HIP(hipMemsetAsync(nd, 0, ncap * sizeof(uint4), st));  // a never-set wire reads as the zero label
+            if (d) GC_HIP(hipMemcpyAsync(nd, d, cap * sizeof(uint4), hipMemcpyDeviceToDevice, st));
+            GC_HIP(hipStreamSynchronize(st));
+            if (d) (void)hipFree(d);
+            d = nd;
+            cap = ncap;
+        }
+        for (size_t i = 0; i < dirty.size();) {
+            size_t j = i + 1;
+            while (j < dirty.size() && dirty[j] == dirty[j - 1] + 1) j++;
+            // a wire set twice keeps its last value in host[]; one that a circuit overwrote meanwhile is skipped
+            bool all_host = true;
+            for (size_t k = i; k < j; k++) all_host = all_host && !on_dev[dirty[k]];
+            if (all_host)
+                GC_HIP(hipMemcpyAsync(d + dirty[i], &host[dirty[i]], (j - i) * sizeof(gc_label), hipMemcpyHostToDevice, st));
+            else
+                for (size_t k = i; k < j; k++)
+                    if (!on_dev[dirty[k]])
+                        GC_HIP(hipMemcpyAsync(d + dirty[k], &host[dirty[k]], sizeof(gc_label), hipMemcpyHostToDevice, st));
+            i = j;
+        }
+        dirty.clear();
+        return GC_OK;
+    }
+    int get(gc_ctx *ctx, uint32_t w, gc_label *out) {
+        if (w >= host.size()) return GC_E_ARG;
+        if (!on_dev[w]) {
+            *out = host[w];
+            return GC_OK;
+        }
+        GC_HIP(hipSetDevice(ctx->device));
+        GC_HIP(hipMemcpyAsync(out, d + w, sizeof(gc_label), hipMemcpyDeviceToHost, ctx->stream));
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+        host[w] = *out;  // cache: unchanged until a circuit writes the wire again
+        on_dev[w] = 0;
+        return GC_OK;
+    }
+    void release() {
+        if (d) (void)hipFree(d);
+        d = nullptr;
+        cap = 0;
+    }
+};
+
 struct gc_stream {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
     gc_label r{};
-    std::vector<gc_label> l0;     // global wire -> L0 (L1 = L0 ^ R)
-    std::vector<gc_label> tmp_l0; // stream.tmp (only outputs of the current circuit are meaningful)
+    DevStore store;               // global wire -> L0 (L1 = L0 ^ R)
     CircCache cache;
     std::vector<uint32_t> alias_gen, alias_j;  // in[] / out[] aliasing check: stamp + index in out[] per global wire
     uint32_t gen = 0;
     std::vector<gc_gate> rewritten;            // gate list with aliased reads redirected (rare)
-    uint32_t *d_io = nullptr;   // in[] then out[] of the current call
+    std::vector<uint32_t> io_host;             // in[], out[], out[] with 0xffffffff where nothing is stored
+    uint32_t *d_io = nullptr;   // device copy of io_host for the call in flight
     size_t io_cap = 0;
     uint64_t *d_boff = nullptr; // per block of kSerGates gates: byte size, then exclusive offset; [nblocks] = total
     size_t boff_cap = 0;
-    uint8_t *d_bytes = nullptr; // the serialised circuit
-    size_t bytes_cap = 0;
+    // two steps may be in flight (gc_stream_garble_begin / _finish): their serialised bytes, sizes and completion events
+    uint8_t *d_bytes[2] = {nullptr, nullptr};
+    size_t bytes_cap[2] = {0, 0};
+    uint64_t *need_host = nullptr;  // pinned [2]
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    uint32_t head = 0, pending = 0;  // slot of the oldest step in flight, steps in flight
 };
 
 namespace {
@@ -227,31 +307,40 @@ inline uint64_t be64(const uint8_t *p) {
     return v;
 }
 inline void ensure(gc_stream *s, uint32_t max) {  // ensureWires, 64 Ki-wire pages (:95-100)
-    if (max < s->l0.size()) return;
-    s->l0.resize(((size_t)max / 0x10000 + 1) * 0x10000, gc_label{0, 0});
+    if (max < s->store.host.size()) return;
+    s->store.ensure(((size_t)max / 0x10000 + 1) * 0x10000);
 }
 
 // content hash of a circuit (cache key): four independent multiply-xor lanes over the gate words, so the
 // multiplies of consecutive gates overlap (one dependent chain was 0.2 ms per 131 072-gate step)
-uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout) {
-    constexpr uint64_t kPrime = 1099511628211ull;
-    uint64_t h[4] = {1469598103934665603ull ^ ngates, 0x9e3779b97f4a7c15ull ^ nwires, 0xc2b2ae3d27d4eb4full ^ nin,
-                     0x165667b19e3779f9ull ^ nout};
-    auto mix = [&](int l, const gc_gate &g) {
-        h[l] = (h[l] ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
-        h[l] = (h[l] ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
-    };
-    uint32_t i = 0;
-    for (; i + 4 <= ngates; i += 4) {
-        mix(0, gates[i]);
-        mix(1, gates[i + 1]);
-        mix(2, gates[i + 2]);
-        mix(3, gates[i + 3]);
+struct CircuitHash {  // incremental form: the evaluator hashes while it renumbers (one pass over the gates less)
+    static constexpr uint64_t kPrime = 1099511628211ull;
+    uint64_t h[4];
+    CircuitHash(uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout)
+        : h{1469598103934665603ull ^ ngates, 0x9e3779b97f4a7c15ull ^ nwires, 0xc2b2ae3d27d4eb4full ^ nin,
+            0x165667b19e3779f9ull ^ nout} {}
+    inline void mix(uint32_t i, const gc_gate &g) {
+        uint64_t &v = h[i & 3];
+        v = (v ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
+        v = (v ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
     }
-    for (; i < ngates; i++) mix(i & 3, gates[i]);
-    uint64_t r = 0;
-    for (int l = 0; l < 4; l++) r = (r ^ h[l]) * kPrime + (r >> 29);
-    return r;
+    uint64_t done() const {
+        uint64_t r = 0;
+        for (int l = 0; l < 4; l++) r = (r ^ h[l]) * kPrime + (r >> 29);
+        return r;
+    }
+};
+uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout) {
+    CircuitHash ch(ngates, nwires, nin, nout);
+    uint32_t i = 0;
+    for (; i + 4 <= ngates; i += 4) {  // four independent lanes: the multiplies of consecutive gates overlap
+        ch.mix(0, gates[i]);
+        ch.mix(1, gates[i + 1]);
+        ch.mix(2, gates[i + 2]);
+        ch.mix(3, gates[i + 3]);
+    }
+    for (; i < ngates; i++) ch.mix(i, gates[i]);
+    return ch.done();
 }
 
 gc_circ *cache_find(const CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
@@ -301,7 +390,17 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
         for (uint32_t i = 0; i < ninputs; i++) mx = std::max(mx, inputs[i]);
         ensure(s, mx);
         for (uint32_t i = 0; i < ninputs; i++)
-            s->l0[inputs[i]] = gc_label{be64(rnd + 16 * ((size_t)i + 1)), be64(rnd + 16 * ((size_t)i + 1) + 8)};
+            s->store.set(inputs[i], gc_label{be64(rnd + 16 * ((size_t)i + 1)), be64(rnd + 16 * ((size_t)i + 1) + 8)});
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->need_host, 2 * sizeof(uint64_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            set_error("gc_stream_create", e);
+            rc = GC_E_HIP;
+            gc_stream_free(s);
+            s = nullptr;
+        }
     }
     if (status) *status = rc;
     return s;
@@ -313,23 +412,45 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
 
 void gc_stream_free(gc_stream *s) {
     if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    if (s->copy_stream) {
+        (void)hipStreamSynchronize(s->copy_stream);
+        (void)hipStreamDestroy(s->copy_stream);
+    }
     for (auto &kv : s->cache) gc_circ_free(kv.second.circ);
     if (s->d_io) (void)hipFree(s->d_io);
     if (s->d_boff) (void)hipFree(s->d_boff);
-    if (s->d_bytes) (void)hipFree(s->d_bytes);
+    for (int i = 0; i < 2; i++) {
+        if (s->d_bytes[i]) (void)hipFree(s->d_bytes[i]);
+        if (s->done[i]) (void)hipEventDestroy(s->done[i]);
+    }
+    if (s->need_host) (void)hipHostFree(s->need_host);
+    s->store.release();
     delete s;
 }
 
 int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) {  // Streaming.GetInput (:117-119)
-    if (!s || !out || w >= s->l0.size()) return GC_E_ARG;
-    out->l0 = s->l0[w];
-    out->l1 = gc_label{s->l0[w].d0 ^ s->r.d0, s->l0[w].d1 ^ s->r.d1};
+    if (!s || !out) return GC_E_ARG;
+    gc_label l0;
+    int rc = s->store.get(s->ctx, w, &l0);
+    if (rc != GC_OK) return rc;
+    out->l0 = l0;
+    out->l1 = gc_label{l0.d0 ^ s->r.d0, l0.d1 ^ s->r.d1};
     return GC_OK;
 }
 
-int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
-                     uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) try {
-    if (!s || (!gates && ngates) || (nin && !in) || (nout && !out) || !buf || !written) return GC_E_ARG;
+// Streaming.Garble in two halves (additive): _begin enqueues everything for one circuit — the sizes of its serialisation,
+// the gather of its input labels from the device-resident wire store, the garbling, the scatter of its output labels
+// and the serialiser — and returns WITHOUT waiting; _finish hands out the bytes of the oldest circuit in flight.  With
+// begin(k + 1) before finish(k) the host's share of a step (content hash, cache look-up, launches) overlaps the GPU's
+// share of the step before: the bytes still leave in order.  At most two circuits in flight.
+int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                           uint32_t nin, const uint32_t *out, uint32_t nout) try {
+    if (!s || (!gates && ngates) || (nin && !in) || (nout && !out)) return GC_E_ARG;
+    if (s->pending >= 2) return GC_E_ARG;
     // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
     // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
     if (nin > nwires || nout > nwires) return GC_E_ARG;
@@ -339,8 +460,16 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     for (uint32_t i = 0; i < nin; i++) mx = std::max(mx, in[i]);
     for (uint32_t i = 0; i < nout; i++) mx = std::max(mx, out[i]);
     ensure(s, mx);
-    *written = 0;
-    if (ngates == 0) return GC_OK;
+    const uint32_t slot = (s->head + s->pending) & 1u;
+    gc_ctx *ctx = s->ctx;
+    hipStream_t st = ctx->stream;
+    GC_HIP(hipSetDevice(ctx->device));
+    if (ngates == 0) {  // nothing on the wire
+        s->need_host[slot] = 0;
+        GC_HIP(hipEventRecord(s->done[slot], st));
+        s->pending++;
+        return GC_OK;
+    }
     StreamTrace tr;
 
     // in[] / out[] naming the same GLOBAL wire (wire-id re-use, in-place update): the reference resolves
@@ -348,9 +477,9 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     // output-mapped one sees the NEW label.  The device garbles from a snapshot of the inputs: redirect such reads to
     // the producing circuit wire (same global id and flags on the wire, so the serialised bytes do not change).
     {
-        if (s->alias_gen.size() < s->l0.size()) {
-            s->alias_gen.resize(s->l0.size(), 0);
-            s->alias_j.resize(s->l0.size(), 0);
+        if (s->alias_gen.size() < s->store.host.size()) {
+            s->alias_gen.resize(s->store.host.size(), 0);
+            s->alias_j.resize(s->store.host.size(), 0);
         }
         if (++s->gen == 0) {
             std::fill(s->alias_gen.begin(), s->alias_gen.end(), 0);
@@ -388,9 +517,9 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
             if (gates[i].op > GC_INV) return GC_E_GATE;
             if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
         }
-        int st = GC_OK;
-        circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &st);
-        if (!circ) return st;
+        int stc = GC_OK;
+        circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &stc);
+        if (!circ) return stc;
         std::vector<uint32_t> gw((size_t)3 * ngates);
         for (uint32_t i = 0; i < ngates; i++) {
             gw[3 * (size_t)i] = gates[i].in0;
@@ -406,22 +535,31 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
         cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
     }
     tr.lap("alias + hash + cache");
-    gc_ctx *ctx = s->ctx;
-    hipStream_t st = ctx->stream;
     const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
 
-    // (1) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form)
+    // (1) this call's wire maps on the device: in[], out[], and out[] with "no store" marks for the scatter (an output
+    //     wire that is an input wire has no gate: no Set); host-set labels of the store are uploaded
+    s->io_host.resize((size_t)nin + 2 * (size_t)nout + 1);
+    for (uint32_t i = 0; i < nin; i++) s->io_host[i] = in[i];
+    for (uint32_t j = 0; j < nout; j++) {
+        s->io_host[nin + j] = out[j];
+        s->io_host[nin + nout + j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
+    }
     SerArgs a{};
-    uint64_t need = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        hipError_t e = hipSetDevice(ctx->device);
-        if (e == hipSuccess) e = grow(&s->d_io, &s->io_cap, (size_t)nin + nout + 1);
+        int rcs = s->store.flush(ctx);
+        if (rcs != GC_OK) return rcs;
+        hipError_t e = grow(&s->d_io, &s->io_cap, s->io_host.size());
         if (e == hipSuccess) e = grow(&s->d_boff, &s->boff_cap, (size_t)nblocks + 1);
-        if (e == hipSuccess && nin) e = hipMemcpyAsync(s->d_io, in, nin * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && nout)
-            e = hipMemcpyAsync(s->d_io + nin, out, nout * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return GC_E_HIP;
+        // the bytes of this step: 13 header bytes + 3 rows per gate at most
+        if (e == hipSuccess) e = grow(&s->d_bytes[slot], &s->bytes_cap[slot], (size_t)ngates * 61 + 16);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(s->d_io, s->io_host.data(), s->io_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            set_error("gc_stream_garble", e);
+            return e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        }
         a.gw = circ->d_gwires;
         a.ops = circ->d_ops;
         a.row_of_gate = circ->d_row_of_gate;
@@ -430,42 +568,65 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
         a.ngates = ngates;
         a.first_tmp = first_tmp;
         a.first_out = first_out;
+        // (2) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form)
         hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff);
         hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, st, s->d_boff, nblocks);
-        e = hipMemcpyAsync(&need, s->d_boff + nblocks, sizeof(need), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return GC_E_HIP;
+        GC_HIP(hipMemcpyAsync(&s->need_host[slot], s->d_boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }
-    *written = (size_t)need;
-    if (need > cap) return GC_E_ARG;
-    tr.lap("sizes + scan + sync");
-
-    // (2) input labels through in[] (Get, :131-141); garble; outputs into the global store (Set, :143-157)
-    std::vector<gc_label> inl(nin), outl(std::max<uint32_t>(nout, 1));
-    for (uint32_t i = 0; i < nin; i++) inl[i] = s->l0[in[i]];
+    tr.lap("uploads + sizes");
+    // (3) input labels through in[] (Get, :131-141), garble, outputs into the store (Set, :143-157) — all on the device
     gc_batch *b = nullptr;
-    int rc = gc_garble_labels_keep(circ, s->key.data(), s->key.size(), &s->r, inl.data(), outl.data(), &b);
+    int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, s->d_io, s->d_io + nin + nout, nullptr, 0, &b);
     if (rc != GC_OK) return rc;
-    tr.lap("inputs + garble + outs");
     for (uint32_t j = 0; j < nout; j++)
-        if (first_out + j >= first_tmp) s->l0[out[j]] = outl[j];  // an output wire that is an input wire has no gate: no Set
-
-    // (3) wire format (:391-446) written by the device at the scanned offsets, one copy into the caller's buffer
+        if (first_out + j >= first_tmp) s->store.on_dev[out[j]] = 1;
+    // (4) wire format (:391-446) written by the device at the scanned offsets
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        hipError_t e = grow(&s->d_bytes, &s->bytes_cap, (size_t)need);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff, b->d_T, b->g.lt, s->d_bytes);
-            e = hipMemcpyAsync(buf, s->d_bytes, (size_t)need, hipMemcpyDeviceToHost, st);
+        hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff, b->d_T, b->g.lt, s->d_bytes[slot]);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(s->done[slot], st);
+        if (e != hipSuccess) {
+            set_error("gc_stream_garble", e);
+            rc = GC_E_HIP;
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = GC_E_HIP;
     }
-    tr.lap("serialise + d2h");
-    gc_circ_release_batch(circ, b);
+    gc_circ_release_batch(circ, b);  // later passes on the same stream may reuse it: stream order protects the tables
+    if (rc == GC_OK) s->pending++;
+    tr.lap("enqueue pass + serialiser");
     return rc;
 } catch (...) {
     return gc::on_exception();
+}
+
+int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
+    if (!s || !buf || !written || s->pending == 0) return GC_E_ARG;
+    StreamTrace tr;
+    const uint32_t slot = s->head;
+    s->head ^= 1u;
+    s->pending--;
+    gc_ctx *ctx = s->ctx;
+    GC_HIP(hipSetDevice(ctx->device));
+    GC_HIP(hipEventSynchronize(s->done[slot]));
+    const uint64_t need = s->need_host[slot];
+    *written = (size_t)need;
+    if (need > cap) return GC_E_ARG;
+    if (need) {  // on its own stream: the next circuit's kernels are already queued on the ctx stream
+        GC_HIP(hipMemcpyAsync(buf, s->d_bytes[slot], (size_t)need, hipMemcpyDeviceToHost, s->copy_stream));
+        GC_HIP(hipStreamSynchronize(s->copy_stream));
+    }
+    tr.lap("wait + d2h");
+    return GC_OK;
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                     uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) {
+    if (!s || !buf || !written || s->pending) return GC_E_ARG;
+    int rc = gc_stream_garble_begin(s, gates, ngates, nwires, in, nin, out, nout);
+    if (rc != GC_OK) return rc;
+    return gc_stream_garble_finish(s, buf, cap, written);
 }
 
 // ---- streaming evaluator ----------------------------------------------------------------
@@ -475,13 +636,23 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
 struct gc_stream_eval {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
-    std::vector<gc_label> wires;  // StreamEval.wires (global store)
+    DevStore store;  // StreamEval.wires (global store), device-resident
     CircCache cache;
+    std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
+    uint32_t *d_io = nullptr;
+    size_t io_cap = 0;
     // per-circuit scratch, kept across calls: last writer of every tmp / global wire with a generation stamp
-    std::vector<uint32_t> cur_t, stamp_t, cur_w, stamp_w;
+    std::vector<uint64_t> last_t, last_w;  // per tmp / global wire: generation stamp << 32 | current id (one load per look-up)
     uint32_t gen = 0;
     std::vector<gc_gate> gates;
-    std::vector<gc_label> slab;
+    std::vector<uint64_t> dst_pack;   // per gate: destination index | tmp flag << 32 (parser scratch, kept across calls)
+    std::vector<uint32_t> in_idx, id_of;
+    // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
+    // may still be in flight while block k + 1 is parsed
+    gc_label *slab_pin[2] = {nullptr, nullptr};
+    size_t slab_cap[2] = {0, 0};
+    hipEvent_t slab_ev[2] = {nullptr, nullptr};
+    uint32_t slab_turn = 0;
 };
 
 extern "C" {
@@ -507,23 +678,31 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
 
 void gc_stream_eval_free(gc_stream_eval *e) {
     if (!e) return;
+    if (e->ctx) {
+        (void)hipSetDevice(e->ctx->device);
+        (void)hipStreamSynchronize(e->ctx->stream);
+    }
     for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
+    if (e->d_io) (void)hipFree(e->d_io);
+    for (int i = 0; i < 2; i++) {
+        if (e->slab_pin[i]) (void)hipHostFree(e->slab_pin[i]);
+        if (e->slab_ev[i]) (void)hipEventDestroy(e->slab_ev[i]);
+    }
+    e->store.release();
     delete e;
 }
 
 int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) try {
     if (!e || !l) return GC_E_ARG;
-    if (w >= e->wires.size()) e->wires.resize((size_t)w + 1, gc_label{0, 0});
-    e->wires[w] = *l;
+    e->store.set(w, *l);
     return GC_OK;
 } catch (...) {
     return gc::on_exception();
 }
 
 int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
-    if (!e || !l || w >= e->wires.size()) return GC_E_ARG;
-    *l = e->wires[w];
-    return GC_OK;
+    if (!e || !l) return GC_E_ARG;
+    return e->store.get(e->ctx, w, l);
 }
 
 int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
@@ -535,8 +714,9 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     // ids must stay below the numWires of the block's own header (the reference indexes its store with them,
     // stream_evaluator.go:29-96: an id beyond it panics there) and tmp ids below numTmpWires.
     if ((size_t)ngates > len / 5) return GC_E_ROWS;
-    if (e->wires.size() < nwires) e->wires.resize(nwires, gc_label{0, 0});  // InitCircuit(numWires, numTmpWires)
+    e->store.ensure(nwires);  // InitCircuit(numWires, numTmpWires)
     if (ngates == 0) return GC_OK;
+    StreamTrace tr;
     // Parse the gate stream (stream_evaluator.go:272-345) into an SSA gate list.  Wire ids of the device circuit:
     //   [0, nin)            wires read before this circuit writes them, in order of first use
     //   then one id per gate: first the gates that write a tmp wire, last the gates that write a global wire —
@@ -545,22 +725,46 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     // A tmp wire is private to its OpCircuit block (stream_garble.go:131-157 gives every non-input, non-output
     // wire of the circuit a tmp id, written by a gate before any gate reads it): a block that reads a tmp it has
     // not written is rejected instead of evaluated on a stale label.
-    struct Ref { bool tmp; uint32_t idx; };
-    if (e->stamp_t.size() < ntmp) {
-        e->stamp_t.resize(ntmp, 0);
-        e->cur_t.resize(ntmp, 0);
+    if (e->last_t.size() < ntmp) {
+        e->last_t.resize(ntmp, 0);
     }
     if (++e->gen == 0) {  // stamp wrap-around
-        std::fill(e->stamp_t.begin(), e->stamp_t.end(), 0);
-        std::fill(e->stamp_w.begin(), e->stamp_w.end(), 0);
+        std::fill(e->last_t.begin(), e->last_t.end(), 0);
+        std::fill(e->last_w.begin(), e->last_w.end(), 0);
         e->gen = 1;
     }
     const uint32_t gen = e->gen;
     std::vector<gc_gate> &gates = e->gates;
-    std::vector<gc_label> &slab = e->slab;
+    const uint32_t sb = e->slab_turn & 1u;
+    e->slab_turn++;
+    {
+        GC_HIP(hipSetDevice(e->ctx->device));
+        if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
+        else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the H2D of the block two calls ago (long done)
+        const size_t want = (size_t)ngates * 3 + 1;
+        if (e->slab_cap[sb] < want) {
+            if (e->slab_pin[sb]) (void)hipHostFree(e->slab_pin[sb]);
+            e->slab_pin[sb] = nullptr;
+            e->slab_cap[sb] = 0;
+            GC_HIP(hipHostMalloc((void **)&e->slab_pin[sb], (want + want / 2) * sizeof(gc_label), hipHostMallocDefault));
+            e->slab_cap[sb] = want + want / 2;
+        }
+    }
+    gc_label *slab = e->slab_pin[sb];
+    size_t nrows = 0;
     gates.resize(ngates);
-    slab.clear();
-    std::vector<Ref> dst(ngates), inputs;
+    struct Dst { bool tmp; uint32_t idx; };
+    std::vector<uint64_t> &dstp = e->dst_pack;  // no per-call allocation: a block has ~10^5 gates
+    std::vector<uint32_t> &inputs = e->in_idx;
+    dstp.resize(ngates);
+    inputs.clear();
+    auto dst_of = [&](uint32_t g) { return Dst{(dstp[g] >> 32) != 0, (uint32_t)dstp[g]}; };
+    auto load_be64 = [](const uint8_t *p) {
+        uint64_t v;
+        std::memcpy(&v, p, 8);
+        return __builtin_bswap64(v);
+    };
+    static const uint8_t kRowsOf[5] = {0, 0, 2, 3, 1}, kWiresOf[5] = {3, 3, 3, 3, 2};
     uint32_t n_global = 0;
     size_t pos = 0;
     for (uint32_t g = 0; g < ngates; g++) {
@@ -569,41 +773,44 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         const bool at = gop & 0x80, bt = gop & 0x40, ct = gop & 0x20, shortf = gop & 0x10;
         gop &= 0x0f;
         if (gop > GC_INV) return GC_E_GATE;  // "invalid operation"
-        const int nw = gop == GC_INV ? 2 : 3;
-        const size_t sz = shortf ? 2 : 4;
-        const uint32_t rows = gop == GC_AND ? 2 : gop == GC_OR ? 3 : gop == GC_INV ? 1 : 0;
-        if (pos + sz * nw + 16 * (size_t)rows > len) return GC_E_ROWS;
+        const int nw = kWiresOf[gop];
+        const uint32_t rows = kRowsOf[gop];
         uint32_t w[3] = {0, 0, 0};
-        for (int i = 0; i < nw; i++) {
-            for (size_t b = 0; b < sz; b++) w[i] = (w[i] << 8) | buf[pos + b];
-            pos += sz;
+        if (shortf) {
+            if (pos + 2 * (size_t)nw + 16 * (size_t)rows > len) return GC_E_ROWS;
+            for (int i = 0; i < nw; i++) w[i] = ((uint32_t)buf[pos + 2 * i] << 8) | buf[pos + 2 * i + 1];
+            pos += 2 * (size_t)nw;
+        } else {
+            if (pos + 4 * (size_t)nw + 16 * (size_t)rows > len) return GC_E_ROWS;
+            for (int i = 0; i < nw; i++) {
+                uint32_t v;
+                std::memcpy(&v, buf + pos + 4 * i, 4);
+                w[i] = __builtin_bswap32(v);
+            }
+            pos += 4 * (size_t)nw;
         }
         for (uint32_t r = 0; r < rows; r++) {
-            slab.push_back(gc_label{be64(buf + pos), be64(buf + pos + 8)});
+            slab[nrows++] = gc_label{load_be64(buf + pos), load_be64(buf + pos + 8)};
             pos += 16;
         }
         int err = GC_OK;
         auto use = [&](bool t, uint32_t idx) -> uint32_t {  // current id of a wire; bit 31: a circuit input
             if (t) {
-                if (idx >= ntmp || e->stamp_t[idx] != gen) {
+                if (idx >= ntmp || (e->last_t[idx] >> 32) != gen) {
                     err = GC_E_ARG;
                     return 0;
                 }
-                return e->cur_t[idx];
+                return (uint32_t)e->last_t[idx];
             }
             if (idx >= nwires) {
                 err = GC_E_ARG;
                 return 0;
             }
-            if (idx >= e->stamp_w.size()) {
-                e->stamp_w.resize((size_t)idx + 1 + e->stamp_w.size() / 2, 0);
-                e->cur_w.resize(e->stamp_w.size(), 0);
-            }
-            if (e->stamp_w[idx] == gen) return e->cur_w[idx];
+            if (idx >= e->last_w.size()) e->last_w.resize((size_t)idx + 1 + e->last_w.size() / 2, 0);
+            if ((e->last_w[idx] >> 32) == gen) return (uint32_t)e->last_w[idx];
             const uint32_t id = 0x80000000u | (uint32_t)inputs.size();
-            inputs.push_back(Ref{false, idx});
-            e->stamp_w[idx] = gen;
-            e->cur_w[idx] = id;
+            inputs.push_back(idx);
+            e->last_w[idx] = ((uint64_t)gen << 32) | id;
             return id;
         };
         gates[g].in0 = use(at, w[0]);
@@ -612,38 +819,39 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         gates[g].op = gop;
         gates[g].level = 0;
         const uint32_t ci = w[nw - 1];
-        dst[g] = Ref{ct, ci};
+        dstp[g] = (uint64_t)ci | ((uint64_t)(ct ? 1 : 0) << 32);
         if (ct) {
             if (ci >= ntmp) return GC_E_ARG;
-            e->stamp_t[ci] = gen;
-            e->cur_t[ci] = g;
+            e->last_t[ci] = ((uint64_t)gen << 32) | g;
         } else {
             if (ci >= nwires) return GC_E_ARG;
-            if (ci >= e->stamp_w.size()) {
-                e->stamp_w.resize((size_t)ci + 1 + e->stamp_w.size() / 2, 0);
-                e->cur_w.resize(e->stamp_w.size(), 0);
-            }
-            e->stamp_w[ci] = gen;
-            e->cur_w[ci] = g;
+            if (ci >= e->last_w.size()) e->last_w.resize((size_t)ci + 1 + e->last_w.size() / 2, 0);
+            e->last_w[ci] = ((uint64_t)gen << 32) | g;
             n_global++;
         }
         gates[g].out = g;  // gate index for now; numbered below
     }
+    tr.lap("eval: parse");
     const uint32_t nin = (uint32_t)inputs.size(), nout = n_global, n_tmp = ngates - n_global;
+    uint64_t h = 0;
     {
-        std::vector<uint32_t> id_of(ngates);
+        std::vector<uint32_t> &id_of = e->id_of;
+        id_of.resize(ngates);
         uint32_t kt = 0, kg = 0;
-        for (uint32_t g = 0; g < ngates; g++) id_of[g] = dst[g].tmp ? nin + kt++ : nin + n_tmp + kg++;
+        for (uint32_t g = 0; g < ngates; g++) id_of[g] = (dstp[g] >> 32) ? nin + kt++ : nin + n_tmp + kg++;
+        CircuitHash ch(ngates, nin + ngates, nin, nout);
         for (uint32_t g = 0; g < ngates; g++) {
             auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : id_of[v]; };
             gates[g].in0 = fix(gates[g].in0);
             gates[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
             gates[g].out = id_of[g];
+            ch.mix(g, gates[g]);
         }
+        h = ch.done();
     }
     const uint32_t cw = nin + ngates;
+    tr.lap("eval: renumber");
     // device circuit, cached by content
-    const uint64_t h = circuit_hash(gates.data(), ngates, cw, nin, nout);
     gc_circ *circ = cache_find(e->cache, h, gates.data(), ngates, cw, nin, nout);
     if (!circ) {
         int st = GC_OK;
@@ -651,21 +859,42 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (!circ) return st;
         cache_put(e->cache, h, circ, gates.data(), ngates, cw, nin, nout);
     }
-    std::vector<gc_label> inl(std::max<uint32_t>(nin, 1)), outl(std::max<uint32_t>(nout, 1));
-    for (uint32_t i = 0; i < nin; i++) {
-        const Ref &r = inputs[i];
-        if (r.idx >= e->wires.size()) e->wires.resize((size_t)r.idx + 1, gc_label{0, 0});
-        inl[i] = e->wires[r.idx];
+    tr.lap("eval: hash + cache");
+    // Input labels are gathered from, output labels scattered into, the device-resident store: nothing waits for the
+    // GPU, so the parsing of the next block overlaps the evaluation of this one.  Only the LAST gate of the block that
+    // writes a global wire stores it (streaming.Set in gate order, :346-432: the last write wins).
+    e->io_host.resize((size_t)nin + nout + 1);
+    for (uint32_t i = 0; i < nin; i++) e->io_host[i] = inputs[i];
+    {
+        uint32_t k = 0;
+        for (uint32_t g = 0; g < ngates; g++) {
+            const Dst d = dst_of(g);
+            if (d.tmp) continue;
+            e->io_host[nin + k++] = (uint32_t)e->last_w[d.idx] == g ? d.idx : 0xffffffffu;
+        }
     }
-    int rc = gc_eval(circ, e->key.data(), e->key.size(), 1, nullptr, inl.data(), slab.data(), slab.size(), outl.data());
+    gc_ctx *ctx = e->ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        GC_HIP(hipSetDevice(ctx->device));
+        int rcs = e->store.flush(ctx);
+        if (rcs != GC_OK) return rcs;
+        hipError_t er = grow(&e->d_io, &e->io_cap, e->io_host.size());
+        if (er == hipSuccess)
+            er = hipMemcpyAsync(e->d_io, e->io_host.data(), e->io_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (er != hipSuccess) {
+            set_error("gc_stream_eval_circuit", er);
+            return er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        }
+    }
+    gc_batch *b = nullptr;
+    int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, e->d_io, e->d_io + nin, slab, nrows, &b);
     if (rc != GC_OK) return rc;
-    uint32_t k = 0;
-    for (uint32_t g = 0; g < ngates; g++) {  // streaming.Set(cTmp, cIndex, output) of the global wires, in gate order
-        const Ref &d = dst[g];
-        if (d.tmp) continue;
-        if (d.idx >= e->wires.size()) e->wires.resize((size_t)d.idx + 1, gc_label{0, 0});
-        e->wires[d.idx] = outl[k++];
-    }
+    GC_HIP(hipEventRecord(e->slab_ev[sb], ctx->stream));
+    gc_circ_release_batch(circ, b);
+    for (uint32_t g = 0; g < ngates; g++)
+        if (!(dstp[g] >> 32)) e->store.on_dev[(uint32_t)dstp[g]] = 1;
+    tr.lap("eval: enqueue");
     *consumed = pos;
     return GC_OK;
 } catch (...) {

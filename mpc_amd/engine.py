@@ -85,6 +85,8 @@ def lib():
         "gc_stream_free": (None, [vp]),
         "gc_stream_get_wire": (i32, [vp, u32, vp]),
         "gc_stream_garble": (i32, [vp, vp, u32, u32, vp, u32, vp, u32, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_garble_begin": (i32, [vp, vp, u32, u32, vp, u32, vp, u32]),
+        "gc_stream_garble_finish": (i32, [vp, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
         "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
@@ -543,6 +545,24 @@ class Stream:
         _check(lib().gc_stream_garble(self.h, _p(g), len(g), nwires, _p(i), len(i), _p(o), len(o), _p(buf), len(buf),
                                       C.byref(n)), "gc_stream_garble")
         return buf[: n.value].tobytes()
+
+    def garble_begin(self, gates, nwires, in_, out_):
+        """gc_stream_garble_begin: enqueue one circuit, do not wait (at most two in flight)"""
+        g = np.ascontiguousarray(gates, dtype=GATE)
+        i = np.ascontiguousarray(in_, dtype=np.uint32)
+        o = np.ascontiguousarray(out_, dtype=np.uint32)
+        need = len(g) * 61 + 16
+        buf = getattr(self, "_buf", None)
+        if buf is None or len(buf) < need:
+            self._buf = np.empty(need + need // 2, np.uint8)
+        _check(lib().gc_stream_garble_begin(self.h, _p(g), len(g), nwires, _p(i), len(i), _p(o), len(o)),
+               "gc_stream_garble_begin")
+
+    def garble_finish(self):
+        """gc_stream_garble_finish: the bytes of the oldest circuit in flight"""
+        n = C.c_size_t(0)
+        _check(lib().gc_stream_garble_finish(self.h, _p(self._buf), len(self._buf), C.byref(n)), "gc_stream_garble_finish")
+        return self._buf[: n.value].tobytes()
 
     def close(self):
         if self.h:

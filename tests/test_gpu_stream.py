@@ -224,3 +224,46 @@ def test_stream_outputs_that_are_input_wires():
     z = gg.get(20)["l0"]
     assert int(z["d0"]) == 0 and int(z["d1"]) == 0  # never set
     gg.close(); ctx.close()
+
+
+def test_stream_pipelined_begin_finish_matches_oracle():
+    """gc_stream_garble_begin / _finish with two circuits in flight: the bytes come out in order and equal the oracle's
+    (so does every wire afterwards); a third begin is refused; the evaluator, whose calls return before the GPU is done,
+    decodes the same stream to the oracle's labels"""
+    ctx = engine.Context(0)
+    steps, prim = make_program(0x20000)
+    key = drbg("pkey", 32)
+    rnd = drbg("pipe", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("pbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = gg.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    prog = steps * 3
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in prog]
+    got = []
+    gg.garble_begin(prog[0][0].Gates, prog[0][0].NumWires, prog[0][1], prog[0][2])
+    for k in range(len(prog)):
+        if k + 1 < len(prog):
+            c1, in1, out1 = prog[k + 1]
+            gg.garble_begin(c1.Gates, c1.NumWires, in1, out1)
+            if k + 2 < len(prog):  # two in flight: a third is refused and changes nothing
+                with pytest.raises(engine.EngineError) as e:
+                    gg.garble_begin(prog[k + 2][0].Gates, prog[k + 2][0].NumWires, prog[k + 2][1], prog[k + 2][2])
+                assert e.value.code == engine.GC_E_ARG
+        got.append(gg.garble_finish())
+    assert got == want
+    for c, in_, out_ in prog:
+        for o in out_:
+            assert gg.get(o) == og.get(o)
+    for (c, in_, out_), data in zip(prog, got):  # evaluator: no waiting between blocks
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    for c, in_, out_ in prog:
+        for o in out_:
+            assert ge.get(o) == oe.get(o)
+    gg.close(); ge.close(); ctx.close()
