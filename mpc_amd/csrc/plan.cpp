@@ -603,7 +603,13 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;
     }
-    build_flat(gates, ngates, nwires, ninputs, noutputs, src0, src1, cur, &p);
+    // The flattened plan costs ~0.5 us per gate to build (term lists, bank-aware item order) and is only good for circuits
+    // whose live labels fit the ~5.5 k LDS slots of a one-instance tile.  When the level-walking plan's high-water mark is
+    // more than four times that, flattening (which drops dead and intermediate XOR outputs: aes_128 1.5 k -> 1.05 k labels)
+    // cannot bring it in range: skip it — a streamed 131 072-gate step then costs 25 ms on first use instead of 90.
+    constexpr uint32_t kHopelessLive = 4 * 5500;
+    const bool hopeless = p.n_lds_slots == 0xffffffffu || p.n_lds_slots > kHopelessLive;
+    if (!hopeless || std::getenv("GC_PLAN_ALWAYS_FLAT")) build_flat(gates, ngates, nwires, ninputs, noutputs, src0, src1, cur, &p);
     p.info.n_flat_slots = p.n_flat_slots;
     p.info.n_flat_outs = p.n_flat_outs;
     p.info.n_flat_terms = p.n_flat_terms;
