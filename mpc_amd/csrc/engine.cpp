@@ -250,7 +250,8 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
     }
     if (rc == GC_OK) {
         c->ctx = ctx;
-        rc = build_plan(gates, ngates, nwires, ninputs, noutputs, &c->plan.p);
+        // the flattened plan (70 % of the build) is deferred: ONE instance of a wide circuit never needs it
+        rc = build_plan(gates, ngates, nwires, ninputs, noutputs, &c->plan.p, /*defer_flat=*/true);
     }
     if (rc == GC_OK) {
         const Plan &p = c->plan.p;
@@ -275,19 +276,6 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
         up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
         up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
         up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
-        {
-            // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
-            // stage buffer of zero padding behind the real data
-            std::vector<uint32_t> prog(p.fl_prog);
-            prog.resize(prog.size() + 4 * 1024, 0);
-            std::vector<FUnit> units(p.fl_units);
-            units.resize(units.size() + 2, FUnit{});
-            up((void **)&c->d_fl_prog, prog.data(), prog.size() * sizeof(uint32_t));
-            up((void **)&c->d_fl_units, units.data(), units.size() * sizeof(FUnit));
-        }
-        up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
-        up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
-        up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -330,7 +318,47 @@ void gc_circ_free(gc_circ *c) {
     delete c;
 }
 
-const gc_plan *gc_circ_plan(const gc_circ *c) { return c ? &c->plan : nullptr; }
+// Flattened plan + its device arrays, on first demand (thread-safe; a failure leaves the circuit without a flattened
+// plan: the level-walking / HBM-wire kernels serve it)
+static void circ_ensure_flat(gc_circ *c) {
+    std::lock_guard<std::mutex> lk(c->flat_mu);
+    if (c->flat_ready) return;
+    c->flat_ready = true;
+    Plan &p = c->plan.p;
+    finish_flat(&p);
+    if (p.n_flat_slots == 0xffffffffu) return;
+    hipError_t e = hipSetDevice(c->ctx->device);
+    auto up = [&](void **dptr, const void *src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(dptr, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+    };
+    {
+        // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
+        // stage buffer of zero padding behind the real data
+        std::vector<uint32_t> prog(p.fl_prog);
+        prog.resize(prog.size() + 4 * 1024, 0);
+        std::vector<FUnit> units(p.fl_units);
+        units.resize(units.size() + 2, FUnit{});
+        up((void **)&c->d_fl_prog, prog.data(), prog.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_units, units.data(), units.size() * sizeof(FUnit));
+    }
+    up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
+    up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
+    up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));
+    if (e != hipSuccess) {  // no device arrays: behave as if the circuit had no flattened plan
+        set_error("circ_ensure_flat", e);
+        p.n_flat_slots = 0xffffffffu;
+        p.info.n_flat_slots = 0xffffffffu;
+    }
+}
+
+// introspection wants the whole plan
+const gc_plan *gc_circ_plan(const gc_circ *c) {
+    if (!c) return nullptr;
+    circ_ensure_flat(const_cast<gc_circ *>(c));
+    return &c->plan;
+}
 
 int gc_circ_set_schedule(gc_circ *c, int schedule) {
     if (!c || schedule < 0 || schedule > 2) return GC_E_ARG;
@@ -359,7 +387,14 @@ static void free_buffers(gc_batch *b) {
 // The flattened kernels are the choice unless every wire has to be materialised (store_all), schedule 2 was asked
 // for, or the circuit has no flattened plan.  They address a tile's table rows with 32-bit BYTE offsets:
 // slab_rows * 64 instances * 16 B < 2^32 (a circuit with >= 4 Mi table rows does not fit an LDS plan anyway).
+// ONE instance of a wide circuit: one launch per level with the gates on the lanes (run_levels); needs no LDS plan
+static bool one_wide(const gc_batch *b) {
+    return b->schedule == 1 && b->g.batch == 1 && !b->d_prof && wide_for_one_instance(b->circ->plan.p, false);
+}
+
 static bool want_flat(const gc_batch *b) {
+    if (one_wide(b)) return false;
+    circ_ensure_flat(b->circ);
     const Plan &p = b->circ->plan.p;
     return !b->store_all && !b->single_phase && p.n_flat_slots != 0xffffffffu && p.info.slab_rows < (1u << 22);
 }
@@ -367,7 +402,7 @@ static bool want_flat(const gc_batch *b) {
 static BatchGeom geom_for(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
     const bool flat = want_flat(b);
-    const uint32_t nls = flat ? p.n_flat_slots : p.n_lds_slots;
+    const uint32_t nls = one_wide(b) ? 0xffffffffu : flat ? p.n_flat_slots : p.n_lds_slots;
     // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
     const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
     return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat, p.fl_unit_stride);

@@ -65,6 +65,8 @@ struct gc_circ {
     gc::FUnit *d_fl_units = nullptr;
     uint32_t *d_fl_hgslot = nullptr, *d_fl_ogslot = nullptr;
     uint16_t *d_fl_in_lds = nullptr;
+    std::mutex flat_mu;       // the flattened plan and its device arrays are built on first demand (circ_ensure_flat)
+    bool flat_ready = false;
     int schedule = 1;  // default schedule of pooled batches
     bool single_phase = false;
     std::mutex pool_mu;

@@ -31,7 +31,17 @@ static void symdiff(const std::vector<uint32_t> &a, const std::vector<uint32_t> 
     }
 }
 
-static void build_flat(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+namespace {
+struct OpView {  // build_flat only reads gates[g].op: it runs from the gate list or from the ops kept for a deferred build
+    const uint8_t *ops;
+    struct G {
+        uint8_t op;
+    };
+    G operator[](uint32_t g) const { return G{ops[g]}; }
+};
+}  // namespace
+
+static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
                        const std::vector<uint32_t> &src0, const std::vector<uint32_t> &src1,
                        const std::vector<uint32_t> &cur, Plan *out) {
     Plan &p = *out;
@@ -375,8 +385,30 @@ int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits) {
     return GC_OK;
 }
 
+bool wide_for_one_instance(const Plan &p, bool eval) {
+    const uint64_t passes = eval ? p.passes_eval : p.passes_garble;
+    return p.levels.size() >= 2 && passes * 2 >= (uint64_t)p.levels.size() * 5;
+}
+
+void finish_flat(Plan *pp) {
+    Plan &p = *pp;
+    if (p.flat_built) return;
+    build_flat(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
+               p.lazy_src1, p.lazy_cur, &p);
+    p.flat_built = true;
+    p.info.n_flat_slots = p.n_flat_slots;
+    p.info.n_flat_outs = p.n_flat_outs;
+    p.info.n_flat_terms = p.n_flat_terms;
+    p.info.n_flat_steps = p.n_flat_steps;
+    p.info.n_flat_units = (uint32_t)p.fl_units.size();
+    std::vector<uint8_t>().swap(p.lazy_ops);
+    std::vector<uint32_t>().swap(p.lazy_src0);
+    std::vector<uint32_t>().swap(p.lazy_src1);
+    std::vector<uint32_t>().swap(p.lazy_cur);
+}
+
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
-               Plan *out) {
+               Plan *out, bool defer_flat) {
     if ((!gates && ngates) || !out) return GC_E_ARG;
     if (ninputs > nwires || noutputs > nwires) return GC_E_ARG;
     if ((uint64_t)ninputs + ngates >= 0xffffffffull) return GC_E_ARG;
@@ -603,18 +635,18 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;
     }
-    // The flattened plan costs ~0.5 us per gate to build (term lists, bank-aware item order) and is only good for circuits
-    // whose live labels fit the ~5.5 k LDS slots of a one-instance tile.  When the level-walking plan's high-water mark is
-    // more than four times that, flattening (which drops dead and intermediate XOR outputs: aes_128 1.5 k -> 1.05 k labels)
-    // cannot bring it in range: skip it — a streamed 131 072-gate step then costs 25 ms on first use instead of 90.
-    constexpr uint32_t kHopelessLive = 4 * 5500;
-    const bool hopeless = p.n_lds_slots == 0xffffffffu || p.n_lds_slots > kHopelessLive;
-    if (!hopeless || std::getenv("GC_PLAN_ALWAYS_FLAT")) build_flat(gates, ngates, nwires, ninputs, noutputs, src0, src1, cur, &p);
-    p.info.n_flat_slots = p.n_flat_slots;
-    p.info.n_flat_outs = p.n_flat_outs;
-    p.info.n_flat_terms = p.n_flat_terms;
-    p.info.n_flat_steps = p.n_flat_steps;
-    p.info.n_flat_units = (uint32_t)p.fl_units.size();
+    for (const Step &st : p.levels) {  // passes of 1024 lanes per level for ONE instance (kernels.h: level1_passes)
+        const uint32_t fr = st.count - st.nonfree;
+        p.passes_garble += (((st.n_and + st.n_or) << 2) + (st.n_inv << 1) + fr + 1023) / 1024;
+        p.passes_eval += ((st.n_and << 1) + st.n_or + st.n_inv + fr + 1023) / 1024;
+    }
+    p.lazy_ops.resize(ngates);
+    for (uint32_t g = 0; g < ngates; g++) p.lazy_ops[g] = gates[g].op;
+    p.lazy_src0.swap(src0);
+    p.lazy_src1.swap(src1);
+    p.lazy_cur.swap(cur);
+    p.info.n_flat_slots = 0xffffffffu;
+    if (!defer_flat) finish_flat(&p);
     return GC_OK;
 }
 

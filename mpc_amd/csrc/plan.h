@@ -137,11 +137,23 @@ struct Plan {
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
     uint32_t n_lds_slots = 0;           // high-water mark of live labels
     uint32_t n_hash_phases = 0;
+    // The flattened plan is 70 % of the build time (~0.5 us per gate) and some users never need it (ONE instance of a wide
+    // circuit runs level launches, kernels.h): build_plan(..., defer_flat) keeps what build_flat needs instead
+    // (gate ops and the resolved producers of pass 1) and finish_flat() builds it on first demand.
+    bool flat_built = false;
+    std::vector<uint8_t> lazy_ops;                          // op of every gate
+    std::vector<uint32_t> lazy_src0, lazy_src1, lazy_cur;   // producer of input 0 / 1 of every gate, of every wire
+    uint32_t passes_garble = 0, passes_eval = 0;            // 1024-lane passes of all levels, one instance (kernels.h)
 };
 
 // returns GC_OK or GC_E_GATE / GC_E_WIRE / GC_E_ARG
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
-               Plan *out);
+               Plan *out, bool defer_flat = false);
+// builds the flattened schedule of a plan made with defer_flat (no-op once built); not thread-safe: callers serialise
+void finish_flat(Plan *p);
+// ONE instance of this circuit is better off as one launch per level with the level's passes spread over workgroups
+// (its levels average >= 2.5 passes of 1024 lanes) than as a single workgroup walking it
+bool wide_for_one_instance(const Plan &p, bool eval);
 
 // plaintext walk of the flattened unit program (host-side self-check, see plan.cpp)
 int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits);
