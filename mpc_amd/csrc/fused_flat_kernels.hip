@@ -332,10 +332,12 @@ __device__ __forceinline__ uint32_t whiten_col(uint32_t xc, uint32_t xc1, uint32
     return xor3(kcol, c == 3 ? tweak : 0u, k0);
 }
 
-template <int NR>
+template <int NR, bool PROF = false>
 __device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
                                                    uint32_t tim, uint4 *wl, const uint4 *rl, uint4 *Tt, uint4 *Wt,
-                                                   uint32_t lo, const HashSplit hs) {
+                                                   uint32_t lo, const HashSplit hs, uint64_t *pacc = nullptr,
+                                                   uint64_t *plast_p = nullptr) {
+    uint64_t plast = PROF ? *plast_p : 0;
     const uint32_t TI = 1u << ti_log2;
     const uint32_t j = threadIdx.x - hs.tail_tid;  // column lane j = 4 * (block of the tail) + column
     if (threadIdx.x < hs.tail_tid || j >= 4u * hs.tail) return;
@@ -356,7 +358,10 @@ __device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit
     const uint32_t k0 = lds_word(keyaddr);
     const uint32_t modd = (q & 1u) ? ~0u : 0u;
     const uint32_t xc = __builtin_amdgcn_bitop3_b32(bc, rc, modd, 0x78), xc1 = __builtin_amdgcn_bitop3_b32(bc1, rc1, modd, 0x78);
+    GC_FPROF(6)
     const uint32_t h = hash_col_whitened<NR>(whiten_col(xc, xc1, c, d.tweak + (q >> 1), k0), keyaddr, lo);
+    GC_FPROF(7)
+    if constexpr (PROF) *plast_p = plast;
     const uint32_t rowb = ((((d.row_op & kRowMask) << ti_log2) + inst) << 4) + wo;
     auto row = [&](uint32_t r) -> uint32_t & { return *(uint32_t *)((char *)Tt + (rowb + (r << 4))); };
     auto put = [&](uint32_t v) {
@@ -385,10 +390,11 @@ __device__ __forceinline__ void garble_hash_narrow(const uint4 *buf, const FUnit
     }
 }
 
-template <int NR>
+template <int NR, bool PROF = false>
 __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &u, const FlArgs &a, uint32_t ti_log2,
                                                  uint32_t tim, uint4 *wl, const uint4 *Tt, uint4 *Wt, uint32_t lo,
-                                                 const HashSplit hs) {
+                                                 const HashSplit hs, uint64_t *pacc = nullptr, uint64_t *plast_p = nullptr) {
+    uint64_t plast = PROF ? *plast_p : 0;
     const uint32_t TI = 1u << ti_log2;
     const uint32_t j = threadIdx.x - hs.tail_tid;
     if (threadIdx.x < hs.tail_tid || j >= 4u * hs.tail) return;
@@ -404,7 +410,10 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
     const uint32_t tab = *(const uint32_t *)((const char *)Tt + (rowb + ((q ? TI : 0u) << 4)));  // lands during the AES
     const uint32_t xc = lds_word(so + wo), xc1 = lds_word(so + (wo1 & 12u)), xy = lds_word(so + 4);
     const uint32_t ac = lds_word(sa + wo), k0 = lds_word(keyaddr);
+    GC_FPROF(6)
     const uint32_t h = hash_col_whitened<NR>(whiten_col(xc, xc1, c, d.tweak + q, k0), keyaddr, lo);
+    GC_FPROF(7)
+    if constexpr (PROF) *plast_p = plast;
     const uint32_t sm = (uint32_t)((int32_t)xy >> 31);
     auto put = [&](uint32_t v) {
         if (q == 0) {
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
         GC_FPROF(0)
         const uint32_t e_hash = hlanes<2, 2, 1>(u, ti_log2);
         if (nh && u.n_or == 0 && e_hash <= kNarrowLanes) {  // a narrow unit: column-sliced as a whole
-            garble_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo, HashSplit{0, e_hash, 0});
+            garble_hash_narrow<NR, PROF>(buf, u, a, ti_log2, tim, wl, rl, Tt, Wt, lo, HashSplit{0, e_hash, 0}, pacc, &plast);
         } else if (nh) {
             // wide form for whole sets of four waves, column-sliced form for what is left of the last pass
             const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0, kTailMaxGarble);
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
         GC_FPROF(0)
         const uint32_t e_hash = hlanes<1, 0, 0>(u, ti_log2);
         if (nh && u.n_or == 0 && e_hash <= kNarrowLanes) {  // a narrow unit: column-sliced as a whole
-            eval_hash_narrow<NR>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo, HashSplit{0, e_hash, 0});
+            eval_hash_narrow<NR, PROF>(buf, u, a, ti_log2, tim, wl, Tt, Wt, lo, HashSplit{0, e_hash, 0}, pacc, &plast);
         } else if (nh) {
             // wide form for whole sets of four waves, column-sliced form for what is left of the last pass
             const HashSplit hs = split_hash_lanes(e_hash, u.n_or != 0);

@@ -324,6 +324,11 @@ struct CircuitHash {  // incremental form: the evaluator hashes while it renumbe
         v = (v ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
         v = (v ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
     }
+    inline void mix(uint32_t i, const CircKey &g) {
+        uint64_t &v = h[i & 3];
+        v = (v ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
+        v = (v ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
+    }
     uint64_t done() const {
         uint64_t r = 0;
         for (int l = 0; l < 4; l++) r = (r ^ h[l]) * kPrime + (r >> 29);
@@ -356,6 +361,28 @@ gc_circ *cache_find(const CircCache &cache, uint64_t h, const gc_gate *gates, ui
         if (same) return e.circ;
     }
     return nullptr;
+}
+
+// the same on the evaluator's packed gate records (16 bytes, no padding: one memcmp)
+gc_circ *cache_find_keys(const CircCache &cache, uint64_t h, const std::vector<CircKey> &keys, uint32_t nwires, uint32_t nin,
+                         uint32_t nout) {
+    static_assert(sizeof(CircKey) == 16, "CircKey must be four packed words");
+    auto range = cache.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        const CircEntry &e = it->second;
+        if (e.gates.size() != keys.size() || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
+        if (std::memcmp(e.gates.data(), keys.data(), keys.size() * sizeof(CircKey)) == 0) return e.circ;
+    }
+    return nullptr;
+}
+
+void cache_put_keys(CircCache &cache, uint64_t h, gc_circ *circ, const std::vector<CircKey> &keys, uint32_t nwires,
+                    uint32_t nin, uint32_t nout) {
+    CircEntry e;
+    e.circ = circ;
+    e.nwires = nwires, e.nin = nin, e.nout = nout;
+    e.gates = keys;
+    cache.emplace(h, std::move(e));
 }
 
 void cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
@@ -644,7 +671,8 @@ struct gc_stream_eval {
     // per-circuit scratch, kept across calls: last writer of every tmp / global wire with a generation stamp
     std::vector<uint64_t> last_t, last_w;  // per tmp / global wire: generation stamp << 32 | current id (one load per look-up)
     uint32_t gen = 0;
-    std::vector<gc_gate> gates;
+    std::vector<gc_gate> gates;       // only materialised for a circuit the cache does not know
+    std::vector<CircKey> keys;        // the block's gates as packed records {in0, in1, out, op}
     std::vector<uint64_t> dst_pack;   // per gate: destination index | tmp flag << 32 (parser scratch, kept across calls)
     std::vector<uint32_t> in_idx, id_of;
     // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
@@ -734,7 +762,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         e->gen = 1;
     }
     const uint32_t gen = e->gen;
-    std::vector<gc_gate> &gates = e->gates;
+    std::vector<CircKey> &gates = e->keys;
     const uint32_t sb = e->slab_turn & 1u;
     e->slab_turn++;
     {
@@ -753,12 +781,14 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     gc_label *slab = e->slab_pin[sb];
     size_t nrows = 0;
     gates.resize(ngates);
-    struct Dst { bool tmp; uint32_t idx; };
-    std::vector<uint64_t> &dstp = e->dst_pack;  // no per-call allocation: a block has ~10^5 gates
-    std::vector<uint32_t> &inputs = e->in_idx;
-    dstp.resize(ngates);
+    // The cache is keyed on the block AS PARSED — {in0, in1, writes-a-tmp, op} per gate, operands named by the gate
+    // that wrote them (bit 31: the k-th distinct input) — which fixes the device circuit completely; its wire ids
+    // (inputs, tmp-writing gates, global-writing gates) are only worked out when the cache does not know the block.
+    std::vector<uint64_t> &glob = e->dst_pack;  // (gate << 32 | global wire) of the gates that write a global wire
+    std::vector<uint32_t> &inputs = e->in_idx;  // no per-call allocation: a block has ~10^5 gates
+    glob.clear();
     inputs.clear();
-    auto dst_of = [&](uint32_t g) { return Dst{(dstp[g] >> 32) != 0, (uint32_t)dstp[g]}; };
+    CircuitHash ph(ngates, 0, 0, 0);
     auto load_be64 = [](const uint8_t *p) {
         uint64_t v;
         std::memcpy(&v, p, 8);
@@ -813,13 +843,14 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             e->last_w[idx] = ((uint64_t)gen << 32) | id;
             return id;
         };
-        gates[g].in0 = use(at, w[0]);
-        gates[g].in1 = nw == 3 ? use(bt, w[1]) : gates[g].in0;
+        CircKey &k = gates[g];
+        k.in0 = use(at, w[0]);
+        k.in1 = nw == 3 ? use(bt, w[1]) : k.in0;
         if (err != GC_OK) return err;
-        gates[g].op = gop;
-        gates[g].level = 0;
+        k.op = gop;
+        k.out = ct ? 1u : 0u;
+        ph.mix(g, k);
         const uint32_t ci = w[nw - 1];
-        dstp[g] = (uint64_t)ci | ((uint64_t)(ct ? 1 : 0) << 32);
         if (ct) {
             if (ci >= ntmp) return GC_E_ARG;
             e->last_t[ci] = ((uint64_t)gen << 32) | g;
@@ -827,37 +858,35 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             if (ci >= nwires) return GC_E_ARG;
             if (ci >= e->last_w.size()) e->last_w.resize((size_t)ci + 1 + e->last_w.size() / 2, 0);
             e->last_w[ci] = ((uint64_t)gen << 32) | g;
-            n_global++;
+            glob.push_back(((uint64_t)g << 32) | ci);
         }
-        gates[g].out = g;  // gate index for now; numbered below
     }
+    n_global = (uint32_t)glob.size();
     tr.lap("eval: parse");
     const uint32_t nin = (uint32_t)inputs.size(), nout = n_global, n_tmp = ngates - n_global;
-    uint64_t h = 0;
-    {
+    const uint32_t cw = nin + ngates;
+    const uint64_t h = ((ph.done() ^ nin) * CircuitHash::kPrime ^ nout) * CircuitHash::kPrime;
+    // device circuit, cached by content
+    gc_circ *circ = cache_find_keys(e->cache, h, gates, cw, nin, nout);
+    if (!circ) {
+        // wire ids of the device circuit: inputs, then the tmp-writing gates, then the global-writing gates
+        int st = GC_OK;
         std::vector<uint32_t> &id_of = e->id_of;
         id_of.resize(ngates);
         uint32_t kt = 0, kg = 0;
-        for (uint32_t g = 0; g < ngates; g++) id_of[g] = (dstp[g] >> 32) ? nin + kt++ : nin + n_tmp + kg++;
-        CircuitHash ch(ngates, nin + ngates, nin, nout);
+        for (uint32_t g = 0; g < ngates; g++) id_of[g] = gates[g].out ? nin + kt++ : nin + n_tmp + kg++;
+        std::vector<gc_gate> &full = e->gates;
+        full.assign(ngates, gc_gate{});
+        auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : id_of[v]; };
         for (uint32_t g = 0; g < ngates; g++) {
-            auto fix = [&](uint32_t v) { return (v & 0x80000000u) ? (v & 0x7fffffffu) : id_of[v]; };
-            gates[g].in0 = fix(gates[g].in0);
-            gates[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
-            gates[g].out = id_of[g];
-            ch.mix(g, gates[g]);
+            full[g].in0 = fix(gates[g].in0);
+            full[g].in1 = gates[g].op == GC_INV ? 0 : fix(gates[g].in1);
+            full[g].out = id_of[g];
+            full[g].op = (uint8_t)gates[g].op;
         }
-        h = ch.done();
-    }
-    const uint32_t cw = nin + ngates;
-    tr.lap("eval: renumber");
-    // device circuit, cached by content
-    gc_circ *circ = cache_find(e->cache, h, gates.data(), ngates, cw, nin, nout);
-    if (!circ) {
-        int st = GC_OK;
-        circ = gc_circ_load(e->ctx, gates.data(), ngates, cw, nin, nout, &st);
+        circ = gc_circ_load(e->ctx, full.data(), ngates, cw, nin, nout, &st);
         if (!circ) return st;
-        cache_put(e->cache, h, circ, gates.data(), ngates, cw, nin, nout);
+        cache_put_keys(e->cache, h, circ, gates, cw, nin, nout);
     }
     tr.lap("eval: hash + cache");
     // Input labels are gathered from, output labels scattered into, the device-resident store: nothing waits for the
@@ -865,13 +894,9 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     // writes a global wire stores it (streaming.Set in gate order, :346-432: the last write wins).
     e->io_host.resize((size_t)nin + nout + 1);
     for (uint32_t i = 0; i < nin; i++) e->io_host[i] = inputs[i];
-    {
-        uint32_t k = 0;
-        for (uint32_t g = 0; g < ngates; g++) {
-            const Dst d = dst_of(g);
-            if (d.tmp) continue;
-            e->io_host[nin + k++] = (uint32_t)e->last_w[d.idx] == g ? d.idx : 0xffffffffu;
-        }
+    for (uint32_t k = 0; k < nout; k++) {
+        const uint32_t g = (uint32_t)(glob[k] >> 32), idx = (uint32_t)glob[k];
+        e->io_host[nin + k] = (uint32_t)e->last_w[idx] == g ? idx : 0xffffffffu;
     }
     gc_ctx *ctx = e->ctx;
     {
@@ -892,8 +917,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     if (rc != GC_OK) return rc;
     GC_HIP(hipEventRecord(e->slab_ev[sb], ctx->stream));
     gc_circ_release_batch(circ, b);
-    for (uint32_t g = 0; g < ngates; g++)
-        if (!(dstp[g] >> 32)) e->store.on_dev[(uint32_t)dstp[g]] = 1;
+    for (uint32_t k = 0; k < nout; k++) e->store.on_dev[(uint32_t)glob[k]] = 1;
     tr.lap("eval: enqueue");
     *consumed = pos;
     return GC_OK;
