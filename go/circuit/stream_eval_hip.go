@@ -131,6 +131,16 @@ func (stream *StreamEval) evalBlock(conn *p2p.Conn, numGates, numTmpWires, numWi
 	return nil
 }
 
+// Stats reports how many OpCircuit blocks were decoded gate by gate and how many were recognised as a block seen before
+// up to their rows and global wires (gc_stream_eval_stats; additive, for logging next to the timing lines).
+func (stream *StreamEval) Stats() (parsed, matched uint64) {
+	var p, m C.uint64_t
+	if stream.h != nil {
+		C.gc_stream_eval_stats(stream.h, &p, &m)
+	}
+	return uint64(p), uint64(m)
+}
+
 // Close releases the device state (additive).
 func (stream *StreamEval) Close() {
 	if stream.h != nil {

@@ -250,6 +250,10 @@ int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /*
  * nothing is sized by it before these checks, and allocation failures come back as GC_E_NOMEM. */
 int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
                            size_t len, size_t *consumed);
+/* Blocks handed to gc_stream_eval_circuit so far: parsed[0] gate by gate, parsed[1] recognised as a block seen before up
+ * to its table rows and the global wires it is bound to (same op / flag bytes and tmp ids at the same offsets, global ids
+ * repeating in the same pattern): those are not decoded again.  Either pointer may be NULL. */
+int gc_stream_eval_stats(const gc_stream_eval *, uint64_t *parsed, uint64_t *matched);
 
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,

@@ -660,6 +660,28 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
 
 }  // extern "C"
 
+// Byte skeleton of a block the evaluator has parsed before.  A stream repeats its circuits (every call of a function
+// compiles to the same block up to the global wires it is bound to), and the garbler serialises a given circuit the same
+// way every time: the same op / flag bytes and tmp ids at the same offsets, only the table rows and the global ids
+// differ.  A new block that equals a skeleton on every other byte, and whose global ids repeat in the same pattern, IS
+// that circuit: no gate is decoded, the rows are copied out, the global ids are read at their known offsets.
+struct EvalSkel {
+    struct Chunk {
+        uint32_t cmp;    // bytes that must equal the reference block
+        uint16_t skip;   // then a global id field (2 / 4 bytes), 0: none
+        uint16_t nrows;  // then table rows (16 bytes each)
+    };
+    size_t nbytes = 0;
+    uint32_t nrows = 0, nin = 0, nout = 0;
+    gc_circ *circ = nullptr;                 // owned by the stream's circuit cache
+    std::vector<uint8_t> bytes;              // the reference block
+    std::vector<Chunk> chunks;
+    std::vector<uint32_t> gf_off;            // global id fields in stream order: byte offset | 1 << 31 for 4-byte ids
+    std::vector<uint32_t> gf_canon;          // index of the first field that names the same wire (the repeat pattern)
+    std::vector<uint32_t> in_gf, out_gf;     // field of input k (its first read) / of the k-th global write
+    std::vector<uint8_t> out_live;           // 0: a later gate of the block writes the same wire (streaming.Set: last wins)
+};
+
 struct gc_stream_eval {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
@@ -675,6 +697,11 @@ struct gc_stream_eval {
     std::vector<CircKey> keys;        // the block's gates as packed records {in0, in1, out, op}
     std::vector<uint64_t> dst_pack;   // per gate: destination index | tmp flag << 32 (parser scratch, kept across calls)
     std::vector<uint32_t> in_idx, id_of;
+    std::unordered_map<uint64_t, std::vector<EvalSkel>> skels;  // by (ngates, ntmp); a few byte layouts per key
+    std::vector<uint32_t> gf_ids, wr_ids;   // scratch: the block's global ids by field / the wires it writes
+    EvalSkel rec;                           // skeleton of the block being parsed (kept when the parse succeeds)
+    bool use_skels = true;                  // GC_STREAM_NO_SKELETON (read at creation): every block is parsed
+    uint64_t n_parsed = 0, n_matched = 0;
     // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
     // may still be in flight while block k + 1 is parsed
     gc_label *slab_pin[2] = {nullptr, nullptr};
@@ -695,6 +722,7 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
     if (e) {
         e->ctx = ctx;
         e->key.assign(key, key + keylen);
+        e->use_skels = std::getenv("GC_STREAM_NO_SKELETON") == nullptr;
     }
     if (status) *status = rc;
     return e;
@@ -728,6 +756,13 @@ int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) tr
     return gc::on_exception();
 }
 
+int gc_stream_eval_stats(const gc_stream_eval *e, uint64_t *parsed, uint64_t *matched) {
+    if (!e) return GC_E_ARG;
+    if (parsed) *parsed = e->n_parsed;
+    if (matched) *matched = e->n_matched;
+    return GC_OK;
+}
+
 int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
     if (!e || !l) return GC_E_ARG;
     return e->store.get(e->ctx, w, l);
@@ -756,12 +791,6 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     if (e->last_t.size() < ntmp) {
         e->last_t.resize(ntmp, 0);
     }
-    if (++e->gen == 0) {  // stamp wrap-around
-        std::fill(e->last_t.begin(), e->last_t.end(), 0);
-        std::fill(e->last_w.begin(), e->last_w.end(), 0);
-        e->gen = 1;
-    }
-    const uint32_t gen = e->gen;
     std::vector<CircKey> &gates = e->keys;
     const uint32_t sb = e->slab_turn & 1u;
     e->slab_turn++;
@@ -780,6 +809,109 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }
     gc_label *slab = e->slab_pin[sb];
     size_t nrows = 0;
+    tr.lap("eval: row buffer free");
+    auto load_be64 = [](const uint8_t *p) {
+        uint64_t v;
+        std::memcpy(&v, p, 8);
+        return __builtin_bswap64(v);
+    };
+    auto field_id = [&](uint32_t f) -> uint32_t {  // global id field (offset | 1 << 31 for the 4-byte form)
+        const uint8_t *q = buf + (f & 0x7fffffffu);
+        return (f >> 31) ? ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]
+                         : ((uint32_t)q[0] << 8) | q[1];
+    };
+    // repeat pattern of a block's global ids: per field, the index of the first field naming the same wire
+    // (stamps in last_w under a generation of their own)
+    auto canon_of = [&](const std::vector<uint32_t> &gf_off, std::vector<uint32_t> *ids, const uint32_t *expect,
+                        std::vector<uint32_t> *canon) -> bool {
+        if (++e->gen == 0) {
+            std::fill(e->last_t.begin(), e->last_t.end(), 0);
+            std::fill(e->last_w.begin(), e->last_w.end(), 0);
+            e->gen = 1;
+        }
+        const uint64_t stamp = (uint64_t)e->gen << 32;
+        ids->resize(gf_off.size());
+        if (canon) canon->resize(gf_off.size());
+        for (uint32_t f = 0; f < gf_off.size(); f++) {
+            const uint32_t id = field_id(gf_off[f]);
+            if (id >= nwires) return false;
+            if (id >= e->last_w.size()) e->last_w.resize((size_t)id + 1 + e->last_w.size() / 2, 0);
+            uint32_t first = f;
+            if ((e->last_w[id] >> 32) == e->gen) first = (uint32_t)e->last_w[id];
+            else e->last_w[id] = stamp | f;
+            if (expect && expect[f] != first) return false;
+            if (canon) (*canon)[f] = first;
+            (*ids)[f] = id;
+        }
+        return true;
+    };
+    gc_circ *circ = nullptr;
+    uint32_t nin = 0, nout = 0;
+    size_t pos = 0;
+    std::vector<uint32_t> &gf_ids = e->gf_ids, &wr_ids = e->wr_ids;
+    // ---- a block seen before, up to its rows and global ids?
+    {
+        auto it = e->skels.find(((uint64_t)ngates << 32) | ntmp);
+        if (e->use_skels && it != e->skels.end())
+            for (const EvalSkel &sk : it->second) {
+                if (sk.nbytes > len) continue;
+                const uint8_t *p = buf, *q = sk.bytes.data();
+                size_t nr = 0;
+                bool same = true;
+                for (const EvalSkel::Chunk &c : sk.chunks) {
+                    uint64_t acc = 0;
+                    uint32_t i = 0;
+                    for (; i + 8 <= c.cmp; i += 8) {
+                        uint64_t x, y;
+                        std::memcpy(&x, p + i, 8);
+                        std::memcpy(&y, q + i, 8);
+                        acc |= x ^ y;
+                    }
+                    if (i < c.cmp) {
+                        if (c.cmp >= 8) {  // the last, partial word: re-read the run's final 8 bytes
+                            uint64_t x, y;
+                            std::memcpy(&x, p + c.cmp - 8, 8);
+                            std::memcpy(&y, q + c.cmp - 8, 8);
+                            acc |= x ^ y;
+                        } else {
+                            for (; i < c.cmp; i++) acc |= (uint64_t)(p[i] ^ q[i]);
+                        }
+                    }
+                    if (acc) {
+                        same = false;
+                        break;
+                    }
+                    p += c.cmp + c.skip;
+                    q += c.cmp + c.skip;
+                    for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{load_be64(p), load_be64(p + 8)};
+                    q += 16u * c.nrows;
+                }
+                if (!same || !canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) continue;
+                circ = sk.circ;
+                nin = sk.nin, nout = sk.nout;
+                nrows = nr;
+                pos = sk.nbytes;
+                e->io_host.resize((size_t)nin + nout + 1);
+                for (uint32_t k = 0; k < nin; k++) e->io_host[k] = gf_ids[sk.in_gf[k]];
+                wr_ids.resize(nout);
+                for (uint32_t k = 0; k < nout; k++) {
+                    wr_ids[k] = gf_ids[sk.out_gf[k]];
+                    e->io_host[nin + k] = sk.out_live[k] ? wr_ids[k] : 0xffffffffu;
+                }
+                break;
+            }
+    }
+    if (circ) {
+        e->n_matched++;
+        tr.lap("eval: skeleton match");
+    }
+    if (!circ) {
+    if (++e->gen == 0) {  // stamp wrap-around
+        std::fill(e->last_t.begin(), e->last_t.end(), 0);
+        std::fill(e->last_w.begin(), e->last_w.end(), 0);
+        e->gen = 1;
+    }
+    const uint32_t gen = e->gen;
     gates.resize(ngates);
     // The cache is keyed on the block AS PARSED — {in0, in1, writes-a-tmp, op} per gate, operands named by the gate
     // that wrote them (bit 31: the k-th distinct input) — which fixes the device circuit completely; its wire ids
@@ -788,15 +920,16 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     std::vector<uint32_t> &inputs = e->in_idx;  // no per-call allocation: a block has ~10^5 gates
     glob.clear();
     inputs.clear();
-    CircuitHash ph(ngates, 0, 0, 0);
-    auto load_be64 = [](const uint8_t *p) {
-        uint64_t v;
-        std::memcpy(&v, p, 8);
-        return __builtin_bswap64(v);
+    EvalSkel &rec = e->rec;  // the block's skeleton, recorded on the way
+    rec.chunks.clear(), rec.gf_off.clear(), rec.in_gf.clear(), rec.out_gf.clear();
+    size_t run_start = 0;
+    bool rec_ok = len < 0x7fffffffu;
+    auto cut = [&](size_t at, uint32_t skip, uint32_t rows) {  // the compare run ends at `at`: a global id or rows follow
+        rec.chunks.push_back(EvalSkel::Chunk{(uint32_t)(at - run_start), (uint16_t)skip, (uint16_t)rows});
+        run_start = at + skip + 16u * (size_t)rows;
     };
+    CircuitHash ph(ngates, 0, 0, 0);
     static const uint8_t kRowsOf[5] = {0, 0, 2, 3, 1}, kWiresOf[5] = {3, 3, 3, 3, 2};
-    uint32_t n_global = 0;
-    size_t pos = 0;
     for (uint32_t g = 0; g < ngates; g++) {
         if (pos + 1 > len) return GC_E_ROWS;
         uint8_t gop = buf[pos++];
@@ -806,6 +939,8 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         const int nw = kWiresOf[gop];
         const uint32_t rows = kRowsOf[gop];
         uint32_t w[3] = {0, 0, 0};
+        const size_t idpos = pos;
+        const uint32_t idsz = shortf ? 2u : 4u;
         if (shortf) {
             if (pos + 2 * (size_t)nw + 16 * (size_t)rows > len) return GC_E_ROWS;
             for (int i = 0; i < nw; i++) w[i] = ((uint32_t)buf[pos + 2 * i] << 8) | buf[pos + 2 * i + 1];
@@ -819,12 +954,14 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             }
             pos += 4 * (size_t)nw;
         }
-        for (uint32_t r = 0; r < rows; r++) {
-            slab[nrows++] = gc_label{load_be64(buf + pos), load_be64(buf + pos + 8)};
-            pos += 16;
-        }
+        auto global_field = [&](int i) -> uint32_t {  // field i of this gate names a global wire: its field number
+            const size_t o = idpos + (size_t)idsz * i;
+            cut(o, idsz, 0);
+            rec.gf_off.push_back((uint32_t)o | (shortf ? 0u : 0x80000000u));
+            return (uint32_t)rec.gf_off.size() - 1;
+        };
         int err = GC_OK;
-        auto use = [&](bool t, uint32_t idx) -> uint32_t {  // current id of a wire; bit 31: a circuit input
+        auto use = [&](bool t, uint32_t idx, int field) -> uint32_t {  // current id of a wire; bit 31: a circuit input
             if (t) {
                 if (idx >= ntmp || (e->last_t[idx] >> 32) != gen) {
                     err = GC_E_ARG;
@@ -836,16 +973,18 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                 err = GC_E_ARG;
                 return 0;
             }
+            const uint32_t f = global_field(field);
             if (idx >= e->last_w.size()) e->last_w.resize((size_t)idx + 1 + e->last_w.size() / 2, 0);
             if ((e->last_w[idx] >> 32) == gen) return (uint32_t)e->last_w[idx];
             const uint32_t id = 0x80000000u | (uint32_t)inputs.size();
             inputs.push_back(idx);
+            rec.in_gf.push_back(f);
             e->last_w[idx] = ((uint64_t)gen << 32) | id;
             return id;
         };
         CircKey &k = gates[g];
-        k.in0 = use(at, w[0]);
-        k.in1 = nw == 3 ? use(bt, w[1]) : k.in0;
+        k.in0 = use(at, w[0], 0);
+        k.in1 = nw == 3 ? use(bt, w[1], 1) : k.in0;
         if (err != GC_OK) return err;
         k.op = gop;
         k.out = ct ? 1u : 0u;
@@ -856,18 +995,25 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             e->last_t[ci] = ((uint64_t)gen << 32) | g;
         } else {
             if (ci >= nwires) return GC_E_ARG;
+            rec.out_gf.push_back(global_field(nw - 1));
             if (ci >= e->last_w.size()) e->last_w.resize((size_t)ci + 1 + e->last_w.size() / 2, 0);
             e->last_w[ci] = ((uint64_t)gen << 32) | g;
             glob.push_back(((uint64_t)g << 32) | ci);
         }
+        if (rows) cut(pos, 0, rows);
+        for (uint32_t r = 0; r < rows; r++) {
+            slab[nrows++] = gc_label{load_be64(buf + pos), load_be64(buf + pos + 8)};
+            pos += 16;
+        }
     }
-    n_global = (uint32_t)glob.size();
+    cut(pos, 0, 0);
     tr.lap("eval: parse");
-    const uint32_t nin = (uint32_t)inputs.size(), nout = n_global, n_tmp = ngates - n_global;
+    nin = (uint32_t)inputs.size(), nout = (uint32_t)glob.size();
+    const uint32_t n_tmp = ngates - nout;
     const uint32_t cw = nin + ngates;
     const uint64_t h = ((ph.done() ^ nin) * CircuitHash::kPrime ^ nout) * CircuitHash::kPrime;
     // device circuit, cached by content
-    gc_circ *circ = cache_find_keys(e->cache, h, gates, cw, nin, nout);
+    circ = cache_find_keys(e->cache, h, gates, cw, nin, nout);
     if (!circ) {
         // wire ids of the device circuit: inputs, then the tmp-writing gates, then the global-writing gates
         int st = GC_OK;
@@ -894,10 +1040,30 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     // writes a global wire stores it (streaming.Set in gate order, :346-432: the last write wins).
     e->io_host.resize((size_t)nin + nout + 1);
     for (uint32_t i = 0; i < nin; i++) e->io_host[i] = inputs[i];
+    wr_ids.resize(nout);
+    rec.out_live.resize(nout);
     for (uint32_t k = 0; k < nout; k++) {
         const uint32_t g = (uint32_t)(glob[k] >> 32), idx = (uint32_t)glob[k];
-        e->io_host[nin + k] = (uint32_t)e->last_w[idx] == g ? idx : 0xffffffffu;
+        wr_ids[k] = idx;
+        rec.out_live[k] = (uint32_t)e->last_w[idx] == g;
+        e->io_host[nin + k] = rec.out_live[k] ? idx : 0xffffffffu;
     }
+    // keep the skeleton: the next block of this circuit is matched byte-wise instead of parsed
+    e->n_parsed++;
+    if (e->use_skels && rec_ok) {
+        std::vector<EvalSkel> &v = e->skels[((uint64_t)ngates << 32) | ntmp];
+        if (v.size() >= 8) v.erase(v.begin());
+        EvalSkel sk;
+        sk.nbytes = pos;
+        sk.nrows = (uint32_t)nrows, sk.nin = nin, sk.nout = nout;
+        sk.circ = circ;
+        sk.bytes.assign(buf, buf + pos);
+        sk.chunks = rec.chunks;
+        sk.gf_off = rec.gf_off;
+        sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
+        if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) v.push_back(std::move(sk));
+    }
+    }  // parsed
     gc_ctx *ctx = e->ctx;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -917,7 +1083,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     if (rc != GC_OK) return rc;
     GC_HIP(hipEventRecord(e->slab_ev[sb], ctx->stream));
     gc_circ_release_batch(circ, b);
-    for (uint32_t k = 0; k < nout; k++) e->store.on_dev[(uint32_t)glob[k]] = 1;
+    for (uint32_t k = 0; k < nout; k++) e->store.on_dev[e->wr_ids[k]] = 1;
     tr.lap("eval: enqueue");
     *consumed = pos;
     return GC_OK;

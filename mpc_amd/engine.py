@@ -92,6 +92,7 @@ def lib():
         "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
         "gc_stream_eval_get_wire": (i32, [vp, u32, vp]),
         "gc_stream_eval_circuit": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_eval_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
         "gc_ctx_capture_begin": (i32, [vp]),
@@ -594,6 +595,12 @@ class StreamEval:
         _check(lib().gc_stream_eval_circuit(self.h, ngates, ntmp, nwires, _p(b), len(data), C.byref(n)),
                "gc_stream_eval_circuit")
         return n.value
+
+    def stats(self):
+        """(blocks parsed gate by gate, blocks recognised by their byte skeleton)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().gc_stream_eval_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_stats")
+        return a.value, b.value
 
     def close(self):
         if self.h:

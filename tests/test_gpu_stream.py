@@ -267,3 +267,76 @@ def test_stream_pipelined_begin_finish_matches_oracle():
         for o in out_:
             assert ge.get(o) == oe.get(o)
     gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_evaluator_recognises_repeated_blocks():
+    """one circuit streamed many times under different bindings: the evaluator decodes a block it has seen before only up
+    to its rows and global ids (byte skeleton, gc_stream_eval_stats) — a binding with another repeat pattern among
+    the ids, other id widths, or a changed byte must take the gate-by-gate path, and every label must equal the
+    oracle's StreamEval either way"""
+    import os
+    from mpc_amd.circuit import synthetic_levelised
+    ctx = engine.Context(0)
+    c = synthetic_levelised(6, 40, 0.4, seed=77, ninputs=12, inv_frac=0.1, xnor_frac=0.1)
+    nout = c.num_outputs
+    prim = list(range(40)) + [0x20000 + i for i in range(24)]
+    key = drbg("skelkey", 32)
+    rnd = drbg("skelrnd", 16 * (len(prim) + 1))
+    gg = engine.Stream(ctx, key, rnd, prim)
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    os.environ["GC_STREAM_NO_SKELETON"] = "1"
+    try:
+        gp = engine.StreamEval(ctx, key)  # the same stream, every block parsed
+    finally:
+        del os.environ["GC_STREAM_NO_SKELETON"]
+    bits = np.frombuffer(drbg("skelbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = gg.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        for ev in (ge, oe, gp):
+            ev.set(w, lab)
+    outs = lambda base: [base + i for i in range(nout)]
+    steps = [
+        (prim[0:12], outs(1000), "parse"),                         # first sight
+        (prim[12:24], outs(1100), "match"),                        # same pattern, other wires
+        ([prim[0]] * 2 + prim[2:12], outs(1200), "parse"),         # two inputs name one wire: another circuit
+        ([prim[5]] * 2 + prim[26:36], outs(1300), "match"),
+        (outs(1000)[:12], [outs(1000)[0]] + outs(1400)[1:], "parse"),  # an output lands on an input wire
+        (outs(1100)[:12], [outs(1100)[0]] + outs(1500)[1:], "match"),
+        (prim[40:52], outs(0x30000), "parse"),                     # 32-bit ids: another byte layout
+        (prim[52:64], outs(0x30100), "match"),
+        (prim[24:36], outs(1600), "match"),                        # back to the first layout
+    ]
+    datas = []
+    for in_, out_, how in steps:
+        data = gg.garble(c.Gates, c.NumWires, in_, out_)
+        datas.append((data, max(max(in_), max(out_)) + 1))
+        nw = datas[-1][1]
+        before = ge.stats()
+        for ev in (ge, oe, gp):
+            assert ev.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        after = ge.stats()
+        assert (after[0] - before[0], after[1] - before[1]) == ((1, 0) if how == "parse" else (0, 1)), how
+        for o in out_:
+            assert ge.get(o) == oe.get(o) == gp.get(o)
+    assert gp.stats()[1] == 0
+    # a changed byte outside rows and global ids (an XOR's op byte made XNOR: same lengths) is not the skeleton's block
+    data, nw = datas[1]
+    xor_at = None
+    pos = 0
+    raw = bytearray(data)
+    for g in range(c.NumGates):  # walk the records (stream_garble.go:391-446): op byte, ids, rows
+        op = raw[pos] & 0x0f
+        z = 2 if raw[pos] & 0x10 else 4
+        if op == 0 and xor_at is None:
+            xor_at = pos
+        pos += 1 + z * (2 if op == 4 else 3) + 16 * {0: 0, 1: 0, 2: 2, 3: 3, 4: 1}[op]
+    assert pos == len(raw) and xor_at is not None
+    raw[xor_at] |= 1  # XOR -> XNOR
+    before = ge.stats()
+    for ev in (ge, oe):
+        assert ev.circuit(c.NumGates, c.NumWires, nw, bytes(raw)) == len(raw)
+    assert ge.stats()[0] == before[0] + 1
+    for o in steps[1][1]:
+        assert ge.get(o) == oe.get(o)
+    gg.close(); ge.close(); gp.close(); ctx.close()
