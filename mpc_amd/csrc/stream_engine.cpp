@@ -702,6 +702,7 @@ struct gc_stream_eval {
     EvalSkel rec;                           // skeleton of the block being parsed (kept when the parse succeeds)
     bool use_skels = true;                  // GC_STREAM_NO_SKELETON (read at creation): every block is parsed
     uint64_t n_parsed = 0, n_matched = 0;
+    size_t skel_bytes = 0;                  // reference bytes held by skels (capped: the blocks are the peer's data)
     // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
     // may still be in flight while block k + 1 is parsed
     gc_label *slab_pin[2] = {nullptr, nullptr};
@@ -1050,9 +1051,13 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }
     // keep the skeleton: the next block of this circuit is matched byte-wise instead of parsed
     e->n_parsed++;
-    if (e->use_skels && rec_ok) {
+    constexpr size_t kSkelCap = (size_t)1 << 30;  // beyond 1 GiB of reference blocks every new circuit is parsed each time
+    if (e->use_skels && rec_ok && e->skel_bytes + pos <= kSkelCap) {
         std::vector<EvalSkel> &v = e->skels[((uint64_t)ngates << 32) | ntmp];
-        if (v.size() >= 8) v.erase(v.begin());
+        if (v.size() >= 8) {
+            e->skel_bytes -= v.front().bytes.size();
+            v.erase(v.begin());
+        }
         EvalSkel sk;
         sk.nbytes = pos;
         sk.nrows = (uint32_t)nrows, sk.nin = nin, sk.nout = nout;
@@ -1061,7 +1066,10 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         sk.chunks = rec.chunks;
         sk.gf_off = rec.gf_off;
         sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
-        if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) v.push_back(std::move(sk));
+        if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) {
+            e->skel_bytes += sk.bytes.size();
+            v.push_back(std::move(sk));
+        }
     }
     }  // parsed
     gc_ctx *ctx = e->ctx;
