@@ -271,11 +271,6 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
             up((void **)&c->d_ops, ops.data(), ops.size());
             up((void **)&c->d_row_of_gate, p.row_of_gate.data(), p.row_of_gate.size() * sizeof(uint32_t));
         }
-        up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
-        up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
-        up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
-        up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
-        up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
         if (e != hipSuccess) {
             set_error("gc_circ_load", e);
             rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -326,13 +321,27 @@ static void circ_ensure_flat(gc_circ *c) {
     c->flat_ready = true;
     Plan &p = c->plan.p;
     finish_flat(&p);
-    if (p.n_flat_slots == 0xffffffffu) return;
     hipError_t e = hipSetDevice(c->ctx->device);
     auto up = [&](void **dptr, const void *src, size_t bytes) {
         if (e != hipSuccess) return;
         e = hipMalloc(dptr, bytes ? bytes : 16);
         if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
     };
+    // the level-walking fused schedule (fused_lds_kernels.hip: store_all / schedule 2 / circuits without a flattened plan)
+    up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
+    up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
+    up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
+    up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
+    up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
+    if (e != hipSuccess) {  // without them only the HBM-wire kernels can serve the circuit
+        set_error("circ_ensure_flat", e);
+        p.n_lds_slots = 0xffffffffu;
+        p.info.n_lds_slots = 0xffffffffu;
+        p.n_flat_slots = 0xffffffffu;
+        p.info.n_flat_slots = 0xffffffffu;
+        return;
+    }
+    if (p.n_flat_slots == 0xffffffffu) return;
     {
         // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
         // stage buffer of zero padding behind the real data

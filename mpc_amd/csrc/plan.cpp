@@ -2,6 +2,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -320,202 +321,17 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     emit();
 }
 
-// Host-side self-check of the flattened schedule: evaluates the PLAINTEXT function by walking the exact unit
-// program, LDS slot assignment, part joins and global stores the kernels use, with the kernels' parallel semantics
-// (inside a hash part / an XOR part every read happens before any write).  A slot recycled too early, a missing
-// materialisation or a wrong term list shows up as a wrong output bit — without a GPU.
-int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits) {
-    if (p.n_flat_slots == 0xffffffffu) return GC_E_ARG;
-    const uint32_t nin = p.info.ninputs;
-    std::vector<uint8_t> lds(p.n_flat_slots, 0), glob(p.info.nslots, 0);
-    std::vector<uint8_t> poison(p.n_flat_slots, 0);  // 1 = holds a value, 0 = never written (reads of those are errors)
-    const uint32_t zslot = p.n_flat_slots - 1;
-    poison[zslot] = 1;
-    for (uint32_t w = 0; w < nin; w++) {
-        glob[w] = in_bits[w] & 1;
-        if (p.fl_in_lds[w] != 0xffff) lds[p.fl_in_lds[w]] = glob[w], poison[p.fl_in_lds[w]] = 1;
-    }
-    for (const FUnit &u : p.fl_units) {
-        const uint32_t *img = p.fl_prog.data() + (size_t)u.off16 * 4;
-        const uint32_t nh = u.n_and + u.n_or + u.n_inv;
-        std::vector<std::pair<uint32_t, uint8_t>> writes;
-        for (uint32_t g = 0; g < nh; g++) {
-            const uint32_t lin = img[4 * g], lout = img[4 * g + 1], op = img[4 * g + 3] >> kOpShift;
-            const uint32_t sa = lin & 0xffffu, sb = lin >> 16;
-            if (!poison[sa] || (op != GC_INV && !poison[sb])) return GC_E_WIRE;
-            if ((g < u.n_and) != (op == GC_AND) || (g >= u.n_and + u.n_or) != (op == GC_INV)) return GC_E_GATE;
-            const uint8_t a = lds[sa], b = lds[sb];
-            const uint8_t v = op == GC_AND ? (a & b) : op == GC_OR ? (a | b) : (uint8_t)(a ^ 1);
-            writes.emplace_back(lout & 0xffffu, v);
-            if (lout & kFStoreGlobal) glob[p.fl_hgslot[u.hfirst + g]] = v;
-        }
-        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
-        writes.clear();
-        const uint32_t *outs = img + (size_t)u.outs_off16 * 4;
-        std::vector<uint8_t> partial(u.nout, 0);
-        for (uint32_t o = 0; o < u.nout; o++) {
-            const uint32_t *x = outs + 6 * o;
-            const uint32_t n = x[5] & 0xffffu;
-            uint8_t acc = 0;
-            for (uint32_t k = 0; k < (n > 4 ? 8u : 4u); k++) {  // the kernel reads 4 or 8 slots, padding = zero slot
-                const uint32_t sl = (x[k / 2] >> (16 * (k & 1))) & 0xffffu;
-                if (k < n ? !poison[sl] : sl != zslot) return GC_E_WIRE;
-                acc ^= lds[sl];
-            }
-            partial[o] = acc;
-        }
-        for (uint32_t o = 0; o < u.nout; o++) {
-            const uint32_t *x = outs + 6 * o;
-            const uint32_t flags = x[4] >> 16, slot = x[4] & 0xffffu;
-            if (flags & kXoPart) continue;
-            uint8_t acc = partial[o];
-            const uint32_t parts = (flags & kXoJoin4) ? 4u : (flags & kXoJoin2) ? 2u : 1u;
-            if (parts > u.xparts || o % parts || o + parts > u.nout) return GC_E_ARG;
-            for (uint32_t k = 1; k < parts; k++) {
-                if (!((outs[6 * (o + k) + 4] >> 16) & kXoPart)) return GC_E_ARG;
-                acc ^= partial[o + k];
-            }
-            if (flags & kXoRpar) acc ^= 1;  // XNOR: the garbler's "XOR R once" is the plaintext complement
-            writes.emplace_back(slot, acc);
-            if (flags & kXoStore) glob[p.fl_ogslot[u.ofirst + o]] = acc;
-        }
-        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
-    }
-    for (uint32_t j = 0; j < p.info.noutputs; j++) out_bits[j] = glob[p.out_slots[j]];
-    return GC_OK;
-}
-
-bool wide_for_one_instance(const Plan &p, bool eval) {
-    const uint64_t passes = eval ? p.passes_eval : p.passes_garble;
-    return p.levels.size() >= 2 && passes * 2 >= (uint64_t)p.levels.size() * 5;
-}
-
-void finish_flat(Plan *pp) {
-    Plan &p = *pp;
-    if (p.flat_built) return;
-    build_flat(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
-               p.lazy_src1, p.lazy_cur, &p);
-    p.flat_built = true;
-    p.info.n_flat_slots = p.n_flat_slots;
-    p.info.n_flat_outs = p.n_flat_outs;
-    p.info.n_flat_terms = p.n_flat_terms;
-    p.info.n_flat_steps = p.n_flat_steps;
-    p.info.n_flat_units = (uint32_t)p.fl_units.size();
-    std::vector<uint8_t>().swap(p.lazy_ops);
-    std::vector<uint32_t>().swap(p.lazy_src0);
-    std::vector<uint32_t>().swap(p.lazy_src1);
-    std::vector<uint32_t>().swap(p.lazy_cur);
-}
-
-int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
-               Plan *out, bool defer_flat) {
-    if ((!gates && ngates) || !out) return GC_E_ARG;
-    if (ninputs > nwires || noutputs > nwires) return GC_E_ARG;
-    if ((uint64_t)ninputs + ngates >= 0xffffffffull) return GC_E_ARG;
+// ---- hash-phase schedule + LDS slot allocation of the level-walking fused kernels (fused_lds_kernels.hip) ------------
+// key of a value = (a, x): available after hash phase a and x XOR sub-levels following it.
+//   table-producing gate: runs in hash phase max_a(inputs) + 1       -> key (that, 0)
+//   XOR / XNOR gate:      runs in sub-level x+1 of its inputs' max key -> key (a, x+1)
+// Producer ids: < ninputs = input wire, else ninputs + gate (as in pass 1 of build_plan).  Built with the flattened plan,
+// on first demand (finish_flat): ONE instance of a wide circuit, which takes the level launches, needs neither.
+static void build_fused(const OpView gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+                        const std::vector<uint32_t> &src0, const std::vector<uint32_t> &src1,
+                        const std::vector<uint32_t> &cur, Plan *out) {
     Plan &p = *out;
-    p = Plan{};
-    p.info.ngates = ngates;
-    p.info.nwires = nwires;
-    p.info.ninputs = ninputs;
-    p.info.noutputs = noutputs;
-    p.info.nslots = ninputs + ngates;
-
     const uint32_t NONE = 0xffffffffu;
-    p.level_of_gate.resize(ngates);
-    p.tweak_of_gate.resize(ngates);
-    p.row_of_gate.resize((size_t)ngates + 1);
-    p.slot_of_gate.resize(ngates);
-    p.slot_of_wire.assign(nwires, NONE);
-    for (uint32_t w = 0; w < ninputs; w++) p.slot_of_wire[w] = w;
-
-    // pass 1 (original order): levels, tweaks, rows, resolve reads to the producing gate.
-    // A gate's slot is only known after sorting, so reads are first recorded as
-    // "input wire w" (< ninputs) or "gate g" (ninputs + g).
-    std::vector<uint32_t> wire_level(nwires, 0);
-    std::vector<uint32_t> src0(ngates), src1(ngates);
-    std::vector<uint32_t> cur(nwires, NONE);  // producer id of the wire's current value
-    for (uint32_t w = 0; w < ninputs; w++) cur[w] = w;
-    uint32_t id = 0, row = 0, max_level = 0;
-    for (uint32_t g = 0; g < ngates; g++) {
-        const gc_gate &G = gates[g];
-        if (G.op > GC_INV) return GC_E_GATE;
-        const bool unary = (G.op == GC_INV);
-        if (G.in0 >= nwires || G.out >= nwires || (!unary && G.in1 >= nwires)) return GC_E_WIRE;
-        if (cur[G.in0] == NONE || (!unary && cur[G.in1] == NONE)) return GC_E_WIRE;
-        uint32_t level = wire_level[G.in0];
-        if (!unary) level = std::max(level, wire_level[G.in1]);
-        p.level_of_gate[g] = level;
-        src0[g] = cur[G.in0];
-        src1[g] = unary ? cur[G.in0] : cur[G.in1];
-        p.tweak_of_gate[g] = id;
-        p.row_of_gate[g] = row;
-        switch (G.op) {
-        case GC_AND: id += 2; row += 2; p.info.n_and++; break;
-        case GC_OR: id += 1; row += 3; p.info.n_or++; break;
-        case GC_INV: id += 1; row += 1; p.info.n_inv++; break;
-        case GC_XOR: p.info.n_xor++; break;
-        default: p.info.n_xnor++; break;
-        }
-        if (row > kRowMask) return GC_E_ARG;
-        wire_level[G.out] = level + 1;
-        max_level = std::max(max_level, level + 1);
-        cur[G.out] = ninputs + g;
-    }
-    p.row_of_gate[ngates] = row;
-    p.info.slab_rows = row;
-    p.info.nlevels = max_level;
-
-    // pass 2: stable sort by (level, class)
-    std::vector<uint32_t> order(ngates);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        if (p.level_of_gate[a] != p.level_of_gate[b]) return p.level_of_gate[a] < p.level_of_gate[b];
-        return op_class(gates[a].op) < op_class(gates[b].op);
-    });
-    for (uint32_t k = 0; k < ngates; k++) p.slot_of_gate[order[k]] = ninputs + k;
-    auto slot_of_src = [&](uint32_t s) { return s < ninputs ? s : p.slot_of_gate[s - ninputs]; };
-
-    p.descs.resize(ngates);
-    p.gate_of_desc = order;
-    uint32_t width = 0;
-    for (uint32_t k = 0; k < ngates;) {
-        uint32_t lvl = p.level_of_gate[order[k]];
-        Step st{k, 0, 0, 0, 0, 0};
-        while (k < ngates && p.level_of_gate[order[k]] == lvl) {
-            uint32_t g = order[k];
-            GateDesc &d = p.descs[k];
-            d.in0 = slot_of_src(src0[g]);
-            d.in1 = slot_of_src(src1[g]);
-            d.tweak = p.tweak_of_gate[g];
-            d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
-            if (op_class(gates[g].op) != 3) st.nonfree++;
-            if (gates[g].op == GC_AND) st.n_and++;
-            else if (gates[g].op == GC_OR) st.n_or++;
-            else if (gates[g].op == GC_INV) st.n_inv++;
-            st.count++;
-            k++;
-        }
-        width = std::max(width, st.count);
-        p.levels.push_back(st);
-    }
-    p.info.max_width = width;
-    p.info.n_steps = (uint32_t)p.levels.size();
-
-    for (uint32_t w = ninputs; w < nwires; w++)
-        if (cur[w] != NONE) p.slot_of_wire[w] = slot_of_src(cur[w]);
-    p.out_slots.resize(noutputs);
-    for (uint32_t j = 0; j < noutputs; j++) {
-        uint32_t s = p.slot_of_wire[nwires - noutputs + j];
-        if (s == NONE) return GC_E_WIRE;
-        p.out_slots[j] = s;
-    }
-
-    // ---- hash-phase schedule + LDS slot allocation -------------------------------------------------
-    // key of a value = (a, x): available after hash phase a and x XOR sub-levels following it.
-    //   table-producing gate: runs in hash phase max_a(inputs) + 1       -> key (that, 0)
-    //   XOR / XNOR gate:      runs in sub-level x+1 of its inputs' max key -> key (a, x+1)
-    // Producer ids: < ninputs = input wire, else ninputs + gate (as in pass 1).
-    {
         const uint32_t nprod = ninputs + ngates;
         std::vector<uint32_t> ka(nprod, 0), kx(nprod, 0);
         std::vector<uint64_t> gkey(ngates);
@@ -634,7 +450,214 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
         p.info.n_hash_phases = p.n_hash_phases;
         p.info.n_fused_steps = (uint32_t)p.fsteps.size();
         p.info.n_lds_slots = p.n_lds_slots;
+}
+
+// Host-side self-check of the flattened schedule: evaluates the PLAINTEXT function by walking the exact unit
+// program, LDS slot assignment, part joins and global stores the kernels use, with the kernels' parallel semantics
+// (inside a hash part / an XOR part every read happens before any write).  A slot recycled too early, a missing
+// materialisation or a wrong term list shows up as a wrong output bit — without a GPU.
+int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits) {
+    if (p.n_flat_slots == 0xffffffffu) return GC_E_ARG;
+    const uint32_t nin = p.info.ninputs;
+    std::vector<uint8_t> lds(p.n_flat_slots, 0), glob(p.info.nslots, 0);
+    std::vector<uint8_t> poison(p.n_flat_slots, 0);  // 1 = holds a value, 0 = never written (reads of those are errors)
+    const uint32_t zslot = p.n_flat_slots - 1;
+    poison[zslot] = 1;
+    for (uint32_t w = 0; w < nin; w++) {
+        glob[w] = in_bits[w] & 1;
+        if (p.fl_in_lds[w] != 0xffff) lds[p.fl_in_lds[w]] = glob[w], poison[p.fl_in_lds[w]] = 1;
     }
+    for (const FUnit &u : p.fl_units) {
+        const uint32_t *img = p.fl_prog.data() + (size_t)u.off16 * 4;
+        const uint32_t nh = u.n_and + u.n_or + u.n_inv;
+        std::vector<std::pair<uint32_t, uint8_t>> writes;
+        for (uint32_t g = 0; g < nh; g++) {
+            const uint32_t lin = img[4 * g], lout = img[4 * g + 1], op = img[4 * g + 3] >> kOpShift;
+            const uint32_t sa = lin & 0xffffu, sb = lin >> 16;
+            if (!poison[sa] || (op != GC_INV && !poison[sb])) return GC_E_WIRE;
+            if ((g < u.n_and) != (op == GC_AND) || (g >= u.n_and + u.n_or) != (op == GC_INV)) return GC_E_GATE;
+            const uint8_t a = lds[sa], b = lds[sb];
+            const uint8_t v = op == GC_AND ? (a & b) : op == GC_OR ? (a | b) : (uint8_t)(a ^ 1);
+            writes.emplace_back(lout & 0xffffu, v);
+            if (lout & kFStoreGlobal) glob[p.fl_hgslot[u.hfirst + g]] = v;
+        }
+        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
+        writes.clear();
+        const uint32_t *outs = img + (size_t)u.outs_off16 * 4;
+        std::vector<uint8_t> partial(u.nout, 0);
+        for (uint32_t o = 0; o < u.nout; o++) {
+            const uint32_t *x = outs + 6 * o;
+            const uint32_t n = x[5] & 0xffffu;
+            uint8_t acc = 0;
+            for (uint32_t k = 0; k < (n > 4 ? 8u : 4u); k++) {  // the kernel reads 4 or 8 slots, padding = zero slot
+                const uint32_t sl = (x[k / 2] >> (16 * (k & 1))) & 0xffffu;
+                if (k < n ? !poison[sl] : sl != zslot) return GC_E_WIRE;
+                acc ^= lds[sl];
+            }
+            partial[o] = acc;
+        }
+        for (uint32_t o = 0; o < u.nout; o++) {
+            const uint32_t *x = outs + 6 * o;
+            const uint32_t flags = x[4] >> 16, slot = x[4] & 0xffffu;
+            if (flags & kXoPart) continue;
+            uint8_t acc = partial[o];
+            const uint32_t parts = (flags & kXoJoin4) ? 4u : (flags & kXoJoin2) ? 2u : 1u;
+            if (parts > u.xparts || o % parts || o + parts > u.nout) return GC_E_ARG;
+            for (uint32_t k = 1; k < parts; k++) {
+                if (!((outs[6 * (o + k) + 4] >> 16) & kXoPart)) return GC_E_ARG;
+                acc ^= partial[o + k];
+            }
+            if (flags & kXoRpar) acc ^= 1;  // XNOR: the garbler's "XOR R once" is the plaintext complement
+            writes.emplace_back(slot, acc);
+            if (flags & kXoStore) glob[p.fl_ogslot[u.ofirst + o]] = acc;
+        }
+        for (auto &w : writes) lds[w.first] = w.second, poison[w.first] = 1;
+    }
+    for (uint32_t j = 0; j < p.info.noutputs; j++) out_bits[j] = glob[p.out_slots[j]];
+    return GC_OK;
+}
+
+bool wide_for_one_instance(const Plan &p, bool eval) {
+    const uint64_t passes = eval ? p.passes_eval : p.passes_garble;
+    return p.levels.size() >= 2 && passes * 2 >= (uint64_t)p.levels.size() * 5;
+}
+
+void finish_flat(Plan *pp) {
+    Plan &p = *pp;
+    if (p.flat_built) return;
+    build_fused(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
+                p.lazy_src1, p.lazy_cur, &p);
+    build_flat(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
+               p.lazy_src1, p.lazy_cur, &p);
+    p.flat_built = true;
+    p.info.n_flat_slots = p.n_flat_slots;
+    p.info.n_flat_outs = p.n_flat_outs;
+    p.info.n_flat_terms = p.n_flat_terms;
+    p.info.n_flat_steps = p.n_flat_steps;
+    p.info.n_flat_units = (uint32_t)p.fl_units.size();
+    std::vector<uint8_t>().swap(p.lazy_ops);
+    std::vector<uint32_t>().swap(p.lazy_src0);
+    std::vector<uint32_t>().swap(p.lazy_src1);
+    std::vector<uint32_t>().swap(p.lazy_cur);
+}
+
+int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
+               Plan *out, bool defer_flat) {
+    if ((!gates && ngates) || !out) return GC_E_ARG;
+    const bool tr__ = std::getenv("GC_TRACE") != nullptr;
+    auto t__ = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!tr__) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gc trace] plan: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t__).count());
+        t__ = n;
+    };
+    if (ninputs > nwires || noutputs > nwires) return GC_E_ARG;
+    if ((uint64_t)ninputs + ngates >= 0xffffffffull) return GC_E_ARG;
+    Plan &p = *out;
+    p = Plan{};
+    p.info.ngates = ngates;
+    p.info.nwires = nwires;
+    p.info.ninputs = ninputs;
+    p.info.noutputs = noutputs;
+    p.info.nslots = ninputs + ngates;
+
+    const uint32_t NONE = 0xffffffffu;
+    p.level_of_gate.resize(ngates);
+    p.tweak_of_gate.resize(ngates);
+    p.row_of_gate.resize((size_t)ngates + 1);
+    p.slot_of_gate.resize(ngates);
+    p.slot_of_wire.assign(nwires, NONE);
+    for (uint32_t w = 0; w < ninputs; w++) p.slot_of_wire[w] = w;
+
+    // pass 1 (original order): levels, tweaks, rows, resolve reads to the producing gate.
+    // A gate's slot is only known after sorting, so reads are first recorded as
+    // "input wire w" (< ninputs) or "gate g" (ninputs + g).
+    std::vector<uint32_t> wire_level(nwires, 0);
+    std::vector<uint32_t> src0(ngates), src1(ngates);
+    std::vector<uint32_t> cur(nwires, NONE);  // producer id of the wire's current value
+    for (uint32_t w = 0; w < ninputs; w++) cur[w] = w;
+    uint32_t id = 0, row = 0, max_level = 0;
+    for (uint32_t g = 0; g < ngates; g++) {
+        const gc_gate &G = gates[g];
+        if (G.op > GC_INV) return GC_E_GATE;
+        const bool unary = (G.op == GC_INV);
+        if (G.in0 >= nwires || G.out >= nwires || (!unary && G.in1 >= nwires)) return GC_E_WIRE;
+        if (cur[G.in0] == NONE || (!unary && cur[G.in1] == NONE)) return GC_E_WIRE;
+        uint32_t level = wire_level[G.in0];
+        if (!unary) level = std::max(level, wire_level[G.in1]);
+        p.level_of_gate[g] = level;
+        src0[g] = cur[G.in0];
+        src1[g] = unary ? cur[G.in0] : cur[G.in1];
+        p.tweak_of_gate[g] = id;
+        p.row_of_gate[g] = row;
+        switch (G.op) {
+        case GC_AND: id += 2; row += 2; p.info.n_and++; break;
+        case GC_OR: id += 1; row += 3; p.info.n_or++; break;
+        case GC_INV: id += 1; row += 1; p.info.n_inv++; break;
+        case GC_XOR: p.info.n_xor++; break;
+        default: p.info.n_xnor++; break;
+        }
+        if (row > kRowMask) return GC_E_ARG;
+        wire_level[G.out] = level + 1;
+        max_level = std::max(max_level, level + 1);
+        cur[G.out] = ninputs + g;
+    }
+    p.row_of_gate[ngates] = row;
+    p.info.slab_rows = row;
+    p.info.nlevels = max_level;
+
+    lap("pass 1");
+    // pass 2: stable sort by (level, class)
+    std::vector<uint32_t> order(ngates);
+    {  // counting sort (stable): key = level * 4 + class
+        std::vector<uint32_t> start(((size_t)max_level + 1) * 4 + 1, 0);
+        auto key_of = [&](uint32_t g) { return (size_t)p.level_of_gate[g] * 4 + (size_t)op_class(gates[g].op); };
+        for (uint32_t g = 0; g < ngates; g++) start[key_of(g) + 1]++;
+        for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+        for (uint32_t g = 0; g < ngates; g++) order[start[key_of(g)]++] = g;
+    }
+    lap("sort by level");
+    for (uint32_t k = 0; k < ngates; k++) p.slot_of_gate[order[k]] = ninputs + k;
+    auto slot_of_src = [&](uint32_t s) { return s < ninputs ? s : p.slot_of_gate[s - ninputs]; };
+
+    p.descs.resize(ngates);
+    p.gate_of_desc = order;
+    uint32_t width = 0;
+    for (uint32_t k = 0; k < ngates;) {
+        uint32_t lvl = p.level_of_gate[order[k]];
+        Step st{k, 0, 0, 0, 0, 0};
+        while (k < ngates && p.level_of_gate[order[k]] == lvl) {
+            uint32_t g = order[k];
+            GateDesc &d = p.descs[k];
+            d.in0 = slot_of_src(src0[g]);
+            d.in1 = slot_of_src(src1[g]);
+            d.tweak = p.tweak_of_gate[g];
+            d.row_op = p.row_of_gate[g] | ((uint32_t)gates[g].op << kOpShift);
+            if (op_class(gates[g].op) != 3) st.nonfree++;
+            if (gates[g].op == GC_AND) st.n_and++;
+            else if (gates[g].op == GC_OR) st.n_or++;
+            else if (gates[g].op == GC_INV) st.n_inv++;
+            st.count++;
+            k++;
+        }
+        width = std::max(width, st.count);
+        p.levels.push_back(st);
+    }
+    p.info.max_width = width;
+    p.info.n_steps = (uint32_t)p.levels.size();
+
+    for (uint32_t w = ninputs; w < nwires; w++)
+        if (cur[w] != NONE) p.slot_of_wire[w] = slot_of_src(cur[w]);
+    p.out_slots.resize(noutputs);
+    for (uint32_t j = 0; j < noutputs; j++) {
+        uint32_t s = p.slot_of_wire[nwires - noutputs + j];
+        if (s == NONE) return GC_E_WIRE;
+        p.out_slots[j] = s;
+    }
+
+    lap("descs + levels");
+    lap("hash-phase schedule");
     for (const Step &st : p.levels) {  // passes of 1024 lanes per level for ONE instance (kernels.h: level1_passes)
         const uint32_t fr = st.count - st.nonfree;
         p.passes_garble += (((st.n_and + st.n_or) << 2) + (st.n_inv << 1) + fr + 1023) / 1024;
@@ -646,7 +669,9 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
     p.lazy_src1.swap(src1);
     p.lazy_cur.swap(cur);
     p.info.n_flat_slots = 0xffffffffu;
+    lap("lazy copies");
     if (!defer_flat) finish_flat(&p);
+    lap("flat");
     return GC_OK;
 }
 
