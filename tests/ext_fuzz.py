@@ -55,14 +55,17 @@ bad3 = 0
 for seed in range(max(1, N // 4)):
     rng = np.random.default_rng(91000 + seed)
     base = int(rng.choice([0, 300, 0xff00, 0x10000, 70000]))
-    nsteps = int(rng.integers(1, 5))
+    nsteps = int(rng.integers(1, 9))
     key = drbg("sk%d" % seed, int(rng.choice([16, 24, 32])))
     steps, prim, avail = [], [], []
     nextid = base
     for k in range(nsteps):
         ninputs = int(rng.integers(2, 40))
-        c = random_circuit(rng, ninputs, int(rng.integers(1, 1500)), p_xor=float(rng.choice([0.3, 0.7, 0.9])),
-                           reuse=0.0, nout=int(rng.integers(1, 20)))
+        if steps and rng.random() < 0.5:  # a circuit of an earlier step under a new binding: the evaluator recognises
+            c = steps[int(rng.integers(0, len(steps)))][0]  # the block by its byte skeleton when the ids repeat alike
+        else:
+            c = random_circuit(rng, ninputs, int(rng.integers(1, 1500)), p_xor=float(rng.choice([0.3, 0.7, 0.9])),
+                               reuse=0.0, nout=int(rng.integers(1, 20)))
         in_ = []
         for i in range(c.num_inputs):  # earlier results or fresh primary inputs
             if avail and rng.random() < 0.5:
