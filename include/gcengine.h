@@ -252,7 +252,8 @@ int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uin
                            size_t len, size_t *consumed);
 /* Blocks handed to gc_stream_eval_circuit so far: parsed[0] gate by gate, parsed[1] recognised as a block seen before up
  * to its table rows and the global wires it is bound to (same op / flag bytes and tmp ids at the same offsets, global ids
- * repeating in the same pattern): those are not decoded again.  Either pointer may be NULL. */
+ * repeating in the same pattern): those are not decoded again.  Either pointer may be NULL.  (GC_STREAM_NO_SKELETON in the
+ * environment at gc_stream_eval_create time switches the recognition off: every block is decoded.) */
 int gc_stream_eval_stats(const gc_stream_eval *, uint64_t *parsed, uint64_t *matched);
 
 /* ------------------------------------------------------------------------------------------
