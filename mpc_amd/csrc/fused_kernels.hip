@@ -306,7 +306,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
     // (scripts/prof_fused_synth.py).  Now it is paid once per group, overlapped with the next group's loads.
     // the next level's step record and the descriptors of its first group are fetched before the barrier of the current
     // level (they do not depend on anything the level computes): narrow, deep circuits pay one load latency per level
-    // instead of three
+    // instead of three.  Only the single-pass instantiation takes the prefetched descriptor: in the grouped one the
+    // choice between the two descriptor sources (prefetched registers / a load) is what this compiler has turned into
+    // faulting code under small perturbations of the surrounding loop (the instrumented build on mixed levels, every
+    // variant of the loop tried in round 2), and a level of several passes does not notice one more load latency.
     Step st_next = steps[0];
     LanePos lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
         if (e_all <= (uint32_t)kFusedThreads) garble_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
         else
             for (uint32_t t0 = 0; t0 < e_all; t0 += kGroup * kFusedThreads)
-                garble_group<NR, PROF, kGroup>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
+                garble_group<NR, PROF, kGroup, false>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
         if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
         if (e_all <= (uint32_t)kFusedThreads) eval_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
         else
             for (uint32_t t0 = 0; t0 < e_all; t0 += kGroup * kFusedThreads)
-                eval_group<NR, PROF, kGroup>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
+                eval_group<NR, PROF, kGroup, false>(st, t0, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
         if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
