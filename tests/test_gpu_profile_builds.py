@@ -1,0 +1,72 @@
+"""The instrumented builds of the fused kernels (gc_batch_debug_profile: s_memtime marks around the phases of a unit /
+a level, a developer aid) are separate template instantiations of the production code: they must produce the same
+tables and labels as the plain builds, on every kernel family."""
+import numpy as np
+import pytest
+import torch
+
+from mpc_amd import engine
+from mpc_amd.circuit import synthetic_levelised
+
+pytestmark = pytest.mark.gpu
+KEY = bytes(range(32))
+
+
+def run_pair(ctx, c, batch, schedule=1):
+    dc = engine.DeviceCircuit(ctx, c)
+    res = []
+    for prof in (False, True):
+        gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+        if schedule != 1:
+            gb.set_schedule(schedule); ev.set_schedule(schedule)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(99)
+        d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
+        d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
+        d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
+        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        if prof:
+            gb.debug_profile(True); ev.debug_profile(True)
+        gb.garble(KEY, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(KEY, gb)
+        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        ctx.sync()
+        assert int(d_mis.cpu()[0]) == 0
+        out, bits = d_out.cpu().numpy(), d_bits.cpu().numpy()
+        for i in (0, batch - 1):
+            assert (c.compute_bits(bits[i])[c.NumWires - c.num_outputs:] == out[i]).all()
+        if prof:
+            for b in (gb, ev):
+                assert b.debug_profile(True, read=True).sum() > 0
+        res.append(out)
+        gb.close(); ev.close()
+    assert (res[0] == res[1]).all()
+    dc.close()
+
+
+def test_instrumented_flat_kernels(aes_circ, sha_circ):
+    ctx = engine.Context(0)
+    run_pair(ctx, aes_circ, 64)   # wide units with column-sliced tails
+    run_pair(ctx, sha_circ, 5)    # narrow units
+    ctx.close()
+
+
+def test_instrumented_level_walking_kernels(aes_circ):
+    ctx = engine.Context(0)
+    run_pair(ctx, aes_circ, 40, schedule=2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(128, 1024, 0.17), (14, 2500, 0.3), (900, 64, 0.3)])
+def test_instrumented_hbm_wire_kernels(shape):
+    """levels that mix hash lanes and XOR lanes over several passes (the instrumented build of the grouped passes
+    faulted here in round 2), wide levels with every gate type, and single-pass levels"""
+    L, W, f = shape
+    ctx = engine.Context(0)
+    c = synthetic_levelised(L, W, f, seed=105, ninputs=256, or_frac=0.03 if W == 2500 else 0.0,
+                            inv_frac=0.05 if W == 2500 else 0.0, xnor_frac=0.1 if W == 2500 else 0.0)
+    dc = engine.DeviceCircuit(ctx, c)
+    b = engine.Batch(dc, 64)
+    assert not b.lds_wires
+    b.close(); dc.close()
+    run_pair(ctx, c, 64)
+    ctx.close()
