@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 KEY = bytes(range(32))
 
 
-def run_pair(ctx, c, batch, schedule=1):
+def run_pair(ctx, c, batch, schedule=1, key=KEY):
     dc = engine.DeviceCircuit(ctx, c)
     res = []
     for prof in (False, True):
@@ -27,7 +27,7 @@ def run_pair(ctx, c, batch, schedule=1):
         torch.cuda.synchronize()
         if prof:
             gb.debug_profile(True); ev.debug_profile(True)
-        gb.garble(KEY, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(KEY, gb)
+        gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
         gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
         ctx.sync()
         assert int(d_mis.cpu()[0]) == 0
@@ -69,4 +69,7 @@ def test_instrumented_hbm_wire_kernels(shape):
     assert not b.lds_wires
     b.close(); dc.close()
     run_pair(ctx, c, 64)
+    if W == 1024:  # the AES-128 / AES-192 instantiations of the same kernels
+        run_pair(ctx, c, 64, key=KEY[:16])
+        run_pair(ctx, c, 64, key=KEY[:24])
     ctx.close()
