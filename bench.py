@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
+    ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 5 shape) side measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
@@ -369,6 +370,14 @@ def main():
             # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
             from scripts.bench_host_api import run as host_api_run
             res["host_api"] = host_api_run(batch, 3, key)
+        if world == 1 and not args.no_stream and args.circuit.endswith("aes_128.gcf"):
+            # config 5 shape: ONE instance, chained 131 072-gate steps through gc_stream_* (garbler pipelined with
+            # begin / finish, evaluator over the produced bytes); a bounded sample of scripts/bench_stream.py 130000000
+            from scripts.bench_stream import run as stream_run
+            st = stream_run(20_000_000, key=key, ctx=ctx)
+            res["stream"] = {k: st[k] for k in ("steps", "gates", "steady_ms_per_step", "steady_gates_per_s",
+                                                "eval_steady_ms_per_step", "eval_steady_gates_per_s",
+                                                "first_use_ms_per_circuit", "sha256")}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
     gb.close()
