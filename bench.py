@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 5 shape) side measurement")
+    ap.add_argument("--no-config3", action="store_true", help="skip the sha256xor x 256 + 65 536 OTs pipeline (config 3) side measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
@@ -378,6 +379,11 @@ def main():
             res["stream"] = {k: st[k] for k in ("steps", "gates", "steady_ms_per_step", "steady_gates_per_s",
                                                 "eval_steady_ms_per_step", "eval_steady_gates_per_s",
                                                 "first_use_ms_per_circuit", "sha256")}
+        if world == 1 and not args.no_config3 and args.circuit.endswith("aes_128.gcf"):
+            # config 3: sha256xor x 256, the evaluator's labels through the 65 536-OT IKNP extension + COT pads, all on the
+            # device; every digest checked against hashlib inside (scripts/bench_config3.py)
+            from scripts.bench_config3 import run as config3_run
+            res["config3"] = config3_run(256, 10, key)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
     gb.close()

@@ -6,10 +6,10 @@ OUT=$REPO/gpurun_out/r02_collect
 mkdir -p $OUT
 cd $REPO
 python bench.py > $OUT/bench_b1024.json 2> $OUT/bench_b1024.err; echo "bench rc=$?"
-python bench.py --key-bytes 16 --no-cpu-baseline --no-iknp --no-host-api --no-stream > $OUT/bench_b1024_key16.json 2>/dev/null; echo "bench key16 rc=$?"
-python bench.py --batch 8192 --steps 40 --warmup 5 --no-cpu-baseline --no-iknp --no-host-api --no-stream > $OUT/bench_b8192.json 2>/dev/null; echo "bench 8192 rc=$?"
-python bench.py --force-collective --no-cpu-baseline --no-iknp --no-host-api --no-stream > $OUT/bench_b1024_rccl_1rank.json 2>/dev/null; echo "bench coll rc=$?"
-python bench.py --circuit tests/golden/sha256xor.gcf --batch 256 --steps 50 --warmup 5 --no-cpu-baseline --no-iknp --no-host-api --no-stream > $OUT/bench_sha256xor_b256.json 2>/dev/null; echo "bench sha rc=$?"
+python bench.py --key-bytes 16 --no-cpu-baseline --no-iknp --no-host-api --no-stream --no-config3 > $OUT/bench_b1024_key16.json 2>/dev/null; echo "bench key16 rc=$?"
+python bench.py --batch 8192 --steps 40 --warmup 5 --no-cpu-baseline --no-iknp --no-host-api --no-stream --no-config3 > $OUT/bench_b8192.json 2>/dev/null; echo "bench 8192 rc=$?"
+python bench.py --force-collective --no-cpu-baseline --no-iknp --no-host-api --no-stream --no-config3 > $OUT/bench_b1024_rccl_1rank.json 2>/dev/null; echo "bench coll rc=$?"
+python bench.py --circuit tests/golden/sha256xor.gcf --batch 256 --steps 50 --warmup 5 --no-cpu-baseline --no-iknp --no-host-api --no-stream --no-config3 > $OUT/bench_sha256xor_b256.json 2>/dev/null; echo "bench sha rc=$?"
 python scripts/bench_config3.py > $OUT/config3.json 2> $OUT/config3.err; echo "config3 rc=$?"
 python scripts/bench_stream.py 130000000 > $OUT/stream_1e8.json 2> $OUT/stream.err; echo "stream rc=$?"
 python scripts/bench_host_api.py 1024 > $OUT/host_api.json 2>/dev/null; echo "host rc=$?"
