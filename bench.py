@@ -4,8 +4,9 @@
 One "step" = one pass of the hot path over one batch of synthetic instances that are already
 resident in HBM: Circuit.Garble for `batch` instances, hand-over of the evaluator's input labels,
 Circuit.Eval, and BitFromLabel decoding (+ the RCCL all-gather of the decoded outputs when N > 1: gc_comm_allgather of
-libgcengine.so = ncclAllGather over xGMI called from the C ABI; torch.distributed only launches the ranks and carries
-the 128-byte communicator id over a gloo control group).
+libgcengine.so = ncclAllGather over xGMI called from the C ABI).  No torch in this process: device buffers come from
+gc_dev_alloc / gc_dev_upload of the same C ABI a Go host binds, `python -m torch.distributed.run` is only the process
+launcher, and the 128-byte communicator id travels through a file (mpc_amd/dist.py).
 Workload at N=1: BASELINE.json configs[1] — aes_128 (36 663 gates, 6 400 AND) x 1 024 instances,
 32-byte garbling key (AES-256, as circuit.Garbler uses).  N > 1: the same per-GPU batch on every
 rank (weak scaling, independent instances, no data-path collective except the output gather).
@@ -93,6 +94,30 @@ def cpu_baseline(circ, key, seconds=12.0):
     return out
 
 
+def kernel_build_hash():
+    """SHA-256 over the sources the garble / eval kernels are compiled from: profiles/latest_pmc.json carries the hash of
+    the build its counters were measured on, and `roofline.traffic` goes null when the kernels have changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mpc_amd", "csrc")
+    for name in ("aes_device.h", "kernels.h", "plan.h", "plan.cpp", "fused_flat_kernels.hip", "fused_lds_kernels.hip",
+                 "fused_kernels.hip", "gc_kernels.hip"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def sweep_rows_for_line(batch, key, ctx):
+    """SURVEY §8d's synthetic levelised circuits, three rows for the default line (W = 1 024, f in {0, 0.17, 1};
+    `python bench.py --sweep` runs the whole grid)"""
+    from scripts.sweep_synthetic import run as sweep_run
+    rows = sweep_run(batch, 131072, key, ctx=ctx, cases=[(1024, 0.0), (1024, 0.17), (1024, 1.0)], chain=0)
+    keep = ("circuit", "gates", "and", "gates_materialised", "wires_in_lds", "garble_ms", "eval_ms", "and_gates_per_s",
+            "gates_per_s", "hbm_alg_GBs", "hbm_roofline_frac", "hbm_read_roofline_frac", "lds_array_frac", "model_note",
+            "outputs_ok")
+    return [{k: r[k] for k in keep if k in r} for r in rows]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +131,7 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 5 shape) side measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the sha256xor x 256 + 65 536 OTs pipeline (config 3) side measurement")
+    ap.add_argument("--no-synthetic", action="store_true", help="skip the three synthetic levelised rows (SURVEY §8d)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
@@ -125,27 +151,23 @@ def main():
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes); before the runtime starts
     import numpy as np
-    import torch
 
     from mpc_amd import dist as gdist, engine, parse_file
-
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        gdist.init_control()  # gloo: rendezvous + the communicator id, no GPU collective goes through torch
 
     circ = parse_file(args.circuit)
     circ.name = os.path.splitext(os.path.basename(args.circuit))[0]
     key = bytes(range(args.key_bytes))
-    ctx = engine.Context(local_rank)
+    ctx = engine.Context(local_rank)  # one process per GPU: this rank's device, its own HIP stream
+    collective = world > 1 or args.force_collective
+    comm = gdist.open_comm(ctx, rank, world) if collective else None  # gc_comm_init_rank: RCCL, one rank per GPU
     if args.sweep:  # every rank sweeps its own GPU (independent instances); rank 0 reports the job
         from scripts.sweep_synthetic import run as sweep_run
         t0 = time.perf_counter()
         rows = sweep_run(args.batch, 131072, key, ctx=ctx)
         dt = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.barrier()
+            comm.close()
         if rank == 0:
             for r in rows:
                 for k in ("and_gates_per_s", "nonfree_gates_per_s", "gates_per_s", "hbm_alg_GBs"):
@@ -165,105 +187,77 @@ def main():
         b.set_graph(not args.no_graph)
         b.set_schedule(args.schedule)
 
-    # synthetic inputs, resident in HBM before the timed region
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    d_rnd = torch.randint(0, 256, (batch, circ.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
-    d_bits = torch.randint(0, 2, (batch, circ.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
-    collective = world > 1 or args.force_collective
-    comm = gdist.open_comm(ctx, rank, world) if collective else None  # gc_comm_init_rank: RCCL, one rank per GPU
+    # synthetic inputs, resident in HBM before the timed region (gc_dev_alloc + gc_dev_upload: the C ABI's own
+    # device memory, what a Go host uses)
+    nout = circ.num_outputs
+    d_rnd = ctx.random_u8((batch, circ.num_inputs + 1, 16), 256, seed=1234 + rank)
+    d_bits = ctx.random_u8((batch, circ.num_inputs), 2, seed=4321 + rank)
     # Decoded outputs of GATHER_EVERY steps are collected in one accumulator and gathered with ONE all-gather (fewer,
     # larger collectives: 1 MiB per GPU per call at 1 024 instances; a gather per step cost ~3 %).  The gather is
     # enqueued on the engine's stream right behind the decode that fills the last slot (stream order protects the
     # accumulator; no host synchronisation inside the loop).
     K = GATHER_EVERY if collective else 1
-    nacc = 1
-    d_acc = [torch.zeros((K, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nacc)]
-    d_out = d_acc[0][0]
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    d_all = [torch.zeros((world, K, batch, circ.num_outputs), dtype=torch.uint8, device="cuda") for _ in range(nacc)] \
-        if collective else None
+    slot_bytes = batch * nout
+    d_acc = ctx.zeros((K, batch, nout))
+    d_mis = ctx.zeros(1, np.int32)
+    d_all = ctx.zeros((world, K, batch, nout)) if collective else None
 
-    def device_step(a=0, j=0):
-        gb.garble(key, d_rnd.data_ptr())
-        ev.select_inputs(gb, d_bits.data_ptr())
+    def device_step(j=0):
+        gb.garble(key, d_rnd)
+        ev.select_inputs(gb, d_bits)
         ev.eval(key, gb)
-        gb.decode(ev, d_acc[a][j].data_ptr(), d_mis.data_ptr())
+        gb.decode(ev, d_acc + j * slot_bytes, d_mis)
 
     graphs = None  # the step's kernels recorded once per output slot in a hipGraph (gc_ctx_capture_*): one launch per step
-    counter = [0]
 
-    def gather(a):  # the only collective: ncclAllGather of the decoded outputs over RCCL/xGMI, behind the C ABI
-        comm.allgather(d_acc[a].data_ptr(), d_all[a].data_ptr(), d_acc[a].numel())
-
-    def step():
-        i = counter[0]
-        counter[0] += 1
-        a, j = (i // K) % nacc, i % K
+    def launch(j):
         if graphs is not None:
-            graphs[a][j].launch()
+            graphs[j].launch()
         else:
-            device_step(a, j)
-        if collective and j == K - 1:
-            gather(a)
+            device_step(j)
 
-    def flush():  # outputs of the steps since the last full accumulator
-        if collective and counter[0] % K:
-            gather((counter[0] // K) % nacc)
-            counter[0] += K - counter[0] % K
+    def gather(nfresh):  # the only collective: ncclAllGather of the decoded outputs over RCCL/xGMI, behind the C ABI
+        comm.allgather(d_acc, d_all, d_acc.nbytes)
 
     def fence():
         ctx.sync()
-        torch.cuda.synchronize()
         if comm is not None:
             comm.barrier()  # every rank's engine stream has drained (allreduce + stream sync)
-            torch.cuda.synchronize()
 
-    torch.cuda.synchronize()  # inputs were generated on torch's stream; the engine runs on its own
     device_step()  # first call uploads the round keys (not capturable), and warms the allocator
     ctx.sync()
     if not args.no_graph and args.schedule != 0:
         try:
-            graphs = [[ctx.capture(lambda a=a, j=j: device_step(a, j)) for j in range(K)] for a in range(nacc)]
+            graphs = [ctx.capture(lambda j=j: device_step(j)) for j in range(K)]
         except Exception as e:  # capture is an optimisation: fall back to direct launches of the same kernels
             print("bench: hipGraph capture unavailable (%s); launching directly" % e, file=sys.stderr)
             graphs = None
             ctx.sync()
-    for _ in range(args.warmup):
-        step()
-    flush()
-    fence()
-    g_ms, e_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    flush()  # every output of the timed steps is gathered inside the timed region
-    fence()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if comm is not None:
-        elapsed = comm.allreduce_max(elapsed)  # the job's step time is the slowest rank's
+    loop = gdist.StepLoop(K, launch, gather if collective else None)
+    elapsed = gdist.run_timed(loop, fence, args.steps, args.warmup,
+                              allreduce_max=comm.allreduce_max if comm is not None else None)
+    assert loop.steps_gathered == loop.steps_done == args.steps + args.warmup
 
     # per-pass device times (events on the engine stream) from a few extra, untimed-by-wall steps
+    g_ms, e_ms = [], []
     for _ in range(min(20, max(1, args.steps))):
-        gb.garble(key, d_rnd.data_ptr())
+        gb.garble(key, d_rnd)
         g_ms.append(gb.last_ms)
-        ev.select_inputs(gb, d_bits.data_ptr())
+        ev.select_inputs(gb, d_bits)
         ev.eval(key, gb)
         e_ms.append(ev.last_ms)
     ctx.sync()
-    mismatches = int(d_mis.cpu()[0])
+    mismatches = int(d_mis.numpy()[0])
 
     ok = mismatches == 0
-    if collective:  # the gathered tensor holds this rank's outputs at its offset
-        for a in range(nacc):
-            ok = ok and bool(torch.equal(d_all[a][rank], d_acc[a]))
+    acc = d_acc.numpy()
+    if collective:  # the gathered array holds this rank's outputs at its offset
+        ok = ok and bool((d_all.numpy()[rank] == acc).all())
     if args.check:
-        bits = d_bits.cpu().numpy()
-        out = d_out.cpu().numpy()
+        bits = d_bits.numpy()
         for i in range(0, batch, max(1, batch // 16)):  # against plaintext evaluation (circuit/computer.go)
             plain = circ.compute_bits(bits[i])
-            ok = ok and bool((plain[circ.NumWires - circ.num_outputs:] == out[i]).all())
+            ok = ok and bool((plain[circ.NumWires - nout:] == acc[0][i]).all())
 
     n_and = info.n_and
     total_and = n_and * batch * world * args.steps
@@ -281,22 +275,30 @@ def main():
     blocks_g = sum(getattr(info, "n_" + k) * v[0] for k, v in AES_BLOCKS.items())
     blocks_e = sum(getattr(info, "n_" + k) * v[1] for k, v in AES_BLOCKS.items())
     # HBM traffic of the garble launch: PMC counters cannot be read from inside the run; the figure is the one
-    # scripts/profile.sh measured with rocprofv3 --pmc for this batch / schedule / key size (profiles/latest_pmc.json,
-    # kernel named there) — null when the file does not describe this configuration.
+    # scripts/profile.sh measured with rocprofv3 --pmc for this batch / schedule / key size AND this build of the
+    # kernels (profiles/latest_pmc.json carries the hash of the kernel sources) — null otherwise.
     traffic, traffic_src = None, None
+    build_hash = kernel_build_hash()
     pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
                 pj = json.load(f)
-            if pj.get("batch") == batch and pj.get("schedule") == args.schedule and pj.get("key_bytes") == args.key_bytes:
+            if (pj.get("batch") == batch and pj.get("schedule") == args.schedule and pj.get("key_bytes") == args.key_bytes
+                    and pj.get("kernel_build_hash") == build_hash):
                 traffic = pj.get("garble_hbm_bytes_per_launch")
                 traffic_src = "profiles/latest_pmc.json (rocprofv3 --pmc, %s)" % pj.get("source", "scripts/profile.sh")
+            elif pj.get("kernel_build_hash") != build_hash:
+                traffic_src = "null: profiles/latest_pmc.json was measured on kernel build %s, this is %s" % (
+                    pj.get("kernel_build_hash"), build_hash)
         except Exception:
             traffic = None
     read_b = sum(getattr(info, "n_" + k) * (v[0] + v[1]) for k, v in READ_BYTES.items())  # per instance, both passes
     rounds = {16: 10, 24: 12, 32: 14}[args.key_bytes]
     lookups_per_block = 16 * rounds
+    lds_g = blocks_g * batch * lookups_per_block / (g_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS
+    lds_e = blocks_e * batch * lookups_per_block / (e_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS
+    frac_read = value / world * (read_b / max(n_and, 1)) / 1e9 / HBM_PEAK_GBS
     res = {
         "metric": "AND-gates/sec (garble+eval), AES-128 circuit batch",
         "value": value,
@@ -321,6 +323,8 @@ def main():
             "lds_live_labels": int(info.n_flat_slots if args.schedule == 1 else info.n_lds_slots),
             "graph": graphs is not None or (args.schedule == 0 and not args.no_graph),
             "outputs_ok": ok,
+            "device_memory": "gc_dev_alloc / gc_dev_upload (C ABI); no torch in the process",
+            "gathers": loop.gathers,
         },
         "garble_ms": g_avg,
         "eval_ms": e_avg,
@@ -328,19 +332,27 @@ def main():
         "and_gates_per_s_eval_only": n_and * batch / (e_avg * 1e-3),
         "hbm_alg_GBs_garble_plus_eval": 2 * algb * batch / ((g_avg + e_avg) * 1e-3) / 1e9,
         "roofline": {
-            "bound": "hbm",
+            # what binds the dominant kernel: the T-table AES out of LDS (LDS array + VALU issue), not HBM — the wires
+            # never leave the CU.  achieved / peak / frac keep the contract's definition (SURVEY §8d algorithmic bytes of
+            # the garble launch over its HIP-event duration against the 8 TB/s HBM peak): a NOMINAL figure, restated as
+            # frac_nominal_model; frac_read is the north star's "HBM-read roofline" of the whole step; frac_bound prices
+            # the kernel against the resource that binds it.
+            "bound": "lds/valu-issue" if args.schedule != 0 else "hbm",
             "kernel": kernel_name,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            "frac_nominal_model": achieved / HBM_PEAK_GBS,
+            "frac_read": frac_read,
+            "frac_bound": lds_g,
+            "frac_bound_definition": "T-table look-ups/s of the garble launch over the LDS array's ds_read_b32 rate "
+                                     "(75 TB/s / 4 B, MI355X_MICROARCH.md)",
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "kernel_build_hash": build_hash,
             "alg_bytes_per_launch": algb * batch / max(launches, 1),
             "avg_launch_us": g_avg * 1e3 / max(launches, 1),
-            # "achieved" prices the layout-independent byte model of SURVEY §8(d); the fused kernel keeps wires in LDS
-            # and really moves `traffic` bytes: the two honest views of the same launch follow.
-            "frac_read": value / world * (read_b / max(n_and, 1)) / 1e9 / HBM_PEAK_GBS,  # whole step, 393.4 B/AND model
             "hbm_counter_GBs": (traffic / (g_avg * 1e-3) / 1e9) if traffic else None,  # what HBM really carried
             "hbm_counter_frac": (traffic / (g_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "limiter": "LDS array + VALU issue of the T-table AES core (see aes_core); HBM is at hbm_counter_frac",
@@ -354,48 +366,50 @@ def main():
             "frac_eval": blocks_e * batch / (e_avg * 1e-3) / AES_CORE_PEAK_BLOCKS,
             "peak_source": "tools/aes_ubench: the production AES core alone, 16 waves/CU (own micro-benchmark)",
             # against the hardware figure instead: table look-ups/s over the LDS array's ds_read_b32 rate
-            "lds_array_frac_garble": blocks_g * batch * lookups_per_block / (g_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS,
-            "lds_array_frac_eval": blocks_e * batch * lookups_per_block / (e_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS,
+            "lds_array_frac_garble": lds_g,
+            "lds_array_frac_eval": lds_e,
             "lds_array_peak_lookups_per_s": LDS_B32_PEAK_LOOKUPS,
         },
     }
-    if rank == 0:
-        if world == 1 and not args.no_iknp:
+    gb.close()
+    ev.close()
+    dc.close()
+    for d in (d_rnd, d_bits, d_acc, d_mis, d_all):
+        if d is not None:
+            d.close()
+    if rank == 0 and world == 1:
+        aes = args.circuit.endswith("aes_128.gcf")
+        if not args.no_synthetic and aes:
+            # SURVEY §8d / north star: synthetic levelised circuits as absolute numbers and as fractions of the rooflines
+            res["synthetic"] = sweep_rows_for_line(batch, key, ctx)
+        if not args.no_iknp:
             # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):
             # device-resident API, 4 Mi OTs
             from scripts.bench_ot import run as ot_run
             ot = ot_run(1 << 22, 5, ctx=ctx)
             res["iknp"] = ot.pop("iknp")
             res["ot"] = ot
-        if world == 1 and not args.no_host_api and args.circuit.endswith("aes_128.gcf"):
+        if not args.no_host_api and aes:
             # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
             from scripts.bench_host_api import run as host_api_run
             res["host_api"] = host_api_run(batch, 3, key)
-        if world == 1 and not args.no_stream and args.circuit.endswith("aes_128.gcf"):
-            # config 5 shape: ONE instance, chained 131 072-gate steps through gc_stream_* (garbler pipelined with
-            # begin / finish, evaluator over the produced bytes); a bounded sample of scripts/bench_stream.py 130000000
-            from scripts.bench_stream import run as stream_run
-            st = stream_run(20_000_000, key=key, ctx=ctx)
-            res["stream"] = {k: st[k] for k in ("steps", "gates", "steady_ms_per_step", "steady_gates_per_s",
-                                                "eval_steady_ms_per_step", "eval_steady_gates_per_s",
-                                                "first_use_ms_per_circuit", "sha256")}
-        if world == 1 and not args.no_config3 and args.circuit.endswith("aes_128.gcf"):
+        if not args.no_stream and aes:
+            # config 5 shape: ONE instance through gc_stream_* (garbler pipelined, evaluator over the produced bytes);
+            # bounded samples of scripts/bench_stream.py, SHA-256 of the byte streams checked against the oracle-made
+            # goldens (tests/golden/stream_bench_golden.json) inside
+            from scripts.bench_stream import run_for_line as stream_run
+            res["stream"] = stream_run(key=key, ctx=ctx)
+        if not args.no_config3 and aes:
             # config 3: sha256xor x 256, the evaluator's labels through the 65 536-OT IKNP extension + COT pads, all on the
             # device; every digest checked against hashlib inside (scripts/bench_config3.py)
             from scripts.bench_config3 import run as config3_run
             res["config3"] = config3_run(256, 10, key)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
-    gb.close()
-    ev.close()
-    dc.close()
     if comm is not None:
+        comm.barrier()
         comm.close()
     ctx.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         # the JSON line goes out LAST: flush whatever native libraries (RCCL banner) left in C stdio first
         import ctypes

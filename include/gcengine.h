@@ -51,8 +51,9 @@ enum {
 const char *gc_strerror(int status);
 /* thread-local detail of the last GC_E_HIP / GC_E_NOMEM on this thread ("" if none) */
 const char *gc_last_error(void);
-/* ABI version of this header (checked by the bindings) */
-#define GC_ABI_VERSION 1
+/* ABI version of this header (checked by the bindings).  2: + gc_dev_* (device memory for hosts without a HIP
+ * allocator), gc_rot_*, gc_stream_garble_queue / gc_stream_set_depth; every v1 entry point is unchanged. */
+#define GC_ABI_VERSION 2
 int gc_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -189,6 +190,26 @@ void gc_host_free(void *);
 int gc_host_register(void *p, size_t bytes);
 int gc_host_unregister(void *p);
 int gc_host_is_pinned(const void *p);
+
+/* Device memory for the device-resident API below (additive; the reference has no device).  A Go host owns no HIP
+ * allocator, so the library hands out, fills and reads back the buffers that gc_batch_* (d_rnd, d_bits, d_bits_out,
+ * d_mismatch, ...), the *_dev OT calls and gc_comm_allgather take: with these five calls the whole device-resident
+ * pipeline is reachable through this header alone (go/circuit/batch_hip.go; tests/cpp/test_device_pipeline.cpp).
+ * All of them run on the ctx's device and order themselves on the ctx stream:
+ *  gc_dev_alloc     hipMalloc; NULL + *status (GC_E_NOMEM / GC_E_HIP) on failure; contents undefined
+ *  gc_dev_free      waits for the ctx stream (kernels may still use the buffer), then frees; NULL is a no-op
+ *  gc_dev_upload    host -> device behind everything queued on the ctx stream; returns when `src` may be reused
+ *                   (cgo must not leave Go memory referenced after the call)
+ *  gc_dev_download  device -> host after everything queued on the ctx stream; returns with the bytes in `dst`
+ *  gc_dev_memset    stream-ordered fill, asynchronous
+ *  gc_dev_copy      device -> device on the ctx stream, asynchronous (e.g. slot j of an accumulator)
+ * d + offset arithmetic on the returned pointers is the caller's (they are plain device addresses). */
+void *gc_dev_alloc(gc_ctx *, size_t bytes, int *status);
+void gc_dev_free(gc_ctx *, void *d);
+int gc_dev_upload(gc_ctx *, void *d_dst, const void *src, size_t bytes);
+int gc_dev_download(gc_ctx *, void *dst, const void *d_src, size_t bytes);
+int gc_dev_memset(gc_ctx *, void *d, int byte_value, size_t bytes);
+int gc_dev_copy(gc_ctx *, void *d_dst, const void *d_src, size_t bytes);
 
 /* Garble ONE instance whose R and input-wire L0 labels are given instead of drawn from a random
  * stream (what Streaming.Garble needs: the inputs of an SSA-step circuit are wires garbled earlier).

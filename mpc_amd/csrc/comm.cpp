@@ -140,7 +140,7 @@ static gc_comm *comm_new(gc_ctx *ctx, int *rc) {
     return c;
 }
 
-gc_comm *gc_comm_init_rank(gc_ctx *ctx, const uint8_t *id, size_t idlen, int nranks, int rank, int *status) {
+gc_comm *gc_comm_init_rank(gc_ctx *ctx, const uint8_t *id, size_t idlen, int nranks, int rank, int *status) try {
     int rc = GC_OK;
     gc_comm *c = nullptr;
     if (!ctx || !id || idlen < GC_COMM_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks) rc = GC_E_ARG;
@@ -163,9 +163,13 @@ gc_comm *gc_comm_init_rank(gc_ctx *ctx, const uint8_t *id, size_t idlen, int nra
     }
     if (status) *status = rc;
     return c;
+} catch (...) {
+    const int rc__ = gc::on_exception();
+    if (status) *status = rc__;
+    return nullptr;
 }
 
-int gc_comm_init_all(gc_ctx *const *ctxs, int n, gc_comm **out) {
+int gc_comm_init_all(gc_ctx *const *ctxs, int n, gc_comm **out) try {
     if (!ctxs || !out || n < 1) return GC_E_ARG;
     for (int i = 0; i < n; i++) out[i] = nullptr;
     if (!rccl().ok) return rccl_missing();
@@ -196,6 +200,8 @@ int gc_comm_init_all(gc_ctx *const *ctxs, int n, gc_comm **out) {
         }
     }
     return rc;
+} catch (...) {
+    return gc::on_exception();
 }
 
 void gc_comm_destroy(gc_comm *c) {
@@ -215,6 +221,7 @@ int gc_comm_nranks(const gc_comm *c) { return c ? c->nranks : 0; }
 int gc_comm_allgather(gc_comm *c, const void *d_send, void *d_recv, size_t bytes) {
     if (!c || !c->comm || (bytes && (!d_send || !d_recv))) return GC_E_ARG;
     if (bytes == 0) return GC_OK;
+    std::lock_guard<std::mutex> lk(c->ctx->mu);  // the ctx stream is shared with the host-buffer calls
     GC_HIP(hipSetDevice(c->ctx->device));
     GC_NCCL(rccl().AllGather(d_send, d_recv, bytes, ncclUint8, c->comm, c->ctx->stream));
     return GC_OK;
@@ -228,6 +235,7 @@ int gc_comm_allgather_all(gc_comm *const *cs, int n, const void *const *d_send, 
     GC_NCCL(rccl().GroupStart());
     ncclResult_t first = ncclSuccess;
     for (int i = 0; i < n; i++) {
+        std::lock_guard<std::mutex> lk(cs[i]->ctx->mu);
         hipError_t e = hipSetDevice(cs[i]->ctx->device);
         ncclResult_t r = e == hipSuccess
                              ? rccl().AllGather(d_send[i], d_recv[i], bytes, ncclUint8, cs[i]->comm, cs[i]->ctx->stream)
@@ -243,6 +251,7 @@ int gc_comm_allgather_all(gc_comm *const *cs, int n, const void *const *d_send, 
 // every rank's *value -> the maximum over the ranks (bench timing: max-over-ranks step time); synchronous
 int gc_comm_allreduce_max(gc_comm *c, double *value) {
     if (!c || !c->comm || !value) return GC_E_ARG;
+    std::lock_guard<std::mutex> lk(c->ctx->mu);
     GC_HIP(hipSetDevice(c->ctx->device));
     GC_HIP(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->ctx->stream));
     GC_NCCL(rccl().AllReduce(c->d_scratch, c->d_scratch + 1, 1, ncclDouble, ncclMax, c->comm, c->ctx->stream));

@@ -180,6 +180,69 @@ int gc_host_is_pinned(const void *p) {
     return a.type == hipMemoryTypeHost ? 1 : 0;
 }
 
+// ---- device memory for hosts that own no HIP allocator (the Go shim; bench.py and the tests use the same calls) ------
+void *gc_dev_alloc(gc_ctx *c, size_t bytes, int *status) {
+    int rc = GC_OK;
+    void *p = nullptr;
+    if (!c) rc = GC_E_ARG;
+    if (rc == GC_OK) {
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            set_error("gc_dev_alloc", e);
+            rc = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            p = nullptr;
+        }
+    }
+    if (status) *status = rc;
+    return p;
+}
+
+void gc_dev_free(gc_ctx *c, void *d) {
+    if (!c || !d) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);  // kernels queued on the ctx stream may still read / write it
+    (void)hipFree(d);
+}
+
+int gc_dev_upload(gc_ctx *c, void *d_dst, const void *src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !src))) return GC_E_ARG;
+    if (!bytes) return GC_OK;
+    if (c->capturing) return GC_E_ARG;  // a host copy cannot be part of a pipeline graph
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    // the contract is "src may be reused on return" whatever kind of memory it is (pinned sources are read by the DMA
+    // engine after the call returns otherwise)
+    GC_HIP(hipStreamSynchronize(c->stream));
+    return GC_OK;
+}
+
+int gc_dev_download(gc_ctx *c, void *dst, const void *d_src, size_t bytes) {
+    if (!c || (bytes && (!dst || !d_src))) return GC_E_ARG;
+    if (!bytes) return GC_OK;
+    if (c->capturing) return GC_E_ARG;
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GC_HIP(hipStreamSynchronize(c->stream));
+    return GC_OK;
+}
+
+int gc_dev_memset(gc_ctx *c, void *d, int byte_value, size_t bytes) {
+    if (!c || (bytes && !d)) return GC_E_ARG;
+    if (!bytes) return GC_OK;
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipMemsetAsync(d, byte_value, bytes, c->stream));
+    return GC_OK;
+}
+
+int gc_dev_copy(gc_ctx *c, void *d_dst, const void *d_src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !d_src))) return GC_E_ARG;
+    if (!bytes) return GC_OK;
+    GC_HIP(hipSetDevice(c->device));
+    GC_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return GC_OK;
+}
+
 int gc_ctx_sync(gc_ctx *c) {
     if (!c) return GC_E_ARG;
     GC_HIP(hipSetDevice(c->device));
@@ -318,47 +381,60 @@ void gc_circ_free(gc_circ *c) {
 static void circ_ensure_flat(gc_circ *c) {
     std::lock_guard<std::mutex> lk(c->flat_mu);
     if (c->flat_ready) return;
-    c->flat_ready = true;
     Plan &p = c->plan.p;
-    finish_flat(&p);
-    hipError_t e = hipSetDevice(c->ctx->device);
-    auto up = [&](void **dptr, const void *src, size_t bytes) {
-        if (e != hipSuccess) return;
-        e = hipMalloc(dptr, bytes ? bytes : 16);
-        if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
-    };
-    // the level-walking fused schedule (fused_lds_kernels.hip: store_all / schedule 2 / circuits without a flattened plan)
-    up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
-    up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
-    up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
-    up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
-    up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
-    if (e != hipSuccess) {  // without them only the HBM-wire kernels can serve the circuit
-        set_error("circ_ensure_flat", e);
+    // flat_ready flips only when the plan is in its final state — complete, or marked "no LDS / flattened plan" —
+    // so a later call never launches the LDS kernels on a half-built plan
+    struct Done {
+        gc_circ *c;
+        ~Done() { c->flat_ready = true; }
+    } done{c};
+    auto no_plans = [&] {
         p.n_lds_slots = 0xffffffffu;
         p.info.n_lds_slots = 0xffffffffu;
         p.n_flat_slots = 0xffffffffu;
         p.info.n_flat_slots = 0xffffffffu;
-        return;
-    }
-    if (p.n_flat_slots == 0xffffffffu) return;
-    {
-        // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
-        // stage buffer of zero padding behind the real data
-        std::vector<uint32_t> prog(p.fl_prog);
-        prog.resize(prog.size() + 4 * 1024, 0);
-        std::vector<FUnit> units(p.fl_units);
-        units.resize(units.size() + 2, FUnit{});
-        up((void **)&c->d_fl_prog, prog.data(), prog.size() * sizeof(uint32_t));
-        up((void **)&c->d_fl_units, units.data(), units.size() * sizeof(FUnit));
-    }
-    up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
-    up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
-    up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));
-    if (e != hipSuccess) {  // no device arrays: behave as if the circuit had no flattened plan
-        set_error("circ_ensure_flat", e);
-        p.n_flat_slots = 0xffffffffu;
-        p.info.n_flat_slots = 0xffffffffu;
+    };
+    try {
+        finish_flat(&p);
+        hipError_t e = hipSetDevice(c->ctx->device);
+        auto up = [&](void **dptr, const void *src, size_t bytes) {
+            if (e != hipSuccess) return;
+            e = hipMalloc(dptr, bytes ? bytes : 16);
+            if (e == hipSuccess && bytes) e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+        };
+        // the level-walking fused schedule (fused_lds_kernels.hip: store_all / schedule 2 / circuits without a flattened plan)
+        up((void **)&c->d_fdescs, p.fdescs.data(), p.fdescs.size() * sizeof(FDesc));
+        up((void **)&c->d_fgslot, p.fgslot.data(), p.fgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fsteps, p.fsteps.data(), p.fsteps.size() * sizeof(Step));
+        up((void **)&c->d_in_lds, p.in_lds.data(), p.in_lds.size() * sizeof(uint16_t));
+        up((void **)&c->d_fchunks, p.fchunks.data(), p.fchunks.size() * sizeof(Chunk));
+        if (e != hipSuccess) {  // without them only the HBM-wire kernels can serve the circuit
+            set_error("circ_ensure_flat", e);
+            no_plans();
+            return;
+        }
+        if (p.n_flat_slots == 0xffffffffu) return;
+        {
+            // the kernels fetch headers / images two units ahead without bounds checks: two zero records and one
+            // stage buffer of zero padding behind the real data
+            std::vector<uint32_t> prog(p.fl_prog);
+            prog.resize(prog.size() + 4 * 1024, 0);
+            std::vector<FUnit> units(p.fl_units);
+            units.resize(units.size() + 2, FUnit{});
+            up((void **)&c->d_fl_prog, prog.data(), prog.size() * sizeof(uint32_t));
+            up((void **)&c->d_fl_units, units.data(), units.size() * sizeof(FUnit));
+        }
+        up((void **)&c->d_fl_hgslot, p.fl_hgslot.data(), p.fl_hgslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_ogslot, p.fl_ogslot.data(), p.fl_ogslot.size() * sizeof(uint32_t));
+        up((void **)&c->d_fl_in_lds, p.fl_in_lds.data(), p.fl_in_lds.size() * sizeof(uint16_t));
+        if (e != hipSuccess) {  // no device arrays: behave as if the circuit had no flattened plan
+            set_error("circ_ensure_flat", e);
+            p.n_flat_slots = 0xffffffffu;
+            p.info.n_flat_slots = 0xffffffffu;
+        }
+    } catch (...) {  // bad_alloc on a huge streamed circuit: the HBM-wire kernels serve it
+        (void)gc::on_exception();
+        no_plans();
     }
 }
 

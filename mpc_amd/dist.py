@@ -2,11 +2,14 @@
 the only exchange is a terminal all-gather of the decoded output bits / output labels.
 
 The data-path collective is gc_comm_allgather of libgcengine.so (ncclAllGather of RCCL over xGMI, called from the
-C ABI — what a Go host binds).  torch.distributed appears here only as the launcher's control plane: a gloo (CPU)
-group that hands the 128-byte ncclUniqueId from rank 0 to the other ranks — the job a Go host does over its own
-p2p.Conn — and, in the CPU tests, stands in as the gather transport so that the sharding / padding / reassembly
-logic is exercised with world_size 2 without a GPU."""
+C ABI — what a Go host binds).  The ranks of bench.py import no torch at all: `python -m torch.distributed.run` is only
+the process launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment), the 128-byte ncclUniqueId travels from rank 0
+to the other ranks of the node through a file (exchange_unique_id_file — the job a Go host does over its own
+p2p.Conn), barrier and max-over-ranks timing are gc_comm_* calls.  In the CPU tests a gloo group stands in as the
+gather transport (GlooGather) so that the sharding / padding / reassembly logic and the bench's step loop (StepLoop,
+run_timed) are exercised with world_size 2 and 3 without a GPU."""
 import os
+import time
 
 import numpy as np
 
@@ -60,13 +63,116 @@ def exchange_unique_id(make_id, rank, world):
     return box[0]
 
 
+def exchange_unique_id_file(make_id, rank, world, timeout=180.0, directory=None):
+    """The same hand-over without any torch: the ranks of ONE node share a file.  Rank 0 draws the id and publishes it
+    atomically (write + rename); the others poll for it.  The name carries the launcher's pid (the common parent of
+    all ranks of this launch) and MASTER_PORT, so neither concurrent nor earlier launches collide; rank 0 removes
+    leftovers of a crashed launch with a recycled pid before it publishes, the readers remove nothing."""
+    if world == 1:
+        return make_id()
+    directory = directory or os.environ.get("GC_RENDEZVOUS_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    name = os.path.join(directory, "gc_comm_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    if rank == 0:
+        uid = make_id()
+        tmp = "%s.tmp.%d" % (name, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, name)
+        return uid
+    t0 = time.monotonic()
+    start = time.time()
+    while True:
+        try:
+            st = os.stat(name)
+            # a file older than this process is a leftover of an earlier launch whose pid was recycled: wait for rank 0
+            if st.st_mtime >= start - 600 and st.st_size > 0:
+                with open(name, "rb") as f:
+                    return f.read()
+        except OSError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError("rank %d: no communicator id from rank 0 within %.0f s (%s)" % (rank, timeout, name))
+        time.sleep(0.01)
+
+
+def cleanup_unique_id_file(rank, directory=None):
+    """rank 0, after the communicator exists on every rank (i.e. after a barrier)"""
+    if rank != 0:
+        return
+    directory = directory or os.environ.get("GC_RENDEZVOUS_DIR") or os.environ.get("TMPDIR") or "/tmp"
+    try:
+        os.unlink(os.path.join(directory, "gc_comm_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))))
+    except OSError:
+        pass
+
+
 def open_comm(ctx, rank, world):
-    """the RCCL communicator of this rank's gc_ctx (gc_comm_init_rank)"""
+    """the RCCL communicator of this rank's gc_ctx (gc_comm_init_rank); no torch involved"""
     from . import engine
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
-    uid = exchange_unique_id(engine.comm_unique_id, rank, world)
-    return engine.Comm(ctx, uid, world, rank)
+    uid = exchange_unique_id_file(engine.comm_unique_id, rank, world)
+    comm = engine.Comm(ctx, uid, world, rank)
+    if world > 1:
+        comm.barrier()
+        cleanup_unique_id_file(rank)
+    return comm
+
+
+class StepLoop:
+    """The step / gather bookkeeping of bench.py, free of any device type so that the CPU suite runs it at world 2 and 3.
+
+    The decoded outputs of `slots` steps are collected in ONE accumulator and gathered with ONE all-gather (fewer, larger
+    collectives); a tail of fewer than `slots` steps is flushed before the clock stops.
+      launch(j)      enqueue one step of the hot path whose outputs land in slot j of the accumulator
+      gather(nfresh) enqueue the all-gather of the accumulator; the first nfresh slots hold outputs that no earlier
+                     gather carried (None: one rank, nothing to gather)
+    Invariant checked by the tests: after flush() every step's outputs were gathered exactly once."""
+
+    def __init__(self, slots, launch, gather=None):
+        self.slots = max(1, int(slots)) if gather is not None else 1
+        self.launch, self.gather = launch, gather
+        self.pos = 0            # next free slot
+        self.steps_done = 0
+        self.steps_gathered = 0
+        self.gathers = 0
+
+    def step(self):
+        self.launch(self.pos)
+        self.pos += 1
+        self.steps_done += 1
+        if self.pos == self.slots:
+            self._gather()
+
+    def _gather(self):
+        if self.gather is not None and self.pos:
+            self.gather(self.pos)
+            self.gathers += 1
+        self.steps_gathered += self.pos
+        self.pos = 0
+
+    def flush(self):
+        """outputs of the steps since the last full accumulator"""
+        if self.pos:
+            self._gather()
+
+
+def run_timed(loop, fence, steps, warmup, allreduce_max=None, clock=time.perf_counter):
+    """W untimed steps, then EXACTLY `steps` steps between two fences (barrier + device sync on both sides); the tail
+    gather is inside the timed region; the job's time is the slowest rank's."""
+    for _ in range(warmup):
+        loop.step()
+    loop.flush()
+    fence()
+    t0 = clock()
+    for _ in range(steps):
+        loop.step()
+    loop.flush()
+    fence()
+    elapsed = clock() - t0
+    if allreduce_max is not None:
+        elapsed = allreduce_max(elapsed)
+    return elapsed
 
 
 class GlooGather:

@@ -17,6 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("GC_LIB") or os.path.join(CSRC, "libgcengine.so")  # GC_LIB: developer builds
 HEADER = os.path.join(os.path.dirname(HERE), "include", "gcengine.h")
 
+ABI_VERSION = 2  # GC_ABI_VERSION of include/gcengine.h
 GC_OK, GC_E_KEYSIZE, GC_E_RAND, GC_E_GATE, GC_E_ROWS, GC_E_ARG, GC_E_HIP, GC_E_NOMEM, GC_E_WIRE = (
     0, -1, -2, -3, -4, -5, -6, -7, -8)
 
@@ -154,6 +155,12 @@ def lib():
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
         "gc_garble_wire": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, sz]),
         "gc_eval_wire": (i32, [vp, vp, sz, u32, vp, vp, sz, vp, vp]),
+        "gc_dev_alloc": (vp, [vp, sz, ip]),
+        "gc_dev_free": (None, [vp, vp]),
+        "gc_dev_upload": (i32, [vp, vp, vp, sz]),
+        "gc_dev_download": (i32, [vp, vp, vp, sz]),
+        "gc_dev_memset": (i32, [vp, vp, i32, sz]),
+        "gc_dev_copy": (i32, [vp, vp, vp, sz]),
         "gc_host_alloc": (vp, [sz]),
         "gc_host_free": (None, [vp]),
         "gc_host_register": (i32, [vp, sz]),
@@ -177,8 +184,8 @@ def lib():
         f.restype = res
         f.argtypes = args
     _lib = L
-    if L.gc_abi_version() != 1:
-        raise ImportError("libgcengine.so ABI %d != 1" % L.gc_abi_version())
+    if L.gc_abi_version() != ABI_VERSION:
+        raise ImportError("libgcengine.so ABI %d != %d" % (L.gc_abi_version(), ABI_VERSION))
     return L
 
 
@@ -186,6 +193,11 @@ def _p(a):
     if a is None:
         return None
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(d):
+    """device pointer argument: a DeviceBuffer, or a raw device address (int)"""
+    return C.c_void_p(d.ptr if isinstance(d, DeviceBuffer) else d)
 
 
 def _u8(b):
@@ -295,10 +307,95 @@ class Context:
         _check(lib().gc_ctx_capture_end(self.h, C.byref(g)), "gc_ctx_capture_end")
         return Graph(g)
 
+    def zeros(self, shape, dtype=np.uint8):
+        """zero-filled device buffer (gc_dev_alloc + gc_dev_memset)"""
+        return DeviceBuffer(self, shape, dtype, zero=True)
+
+    def empty(self, shape, dtype=np.uint8):
+        return DeviceBuffer(self, shape, dtype)
+
+    def random_u8(self, shape, high=256, seed=0):
+        """synthetic uniform bytes in [0, high) (numpy Generator on the host, uploaded once): bench / profiling inputs"""
+        return DeviceBuffer(self, data=np.random.default_rng(seed).integers(0, high, shape, dtype=np.uint8))
+
+    def to_device(self, data):
+        """host bytes / array -> device buffer (gc_dev_alloc + gc_dev_upload)"""
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            data = np.frombuffer(bytes(data), np.uint8)
+        return DeviceBuffer(self, data=data)
+
     def close(self):
         if self.h:
             lib().gc_ctx_destroy(self.h)
             self.h = None
+
+
+class DeviceBuffer:
+    """gc_dev_alloc: a device buffer owned through the C ABI (no torch, no HIP binding on the host side) — what the
+    device-resident calls take as d_* pointers.  .ptr is the device address (int); offsets are plain arithmetic.
+    dtype / shape are host-side book-keeping for numpy() only."""
+
+    def __init__(self, ctx, shape=None, dtype=np.uint8, data=None, zero=False):
+        self.ctx = ctx
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            shape, dtype = data.shape, data.dtype
+        self.dtype = np.dtype(dtype)
+        self.shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        st = C.c_int(0)
+        self.ptr = lib().gc_dev_alloc(ctx.h, max(self.nbytes, 16), C.byref(st))
+        if not self.ptr:
+            raise EngineError(st.value, "gc_dev_alloc(%d)" % self.nbytes)
+        if data is not None:
+            self.upload(data)
+        elif zero:
+            self.zero()
+
+    def upload(self, data, offset=0):
+        a = np.ascontiguousarray(data)
+        assert offset + a.nbytes <= self.nbytes
+        _check(lib().gc_dev_upload(self.ctx.h, C.c_void_p(self.ptr + offset), _p(a) if a.nbytes else None, a.nbytes),
+               "gc_dev_upload")
+        return self
+
+    def download(self, dtype=np.uint8, shape=None, offset=0, nbytes=None):
+        dtype = np.dtype(dtype)
+        n = (self.nbytes - offset if nbytes is None else nbytes) if shape is None else int(np.prod(shape)) * dtype.itemsize
+        assert offset + n <= self.nbytes
+        out = np.empty(n // dtype.itemsize, dtype)
+        _check(lib().gc_dev_download(self.ctx.h, _p(out) if n else None, C.c_void_p(self.ptr + offset), n),
+               "gc_dev_download")
+        return out if shape is None else out.reshape(shape)
+
+    def __add__(self, offset):
+        """device address `offset` bytes into the buffer (plain pointer arithmetic)"""
+        assert 0 <= offset <= self.nbytes
+        return self.ptr + int(offset)
+
+    def numpy(self):
+        """the whole buffer as a host array of the buffer's dtype / shape (waits for the ctx stream)"""
+        return self.download(self.dtype, self.shape)
+
+    def zero(self, value=0):
+        _check(lib().gc_dev_memset(self.ctx.h, C.c_void_p(self.ptr), value, self.nbytes), "gc_dev_memset")
+        return self
+
+    def copy_from(self, d_src, nbytes, offset=0):
+        """device -> device on the ctx stream (d_src: DeviceBuffer or device address)"""
+        src = d_src.ptr if isinstance(d_src, DeviceBuffer) else int(d_src)
+        _check(lib().gc_dev_copy(self.ctx.h, C.c_void_p(self.ptr + offset), C.c_void_p(src), nbytes), "gc_dev_copy")
+
+    def close(self):
+        if getattr(self, "ptr", None) and self.ctx.h:
+            lib().gc_dev_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Graph:
@@ -431,20 +528,20 @@ class Batch:
 
     def garble(self, key, d_rnd):
         k = _u8(key)
-        _check(lib().gc_batch_garble(self.h, _p(k), len(k), C.c_void_p(d_rnd)), "gc_batch_garble")
+        _check(lib().gc_batch_garble(self.h, _p(k), len(k), _dp(d_rnd)), "gc_batch_garble")
 
     def select_inputs(self, garbler, d_bits):
-        _check(lib().gc_batch_select_inputs(self.h, garbler.h, C.c_void_p(d_bits)), "gc_batch_select_inputs")
+        _check(lib().gc_batch_select_inputs(self.h, garbler.h, _dp(d_bits)), "gc_batch_select_inputs")
 
     def set_inputs(self, d_labels):
-        _check(lib().gc_batch_set_inputs(self.h, C.c_void_p(d_labels)), "gc_batch_set_inputs")
+        _check(lib().gc_batch_set_inputs(self.h, _dp(d_labels)), "gc_batch_set_inputs")
 
     def eval(self, key, tables):
         k = _u8(key)
         _check(lib().gc_batch_eval(self.h, _p(k), len(k), tables.h), "gc_batch_eval")
 
     def decode(self, evaluator, d_bits_out, d_mismatch):
-        _check(lib().gc_batch_decode(self.h, evaluator.h, C.c_void_p(d_bits_out), C.c_void_p(d_mismatch)),
+        _check(lib().gc_batch_decode(self.h, evaluator.h, _dp(d_bits_out), _dp(d_mismatch)),
                "gc_batch_decode")
 
     def read_r(self):
@@ -478,26 +575,26 @@ class Batch:
         _check(lib().gc_batch_write_slab(self.h, _p(s)), "gc_batch_write_slab")
 
     def egress_tables(self, d_out, stride):
-        _check(lib().gc_batch_egress_tables(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables")
+        _check(lib().gc_batch_egress_tables(self.h, _dp(d_out), stride), "gc_batch_egress_tables")
 
     def gather_input_wires(self, first, count, d_out):
-        _check(lib().gc_batch_gather_input_wires(self.h, first, count, C.c_void_p(d_out)), "gc_batch_gather_input_wires")
+        _check(lib().gc_batch_gather_input_wires(self.h, first, count, _dp(d_out)), "gc_batch_gather_input_wires")
 
     def set_input_range(self, first, count, d_labels):
-        _check(lib().gc_batch_set_input_range(self.h, first, count, C.c_void_p(d_labels)), "gc_batch_set_input_range")
+        _check(lib().gc_batch_set_input_range(self.h, first, count, _dp(d_labels)), "gc_batch_set_input_range")
 
     def egress_tables_dense(self, d_out, stride):
-        _check(lib().gc_batch_egress_tables_dense(self.h, C.c_void_p(d_out), stride), "gc_batch_egress_tables_dense")
+        _check(lib().gc_batch_egress_tables_dense(self.h, _dp(d_out), stride), "gc_batch_egress_tables_dense")
 
     def ingest_tables_dense(self, d_in, stride):
-        _check(lib().gc_batch_ingest_tables_dense(self.h, C.c_void_p(d_in), stride), "gc_batch_ingest_tables_dense")
+        _check(lib().gc_batch_ingest_tables_dense(self.h, _dp(d_in), stride), "gc_batch_ingest_tables_dense")
 
     def ingest_tables(self, d_in, stride, d_bad):
-        _check(lib().gc_batch_ingest_tables(self.h, C.c_void_p(d_in), stride, C.c_void_p(d_bad)),
+        _check(lib().gc_batch_ingest_tables(self.h, _dp(d_in), stride, _dp(d_bad)),
                "gc_batch_ingest_tables")
 
     def gather_outputs(self, d_out):
-        _check(lib().gc_batch_gather_outputs(self.h, C.c_void_p(d_out)), "gc_batch_gather_outputs")
+        _check(lib().gc_batch_gather_outputs(self.h, _dp(d_out)), "gc_batch_gather_outputs")
 
     def debug_profile(self, enable=True, read=False):
         out = np.zeros(16, np.uint64) if read else None
@@ -650,26 +747,27 @@ class Comm:
         return [cls(ctxs[i], None, n, i, _h=out[i]) for i in range(n)]
 
     def allgather(self, d_send, d_recv, nbytes):
-        _check(lib().gc_comm_allgather(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), nbytes), "gc_comm_allgather")
+        _check(lib().gc_comm_allgather(self.h, _dp(d_send), _dp(d_recv), nbytes), "gc_comm_allgather")
 
     @staticmethod
     def allgather_all(comms, d_sends, d_recvs, nbytes):
         n = len(comms)
         hs = (C.c_void_p * n)(*[c.h for c in comms])
-        ss = (C.c_void_p * n)(*d_sends)
-        rs = (C.c_void_p * n)(*d_recvs)
+        ss = (C.c_void_p * n)(*[_dp(x) for x in d_sends])
+        rs = (C.c_void_p * n)(*[_dp(x) for x in d_recvs])
         _check(lib().gc_comm_allgather_all(hs, n, ss, rs, nbytes), "gc_comm_allgather_all")
 
     def allgather_host(self, local):
-        """host array [rows, ...] -> [nranks, rows, ...]; staged through device buffers (torch as plumbing)"""
-        import torch
-
-        t = torch.from_numpy(np.ascontiguousarray(local)).to("cuda:%d" % self.ctx.device)
-        out = torch.empty((self.nranks,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        torch.cuda.synchronize(t.device)
-        self.allgather(t.data_ptr(), out.data_ptr(), t.numel() * t.element_size())
-        self.ctx.sync()
-        return out.cpu().numpy()
+        """host array [rows, ...] -> [nranks, rows, ...]; staged through gc_dev_* buffers"""
+        a = np.ascontiguousarray(local)
+        d_in = DeviceBuffer(self.ctx, data=a)
+        d_out = DeviceBuffer(self.ctx, a.nbytes * self.nranks)
+        try:
+            self.allgather(d_in.ptr, d_out.ptr, a.nbytes)
+            return d_out.download(a.dtype, (self.nranks,) + a.shape)
+        finally:
+            d_in.close()
+            d_out.close()
 
     def allreduce_max(self, value):
         v = C.c_double(value)
@@ -715,14 +813,14 @@ class IKNPReceiver:
 
     def receive_dev(self, d_choice_packed, n, d_u_out, d_labels_out):
         """device pointers (ints); asynchronous on the ctx stream"""
-        _check(lib().gc_iknp_receive_dev(self.h, d_choice_packed, n, d_u_out, d_labels_out), "gc_iknp_receive_dev")
+        _check(lib().gc_iknp_receive_dev(self.h, _dp(d_choice_packed), n, _dp(d_u_out), _dp(d_labels_out)), "gc_iknp_receive_dev")
 
     @property
     def last_ms(self):
         return float(lib().gc_iknp_last_ms(self.h))
 
     def receive_bits_dev(self, d_choices, n, d_u_out, d_result):
-        _check(lib().gc_iknp_receive_bits_dev(self.h, d_choices, n, d_u_out, d_result), "gc_iknp_receive_bits_dev")
+        _check(lib().gc_iknp_receive_bits_dev(self.h, _dp(d_choices), n, _dp(d_u_out), _dp(d_result)), "gc_iknp_receive_bits_dev")
 
     def receive_bits(self, choices, n):
         ch = np.ascontiguousarray(choices, dtype=np.uint64)
@@ -757,14 +855,14 @@ class IKNPSender:
 
     def send_dev(self, d_u_in, n, d_labels_out):
         """device pointers (ints); asynchronous on the ctx stream"""
-        _check(lib().gc_iknp_send_dev(self.h, d_u_in, n, d_labels_out), "gc_iknp_send_dev")
+        _check(lib().gc_iknp_send_dev(self.h, _dp(d_u_in), n, _dp(d_labels_out)), "gc_iknp_send_dev")
 
     @property
     def last_ms(self):
         return float(lib().gc_iknp_last_ms(self.h))
 
     def send_bits_dev(self, d_u_in, n, d_result):
-        _check(lib().gc_iknp_send_bits_dev(self.h, d_u_in, n, d_result), "gc_iknp_send_bits_dev")
+        _check(lib().gc_iknp_send_bits_dev(self.h, _dp(d_u_in), n, _dp(d_result)), "gc_iknp_send_bits_dev")
 
     def send_bits(self, u, n):
         ub = np.frombuffer(bytes(u), np.uint8) if len(u) else np.zeros(1, np.uint8)
@@ -796,13 +894,13 @@ def cot_send_pads(ctx, seed, delta, data, wires):
 
 
 def cot_send_pads_dev(ctx, seed, delta, d_data, d_wires, n, d_out):
-    _check(lib().gc_cot_send_pads_dev(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), C.c_void_p(d_data), C.c_void_p(d_wires),
-                                      n, C.c_void_p(d_out)), "gc_cot_send_pads_dev")
+    _check(lib().gc_cot_send_pads_dev(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), _dp(d_data), _dp(d_wires),
+                                      n, _dp(d_out)), "gc_cot_send_pads_dev")
 
 
 def cot_receive_unpad_dev(ctx, seed, d_flags, d_sent, d_result, n):
-    _check(lib().gc_cot_receive_unpad_dev(ctx.h, _p(_lab1(seed)), C.c_void_p(d_flags), C.c_void_p(d_sent),
-                                          C.c_void_p(d_result), n), "gc_cot_receive_unpad_dev")
+    _check(lib().gc_cot_receive_unpad_dev(ctx.h, _p(_lab1(seed)), _dp(d_flags), _dp(d_sent),
+                                          _dp(d_result), n), "gc_cot_receive_unpad_dev")
 
 
 def cot_receive_unpad(ctx, seed, flags, sent, result):
@@ -830,7 +928,7 @@ def kos_receiver_tags_dev(ctx, seed2, d_result, d_b, n, choice_vec, bcv):
     cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
     bc = np.ascontiguousarray(bcv, dtype=np.uint8)
     x, t0, t1 = np.zeros(1, LABEL), np.zeros(1, LABEL), np.zeros(1, LABEL)
-    _check(lib().gc_kos_receiver_tags_dev(ctx.h, _p(_lab1(seed2)), C.c_void_p(d_result), C.c_void_p(d_b), n, _p(cv), _p(bc),
+    _check(lib().gc_kos_receiver_tags_dev(ctx.h, _p(_lab1(seed2)), _dp(d_result), _dp(d_b), n, _p(cv), _p(bc),
                                           _p(x), _p(t0), _p(t1)), "gc_kos_receiver_tags_dev")
     f = lambda a: (int(a[0]["d0"]), int(a[0]["d1"]))
     return f(x), f(t0), f(t1)
@@ -839,7 +937,7 @@ def kos_receiver_tags_dev(ctx, seed2, d_result, d_b, n, choice_vec, bcv):
 def kos_sender_check_dev(ctx, seed2, d_result, n, choice_vec, delta, x, t0, t1):
     cv = np.ascontiguousarray(choice_vec, dtype=LABEL)
     ok = C.c_int(0)
-    _check(lib().gc_kos_sender_check_dev(ctx.h, _p(_lab1(seed2)), C.c_void_p(d_result), n, _p(cv), _p(_lab1(delta)),
+    _check(lib().gc_kos_sender_check_dev(ctx.h, _p(_lab1(seed2)), _dp(d_result), n, _p(cv), _p(_lab1(delta)),
                                          _p(_lab1(x)), _p(_lab1(t0)), _p(_lab1(t1)), C.byref(ok)), "gc_kos_sender_check_dev")
     return bool(ok.value)
 

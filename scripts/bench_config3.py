@@ -11,7 +11,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from mpc_amd import engine, parse_file
 from mpc_amd.circuit import LABEL, WIRE
@@ -42,19 +41,18 @@ def run(batch=256, reps=20, key=bytes(range(32))):
     for i in range(batch):
         bits[i, :nin_g] = bits_of_bytes(a[i])
         bits[i, nin_g:] = bits_of_bytes(b[i])
-    d_rnd = torch.frombuffer(bytearray(drbg("rnd", 16 * (c.num_inputs + 1) * batch)), dtype=torch.uint8).cuda()
-    d_bits = torch.from_numpy(bits.copy()).cuda()
+    d_rnd = ctx.to_device(drbg("rnd", 16 * (c.num_inputs + 1) * batch))
+    d_bits = ctx.to_device(bits)
     flags = np.ascontiguousarray(bits[:, nin_g:]).reshape(-1)
     chunks = (n + 511) // 512
     packed = np.zeros(chunks * 64, np.uint8)
     pk = np.packbits(flags, bitorder="little")
     packed[:len(pk)] = pk
-    d_choice, d_flags = torch.from_numpy(packed).cuda(), torch.from_numpy(flags.copy()).cuda()
-    z = lambda *shape: torch.zeros(shape, dtype=torch.uint8, device="cuda")
+    d_choice, d_flags = ctx.to_device(packed), ctx.to_device(flags)
+    z = lambda *shape: ctx.zeros(shape)
     d_wires, d_u, d_lr, d_ls, d_sent = z(n, 32), z(chunks * 8192), z(n, 16), z(n, 16), z(2 * n, 16)
     d_out = z(batch, c.num_outputs)
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+    d_mis = ctx.zeros(1, np.int32)
     base = np.zeros(128, WIRE)
     for i in range(128):
         base[i]["l0"], base[i]["l1"] = lab(drbg("l0/%d" % i, 16)), lab(drbg("l1/%d" % i, 16))
@@ -70,16 +68,16 @@ def run(batch=256, reps=20, key=bytes(range(32))):
         rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
         ctx.sync()
         t0 = time.perf_counter()
-        gb.garble(key, d_rnd.data_ptr())
-        gb.gather_input_wires(nin_g, nin_e, d_wires.data_ptr())
-        rcv.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-        snd.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
-        engine.cot_send_pads_dev(ctx, seed, delta, d_ls.data_ptr(), d_wires.data_ptr(), n, d_sent.data_ptr())
-        engine.cot_receive_unpad_dev(ctx, seed, d_flags.data_ptr(), d_sent.data_ptr(), d_lr.data_ptr(), n)
-        ev.select_inputs(gb, d_bits.data_ptr())
-        ev.set_input_range(nin_g, nin_e, d_lr.data_ptr())
+        gb.garble(key, d_rnd)
+        gb.gather_input_wires(nin_g, nin_e, d_wires)
+        rcv.receive_dev(d_choice, n, d_u, d_lr)
+        snd.send_dev(d_u, n, d_ls)
+        engine.cot_send_pads_dev(ctx, seed, delta, d_ls, d_wires, n, d_sent)
+        engine.cot_receive_unpad_dev(ctx, seed, d_flags, d_sent, d_lr, n)
+        ev.select_inputs(gb, d_bits)
+        ev.set_input_range(nin_g, nin_e, d_lr)
         ev.eval(key, gb)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        gb.decode(ev, d_out, d_mis)
         ctx.sync()
         dt = time.perf_counter() - t0
         rcv.close()
@@ -88,8 +86,8 @@ def run(batch=256, reps=20, key=bytes(range(32))):
 
     one_pass()
     times = [one_pass() for _ in range(reps)]
-    assert int(d_mis.cpu()[0]) == 0
-    out = d_out.cpu().numpy()
+    assert int(d_mis.numpy()[0]) == 0
+    out = d_out.numpy()
     for i in range(batch):
         digest = np.packbits(out[i], bitorder="little").tobytes()
         assert digest == hashlib.sha256(bytes(x ^ y for x, y in zip(a[i], b[i]))).digest(), "instance %d" % i

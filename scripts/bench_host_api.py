@@ -20,11 +20,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-try:  # torch bundles its own ROCm runtime: load it before libgcengine.so pulls in the system one (tests/conftest.py)
-    import torch  # noqa: F401
-except Exception:
-    torch = None
-
 from mpc_amd import engine, parse_file
 from mpc_amd.circuit import LABEL, WIRE
 
@@ -144,37 +139,39 @@ def run(batch=1024, reps=4, key=bytes(range(32)), circuit=None):
 
 def link_probe(n=256 << 20):
     """what the box's host link does for plain pinned-memory DMA (each direction alone, both at once): the bound the
-    figures above are to be read against"""
-    try:
-        import torch
-    except Exception:
-        return None
-    h_out = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    h_in = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-    h_in.fill_(3)
-    d_a = torch.empty(n, dtype=torch.uint8, device="cuda")
-    d_b = torch.empty(n, dtype=torch.uint8, device="cuda")
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    figures above are to be read against.  Pinned host memory from gc_host_alloc, device memory from gc_dev_alloc, the
+    copies are gc_dev_download / gc_dev_upload on two contexts (two streams) driven by two threads."""
+    import threading
+
+    c1, c2 = engine.Context(0), engine.Context(0)
+    h_out, h_in = engine.PinnedArray(n, np.uint8), engine.PinnedArray(n, np.uint8)
+    h_in.a[:] = 3
+    d_a, d_b = c1.zeros(n), c2.empty(n)
+    L = engine.lib()
+
+    def d2h():
+        L.gc_dev_download(c1.h, p(h_out.a), C.c_void_p(d_a.ptr), n)
+
+    def h2d():
+        L.gc_dev_upload(c2.h, C.c_void_p(d_b.ptr), p(h_in.a), n)
+
+    def both():
+        t = threading.Thread(target=d2h)
+        t.start()
+        h2d()
+        t.join()
 
     def timed(fn, reps=4):
         fn()
-        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    def d2h():
-        with torch.cuda.stream(s1):
-            h_out.copy_(d_a, non_blocking=True)
-
-    def h2d():
-        with torch.cuda.stream(s2):
-            d_b.copy_(h_in, non_blocking=True)
-
-    return {"d2h_GBs": n / timed(d2h) / 1e9, "h2d_GBs": n / timed(h2d) / 1e9,
-            "both_at_once_GBs_each": n / timed(lambda: (d2h(), h2d())) / 1e9}
+    out = {"d2h_GBs": n / timed(d2h) / 1e9, "h2d_GBs": n / timed(h2d) / 1e9,
+           "both_at_once_GBs_each": n / timed(both) / 1e9}
+    d_a.close(); d_b.close(); h_out.close(); h_in.close(); c1.close(); c2.close()
+    return out
 
 
 if __name__ == "__main__":

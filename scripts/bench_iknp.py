@@ -7,7 +7,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from mpc_amd import engine
 from mpc_amd.circuit import LABEL, WIRE
@@ -30,23 +29,22 @@ def run(n=1 << 22, reps=10, device=0, ctx=None):
     rx = engine.IKNPReceiver(ctx, base)
     tx = engine.IKNPSender(ctx, delta[0], k0)
     chunks = (n + 511) // 512
-    d_choice = torch.randint(0, 256, (chunks * 64,), dtype=torch.uint8, device="cuda")
-    d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
-    d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-    d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
+    d_choice = ctx.random_u8((chunks * 64,), 256, seed=1)
+    d_u = ctx.zeros(chunks * 8192)
+    d_lr = ctx.zeros((n, 16))
+    d_ls = ctx.zeros((n, 16))
     rms, sms = [], []
     for it in range(reps + 2):
-        rx.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-        tx.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+        rx.receive_dev(d_choice, n, d_u, d_lr)
+        tx.send_dev(d_u, n, d_ls)
         ctx.sync()
         if it >= 2:
             rms.append(rx.last_ms)
             sms.append(tx.last_ms)
     # correlation check on the last round (iknp_test.go:98-113): rcvd = sent ^ b*delta
-    lr = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
-    ls = d_ls.cpu().numpy().view(np.uint64).reshape(n, 2)
-    ch = np.unpackbits(d_choice.cpu().numpy(), bitorder="little")[:n].astype(bool)
+    lr = d_lr.numpy().view(np.uint64).reshape(n, 2)
+    ls = d_ls.numpy().view(np.uint64).reshape(n, 2)
+    ch = np.unpackbits(d_choice.numpy(), bitorder="little")[:n].astype(bool)
     dv = np.array([int(delta["d0"][0]), int(delta["d1"][0])], dtype=np.uint64)
     ok = bool(((lr ^ ls) == np.where(ch[:, None], dv[None, :], 0)).all())
     r, s = float(np.mean(rms)), float(np.mean(sms))

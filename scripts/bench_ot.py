@@ -8,7 +8,6 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from mpc_amd import engine
 from mpc_amd.circuit import LABEL, WIRE
@@ -33,14 +32,13 @@ def run(n=1 << 22, reps=10, ctx=None):
     rng = np.random.default_rng(11)
     lab = lambda: (int(rng.integers(0, 1 << 63)), int(rng.integers(0, 1 << 63)))
     seed, delta, seed2 = lab(), lab(), lab()
-    d_data = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda")
-    d_wires = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
-    d_out = torch.zeros((2 * n, 16), dtype=torch.uint8, device="cuda")
-    d_flags = torch.randint(0, 2, (n,), dtype=torch.uint8, device="cuda")
-    d_res = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    ts = timed(ctx, lambda: engine.cot_send_pads_dev(ctx, seed, delta, d_data.data_ptr(), d_wires.data_ptr(), n, d_out.data_ptr()), reps)
-    tr = timed(ctx, lambda: engine.cot_receive_unpad_dev(ctx, seed, d_flags.data_ptr(), d_out.data_ptr(), d_res.data_ptr(), n), reps)
+    d_data = ctx.random_u8((n, 16), 256, seed=1)
+    d_wires = ctx.random_u8((n, 32), 256, seed=2)
+    d_out = ctx.zeros((2 * n, 16))
+    d_flags = ctx.random_u8((n,), 2, seed=3)
+    d_res = ctx.random_u8((n, 16), 256, seed=4)
+    ts = timed(ctx, lambda: engine.cot_send_pads_dev(ctx, seed, delta, d_data, d_wires, n, d_out), reps)
+    tr = timed(ctx, lambda: engine.cot_receive_unpad_dev(ctx, seed, d_flags, d_out, d_res, n), reps)
     # per OT: sender reads 16 + 32 B, writes 32 B, 2 AES-128 blocks + 1 key schedule; receiver reads 16 + 16(+16) + 1 B, writes 16 B
     res["cot"] = {"send_ms": ts * 1e3, "recv_ms": tr * 1e3, "send_ot_per_s": n / ts, "recv_ot_per_s": n / tr,
                   "send_alg_GBs": 80 * n / ts / 1e9, "recv_alg_GBs": 49 * n / tr / 1e9,
@@ -48,7 +46,7 @@ def run(n=1 << 22, reps=10, ctx=None):
     cv = np.zeros(256, LABEL)
     cv["d0"] = rng.integers(0, 1 << 63, 256, dtype=np.uint64)
     bcv = rng.integers(0, 2, 256).astype(np.uint8)
-    tk = timed(ctx, lambda: engine.kos_receiver_tags_dev(ctx, seed2, d_res.data_ptr(), d_flags.data_ptr(), n, cv, bcv), max(2, reps // 3))
+    tk = timed(ctx, lambda: engine.kos_receiver_tags_dev(ctx, seed2, d_res, d_flags, n, cv, bcv), max(2, reps // 3))
     res["kos"] = {"receiver_tags_ms": tk * 1e3, "ot_per_s": n / tk}
     # bit-COT
     base = np.zeros(128, WIRE)
@@ -56,11 +54,10 @@ def run(n=1 << 22, reps=10, ctx=None):
         base[f]["d0"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
         base[f]["d1"] = rng.integers(0, 1 << 63, 128, dtype=np.uint64)
     rx = engine.IKNPReceiver(ctx, base)
-    d_c = torch.randint(0, 256, (((n + 63) // 64) * 8,), dtype=torch.uint8, device="cuda")
-    d_u = torch.zeros(((n + 511) // 512) * 8192, dtype=torch.uint8, device="cuda")
-    d_r = torch.zeros(((n + 63) // 64) * 8, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    tb = timed(ctx, lambda: rx.receive_bits_dev(d_c.data_ptr(), n, d_u.data_ptr(), d_r.data_ptr()), reps)
+    d_c = ctx.random_u8((((n + 63) // 64) * 8,), 256, seed=5)
+    d_u = ctx.zeros(((n + 511) // 512) * 8192)
+    d_r = ctx.zeros(((n + 63) // 64) * 8)
+    tb = timed(ctx, lambda: rx.receive_bits_dev(d_c, n, d_u, d_r), reps)
     res["bitcot"] = {"receive_bits_ms": tb * 1e3, "ot_per_s": n / tb}
     rx.close()
     if own:

@@ -10,10 +10,6 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-try:
-    import torch  # noqa: F401  (its ROCm runtime first, tests/conftest.py)
-except Exception:
-    torch = None
 from mpc_amd import engine, parse_file
 from mpc_amd.circuit import LABEL, WIRE
 

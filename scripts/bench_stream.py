@@ -115,5 +115,12 @@ def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(
     return res
 
 
+def run_for_line(key=bytes(range(32)), ctx=None):
+    """the `stream` object of bench.py's line: a bounded sample of the big-step program (152 chained 131 072-gate steps)"""
+    st = run(20_000_000, key=key, ctx=ctx)
+    return {k: st[k] for k in ("steps", "gates", "steady_ms_per_step", "steady_gates_per_s", "eval_steady_ms_per_step",
+                               "eval_steady_gates_per_s", "first_use_ms_per_circuit", "sha256") if k in st}
+
+
 if __name__ == "__main__":
     print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000)))

@@ -2,7 +2,6 @@
 """Cycle breakdown of the fused garble / eval kernels (s_memtime instrumentation, developer aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 from mpc_amd import engine, parse_file
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -13,15 +12,14 @@ ctx = engine.Context(0)
 dc = engine.DeviceCircuit(ctx, c)
 gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
 key = bytes(range(keylen))
-d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda")
-d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda")
-torch.cuda.synchronize()
+d_rnd = ctx.random_u8((batch, c.num_inputs + 1, 16), 256, seed=1)
+d_bits = ctx.random_u8((batch, c.num_inputs), 2, seed=2)
 for _ in range(3):
-    gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+    gb.garble(key, d_rnd); ev.select_inputs(gb, d_bits); ev.eval(key, gb)
 ctx.sync()
 print("plain: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
 gb.debug_profile(True); ev.debug_profile(True)
-gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+gb.garble(key, d_rnd); ev.select_inputs(gb, d_bits); ev.eval(key, gb)
 ctx.sync()
 print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
 names = ["header", "hash-post", "barA", "commit", "xor", "barB", "hash-pre", "aes"]

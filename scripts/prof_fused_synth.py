@@ -2,7 +2,6 @@
 """Cycle breakdown (s_memtime instrumentation) of the kernels that run a synthetic wide circuit (developer aid)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 from mpc_amd import engine
 from mpc_amd.circuit import synthetic_levelised
 
@@ -14,15 +13,14 @@ ctx = engine.Context(0)
 dc = engine.DeviceCircuit(ctx, c)
 gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
 key = bytes(range(32))
-d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda")
-d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda")
-torch.cuda.synchronize()
+d_rnd = ctx.random_u8((batch, c.num_inputs + 1, 16), 256, seed=1)
+d_bits = ctx.random_u8((batch, c.num_inputs), 2, seed=2)
 for _ in range(3):
-    gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+    gb.garble(key, d_rnd); ev.select_inputs(gb, d_bits); ev.eval(key, gb)
 ctx.sync()
 print("lds_wires", gb.lds_wires, "tile", gb.tile_instances, "plain: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
 gb.debug_profile(True); ev.debug_profile(True)
-gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
+gb.garble(key, d_rnd); ev.select_inputs(gb, d_bits); ev.eval(key, gb)
 ctx.sync()
 print("instrumented: garble %.3f ms eval %.3f ms" % (gb.last_ms, ev.last_ms))
 for nm, b in (("garble", gb), ("eval", ev)):

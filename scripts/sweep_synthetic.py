@@ -12,7 +12,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from mpc_amd import engine
 from mpc_amd.circuit import and_chain, synthetic_levelised
@@ -23,38 +22,38 @@ BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}
 HBM_PEAK, LDS_LOOKUPS = 8000e9, 75e12 / 4
 
 
-def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4096):
+def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4096, cases=None):
     own = ctx is None
     if own:
         ctx = engine.Context(0)
     rounds = {16: 10, 24: 12, 32: 14}[len(key)]
-    cases = [(w, f) for w in (64, 1024, 16384) for f in (0.0, 0.17, 0.5, 1.0)]
-    circs = [synthetic_levelised(max(2, gates_target // w), w, f, seed=100 + i, ninputs=256) for i, (w, f) in enumerate(cases)]
-    circs.append(and_chain(chain))
+    grid = [(w, f) for w in (64, 1024, 16384) for f in (0.0, 0.17, 0.5, 1.0)]
+    cases = grid if cases is None else cases
+    # the seed of a (W, f) circuit is its position in the full grid, so a subset measures the same circuits
+    circs = [synthetic_levelised(max(2, gates_target // w), w, f, seed=100 + grid.index((w, f)), ninputs=256) for w, f in cases]
+    if chain:
+        circs.append(and_chain(chain))
     rows = []
     for c in circs:
         dc = engine.DeviceCircuit(ctx, c)
         info = dc.info
         gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(5)
-        d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
-        d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
-        d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
+        d_rnd = ctx.random_u8((batch, c.num_inputs + 1, 16), 256, seed=1)
+        d_bits = ctx.random_u8((batch, c.num_inputs), 2, seed=2)
+        d_out = ctx.zeros((batch, c.num_outputs))
+        d_mis = ctx.zeros(1, np.int32)
         g_ms, e_ms = [], []
         for it in range(4):
-            gb.garble(key, d_rnd.data_ptr())
-            ev.select_inputs(gb, d_bits.data_ptr())
+            gb.garble(key, d_rnd)
+            ev.select_inputs(gb, d_bits)
             ev.eval(key, gb)
-            gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+            gb.decode(ev, d_out, d_mis)
             ctx.sync()
             if it:
                 g_ms.append(gb.last_ms)
                 e_ms.append(ev.last_ms)
-        ok = int(d_mis.cpu()[0]) == 0
-        bits, out = d_bits.cpu().numpy(), d_out.cpu().numpy()
+        ok = int(d_mis.numpy()[0]) == 0
+        bits, out = d_bits.numpy(), d_out.numpy()
         for i in (0, batch // 2, batch - 1):
             plain = c.compute_bits(bits[i])  # plaintext evaluation (circuit/computer.go)
             ok = ok and bool((plain[c.NumWires - c.num_outputs:] == out[i]).all())
@@ -65,6 +64,17 @@ def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4
         alg = sum(cnt[k] * ALG[k] for k in ALG)                      # per instance per side
         rd = sum(cnt[k] * (READ[k][0] + READ[k][1]) for k in ALG)    # per instance, both sides
         lookups = sum(cnt[k] * (BLOCKS[k][0] + BLOCKS[k][1]) for k in BLOCKS) * 16 * rounds
+        # gates whose output label really exists somewhere: the flattened schedule folds XOR / XNOR gates that nobody
+        # needs as a label into the term lists of their readers (n_flat_outs of n_xor + n_xnor survive); the other
+        # kernels materialise every gate
+        flat = bool(gb.lds_wires) and info.n_flat_slots != 0xffffffff
+        materialised = int(nonfree + info.n_flat_outs) if flat else int(info.ngates)
+        frac_all = 2 * alg * batch / t / HBM_PEAK
+        note = None
+        if frac_all > 1.0 or materialised * 4 < info.ngates:
+            # the byte model prices labels the kernel never forms: the figure measures the model, not the kernel
+            note = "work elided by XOR flattening: %d of %d gates materialised; model fractions are not kernel efficiencies" % (
+                materialised, info.ngates)
         rows.append({
             "circuit": c.name, "gates": int(info.ngates), "and": cnt["and"], "levels": int(info.nlevels),
             "hash_phases": int(info.n_hash_phases), "batch": batch, "tile_instances": gb.tile_instances,
@@ -76,9 +86,12 @@ def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4
             "gates_per_s": info.ngates * batch / t,
             # fractions of the two rooflines: HBM at 8 TB/s over the layout-independent byte model (all bytes / reads
             # only), and the LDS array's ds_read_b32 rate over the T-table look-ups of the hashes
+            "gates_materialised": materialised,
+            "model_note": note,
             "hbm_alg_GBs": 2 * alg * batch / t / 1e9,
-            "hbm_roofline_frac": 2 * alg * batch / t / HBM_PEAK,
-            "hbm_read_roofline_frac": rd * batch / t / HBM_PEAK,
+            "hbm_roofline_frac": min(frac_all, 1.0) if note else frac_all,
+            "hbm_roofline_frac_uncapped": frac_all,
+            "hbm_read_roofline_frac": min(rd * batch / t / HBM_PEAK, 1.0) if note else rd * batch / t / HBM_PEAK,
             "lds_array_frac": lookups * batch / t / LDS_LOOKUPS,
             "outputs_ok": ok})
         gb.close(); ev.close(); dc.close()

@@ -9,17 +9,20 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# torch bundles its own ROCm runtime (libamdhip64.so.7, same soname as /opt/rocm's).  Whichever copy
-# is loaded first serves the whole process, so load torch's before libgcengine.so pulls in the
-# system one — otherwise a later `import torch` finds "No HIP GPUs".  (bench.py does the same.)
-try:  # pragma: no cover - torch is optional for the CPU suite
-    import torch  # noqa: F401
-except Exception:
-    torch = None
+# No torch anywhere in the suite's own process: device memory comes from the C ABI (gc_dev_alloc / gc_dev_upload /
+# gc_dev_download), so libgcengine.so brings in the system ROCm runtime by itself.  (tests/test_dist_gloo.py launches
+# torch.distributed.run in CHILD processes: the launcher and its gloo control plane, nothing on a GPU.)
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # the product path must not lean on torch: a GPU run of this suite that imported it is a failure
+    if "torch" in sys.modules and not os.environ.get("GC_ALLOW_TORCH"):
+        session.exitstatus = 1
+        sys.stderr.write("\ntests: `torch` was imported into the test process — device memory must come from gc_dev_*\n")
 
 
 @pytest.fixture(scope="session")

@@ -3,7 +3,6 @@ the oracle, batches from 1 to 16 500 instances (tiles of 1 to 64 instances per w
 Run on a GPU box: python tests/ext_fuzz.py [N]"""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 import oracle
 from mpc_amd import engine
 from tests.test_gpu_fuzz import random_circuit, xor_tree, KEY
@@ -122,17 +121,16 @@ for seed in range(max(1, N // 8)):
                 packed = np.zeros(chunks * 64, np.uint8)
                 pk = np.packbits(b, bitorder="little")
                 packed[:len(pk)] = pk
-                d_choice = torch.from_numpy(packed).cuda()
-                d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
-                d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-                d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-                torch.cuda.synchronize()
-                grcv.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-                gsnd.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+                d_choice = ctx.to_device(packed)
+                d_u = ctx.zeros(chunks * 8192)
+                d_lr = ctx.zeros((n, 16))
+                d_ls = ctx.zeros((n, 16))
+                grcv.receive_dev(d_choice, n, d_u, d_lr)
+                gsnd.send_dev(d_u, n, d_ls)
                 ctx.sync()
-                u = d_u.cpu().numpy()[: len(wu)].tobytes()
-                got = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
-                sent = d_ls.cpu().numpy().view(np.uint64).reshape(n, 2)
+                u = d_u.numpy()[: len(wu)].tobytes()
+                got = d_lr.numpy().view(np.uint64).reshape(n, 2)
+                sent = d_ls.numpy().view(np.uint64).reshape(n, 2)
                 got = np.rec.fromarrays([got[:, 0], got[:, 1]], names="d0,d1")
                 sent = np.rec.fromarrays([sent[:, 0], sent[:, 1]], names="d0,d1")
             assert bytes(u) == bytes(wu), "u matrix, call %d n %d" % (call, n)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 45
     for n in names:
         assert hasattr(L, n), "libgcengine.so does not export %s" % n
-    assert L.gc_abi_version() == 1
+    assert L.gc_abi_version() == engine.ABI_VERSION == 2
     assert L.gc_strerror(engine.GC_E_KEYSIZE).decode() == "crypto/aes: invalid key size"
 
 
@@ -202,5 +202,11 @@ def test_go_shim_names_only_declared_entry_points_and_covers_the_table():
             "gc_stream_eval_get_wire", "gc_stream_eval_circuit", "gc_iknp_receiver_create", "gc_iknp_sender_create",
             "gc_iknp_receive", "gc_iknp_send", "gc_iknp_receive_bits", "gc_iknp_send_bits", "gc_kos_receiver_tags",
             "gc_kos_sender_check", "gc_mitccrh_hash", "gc_cot_send_pads", "gc_cot_receive_unpad", "gc_host_alloc",
-            "gc_comm_init_all", "gc_comm_init_rank", "gc_comm_get_unique_id", "gc_comm_allgather_all"}
+            "gc_comm_init_all", "gc_comm_init_rank", "gc_comm_get_unique_id", "gc_comm_allgather_all",
+            "gc_comm_allgather",
+            # the device-resident pipeline must be reachable from Go (go/circuit/batch_hip.go): device memory through
+            # the ABI and the batch calls themselves
+            "gc_dev_alloc", "gc_dev_free", "gc_dev_upload", "gc_dev_download", "gc_dev_memset", "gc_batch_create",
+            "gc_batch_garble", "gc_batch_select_inputs", "gc_batch_eval", "gc_batch_decode", "gc_batch_read_slab",
+            "gc_batch_read_r", "gc_batch_read_outputs", "gc_ctx_capture_begin", "gc_ctx_capture_end", "gc_graph_launch"}
     assert must <= used, sorted(must - used)

@@ -82,7 +82,6 @@ def test_config3_device_resident(sha_circ):
     """the same flow with everything in HBM: garble -> input wires gathered for the OT sender -> IKNP extension ->
     COT pads -> the evaluator's labels scattered into its wire array -> eval -> decode; no host round trip between
     the steps (gc_batch_gather_input_wires, gc_iknp_*_dev, gc_cot_*_dev, gc_batch_set_input_range)"""
-    import torch
     c = sha_circ
     batch = 64
     ctx = engine.Context(0)
@@ -97,47 +96,46 @@ def test_config3_device_resident(sha_circ):
         bits[i, :nin_g] = bits_of_bytes(a[i])
         bits[i, nin_g:] = bits_of_bytes(b[i])
     rnd = drbg("cfg3dev", 16 * (c.num_inputs + 1) * batch)
-    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
-    d_bits = torch.from_numpy(bits.copy()).cuda()
+    d_rnd = ctx.to_device(rnd)
+    d_bits = ctx.to_device(bits)
     flags = np.ascontiguousarray(bits[:, nin_g:]).reshape(-1)
     chunks = (n + 511) // 512
     packed = np.zeros(chunks * 64, np.uint8)
     pk = np.packbits(flags, bitorder="little")
     packed[:len(pk)] = pk
-    d_choice = torch.from_numpy(packed).cuda()
-    d_flags = torch.from_numpy(flags.copy()).cuda()
-    d_wires = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
-    d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
-    d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-    d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-    d_sent = torch.zeros((2 * n, 16), dtype=torch.uint8, device="cuda")
-    d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+    d_choice = ctx.to_device(packed)
+    d_flags = ctx.to_device(flags)
+    d_wires = ctx.zeros((n, 32))
+    d_u = ctx.zeros(chunks * 8192)
+    d_lr = ctx.zeros((n, 16))
+    d_ls = ctx.zeros((n, 16))
+    d_sent = ctx.zeros((2 * n, 16))
+    d_out = ctx.zeros((batch, c.num_outputs))
+    d_mis = ctx.zeros(1, np.int32)
     base, delta, k0 = base_setup("cfg3dev")
     rcv, snd = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
     seed = oracle.label_from_bytes(drbg("cfg3devseed", 16))
-    gb.garble(KEY, d_rnd.data_ptr())
-    gb.gather_input_wires(nin_g, nin_e, d_wires.data_ptr())
-    rcv.receive_dev(d_choice.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-    snd.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
-    engine.cot_send_pads_dev(ctx, seed, delta, d_ls.data_ptr(), d_wires.data_ptr(), n, d_sent.data_ptr())
-    engine.cot_receive_unpad_dev(ctx, seed, d_flags.data_ptr(), d_sent.data_ptr(), d_lr.data_ptr(), n)
-    ev.select_inputs(gb, d_bits.data_ptr())             # the garbler's own input labels (sent in the clear) ...
-    ev.set_input_range(nin_g, nin_e, d_lr.data_ptr())   # ... and the evaluator's through the OT
+    gb.garble(KEY, d_rnd)
+    gb.gather_input_wires(nin_g, nin_e, d_wires)
+    rcv.receive_dev(d_choice, n, d_u, d_lr)
+    snd.send_dev(d_u, n, d_ls)
+    engine.cot_send_pads_dev(ctx, seed, delta, d_ls, d_wires, n, d_sent)
+    engine.cot_receive_unpad_dev(ctx, seed, d_flags, d_sent, d_lr, n)
+    ev.select_inputs(gb, d_bits)             # the garbler's own input labels (sent in the clear) ...
+    ev.set_input_range(nin_g, nin_e, d_lr)   # ... and the evaluator's through the OT
     ev.eval(KEY, gb)
-    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    gb.decode(ev, d_out, d_mis)
     ctx.sync()
-    assert int(d_mis.cpu()[0]) == 0
-    out = d_out.cpu().numpy()
+    assert int(d_mis.numpy()[0]) == 0
+    out = d_out.numpy()
     for i in range(batch):
         digest = np.packbits(out[i], bitorder="little").tobytes()
         assert digest == hashlib.sha256(bytes(x ^ y for x, y in zip(a[i], b[i]))).digest(), "instance %d" % i
     assert np.packbits(out[0], bitorder="little").tobytes().hex() == \
         "4b2f74579fc7c778745121996f604371a326dc5174f9851706032626668abf2e"
     # the OT really delivered the chosen labels: compare with the garbler's wires
-    w = d_wires.cpu().numpy().view(np.uint64).reshape(n, 4)
-    got = d_lr.cpu().numpy().view(np.uint64).reshape(n, 2)
+    w = d_wires.numpy().view(np.uint64).reshape(n, 4)
+    got = d_lr.numpy().view(np.uint64).reshape(n, 2)
     want = np.where(flags[:, None].astype(bool), w[:, 2:], w[:, :2])
     assert (got == want).all()
     rcv.close(); snd.close(); gb.close(); ev.close(); dc.close(); ctx.close()

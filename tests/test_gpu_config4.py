@@ -31,41 +31,38 @@ def aes_inputs(lo, hi):
     return keys, pts, bits
 
 
-def run_shard(ctx, dc, schedule, rnd, bits, torch_device):
-    """garble -> input hand-over -> eval -> decode of one shard; returns (garbler batch, decoded bits tensor)"""
-    import torch
+def run_shard(ctx, dc, schedule, rnd, bits):
+    """garble -> input hand-over -> eval -> decode of one shard; returns (garbler batch, decoded bits buffer).  Every
+    device buffer comes from the C ABI (gc_dev_alloc on the shard's own ctx / device): no torch in the process."""
     batch = len(bits)
     gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
     gb.set_schedule(schedule)
     ev.set_schedule(schedule)
-    with torch.cuda.device(torch_device):
-        d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
-        d_bits = torch.from_numpy(bits).cuda()
-        d_out = torch.zeros((batch, 128), dtype=torch.uint8, device="cuda")
-        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-    gb.garble(KEY256, d_rnd.data_ptr())
-    ev.select_inputs(gb, d_bits.data_ptr())
+    d_rnd = ctx.to_device(rnd)
+    d_bits = ctx.to_device(bits)
+    d_out = ctx.zeros((batch, 128))
+    d_mis = ctx.zeros(1, np.int32)
+    gb.garble(KEY256, d_rnd)
+    ev.select_inputs(gb, d_bits)
     ev.eval(KEY256, gb)
-    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    gb.decode(ev, d_out, d_mis)
     ctx.sync()
-    assert int(d_mis.cpu()[0]) == 0
+    assert int(d_mis.numpy()[0]) == 0
     ev.close()
     return gb, d_out, (d_rnd, d_bits)
 
 
 @pytest.mark.parametrize("schedule", [1, 0])
 def test_aes128_x8192_one_rank_share(aes_circ, schedule):
-    import torch
     c = aes_circ
     ctx = engine.Context(0)
     dc = engine.DeviceCircuit(ctx, c)
     stride = 16 * (c.num_inputs + 1)
     rnd = drbg("c4rnd", stride * PER_GPU)
     keys, pts, bits = aes_inputs(0, PER_GPU)
-    gb, d_out, keep = run_shard(ctx, dc, schedule, rnd, bits, 0)
+    gb, d_out, keep = run_shard(ctx, dc, schedule, rnd, bits)
     assert gb.tile_instances == (4 if schedule == 1 else 1)
-    out = d_out.cpu().numpy()
+    out = d_out.numpy()
     for i in range(PER_GPU):  # every instance: decoded ciphertext == AES-128(key, pt)
         assert int_from_bits(out[i]).to_bytes(16, "big") == oracle.aes_encrypt(keys[i], pts[i]), "instance %d" % i
     # byte parity with the oracle on 16 sampled instances: R, every table row, the output wires' zero labels
@@ -81,10 +78,10 @@ def test_aes128_x8192_one_rank_share(aes_circ, schedule):
     # the terminal exchange: this rank's decoded bits through gc_comm_allgather (one-rank communicator)
     if schedule == 1:
         comm = engine.Comm(ctx, engine.comm_unique_id(), 1, 0)
-        d_all = torch.zeros_like(d_out)
-        comm.allgather(d_out.data_ptr(), d_all.data_ptr(), d_out.numel())
+        d_all = ctx.zeros(d_out.shape)
+        comm.allgather(d_out, d_all, d_out.nbytes)
         comm.barrier()
-        assert torch.equal(d_all, d_out)
+        assert (d_all.numpy() == out).all()
         assert comm.allreduce_max(3.25) == 3.25
         comm.close()
     gb.close(); dc.close(); ctx.close()
@@ -92,7 +89,6 @@ def test_aes128_x8192_one_rank_share(aes_circ, schedule):
 
 def test_two_devices_sharded_gather(aes_circ):
     """the N-rank job in one process: gc_comm_init_all over the box's devices, contiguous shards, one all-gather"""
-    import torch
     ndev = min(engine.device_count(), 8)
     if ndev < 2:
         pytest.skip("one device in this box (the driver's multi-GPU node runs it)")
@@ -109,15 +105,15 @@ def test_two_devices_sharded_gather(aes_circ):
         lo, hi = shard_range(total, d, ndev)
         assert hi - lo == per
         dcs.append(engine.DeviceCircuit(ctxs[d], c))
-        gb, d_out, k = run_shard(ctxs[d], dcs[d], 1, rnd[lo * stride:hi * stride], bits[lo:hi], d)
+        gb, d_out, k = run_shard(ctxs[d], dcs[d], 1, rnd[lo * stride:hi * stride], bits[lo:hi])
         gbs.append(gb); outs.append(d_out); keep.append(k)
-        alls.append(torch.zeros((ndev, per, 128), dtype=torch.uint8, device="cuda:%d" % d))
-    engine.Comm.allgather_all(comms, [o.data_ptr() for o in outs], [a.data_ptr() for a in alls], per * 128)
+        alls.append(ctxs[d].zeros((ndev, per, 128)))
+    engine.Comm.allgather_all(comms, outs, alls, per * 128)
     for cm in comms:
         cm.ctx.sync()
-    ref = alls[0].cpu().numpy().reshape(total, 128)
+    ref = alls[0].numpy().reshape(total, 128)
     for d in range(1, ndev):  # every rank holds the whole result
-        assert (alls[d].cpu().numpy().reshape(total, 128) == ref).all()
+        assert (alls[d].numpy().reshape(total, 128) == ref).all()
     for i in range(total):
         assert int_from_bits(ref[i]).to_bytes(16, "big") == oracle.aes_encrypt(keys[i], pts[i]), "instance %d" % i
     for d in range(ndev):  # shard boundaries against the oracle

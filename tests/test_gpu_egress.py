@@ -14,7 +14,6 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("schedule", [0, 1])
 def test_egress_ingest(schedule, aes_circ):
-    import torch
     ctx = engine.Context(0)
     for c, batch in ((synthetic_levelised(8, 50, 0.3, seed=41, ninputs=32, or_frac=0.1, inv_frac=0.1, xnor_frac=0.05), 37),
                      (aes_circ, 5)):
@@ -24,17 +23,14 @@ def test_egress_ingest(schedule, aes_circ):
         key = bytes(range(32))
         stride_rnd = 16 * (c.num_inputs + 1)
         rnd = drbg("eg%d" % batch, stride_rnd * batch)
-        d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
-        torch.cuda.synchronize()  # torch's stream -> engine stream hand-over (the engine runs on its own stream)
-        gb.garble(key, d_rnd.data_ptr())
+        d_rnd = ctx.to_device(rnd)  # gc_dev_alloc + gc_dev_upload: the buffers come from the C ABI, not from torch
+        gb.garble(key, d_rnd)
         nbytes = dc.tables_wire_bytes
         assert nbytes == 4 + 4 * c.NumGates + 16 * c.slab_rows()
         stride = (nbytes + 63) // 64 * 64
-        d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        gb.egress_tables(d_wire.data_ptr(), stride)
-        ctx.sync()
-        wire = d_wire.cpu().numpy().reshape(batch, stride)
+        d_wire = ctx.zeros(batch * stride)
+        gb.egress_tables(d_wire, stride)
+        wire = d_wire.numpy().reshape(batch, stride)
         slab = gb.read_slab()
         for i in range(batch):
             want = oracle.tables_serialize(c.Gates, slab[i])
@@ -44,19 +40,17 @@ def test_egress_ingest(schedule, aes_circ):
                 assert (slab[i] == ref["slab"]).all()
                 assert (oracle.tables_parse(c.Gates, want) == ref["slab"]).all()
         # evaluator side: ingest the bytes, evaluate, decode
-        d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
-        ev.ingest_tables(d_wire.data_ptr(), stride, d_bad.data_ptr())
+        d_bad = ctx.zeros(1, np.int32)
+        ev.ingest_tables(d_wire, stride, d_bad)
         bits = (np.frombuffer(drbg("egb", batch * c.num_inputs), np.uint8) & 1).reshape(batch, -1)
-        d_bits = torch.from_numpy(bits.copy()).cuda()
-        d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
-        ev.select_inputs(gb, d_bits.data_ptr())
+        d_bits = ctx.to_device(bits)
+        d_out = ctx.zeros((batch, c.num_outputs))
+        d_mis = ctx.zeros(1, np.int32)
+        ev.select_inputs(gb, d_bits)
         ev.eval(key, ev)  # evaluator's OWN ingested tables
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
-        ctx.sync()
-        assert int(d_bad.cpu()[0]) == 0 and int(d_mis.cpu()[0]) == 0
-        out = d_out.cpu().numpy()
+        gb.decode(ev, d_out, d_mis)
+        assert int(d_bad.numpy()[0]) == 0 and int(d_mis.numpy()[0]) == 0
+        out = d_out.numpy()
         for i in range(batch):
             plain = oracle.compute(c.Gates, c.NumWires, c.num_inputs, bits[i])
             assert (out[i] == plain[c.NumWires - c.num_outputs:]).all()
@@ -64,19 +58,16 @@ def test_egress_ingest(schedule, aes_circ):
         w2 = wire.copy()
         w2[0, 3] ^= 1
         w2[min(1, batch - 1), 7] ^= 1
-        d_w2 = torch.from_numpy(w2.reshape(-1)).cuda()
-        d_bad.zero_()
-        torch.cuda.synchronize()
-        ev.ingest_tables(d_w2.data_ptr(), stride, d_bad.data_ptr())
-        ctx.sync()
-        assert int(d_bad.cpu()[0]) == 2
+        d_w2 = ctx.to_device(w2.reshape(-1))
+        d_bad.zero()
+        ev.ingest_tables(d_w2, stride, d_bad)
+        assert int(d_bad.numpy()[0]) == 2
         gb.close(); ev.close(); dc.close()
     ctx.close()
 
 
 def test_dense_encoding_sha2pc(sha_circ):
     """sha2pc/encoding.go:363-411: rows in gate order, BE(D0)||BE(D1) each, garbledTableByteLen = 16 * 42914"""
-    import torch
     c = sha_circ
     batch = 3
     ctx = engine.Context(0)
@@ -85,22 +76,20 @@ def test_dense_encoding_sha2pc(sha_circ):
     key = bytes(range(32))
     stride_rnd = 16 * (c.num_inputs + 1)
     rnd = drbg("dense", stride_rnd * batch)
-    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    d_rnd = ctx.to_device(rnd)
     nbytes = 16 * c.slab_rows()
     assert nbytes == 16 * 42914
-    d_wire = torch.zeros(batch * nbytes, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    gb.garble(key, d_rnd.data_ptr())
-    gb.egress_tables_dense(d_wire.data_ptr(), nbytes)
-    ctx.sync()
-    wire = d_wire.cpu().numpy().reshape(batch, nbytes)
+    d_wire = ctx.zeros(batch * nbytes)
+    gb.garble(key, d_rnd)
+    gb.egress_tables_dense(d_wire, nbytes)
+    wire = d_wire.numpy().reshape(batch, nbytes)
     ref = oracle.garble(c.Gates, c.NumWires, c.num_inputs, key, rnd[:stride_rnd])
     want = b"".join(oracle.label_to_bytes(l) for l in ref["slab"])
     assert wire[0].tobytes() == want
     slab = gb.read_slab()
     for i in range(batch):
         assert wire[i].tobytes() == b"".join(oracle.label_to_bytes(l) for l in slab[i])
-    ev.ingest_tables_dense(d_wire.data_ptr(), nbytes)
+    ev.ingest_tables_dense(d_wire, nbytes)
     ctx.sync()
     assert (ev.read_slab() == slab).all()
     gb.close(); ev.close(); dc.close(); ctx.close()

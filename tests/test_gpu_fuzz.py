@@ -114,7 +114,6 @@ def device_pipeline_case(ctx, seed):
     """one random circuit, random key size, schedule and batch (1 - 16 500 instances) through the device-resident
     pipeline: garble -> select -> (eval | table egress / ingest + eval) -> decode; decoded bits against plaintext
     evaluation, tables of sampled instances against the oracle; raises on a mismatch (tests/ext_fuzz.py runs hundreds)"""
-    import torch
     from tests.test_gpu_garble_eval import oracle_instance, rnd_for
     from tests.util import drbg
     rng = np.random.default_rng(77000 + seed)
@@ -130,42 +129,40 @@ def device_pipeline_case(ctx, seed):
     for b in (gb, ev):
         b.set_schedule(schedule)
     rnd = rnd_for(c, "xd%d" % seed, batch)
-    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    d_rnd = ctx.to_device(rnd)
     bits = (np.frombuffer(drbg("xb%d" % seed, c.num_inputs * batch), np.uint8) & 1).reshape(batch, c.num_inputs)
-    d_bits = torch.from_numpy(bits.copy()).cuda()
-    d_out = torch.zeros((batch, max(c.num_outputs, 1)), dtype=torch.uint8, device="cuda")
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    gb.garble(key, d_rnd.data_ptr())
-    ev.select_inputs(gb, d_bits.data_ptr())
+    d_bits = ctx.to_device(bits)
+    d_out = ctx.zeros((batch, max(c.num_outputs, 1)))
+    d_mis = ctx.zeros(1, np.int32)
+    gb.garble(key, d_rnd)
+    ev.select_inputs(gb, d_bits)
     mode = int(rng.integers(0, 3)) if batch <= 4100 and c.slab_rows() else 0
     if mode == 0:
         ev.eval(key, gb)
     else:  # tables leave the garbler in the driver's wire format (1) / sha2pc's dense form (2) and are ingested again
         nbytes = dc.tables_wire_bytes if mode == 1 else 16 * c.slab_rows()
         stride = (nbytes + 63) // 64 * 64
-        d_wire = torch.zeros(batch * stride, dtype=torch.uint8, device="cuda")
-        d_bad = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
+        d_wire = ctx.zeros(batch * stride)
+        d_bad = ctx.zeros(1, np.int32)
         if mode == 1:
-            gb.egress_tables(d_wire.data_ptr(), stride)
-            ev.ingest_tables(d_wire.data_ptr(), stride, d_bad.data_ptr())
+            gb.egress_tables(d_wire, stride)
+            ev.ingest_tables(d_wire, stride, d_bad)
         else:
-            gb.egress_tables_dense(d_wire.data_ptr(), stride)
-            ev.ingest_tables_dense(d_wire.data_ptr(), stride)
+            gb.egress_tables_dense(d_wire, stride)
+            ev.ingest_tables_dense(d_wire, stride)
         ev.eval(key, ev)
         ctx.sync()
-        assert int(d_bad.cpu()[0]) == 0, "ingest flagged a header"
-        wire = d_wire.cpu().numpy().reshape(batch, stride)
+        assert int(d_bad.numpy()[0]) == 0, "ingest flagged a header"
+        wire = d_wire.numpy().reshape(batch, stride)
         sl = gb.read_slab()
         for i in (0, batch - 1):
             want = oracle.tables_serialize(c.Gates, sl[i]) if mode == 1 else \
                 b"".join(int(x).to_bytes(8, "big") for row in sl[i] for x in (row["d0"], row["d1"]))
             assert wire[i, :nbytes].tobytes() == want, "egress bytes of instance %d (mode %d)" % (i, mode)
-    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    gb.decode(ev, d_out, d_mis)
     ctx.sync()
-    assert int(d_mis.cpu()[0]) == 0, "decode mismatches"
-    out = d_out.cpu().numpy()
+    assert int(d_mis.numpy()[0]) == 0, "decode mismatches"
+    out = d_out.numpy()
     for i in sorted(set(list(range(0, batch, max(1, batch // 7))) + [batch - 1])):
         plain = c.compute_bits(bits[i])
         assert (plain[c.NumWires - c.num_outputs:] == out[i][: c.num_outputs]).all(), "decoded bits of instance %d" % i

@@ -251,19 +251,18 @@ def test_error_behaviour(ctx, add64_circ):
 
 
 def test_graph_and_direct_launch_agree(ctx):
-    import torch
     c = synthetic_levelised(12, 64, 0.25, seed=21, ninputs=64, inv_frac=0.05)
     dc = engine.DeviceCircuit(ctx, c)
     batch = 128
     rnd = rnd_for(c, "graph", batch)
-    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    d_rnd = ctx.to_device(rnd)
     slabs = []
     for graph in (True, False, True):
         b = engine.Batch(dc, batch)
         b.set_schedule(0)
         b.set_graph(graph)
-        b.garble(KEY256, d_rnd.data_ptr())
-        b.garble(KEY256, d_rnd.data_ptr())  # second call replays the captured graph
+        b.garble(KEY256, d_rnd)
+        b.garble(KEY256, d_rnd)  # second call replays the captured graph
         slabs.append(b.read_slab().copy())
         assert b.last_ms > 0 and b.last_launches == dc.info.n_steps  # gate kernels only
         b.close()
@@ -278,7 +277,6 @@ def test_device_resident_pipeline_full_size(ctx, aes_circ, schedule):
     """BASELINE config 2 shape: AES-128 circuit x 1024 instances, device-resident API.
     Size-independent property: decoded outputs == AES-128(key, pt) for every instance; plus byte
     parity with the oracle on sampled instances."""
-    import torch
     c = aes_circ
     batch = 1024
     dc = engine.DeviceCircuit(ctx, c)
@@ -286,24 +284,23 @@ def test_device_resident_pipeline_full_size(ctx, aes_circ, schedule):
     gb.set_schedule(schedule)
     ev.set_schedule(schedule)
     rnd = rnd_for(c, "full", batch)
-    d_rnd = torch.frombuffer(bytearray(rnd), dtype=torch.uint8).cuda()
+    d_rnd = ctx.to_device(rnd)
     keys = [drbg("k%d" % i, 16) for i in range(batch)]
     pts = [drbg("p%d" % i, 16) for i in range(batch)]
     bits = np.zeros((batch, 256), np.uint8)
     for i in range(batch):
         bits[i, :128] = bits_lsb(int.from_bytes(keys[i], "big"), 128)
         bits[i, 128:] = bits_lsb(int.from_bytes(pts[i], "big"), 128)
-    d_bits = torch.from_numpy(bits).cuda()
-    d_out = torch.zeros((batch, 128), dtype=torch.uint8, device="cuda")
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    gb.garble(KEY256, d_rnd.data_ptr())
-    ev.select_inputs(gb, d_bits.data_ptr())
+    d_bits = ctx.to_device(bits)
+    d_out = ctx.zeros((batch, 128))
+    d_mis = ctx.zeros(1, np.int32)
+    gb.garble(KEY256, d_rnd)
+    ev.select_inputs(gb, d_bits)
     ev.eval(KEY256, gb)
-    gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+    gb.decode(ev, d_out, d_mis)
     ctx.sync()
-    assert int(d_mis.cpu()[0]) == 0
-    out = d_out.cpu().numpy()
+    assert int(d_mis.numpy()[0]) == 0
+    out = d_out.numpy()
     for i in range(batch):
         ct = int_from_bits(out[i]).to_bytes(16, "big")
         assert ct == oracle.aes_encrypt(keys[i], pts[i]), "instance %d" % i
@@ -319,22 +316,20 @@ def test_device_resident_pipeline_full_size(ctx, aes_circ, schedule):
 def test_pipeline_graph_replay(ctx, add64_circ):
     """gc_ctx_capture_*: the garble -> select -> eval -> decode sequence recorded once and replayed gives the bytes of
     the direct calls, also after the inputs (same device buffers) changed."""
-    import torch
     c = add64_circ
     batch = 600
     dc = engine.DeviceCircuit(ctx, c)
     gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
-    d_rnd = torch.frombuffer(bytearray(rnd_for(c, "graph0", batch)), dtype=torch.uint8).cuda()
-    d_bits = torch.zeros((batch, c.num_inputs), dtype=torch.uint8, device="cuda")
-    d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-    d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+    d_rnd = ctx.to_device(rnd_for(c, "graph0", batch))
+    d_bits = ctx.zeros((batch, c.num_inputs))
+    d_out = ctx.zeros((batch, c.num_outputs))
+    d_mis = ctx.zeros(1, np.int32)
 
     def step():
-        gb.garble(KEY256, d_rnd.data_ptr())
-        ev.select_inputs(gb, d_bits.data_ptr())
+        gb.garble(KEY256, d_rnd)
+        ev.select_inputs(gb, d_bits)
         ev.eval(KEY256, gb)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        gb.decode(ev, d_out, d_mis)
 
     step()  # uploads the key; not capturable
     ctx.sync()
@@ -342,13 +337,12 @@ def test_pipeline_graph_replay(ctx, add64_circ):
     for rep in range(2):
         rnd = rnd_for(c, "graph%d" % (rep + 1), batch)
         bits = (np.frombuffer(drbg("gbits%d" % rep, batch * c.num_inputs), np.uint8) & 1).reshape(batch, -1)
-        d_rnd.copy_(torch.frombuffer(bytearray(rnd), dtype=torch.uint8))
-        d_bits.copy_(torch.from_numpy(bits.copy()))
-        torch.cuda.synchronize()
+        d_rnd.upload(np.frombuffer(rnd, np.uint8))
+        d_bits.upload(bits)
         g.launch()
         ctx.sync()
-        assert int(d_mis.cpu()[0]) == 0
-        out = d_out.cpu().numpy()
+        assert int(d_mis.numpy()[0]) == 0
+        out = d_out.numpy()
         slab, R = gb.read_slab(), gb.read_r()
         for i in (0, 1, 299, 599):
             ref = oracle_instance(c, KEY256, rnd, i)

@@ -145,14 +145,12 @@ def test_kos_check_matches_oracle(ctx, n):
         bad[n // 2]["d1"] ^= 1 << 40
         assert not engine.kos_sender_check(ctx, seed2, bad, cvs, delta, x, t0, t1)
     # the device-resident forms: labels and choice bytes stay in HBM (what gc_iknp_*_dev leave there)
-    import torch
-    d_got = torch.from_numpy(np.ascontiguousarray(got).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8)).cuda()
-    d_sent = torch.from_numpy(np.ascontiguousarray(sent).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8)).cuda()
-    d_b = torch.from_numpy(b.copy() if n else np.zeros(1, np.uint8)).cuda()
-    torch.cuda.synchronize()
-    assert engine.kos_receiver_tags_dev(ctx, seed2, d_got.data_ptr(), d_b.data_ptr(), n, cvr, bcv) == want
-    assert engine.kos_sender_check_dev(ctx, seed2, d_sent.data_ptr(), n, cvs, delta, x, t0, t1)
-    assert not engine.kos_sender_check_dev(ctx, seed2, d_sent.data_ptr(), n, cvs, delta, x, t0, (t1[0], t1[1] ^ 2))
+    d_got = ctx.to_device(np.ascontiguousarray(got).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8))
+    d_sent = ctx.to_device(np.ascontiguousarray(sent).view(np.uint8).reshape(-1).copy() if n else np.zeros(16, np.uint8))
+    d_b = ctx.to_device(b.copy() if n else np.zeros(1, np.uint8))
+    assert engine.kos_receiver_tags_dev(ctx, seed2, d_got, d_b, n, cvr, bcv) == want
+    assert engine.kos_sender_check_dev(ctx, seed2, d_sent, n, cvs, delta, x, t0, t1)
+    assert not engine.kos_sender_check_dev(ctx, seed2, d_sent, n, cvs, delta, x, t0, (t1[0], t1[1] ^ 2))
 
 
 @pytest.mark.parametrize("n", [64, 1024, 1000, 70, 513])
@@ -175,7 +173,6 @@ def test_bitcot_matches_oracle(ctx, n):
 def test_iknp_device_resident_api_matches_host_api(ctx):
     """gc_iknp_receive_dev / gc_iknp_send_dev (HBM in, HBM out, asynchronous) produce the bytes of the host calls,
     including the persistent stream position across calls of ragged sizes."""
-    import torch
     base, delta, k0 = base_setup("dev")
     rx_h, tx_h = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
     rx_d, tx_d = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
@@ -187,17 +184,16 @@ def test_iknp_device_resident_api_matches_host_api(ctx):
         packed = np.zeros(chunks * 64, np.uint8)
         pb = np.packbits(b, bitorder="little")
         packed[:len(pb)] = pb
-        d_c = torch.from_numpy(packed).cuda()
-        d_u = torch.zeros(chunks * 8192, dtype=torch.uint8, device="cuda")
-        d_lr = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-        d_ls = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        rx_d.receive_dev(d_c.data_ptr(), n, d_u.data_ptr(), d_lr.data_ptr())
-        tx_d.send_dev(d_u.data_ptr(), n, d_ls.data_ptr())
+        d_c = ctx.to_device(packed)
+        d_u = ctx.zeros(chunks * 8192)
+        d_lr = ctx.zeros((n, 16))
+        d_ls = ctx.zeros((n, 16))
+        rx_d.receive_dev(d_c, n, d_u, d_lr)
+        tx_d.send_dev(d_u, n, d_ls)
         ctx.sync()
-        assert d_u.cpu().numpy()[:len(u)].tobytes() == u
-        assert d_lr.cpu().numpy().tobytes() == lr.tobytes()
-        assert d_ls.cpu().numpy().tobytes() == ls.tobytes()
+        assert d_u.numpy()[:len(u)].tobytes() == u
+        assert d_lr.numpy().tobytes() == lr.tobytes()
+        assert d_ls.numpy().tobytes() == ls.tobytes()
         assert rx_d.last_ms > 0 and tx_d.last_ms > 0
     for o in (rx_h, tx_h, rx_d, tx_d):
         o.close()
@@ -232,13 +228,11 @@ def test_iknp_general_first_round(ctx, golden_dir, monkeypatch):
 
 def test_iknp_refuses_graph_capture(ctx):
     """the column streams advance with every call: inside gc_ctx_capture_* the device entry points return GC_E_ARG"""
-    import torch
     base, delta, k0 = base_setup("cap")
     rcv = engine.IKNPReceiver(ctx, base)
-    d = torch.zeros(8192 + 64 + 512 * 16, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
+    d = ctx.zeros(8192 + 64 + 512 * 16)
     with pytest.raises(engine.EngineError) as e:
-        ctx.capture(lambda: rcv.receive_dev(d.data_ptr(), 512, d.data_ptr() + 64, d.data_ptr() + 64 + 8192))
+        ctx.capture(lambda: rcv.receive_dev(d, 512, d + 64, d + 64 + 8192))
     assert e.value.code == engine.GC_E_ARG
     u, got = rcv.receive(np.zeros(3, np.uint8))  # the pair is still usable and at position 0
     wu, wgot = oracle.IKNPReceiver(base).receive(np.zeros(3, np.uint8))
@@ -250,7 +244,6 @@ def test_iknp_refuses_graph_capture(ctx):
 def test_bitcot_device_resident_matches_host(ctx, n):
     """gc_iknp_*_bits_dev: choice words, u-matrix and result words stay in HBM; same bytes as the host calls (and so as
     the oracle's ReceiveBits / SendBits, incl. the whole-word-only choice fold), stream position persisting"""
-    import torch
     base, delta, k0 = base_setup("bitdev%d" % n)
     rx_h, tx_h = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
     rx_d, tx_d = engine.IKNPReceiver(ctx, base), engine.IKNPSender(ctx, delta, k0)
@@ -259,17 +252,16 @@ def test_bitcot_device_resident_matches_host(ctx, n):
         choices = np.frombuffer(drbg("bcd%d/%d" % (n, rep), 8 * words), "<u8").copy()
         u, r = rx_h.receive_bits(choices, n)
         s = tx_h.send_bits(u, n)
-        d_c = torch.from_numpy(choices.view(np.uint8).copy()).cuda()
-        d_u = torch.zeros(((n + 511) // 512) * 8192, dtype=torch.uint8, device="cuda")
-        d_r = torch.zeros(words * 8, dtype=torch.uint8, device="cuda")
-        d_s = torch.zeros(words * 8, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        rx_d.receive_bits_dev(d_c.data_ptr(), n, d_u.data_ptr(), d_r.data_ptr())
-        tx_d.send_bits_dev(d_u.data_ptr(), n, d_s.data_ptr())
+        d_c = ctx.to_device(choices.view(np.uint8).copy())
+        d_u = ctx.zeros(((n + 511) // 512) * 8192)
+        d_r = ctx.zeros(words * 8)
+        d_s = ctx.zeros(words * 8)
+        rx_d.receive_bits_dev(d_c, n, d_u, d_r)
+        tx_d.send_bits_dev(d_u, n, d_s)
         ctx.sync()
-        assert d_u.cpu().numpy()[:len(u)].tobytes() == u
-        assert (d_r.cpu().numpy().view("<u8") == r).all()
-        assert (d_s.cpu().numpy().view("<u8") == s).all()
+        assert d_u.numpy()[:len(u)].tobytes() == u
+        assert (d_r.numpy().view("<u8") == r).all()
+        assert (d_s.numpy().view("<u8") == s).all()
     for h in (rx_h, tx_h, rx_d, tx_d):
         h.close()
 

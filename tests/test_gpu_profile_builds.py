@@ -3,7 +3,6 @@ a level, a developer aid) are separate template instantiations of the production
 tables and labels as the plain builds, on every kernel family."""
 import numpy as np
 import pytest
-import torch
 
 from mpc_amd import engine
 from mpc_amd.circuit import synthetic_levelised
@@ -19,19 +18,18 @@ def run_pair(ctx, c, batch, schedule=1, key=KEY):
         gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
         if schedule != 1:
             gb.set_schedule(schedule); ev.set_schedule(schedule)
-        gen = torch.Generator(device="cuda"); gen.manual_seed(99)
-        d_rnd = torch.randint(0, 256, (batch, c.num_inputs + 1, 16), dtype=torch.uint8, device="cuda", generator=gen)
-        d_bits = torch.randint(0, 2, (batch, c.num_inputs), dtype=torch.uint8, device="cuda", generator=gen)
-        d_out = torch.zeros((batch, c.num_outputs), dtype=torch.uint8, device="cuda")
-        d_mis = torch.zeros(1, dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
+        gen = np.random.default_rng(99)
+        d_rnd = ctx.to_device(gen.integers(0, 256, (batch, c.num_inputs + 1, 16), dtype=np.uint8))
+        d_bits = ctx.to_device(gen.integers(0, 2, (batch, c.num_inputs), dtype=np.uint8))
+        d_out = ctx.zeros((batch, c.num_outputs))
+        d_mis = ctx.zeros(1, np.int32)
         if prof:
             gb.debug_profile(True); ev.debug_profile(True)
-        gb.garble(key, d_rnd.data_ptr()); ev.select_inputs(gb, d_bits.data_ptr()); ev.eval(key, gb)
-        gb.decode(ev, d_out.data_ptr(), d_mis.data_ptr())
+        gb.garble(key, d_rnd); ev.select_inputs(gb, d_bits); ev.eval(key, gb)
+        gb.decode(ev, d_out, d_mis)
         ctx.sync()
-        assert int(d_mis.cpu()[0]) == 0
-        out, bits = d_out.cpu().numpy(), d_bits.cpu().numpy()
+        assert int(d_mis.numpy()[0]) == 0
+        out, bits = d_out.numpy(), d_bits.numpy()
         for i in (0, batch - 1):
             assert (c.compute_bits(bits[i])[c.NumWires - c.num_outputs:] == out[i]).all()
         if prof:
