@@ -52,7 +52,8 @@ const char *gc_strerror(int status);
 /* thread-local detail of the last GC_E_HIP / GC_E_NOMEM on this thread ("" if none) */
 const char *gc_last_error(void);
 /* ABI version of this header (checked by the bindings).  2: + gc_dev_* (device memory for hosts without a HIP
- * allocator), gc_rot_*, gc_stream_garble_queue / gc_stream_set_depth; every v1 entry point is unchanged. */
+ * allocator), gc_rot_* (ot/rot.go), gc_stream_garble_flush / gc_stream_stats and up to 4 096 circuits in flight per
+ * stream (step groups); every v1 entry point is unchanged. */
 #define GC_ABI_VERSION 2
 int gc_abi_version(void);
 
@@ -242,24 +243,38 @@ int gc_stream_get_wire(gc_stream *, uint32_t w, gc_wire *out);
 int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written);
 
-/* The same call in two halves (additive): _begin enqueues one circuit — input labels gathered from the stream's wire store
+/* The same call in two halves (additive): _begin QUEUES one circuit — input labels gathered from the stream's wire store
  * (which lives in HBM), garbling, output labels scattered back, serialisation — and returns without waiting for the GPU;
- * _finish hands out the bytes of the OLDEST circuit in flight.  Calling begin(k + 1) before finish(k) overlaps the host's
- * share of a step (content hash, plan look-up, launches) with the GPU's share of the step before; the bytes still leave in
- * order, so a driver writes them to the connection exactly as before.  At most two circuits in flight (a third _begin
- * returns GC_E_ARG); gc_stream_garble is _begin + _finish and needs nothing in flight; gc_stream_get_wire waits for the
- * circuits in flight.  If cap is too small _finish returns GC_E_ARG with *written = the size needed; that circuit has been
- * garbled (its outputs are set) and its bytes are dropped. */
+ * _finish hands out the bytes of the OLDEST circuit in flight.  Calling begin(k + 1 ... k + d) before finish(k) overlaps
+ * the host's share of a step (content hash, plan look-up, launches) with the GPU's share of the steps before, and gives
+ * the engine STEP-LEVEL PARALLELISM: queued circuits of at most 32 768 gates (8 192 if their levels are wide) that share no global wire through in[] /
+ * out[] (no read-after-write, write-after-write, write-after-read) are garbled side by side by ONE launch sequence —
+ * one workgroup per circuit — the way independent SSA instructions of a compiled program (compiler/ssa/streamer.go:
+ * 412-524 garbles one circuit per instruction) allow; a circuit that depends on a queued one starts the next group, and
+ * larger circuits keep a launch sequence of their own.  The bytes still leave in program order, so a driver writes them
+ * to the connection exactly as before.  At most 4 096 circuits in flight (a further _begin returns GC_E_ARG);
+ * gc_stream_garble is _begin + _finish and needs nothing in flight; gc_stream_get_wire launches what is queued and
+ * waits for it.  _finish launches the group of the oldest circuit if it is still open; gc_stream_garble_flush does the
+ * same without waiting (a driver that wants the GPU to start before it has queued a whole window).  If cap is too small
+ * _finish returns GC_E_ARG with *written = the size needed; that circuit has been garbled (its outputs are set) and its
+ * bytes are dropped. */
 int gc_stream_garble_begin(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                            uint32_t nin, const uint32_t *out, uint32_t nout);
 int gc_stream_garble_finish(gc_stream *, uint8_t *buf, size_t cap, size_t *written);
+int gc_stream_garble_flush(gc_stream *);
+/* launch sequences so far: groups of small circuits, circuits that ran in them, circuits with a sequence of their own
+ * (any pointer may be NULL) */
+int gc_stream_stats(const gc_stream *, uint64_t *groups, uint64_t *grouped_steps, uint64_t *big_steps);
 
 /* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
  * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
  * reading the framing (OpCircuit header: step, numGates, numTmpWires, numWires) and hands the gate bytes over;
  * the gates are parsed back into a circuit, levelised and evaluated with the same kernels as Circuit.Eval.  The wire
  * store lives in HBM: gc_stream_eval_circuit returns once the block is parsed and its kernels are enqueued (the parsing of
- * the next block overlaps them); gc_stream_eval_get_wire waits for them. */
+ * the next block overlaps them) — or, for blocks of at most 32 768 gates, QUEUED: consecutive small blocks that share no
+ * global wire are evaluated side by side by one launch sequence, as on the garbler's side; gc_stream_eval_get_wire
+ * launches what is queued and waits for it.  The per-stream circuit cache is bounded (GC_STREAM_CACHE_GATES gates,
+ * default 8 Mi; least recently used circuits and their byte skeletons go first): the blocks are the peer's data. */
 typedef struct gc_stream_eval gc_stream_eval;
 gc_stream_eval *gc_stream_eval_create(gc_ctx *, const uint8_t *key, size_t keylen, int *status);
 void gc_stream_eval_free(gc_stream_eval *);

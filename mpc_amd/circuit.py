@@ -304,6 +304,79 @@ def synthetic_levelised(levels, width, and_frac, seed, ninputs=256, or_frac=0.0,
                    "synth_L%d_W%d_f%.2f_s%d" % (levels, width, and_frac, seed))
 
 
+def _finish(gates, nw, inputs, outputs, name):
+    arr = np.zeros(len(gates), GATE)
+    for j, (i0, i1, o, op) in enumerate(gates):
+        arr[j] = (i0, i1, o, op, 0)
+    return Circuit(nw, inputs, outputs, arr, name)
+
+
+def adder(bits=64):
+    """a + b mod 2^bits, ripple carry with ONE AND per bit (c' = c ^ ((a ^ c) & (b ^ c)), s = a ^ b ^ c): the shape of
+    the adders a compiled MPCL program streams one per SSA instruction (compiler/ssa/streamer.go:412-524).  Inputs a =
+    wires [0, bits), b = [bits, 2 bits), LSB first; the sum is the LAST `bits` wires (computer.go:77-88)."""
+    gates, nw = [], 2 * bits
+    carry, axb = None, []
+    for i in range(bits):
+        a, b = i, bits + i
+        x = nw; gates.append((a, b, x, XOR)); nw += 1
+        axb.append((x, carry))
+        if i == bits - 1:
+            break
+        if carry is None:
+            c = nw; gates.append((a, b, c, AND)); nw += 1
+        else:
+            t0 = nw; gates.append((a, carry, t0, XOR)); nw += 1
+            t1 = nw; gates.append((b, carry, t1, XOR)); nw += 1
+            t2 = nw; gates.append((t0, t1, t2, AND)); nw += 1
+            c = nw; gates.append((carry, t2, c, XOR)); nw += 1
+        carry = c
+    zero = None
+    for x, c in axb:  # the sum bits last, in order
+        if c is None:  # bit 0: s = a ^ b; re-emit through a free gate so that it is one of the last wires
+            if zero is None:
+                zero = nw; gates.append((0, 0, zero, XOR)); nw += 1
+            o = nw; gates.append((x, zero, o, XOR)); nw += 1
+        else:
+            o = nw; gates.append((x, c, o, XOR)); nw += 1
+    return _finish(gates, nw, [bits, bits], [bits], "adder%d" % bits)
+
+
+def multiplier(bits=64):
+    """a * b mod 2^bits: array multiplier (row j adds (a & b_j) << j into the running sum; only bits < `bits` are formed).
+    64 bits: 2 080 partial-product ANDs + 2 016 one-AND full adders = 12.2 k gates, AND depth ~2 x bits."""
+    gates, nw = [], 2 * bits
+    acc = []
+    for i in range(bits):  # row 0
+        o = nw; gates.append((i, bits, o, AND)); nw += 1
+        acc.append(o)
+    for j in range(1, bits):
+        carry = None
+        for i in range(bits - j):  # pp bit i of row j lands on result bit i + j
+            pp = nw; gates.append((i, bits + j, pp, AND)); nw += 1
+            s_in = acc[i + j]
+            x = nw; gates.append((s_in, pp, x, XOR)); nw += 1
+            last = i == bits - j - 1
+            if carry is None:
+                s = x
+                if not last:
+                    c = nw; gates.append((s_in, pp, c, AND)); nw += 1
+            else:
+                s = nw; gates.append((x, carry, s, XOR)); nw += 1
+                if not last:
+                    t0 = nw; gates.append((s_in, carry, t0, XOR)); nw += 1
+                    t1 = nw; gates.append((pp, carry, t1, XOR)); nw += 1
+                    t2 = nw; gates.append((t0, t1, t2, AND)); nw += 1
+                    c = nw; gates.append((carry, t2, c, XOR)); nw += 1
+            acc[i + j] = s
+            if not last:
+                carry = c
+    zero = nw; gates.append((0, 0, zero, XOR)); nw += 1
+    for i in range(bits):  # the product bits last, in order
+        o = nw; gates.append((acc[i], zero, o, XOR)); nw += 1
+    return _finish(gates, nw, [bits, bits], [bits], "multiplier%d" % bits)
+
+
 def comparator64():
     """Hand-built 64-bit unsigned a > b comparator (config 1 counterpart of millionaire.mpcl,
     apps/garbled/examples/millionaire.mpcl: `return a > b`).  Garbler input a = wires 0..63,

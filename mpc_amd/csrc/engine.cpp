@@ -1335,6 +1335,33 @@ int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const g
     return GC_OK;
 }
 
+bool gc_circ_flat_job(gc_circ *c, gc::FlatJob *j, size_t *lds_bytes, bool *has_or) {
+    if (!c || !j) return false;
+    circ_ensure_flat(c);
+    const Plan &p = c->plan.p;
+    if (p.n_flat_slots == 0xffffffffu || p.fl_units.empty() || p.info.slab_rows >= (1u << 22) || !c->d_fl_prog) return false;
+    const size_t need = fused_flat_bytes(p.n_flat_slots, 0, p.fl_unit_stride);
+    if (need > (size_t)160 * 1024) return false;
+    *j = FlatJob{};
+    j->prog = (const uint4 *)c->d_fl_prog;
+    j->units = c->d_fl_units;
+    j->hgslot = c->d_fl_hgslot;
+    j->ogslot = c->d_fl_ogslot;
+    j->in_lds = c->d_fl_in_lds;
+    j->nunits = (uint32_t)p.fl_units.size();
+    j->ninputs = p.info.ninputs;
+    j->ti_log2 = 0;
+    j->zslot = p.n_flat_slots - 1;
+    j->ustride = p.fl_unit_stride;
+    j->w_tile = p.info.nslots;
+    j->t_tile = std::max<uint32_t>(p.info.slab_rows, 1);
+    j->te0 = c->ctx->d_te0;
+    j->batch = 1;
+    if (lds_bytes) *lds_bytes = need;
+    if (has_or) *has_or = p.info.n_or != 0;
+    return true;
+}
+
 void gc_circ_release_batch(gc_circ *c, gc_batch *b) {
     if (c && b) pool_put(c, b);
 }

@@ -112,6 +112,10 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b);
 // (index 0xffffffff: not stored).  eval: the tables come from the host slab (slab_rows labels).  Everything is
 // enqueued on the ctx stream; nothing is waited for.  The pooled batch comes back in *bout (tables in b->d_T for the
 // garbler's serialiser; later passes on the same stream may reuse it at once).
+// internal: the circuit-constant part of a FlatJob for ONE instance of this circuit as one workgroup (ti_log2 = 0) —
+// plan arrays, geometry, Te0 — and the dynamic LDS the job needs; false when the circuit has no flattened plan or its
+// live labels do not fit next to the AES table.  Builds the flattened plan on first demand (thread-safe).
+bool gc_circ_flat_job(gc_circ *c, gc::FlatJob *job, size_t *lds_bytes, bool *has_or);
 int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
                 const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
                 gc_batch **bout);

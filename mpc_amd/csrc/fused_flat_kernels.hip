@@ -107,27 +107,10 @@ constexpr uint32_t kStageOff = kTeDualBytes / 16 + 16;  // 256 bytes: 15 round k
 #define GC_FPROF_EPILOGUE()                                                                                  \
     if constexpr (PROF) {                                                                                    \
         if (threadIdx.x == 0 || threadIdx.x == 960)                                                          \
-            for (int i = 0; i < 8; i++) a.prof[(size_t)blockIdx.x * 16 + (threadIdx.x ? 8 : 0) + i] = pacc[i]; \
+            for (int i = 0; i < 8; i++) a.prof[(size_t)tile * 16 + (threadIdx.x ? 8 : 0) + i] = pacc[i];       \
     }
 
-struct FlArgs {
-    const uint4 *prog;
-    const FUnit *units;
-    const uint32_t *hgslot, *ogslot;
-    const uint16_t *in_lds;
-    uint32_t nunits, ninputs, ti_log2, zslot;
-    uint32_t ustride;  // uint4 per stage buffer
-    size_t w_tile, t_tile;
-    uint4 *W;
-    const uint4 *R;
-    uint4 *T;
-    const uint32_t *rk;
-    const uint32_t *te0;
-    uint64_t *prof;
-    const uint4 *rnd;  // garbler only: the caller's random stream (nullptr: R / input labels are already in place)
-    uint4 *Rout;       // garbler only: R of every instance, for the later passes of the pipeline
-    uint32_t batch;
-};
+using FlArgs = FlatJob;  // kernels.h
 
 // Unit header i.  Loaded with VECTOR loads on purpose (vz is a zero the compiler cannot see through): scalar loads
 // share the lgkm counter with LDS and return out of order, so with a header in flight the first LDS read of the
@@ -432,7 +415,9 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
     }
 }
 
+// MULTI (job launches): `a` is this workgroup's own record, its tile is 0 and the input labels come from the wire store
 #define GC_FL_PROLOGUE(LOAD_R)                                                                               \
+    const uint32_t tile = MULTI ? 0u : blockIdx.x;                                                           \
     extern __shared__ uint4 smem[];                                                                          \
     uint32_t *te = (uint32_t *)smem;                                                                         \
     const uint32_t ti_log2 = a.ti_log2, TI = 1u << ti_log2, tim = TI - 1;                                    \
@@ -451,13 +436,13 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
         if (threadIdx.x >= 4 * NR) kv ^= a.rk[threadIdx.x - 4 * NR];                                         \
         ((uint32_t *)smem)[kKeyTab / 4 + threadIdx.x] = kv;                                                  \
     }                                                                                                        \
-    uint4 *Wt = a.W + (size_t)blockIdx.x * a.w_tile;                                                         \
+    uint4 *Wt = a.W + (size_t)tile * a.w_tile;                                                               \
     if (threadIdx.x < TI) wl[(a.zslot << ti_log2) + threadIdx.x] = make_uint4(0, 0, 0, 0);                   \
     if (LOAD_R && a.rnd) {                                                                                   \
         /* garbler: draw R and the input zero-labels of the tile straight from the caller's random stream   */ \
         /* ([instance][1 + ninputs] big-endian labels; garble.go:253-258, 271-278) - no separate init kernel */ \
         for (uint32_t i = threadIdx.x; i < ((a.ninputs + 1) << ti_log2); i += TF) {                          \
-            const uint32_t j = i >> ti_log2, inst = i & tim, gi = blockIdx.x * TI + inst;                    \
+            const uint32_t j = i >> ti_log2, inst = i & tim, gi = tile * TI + inst;                          \
             uint4 v = make_uint4(0, 0, 0, 0);                                                                \
             if (gi < a.batch) {                                                                              \
                 const uint4 raw = a.rnd[(size_t)gi * (a.ninputs + 1) + j];                                   \
@@ -467,7 +452,7 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
             if (j == 0) {                                                                                    \
                 v.y |= 0x80000000u; /* R.SetS(true) */                                                       \
                 rl[inst] = v;                                                                                \
-                a.Rout[(size_t)blockIdx.x * TI + inst] = v;                                                  \
+                a.Rout[(size_t)tile * TI + inst] = v;                                                        \
             } else {                                                                                         \
                 const uint32_t ls = a.in_lds[j - 1];                                                         \
                 Wt[((j - 1) << ti_log2) + inst] = v;                                                         \
@@ -475,10 +460,16 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
             }                                                                                                \
         }                                                                                                    \
     } else {                                                                                                 \
-        if (LOAD_R && threadIdx.x < TI) rl[threadIdx.x] = a.R[(size_t)blockIdx.x * TI + threadIdx.x];        \
+        if (LOAD_R && threadIdx.x < TI) rl[threadIdx.x] = a.R[(size_t)tile * TI + threadIdx.x];              \
         for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                \
             const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                               \
-            if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                      \
+            if constexpr (MULTI) { /* Get through in[] (stream_garble.go:131-141) on the device */           \
+                const uint4 v = a.store[a.in_idx[w]];                                                        \
+                Wt[i] = v;                                                                                   \
+                if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = v;                                      \
+            } else if (ls != 0xffffu) {                                                                      \
+                wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                                     \
+            }                                                                                                \
         }                                                                                                    \
     }                                                                                                        \
     FUnit u = uniform_unit(load_unit(a.units, 0, vz));                                             \
@@ -495,10 +486,10 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
 }  // namespace
 
 // HAS_OR = false: the circuit has no OR gate (the common case): the OR paths and their selects are compiled out
-template <int NR, bool PROF, bool HAS_OR>
-__global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
+template <int NR, bool PROF, bool HAS_OR, bool MULTI>
+__device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
     GC_FL_PROLOGUE(true)
-    uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
+    uint4 *Tt = a.T + (size_t)tile * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
@@ -605,9 +596,20 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
 }
 
 template <int NR, bool PROF, bool HAS_OR>
-__global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
+__global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
+    garble_flat_body<NR, PROF, HAS_OR, false>(a);
+}
+// step groups of the streaming engine: workgroup j = job j (a whole, independent one-instance circuit)
+template <int NR, bool HAS_OR>
+__global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs) {
+    const FlArgs a = jobs[blockIdx.x];
+    garble_flat_body<NR, false, HAS_OR, true>(a);
+}
+
+template <int NR, bool PROF, bool HAS_OR, bool MULTI>
+__device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
     GC_FL_PROLOGUE(false)
-    const uint4 *Tt = a.T + (size_t)blockIdx.x * a.t_tile;
+    const uint4 *Tt = a.T + (size_t)tile * a.t_tile;
     for (uint32_t ui = 0; ui < a.nunits; ui++) {
         const uint4 *buf = stage + (ui & 1u) * ustride;
         const uint32_t nh = u.n_and + u.n_or + u.n_inv;
@@ -686,6 +688,16 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     GC_FPROF_EPILOGUE()
 }
 
+template <int NR, bool PROF, bool HAS_OR>
+__global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
+    eval_flat_body<NR, PROF, HAS_OR, false>(a);
+}
+template <int NR, bool HAS_OR>
+__global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs) {
+    const FlArgs a = jobs[blockIdx.x];
+    eval_flat_body<NR, false, HAS_OR, true>(a);
+}
+
 size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride) {
     return (size_t)(kStageOff + 2 * ustride) * sizeof(uint4) + ((size_t)(nls + 1) << ti_log2) * sizeof(uint4);
 }
@@ -732,6 +744,24 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
     return eval ? GC_M2(k_eval_flat) : GC_M2(k_garble_flat);
 #undef GC_M2
 #undef GC_M3
+}
+
+template <typename K>
+static hipError_t launch_jobs(K kern, const FlatJob *jobs, uint32_t njobs, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(njobs), dim3(TF), lds, s, jobs);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, uint32_t njobs,
+                                  size_t lds_bytes, hipStream_t s) {
+    if (njobs == 0) return hipSuccess;
+#define GC_J3(KERN, NR) (has_or ? launch_jobs(KERN<NR, true>, d_jobs, njobs, lds_bytes, s) : launch_jobs(KERN<NR, false>, d_jobs, njobs, lds_bytes, s))
+#define GC_J2(KERN) (rounds == 10 ? GC_J3(KERN, 10) : rounds == 12 ? GC_J3(KERN, 12) : GC_J3(KERN, 14))
+    return eval ? GC_J2(k_eval_flat_jobs) : GC_J2(k_garble_flat_jobs);
+#undef GC_J2
+#undef GC_J3
 }
 
 }  // namespace gc

@@ -122,6 +122,38 @@ struct FusedFlatArgs {
 size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride);
 hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &a, const BatchGeom &g, hipStream_t s);
 
+// What one workgroup of the flattened kernels needs.  The batch launches pass ONE of these as the kernel argument (every
+// workgroup = one tile of the same circuit); the streaming engine's step groups pass an ARRAY in device memory, one
+// record per workgroup (launch_fused_flat_jobs): workgroup j runs ONE instance of job j's circuit — its own plan, wire
+// and table arrays — and takes its input labels straight from the stream's device-resident wire store
+// (W[i] = store[in_idx[i]]), so that independent SSA-step circuits of a stream run side by side in a single launch.
+struct FlatJob {
+    const uint4 *prog;
+    const FUnit *units;
+    const uint32_t *hgslot, *ogslot;
+    const uint16_t *in_lds;
+    uint32_t nunits, ninputs, ti_log2, zslot;
+    uint32_t ustride;  // uint4 per stage buffer
+    size_t w_tile, t_tile;
+    uint4 *W;
+    const uint4 *R;
+    uint4 *T;
+    const uint32_t *rk;
+    const uint32_t *te0;
+    uint64_t *prof;
+    const uint4 *rnd;  // garbler only: the caller's random stream (nullptr: R / input labels are already in place)
+    uint4 *Rout;       // garbler only: R of every instance, for the later passes of the pipeline
+    uint32_t batch;
+    uint32_t pad_;
+    const uint4 *store;       // job launches: the stream's wire store ...
+    const uint32_t *in_idx;   // ... and the store index of every input wire
+};
+// d_jobs: device array of njobs records (ti_log2 = 0, batch = 1, rnd = prof = nullptr); lds_bytes = the largest
+// fused_flat_bytes(nls, 0, ustride) of the group; has_or: some job's circuit has an OR gate; rounds: 10 / 12 / 14 (one
+// key per stream)
+hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, uint32_t njobs,
+                                  size_t lds_bytes, hipStream_t s);
+
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);
 

@@ -10,8 +10,21 @@
 // byte string into the caller's buffer (the per-gate host loop was 4 ms for a 131 072-gate step, ten times the
 // garbling itself).  Circuits are cached by content, so an SSA instruction that repeats re-uses its levelised
 // plan and device buffers.
+//
+// Step-level parallelism (round 3).  A compiled program is a long sequence of SMALL circuits — one per SSA instruction
+// (compiler/ssa/streamer.go:412-524: 64-bit adders, comparators, multipliers ...) — most of which do not depend on
+// their immediate predecessors.  gc_stream_garble_begin QUEUES such a step; consecutive queued steps that share no
+// global wire (no read-after-write, write-after-write or write-after-read through in[] / out[]) form a GROUP that runs
+// as ONE launch sequence: host -> device copy of the group's job records, k_*_flat_jobs (workgroup j = step j: its own
+// circuit plan, input labels gathered from the device-resident wire store), k_stream_finish (output labels scattered
+// into the store, gates serialised into the step's byte slot), one copy of all the group's bytes back into pinned
+// memory.  A step that conflicts with the open group closes it (stream order then carries the dependency); the bytes
+// still leave in program order through gc_stream_garble_finish.  Steps of more than kSmallGates gates keep the
+// per-step path (level launches spread over the chip).  The evaluator groups its blocks the same way.
 #include <algorithm>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <new>
 #include <unordered_map>
 
@@ -50,6 +63,15 @@ struct CircEntry {
     gc_circ *circ = nullptr;
     std::vector<CircKey> gates;
     uint32_t nwires = 0, nin = 0, nout = 0;
+    // step groups: can ONE workgroup run this circuit from LDS (-1: not asked yet), and if so the circuit-constant part
+    // of its job record
+    int small = -1;
+    gc::FlatJob job{};
+    size_t lds = 0;
+    bool has_or = false;
+    uint32_t ser_long = 0;  // bytes of the serialised gates with every id in the 4-byte form (an upper bound)
+    uint64_t last_use = 0;  // LRU stamp (cache eviction)
+    size_t cost = 0;        // gates held (host copy + device plan): what the cache budget counts
 };
 using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
 
@@ -128,27 +150,169 @@ struct DevStore {
     }
 };
 
+// ---- step groups: staging shared by the garbler and the evaluator ----------------------------------------------------
+constexpr uint32_t kSmallGates = 32768;          // a step of at most this many gates may join a group (one workgroup, LDS plan)
+constexpr uint32_t kSmallWideGates = 8192;       // ... unless it is WIDE (levels of >= 2.5 passes) and larger than this: level
+                                                 // launches spread such a circuit over the chip, one workgroup would crawl
+constexpr uint32_t kGroupJobs = 256;             // steps per group at most: one workgroup each = one wave of the chip's 256 CUs
+constexpr size_t kGroupBytes = (size_t)96 << 20; // wire / table arrays + bytes of one group at most
+constexpr uint32_t kMaxPending = 4096;           // circuits queued and not yet finished, at most
+constexpr size_t kCacheGatesDefault = (size_t)8 << 20;  // gates the per-stream circuit cache may hold (LRU beyond it)
+
+static inline size_t up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+static inline size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+// one queued small step, host side
+struct JobRec {
+    CircEntry *ent = nullptr;
+    uint32_t nin = 0, nout = 0, ngates = 0, first_tmp = 0, first_out = 0;
+    size_t off_io = 0;            // upload region: in[nin], out[nout], out-or-skip[nout] (u32 each)
+    size_t off_rows = 0;          // evaluator: the block's table rows in the upload region
+    size_t off_w = 0, off_t = 0;  // arena: wire array [nslots], table array [rows]
+    size_t off_bytes = 0;         // download region: where the serialised gates go (garbler)
+};
+
+struct Slot {
+    enum Kind { kFree, kGroup, kBig } kind = kFree;
+    bool launched = false, synced = false;
+    int error = GC_OK;          // close failed: the group's steps report it
+    uint32_t handed = 0;        // steps whose bytes have been handed out
+    hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
+    std::vector<JobRec> jobs;
+    size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
+    bool has_or = false;
+    uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr;
+    size_t h_up_cap = 0, d_up_cap = 0, arena_cap = 0, d_down_cap = 0, h_down_cap = 0;
+    // a big step (more than kSmallGates gates): its own wire maps, block offsets, byte buffer and size word
+    uint32_t *h_io = nullptr, *d_io = nullptr;  // h_io pinned: the upload is a true asynchronous copy
+    size_t h_io_cap = 0, io_cap = 0;
+    uint64_t *d_boff = nullptr;
+    size_t boff_cap = 0;
+    uint8_t *d_bytes = nullptr;
+    size_t bytes_cap = 0;
+    uint64_t *need = nullptr;   // pinned
+
+    void reset() {
+        kind = kFree;
+        launched = synced = false;
+        error = GC_OK;
+        handed = 0;
+        jobs.clear();
+        up_used = arena_used = down_used = lds = 0;
+        has_or = false;
+    }
+    void release() {
+        if (h_up) (void)hipHostFree(h_up);
+        if (d_up) (void)hipFree(d_up);
+        if (d_arena) (void)hipFree(d_arena);
+        if (d_down) (void)hipFree(d_down);
+        if (h_down) (void)hipHostFree(h_down);
+        if (h_io) (void)hipHostFree(h_io);
+        if (d_io) (void)hipFree(d_io);
+        if (d_boff) (void)hipFree(d_boff);
+        if (d_bytes) (void)hipFree(d_bytes);
+        if (need) (void)hipHostFree(need);
+        if (kdone) (void)hipEventDestroy(kdone);
+        if (done) (void)hipEventDestroy(done);
+    }
+    // pinned upload region with room for `more` further bytes (contents preserved)
+    hipError_t reserve_up(size_t more) {
+        const size_t need_cap = up_used + more;
+        if (need_cap <= h_up_cap) return hipSuccess;
+        size_t ncap = std::max<size_t>((size_t)1 << 20, h_up_cap * 2);
+        while (ncap < need_cap) ncap *= 2;
+        uint8_t *n = nullptr;
+        hipError_t e = hipHostMalloc((void **)&n, ncap, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (up_used) std::memcpy(n, h_up, up_used);
+        if (h_up) (void)hipHostFree(h_up);
+        h_up = n;
+        h_up_cap = ncap;
+        return hipSuccess;
+    }
+};
+
+static hipError_t grow_dev(uint8_t **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 2 + 4096;
+    hipError_t e = hipMalloc((void **)p, n);
+    if (e == hipSuccess) *cap = n;
+    return e;
+}
+static hipError_t grow_pin(uint8_t **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 2 + 4096;
+    hipError_t e = hipHostMalloc((void **)p, n, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = n;
+    return e;
+}
+
+// which global wires the OPEN group reads / writes: a stamp per wire, valid while it equals the group's generation
+struct ConflictStamps {
+    std::vector<uint32_t> rd, wr;
+    uint32_t gen = 1;
+    void next_group() {
+        if (++gen == 0) {
+            std::fill(rd.begin(), rd.end(), 0);
+            std::fill(wr.begin(), wr.end(), 0);
+            gen = 1;
+        }
+    }
+    void ensure(size_t n) {
+        if (rd.size() < n) {
+            rd.resize(n, 0);
+            wr.resize(n, 0);
+        }
+    }
+    // would a step with these reads / writes have to see, or be seen by, a step already in the open group?
+    bool conflicts(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        for (uint32_t i = 0; i < nr; i++)
+            if (wr[reads[i]] == gen) return true;  // read after write
+        for (uint32_t j = 0; j < nw; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            if (wr[writes[j]] == gen || rd[writes[j]] == gen) return true;  // write after write / write after read
+        }
+        return false;
+    }
+    void mark(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        for (uint32_t i = 0; i < nr; i++) rd[reads[i]] = gen;
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) wr[writes[j]] = gen;
+    }
+};
+
+struct StepRef {
+    uint32_t slot, job;
+};
+
 struct gc_stream {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
+    int rounds = 0;
     gc_label r{};
+    uint32_t *d_rk = nullptr;  // expanded key (60 words) and R on the device: the step groups' kernels read them
+    uint4 *d_R = nullptr;
     DevStore store;               // global wire -> L0 (L1 = L0 ^ R)
     CircCache cache;
+    size_t cache_gates = 0, cache_budget = kCacheGatesDefault;
+    uint64_t tick = 0;
     std::vector<uint32_t> alias_gen, alias_j;  // in[] / out[] aliasing check: stamp + index in out[] per global wire
     uint32_t gen = 0;
     std::vector<gc_gate> rewritten;            // gate list with aliased reads redirected (rare)
-    std::vector<uint32_t> io_host;             // in[], out[], out[] with 0xffffffff where nothing is stored
-    uint32_t *d_io = nullptr;   // device copy of io_host for the call in flight
-    size_t io_cap = 0;
-    uint64_t *d_boff = nullptr; // per block of kSerGates gates: byte size, then exclusive offset; [nblocks] = total
-    size_t boff_cap = 0;
-    // two steps may be in flight (gc_stream_garble_begin / _finish): their serialised bytes, sizes and completion events
-    uint8_t *d_bytes[2] = {nullptr, nullptr};
-    size_t bytes_cap[2] = {0, 0};
-    uint64_t *need_host = nullptr;  // pinned [2]
-    hipEvent_t done[2] = {nullptr, nullptr};
+    std::vector<uint32_t> skip_scratch;        // out[] with 0xffffffff where nothing is stored
+    // circuits in flight (gc_stream_garble_begin / _finish), oldest first, and the slots that hold them
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::deque<StepRef> queue;
+    int open = -1;                // slot of the group still accepting steps
+    ConflictStamps stamps;
     hipStream_t copy_stream = nullptr;
-    uint32_t head = 0, pending = 0;  // slot of the oldest step in flight, steps in flight
+    uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
 };
 
 namespace {
@@ -187,6 +351,31 @@ __device__ __forceinline__ SerGate ser_gate(const SerArgs &a, uint32_t i) {
     g.op = (uint8_t)(flags | (g.shortf ? 0x10 : 0));
     g.size = 1 + (g.shortf ? 2u : 4u) * g.wc + 16u * g.rows;
     return g;
+}
+// one gate at p: op byte, 2-3 wire ids (BE u16 if all fit, else BE u32), rows as BE(D0)||BE(D1); T = the dense slab
+__device__ __forceinline__ void ser_put(uint8_t *p, const SerGate &q, uint32_t r0, const uint4 *T, const Layout &lt) {
+    *p++ = q.op;
+    auto put = [&](uint32_t v) {
+        if (!q.shortf) {
+            *p++ = (uint8_t)(v >> 24);
+            *p++ = (uint8_t)(v >> 16);
+        }
+        *p++ = (uint8_t)(v >> 8);
+        *p++ = (uint8_t)v;
+    };
+    put(q.ai);
+    if (q.wc == 3) put(q.bi);
+    put(q.ci);
+    for (uint32_t r = 0; r < q.rows; r++) {
+        const uint4 v = T[lt.at(r0 + r, 0)];  // uint4 label: (x, y) = D0 low / high, (z, w) = D1 low / high
+        const uint32_t w4[4] = {v.y, v.x, v.w, v.z};
+        for (int j = 0; j < 4; j++) {
+            *p++ = (uint8_t)(w4[j] >> 24);
+            *p++ = (uint8_t)(w4[j] >> 16);
+            *p++ = (uint8_t)(w4[j] >> 8);
+            *p++ = (uint8_t)w4[j];
+        }
+    }
 }
 
 // byte size of every block of kSerGates gates
@@ -233,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblo
         run += v;
     }
 }
-// every gate to its byte offset: op byte, 2-3 wire ids (BE u16 if all fit, else BE u32), rows as BE(D0)||BE(D1)
+// every gate to its byte offset
 __global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint64_t *boff, const uint4 *T, Layout lt,
                                                            uint8_t *buf) {
     __shared__ uint32_t wsum[kSerThreads / 64];
@@ -260,31 +449,55 @@ __global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint
     for (uint32_t k = 0; k < kSerPer; k++) {
         const uint32_t i = blockIdx.x * kSerGates + threadIdx.x * kSerPer + k;
         if (i >= a.ngates) break;
-        const SerGate &q = g[k];
-        uint8_t *p = buf + pos;
-        *p++ = q.op;
-        auto put = [&](uint32_t v) {
-            if (!q.shortf) {
-                *p++ = (uint8_t)(v >> 24);
-                *p++ = (uint8_t)(v >> 16);
-            }
-            *p++ = (uint8_t)(v >> 8);
-            *p++ = (uint8_t)v;
-        };
-        put(q.ai);
-        if (q.wc == 3) put(q.bi);
-        put(q.ci);
-        const uint32_t r0 = a.row_of_gate[i];
-        for (uint32_t r = 0; r < q.rows; r++) {
-            const uint4 v = T[lt.at(r0 + r, 0)];  // uint4 label: (x, y) = D0 low / high, (z, w) = D1 low / high
-            const uint32_t w4[4] = {v.y, v.x, v.w, v.z};
-            for (int j = 0; j < 4; j++) {
-                *p++ = (uint8_t)(w4[j] >> 24);
-                *p++ = (uint8_t)(w4[j] >> 16);
-                *p++ = (uint8_t)(w4[j] >> 8);
-                *p++ = (uint8_t)w4[j];
-            }
-        }
+        ser_put(buf + pos, g[k], a.row_of_gate[i], T, lt);
+        pos += g[k].size;
+    }
+}
+
+// ---- the closing kernel of a step group: workgroup j = job j ---------------------------------------------------
+// Set through out[] (stream_garble.go:143-157; streaming.Set on the evaluator's side): store[out_idx[k]] = W[out_slots[k]];
+// then (garbler) the job's gates in the wire format, gate order, into the job's byte slot, the byte count into *size_out.
+struct FinJob {
+    SerArgs a;                 // a.ngates == 0: nothing to serialise (evaluator)
+    const uint4 *W, *T;
+    const uint32_t *out_slots; // wire slot of output k in W
+    const uint32_t *out_idx;   // store index of output k, 0xffffffff: not stored
+    uint32_t nout, pad_;
+    uint8_t *bytes;
+    uint32_t *size_out;
+};
+constexpr uint32_t kFinThreads = 1024;
+__global__ __launch_bounds__(kFinThreads) void k_stream_finish(const FinJob *jobs, uint4 *store) {
+    const FinJob j = jobs[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < j.nout; k += kFinThreads) {
+        const uint32_t idx = j.out_idx[k];
+        if (idx != 0xffffffffu) store[idx] = j.W[j.out_slots[k]];
+    }
+    if (j.a.ngates == 0) return;
+    __shared__ uint32_t wsum[kFinThreads / 64];
+    const uint32_t per = (j.a.ngates + kFinThreads - 1) / kFinThreads;  // consecutive gates per thread: byte order = gate order
+    const uint32_t lo = min(threadIdx.x * per, j.a.ngates), hi = min(lo + per, j.a.ngates);
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += ser_gate(j.a, i).size;
+    uint32_t incl = mine;
+    const uint32_t lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < kFinThreads / 64; w++) {
+        if (w < (threadIdx.x >> 6)) base += wsum[w];
+        total += wsum[w];
+    }
+    if (threadIdx.x == 0) *j.size_out = total;
+    size_t pos = base + (incl - mine);
+    const Layout dense{0, 0, 1, 0};  // one instance: table row r is element r
+    for (uint32_t i = lo; i < hi; i++) {
+        const SerGate q = ser_gate(j.a, i);
+        ser_put(j.bytes + pos, q, j.a.row_of_gate[i], j.T, dense);
         pos += q.size;
     }
 }
@@ -348,51 +561,205 @@ uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, ui
     return ch.done();
 }
 
-gc_circ *cache_find(const CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
-                    uint32_t nin, uint32_t nout) {
+
+CircEntry *cache_find(CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin,
+                      uint32_t nout) {
     auto range = cache.equal_range(h);
     for (auto it = range.first; it != range.second; ++it) {
-        const CircEntry &e = it->second;
+        CircEntry &e = it->second;
         if (e.gates.size() != ngates || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
         bool same = true;
         for (uint32_t i = 0; i < ngates && same; i++)
             same = e.gates[i].in0 == gates[i].in0 && e.gates[i].in1 == gates[i].in1 && e.gates[i].out == gates[i].out &&
                    e.gates[i].op == gates[i].op;
-        if (same) return e.circ;
+        if (same) return &e;
     }
     return nullptr;
 }
 
 // the same on the evaluator's packed gate records (16 bytes, no padding: one memcmp)
-gc_circ *cache_find_keys(const CircCache &cache, uint64_t h, const std::vector<CircKey> &keys, uint32_t nwires, uint32_t nin,
-                         uint32_t nout) {
+CircEntry *cache_find_keys(CircCache &cache, uint64_t h, const std::vector<CircKey> &keys, uint32_t nwires, uint32_t nin,
+                           uint32_t nout) {
     static_assert(sizeof(CircKey) == 16, "CircKey must be four packed words");
     auto range = cache.equal_range(h);
     for (auto it = range.first; it != range.second; ++it) {
-        const CircEntry &e = it->second;
+        CircEntry &e = it->second;
         if (e.gates.size() != keys.size() || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
-        if (std::memcmp(e.gates.data(), keys.data(), keys.size() * sizeof(CircKey)) == 0) return e.circ;
+        if (std::memcmp(e.gates.data(), keys.data(), keys.size() * sizeof(CircKey)) == 0) return &e;
     }
     return nullptr;
 }
 
-void cache_put_keys(CircCache &cache, uint64_t h, gc_circ *circ, const std::vector<CircKey> &keys, uint32_t nwires,
-                    uint32_t nin, uint32_t nout) {
+CircEntry *cache_put_keys(CircCache &cache, uint64_t h, gc_circ *circ, const std::vector<CircKey> &keys, uint32_t nwires,
+                          uint32_t nin, uint32_t nout) {
     CircEntry e;
     e.circ = circ;
     e.nwires = nwires, e.nin = nin, e.nout = nout;
     e.gates = keys;
-    cache.emplace(h, std::move(e));
+    e.cost = keys.size() + 1;
+    return &cache.emplace(h, std::move(e))->second;
 }
 
-void cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
-               uint32_t nin, uint32_t nout) {
+CircEntry *cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+                     uint32_t nin, uint32_t nout) {
     CircEntry e;
     e.circ = circ;
     e.nwires = nwires, e.nin = nin, e.nout = nout;
     e.gates.resize(ngates);
-    for (uint32_t i = 0; i < ngates; i++) e.gates[i] = CircKey{gates[i].in0, gates[i].in1, gates[i].out, gates[i].op};
-    cache.emplace(h, std::move(e));
+    uint64_t ser = 0;
+    for (uint32_t i = 0; i < ngates; i++) {
+        e.gates[i] = CircKey{gates[i].in0, gates[i].in1, gates[i].out, gates[i].op};
+        const uint32_t op = gates[i].op;
+        ser += 1 + 4u * (op == GC_INV ? 2 : 3) + 16u * (op == GC_AND ? 2 : op == GC_OR ? 3 : op == GC_INV ? 1 : 0);
+    }
+    e.ser_long = (uint32_t)std::min<uint64_t>(ser, 0xffffffffu);
+    e.cost = (size_t)ngates + 1;
+    return &cache.emplace(h, std::move(e))->second;
+}
+
+// Room for a circuit of `cost` gates in a cache of at most `budget`: least recently used entries go first.  The CALLER
+// has made sure nothing on the device or in a queue refers to a cached circuit any more (groups closed, streams drained).
+// dropped(circ) is told about every circuit that goes (the evaluator forgets the byte skeletons that point at it).
+template <typename F>
+void cache_make_room(CircCache &cache, size_t *held, size_t budget, size_t cost, F dropped) {
+    while (!cache.empty() && *held + cost > budget) {
+        auto victim = cache.begin();
+        for (auto it = cache.begin(); it != cache.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        *held -= std::min(*held, victim->second.cost);
+        dropped(victim->second.circ);
+        gc_circ_free(victim->second.circ);
+        cache.erase(victim);
+    }
+}
+
+size_t cache_budget_from_env() {
+    const char *v = std::getenv("GC_STREAM_CACHE_GATES");
+    if (v && *v) {
+        const long long n = std::atoll(v);
+        if (n > 0) return (size_t)n;
+    }
+    return kCacheGatesDefault;
+}
+
+// can ONE workgroup run this cached circuit from LDS (step groups)?  asked once per entry
+bool entry_is_small(CircEntry *e) {
+    if (e->small < 0) {
+        e->small = 0;
+        if (e->gates.size() <= kSmallGates && gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or) &&
+            (e->gates.size() <= kSmallWideGates || !wide_for_one_instance(e->circ->plan.p, false)))
+            e->small = 1;
+    }
+    return e->small == 1;
+}
+
+Slot *slot_new(std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index) {
+    for (uint32_t i = 0; i < slots.size(); i++)
+        if (slots[i]->kind == Slot::kFree) {
+            *index = i;
+            return slots[i].get();
+        }
+    std::unique_ptr<Slot> sl(new Slot);
+    if (hipEventCreateWithFlags(&sl->kdone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        sl->release();
+        return nullptr;
+    }
+    slots.push_back(std::move(sl));
+    *index = (uint32_t)slots.size() - 1;
+    return slots.back().get();
+}
+
+// Launch sequence of a group (see the head of this file).  eval: the jobs' table rows are part of the upload region and
+// nothing comes back.  On return the slot is `launched`; a failure is kept in slot.error for the group's steps.
+int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
+                 hipStream_t copy_stream) {
+    hipStream_t st = ctx->stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    g.launched = true;
+    auto fail = [&](const char *what, hipError_t e) {
+        set_error(what, e);
+        g.error = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        return g.error;
+    };
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail("launch_group", e);
+    int rcs = store.flush(ctx);  // host-set labels go up first; the store may move (its pointer is taken below)
+    if (rcs != GC_OK) return g.error = rcs;
+    const uint32_t n = (uint32_t)g.jobs.size();
+    const size_t off_fj = up16(g.up_used), off_fin = off_fj + (size_t)n * sizeof(FlatJob);
+    const size_t total_up = off_fin + (size_t)n * sizeof(FinJob);
+    const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
+    if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
+    if ((e = grow_dev(&g.d_up, &g.d_up_cap, total_up)) != hipSuccess) return fail("launch_group (upload)", e);
+    if ((e = grow_dev(&g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
+    if (!eval) {
+        if ((e = grow_dev(&g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
+        if ((e = grow_pin(&g.h_down, &g.h_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (pinned bytes)", e);
+    }
+    FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
+    FinJob *fin = (FinJob *)(g.h_up + off_fin);
+    for (uint32_t k = 0; k < n; k++) {
+        const JobRec &j = g.jobs[k];
+        const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
+        FlatJob f = j.ent->job;
+        f.W = (uint4 *)(g.d_arena + j.off_w);
+        f.T = eval ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
+        f.R = d_R;
+        f.Rout = nullptr;
+        f.rk = d_rk;
+        f.store = store.d;
+        f.in_idx = d_io;
+        fj[k] = f;
+        FinJob q{};
+        if (!eval) {
+            q.a.gw = j.ent->circ->d_gwires;
+            q.a.ops = j.ent->circ->d_ops;
+            q.a.row_of_gate = j.ent->circ->d_row_of_gate;
+            q.a.in = d_io;
+            q.a.out = d_io + j.nin;
+            q.a.ngates = j.ngates;
+            q.a.first_tmp = j.first_tmp;
+            q.a.first_out = j.first_out;
+            q.bytes = g.d_down + sizes_bytes + j.off_bytes;
+            q.size_out = (uint32_t *)g.d_down + k;
+        }
+        q.W = f.W;
+        q.T = f.T;
+        q.out_slots = j.ent->circ->d_out_slots;
+        q.out_idx = eval ? d_io + j.nin : d_io + j.nin + j.nout;
+        q.nout = j.nout;
+        fin[k] = q;
+    }
+    e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
+    if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_stream_finish, dim3(n), dim3(kFinThreads), 0, st, (const FinJob *)(g.d_up + off_fin), store.d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !eval) {
+        // the bytes travel on the copy stream: the next group's kernels need not wait for them
+        e = hipEventRecord(g.kdone, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(g.h_down, g.d_down, sizes_bytes + g.down_used, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(g.done, copy_stream);
+    } else if (e == hipSuccess) {
+        e = hipEventRecord(g.done, st);
+    }
+    if (e != hipSuccess) return fail("launch_group", e);
+    return GC_OK;
+}
+
+int close_group(gc_stream *s) {
+    if (s->open < 0) return GC_OK;
+    Slot &g = *s->slots[(size_t)s->open];
+    s->open = -1;
+    s->stamps.next_group();
+    s->n_groups++;
+    s->n_group_steps += g.jobs.size();
+    return launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream);
 }
 
 }  // namespace
@@ -412,6 +779,8 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
     if (rc == GC_OK) {
         s->ctx = ctx;
         s->key.assign(key, key + keylen);
+        s->rounds = k.rounds;
+        s->cache_budget = cache_budget_from_env();
         s->r = gc_label{be64(rnd) | 0x8000000000000000ull, be64(rnd + 8)};  // R.SetS(true)
         uint32_t mx = 0;
         for (uint32_t i = 0; i < ninputs; i++) mx = std::max(mx, inputs[i]);
@@ -419,9 +788,11 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
         for (uint32_t i = 0; i < ninputs; i++)
             s->store.set(inputs[i], gc_label{be64(rnd + 16 * ((size_t)i + 1)), be64(rnd + 16 * ((size_t)i + 1) + 8)});
         hipError_t e = hipSetDevice(ctx->device);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s->need_host, 2 * sizeof(uint64_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_rk, sizeof k.w);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_R, sizeof(uint4));
+        if (e == hipSuccess) e = hipMemcpy(s->d_rk, k.w, sizeof k.w, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_R, &s->r, sizeof(gc_label), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("gc_stream_create", e);
             rc = GC_E_HIP;
@@ -448,36 +819,50 @@ void gc_stream_free(gc_stream *s) {
         (void)hipStreamDestroy(s->copy_stream);
     }
     for (auto &kv : s->cache) gc_circ_free(kv.second.circ);
-    if (s->d_io) (void)hipFree(s->d_io);
-    if (s->d_boff) (void)hipFree(s->d_boff);
-    for (int i = 0; i < 2; i++) {
-        if (s->d_bytes[i]) (void)hipFree(s->d_bytes[i]);
-        if (s->done[i]) (void)hipEventDestroy(s->done[i]);
-    }
-    if (s->need_host) (void)hipHostFree(s->need_host);
+    for (auto &sl : s->slots) sl->release();
+    if (s->d_rk) (void)hipFree(s->d_rk);
+    if (s->d_R) (void)hipFree(s->d_R);
     s->store.release();
     delete s;
 }
 
-int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) {  // Streaming.GetInput (:117-119)
+int gc_stream_garble_flush(gc_stream *s) try {
+    if (!s) return GC_E_ARG;
+    return close_group(s);
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_stats(const gc_stream *s, uint64_t *groups, uint64_t *grouped_steps, uint64_t *big_steps) {
+    if (!s) return GC_E_ARG;
+    if (groups) *groups = s->n_groups;
+    if (grouped_steps) *grouped_steps = s->n_group_steps;
+    if (big_steps) *big_steps = s->n_big_steps;
+    return GC_OK;
+}
+
+int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streaming.GetInput (:117-119)
     if (!s || !out) return GC_E_ARG;
+    int rc = close_group(s);  // a queued step may be the one that sets the wire
+    if (rc != GC_OK) return rc;
     gc_label l0;
-    int rc = s->store.get(s->ctx, w, &l0);
+    rc = s->store.get(s->ctx, w, &l0);
     if (rc != GC_OK) return rc;
     out->l0 = l0;
     out->l1 = gc_label{l0.d0 ^ s->r.d0, l0.d1 ^ s->r.d1};
     return GC_OK;
+} catch (...) {
+    return gc::on_exception();
 }
 
-// Streaming.Garble in two halves (additive): _begin enqueues everything for one circuit — the sizes of its serialisation,
-// the gather of its input labels from the device-resident wire store, the garbling, the scatter of its output labels
-// and the serialiser — and returns WITHOUT waiting; _finish hands out the bytes of the oldest circuit in flight.  With
-// begin(k + 1) before finish(k) the host's share of a step (content hash, cache look-up, launches) overlaps the GPU's
-// share of the step before: the bytes still leave in order.  At most two circuits in flight.
+// Streaming.Garble in two halves (additive): _begin queues one circuit and returns WITHOUT waiting; _finish hands out the
+// bytes of the oldest circuit in flight.  With begin(k + 1 ...) before finish(k) the host's share of a step overlaps the
+// GPU's share of the steps before, and small independent steps share one launch sequence (step groups, see the head of
+// this file): the bytes still leave in order.  At most kMaxPending circuits in flight.
 int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                            uint32_t nin, const uint32_t *out, uint32_t nout) try {
     if (!s || (!gates && ngates) || (nin && !in) || (nout && !out)) return GC_E_ARG;
-    if (s->pending >= 2) return GC_E_ARG;
+    if (s->queue.size() >= kMaxPending) return GC_E_ARG;
     // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
     // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
     if (nin > nwires || nout > nwires) return GC_E_ARG;
@@ -487,23 +872,16 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
     for (uint32_t i = 0; i < nin; i++) mx = std::max(mx, in[i]);
     for (uint32_t i = 0; i < nout; i++) mx = std::max(mx, out[i]);
     ensure(s, mx);
-    const uint32_t slot = (s->head + s->pending) & 1u;
     gc_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     GC_HIP(hipSetDevice(ctx->device));
-    if (ngates == 0) {  // nothing on the wire
-        s->need_host[slot] = 0;
-        GC_HIP(hipEventRecord(s->done[slot], st));
-        s->pending++;
-        return GC_OK;
-    }
     StreamTrace tr;
 
     // in[] / out[] naming the same GLOBAL wire (wire-id re-use, in-place update): the reference resolves
     // stream.wire(index) per gate (:131-157), so a gate that reads the input-mapped wire after the gate that Set the
     // output-mapped one sees the NEW label.  The device garbles from a snapshot of the inputs: redirect such reads to
     // the producing circuit wire (same global id and flags on the wire, so the serialised bytes do not change).
-    {
+    if (ngates) {
         if (s->alias_gen.size() < s->store.host.size()) {
             s->alias_gen.resize(s->store.host.size(), 0);
             s->alias_j.resize(s->store.host.size(), 0);
@@ -537,52 +915,163 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
     }
 
     // device circuit (cached by content); a new circuit is validated once (garbleGate's checks, :195-210)
-    const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
-    gc_circ *circ = cache_find(s->cache, h, gates, ngates, nwires, nin, nout);
-    if (!circ) {
-        for (uint32_t i = 0; i < ngates; i++) {
-            if (gates[i].op > GC_INV) return GC_E_GATE;
-            if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
+    CircEntry *ent = nullptr;
+    if (ngates) {
+        const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
+        ent = cache_find(s->cache, h, gates, ngates, nwires, nin, nout);
+        if (!ent) {
+            for (uint32_t i = 0; i < ngates; i++) {
+                if (gates[i].op > GC_INV) return GC_E_GATE;
+                if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
+            }
+            if (s->cache_gates + ngates + 1 > s->cache_budget && !s->cache.empty()) {
+                // over budget: least recently used circuits go.  Nothing may refer to them any more: launch what is queued
+                // and drain both streams first (rare: once per budget's worth of NEW circuits)
+                int rcq = close_group(s);
+                if (rcq != GC_OK) return rcq;
+                GC_HIP(hipStreamSynchronize(st));
+                GC_HIP(hipStreamSynchronize(s->copy_stream));
+                cache_make_room(s->cache, &s->cache_gates, s->cache_budget, (size_t)ngates + 1, [](gc_circ *) {});
+            }
+            int stc = GC_OK;
+            gc_circ *circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &stc);
+            if (!circ) return stc;
+            std::vector<uint32_t> gw((size_t)3 * ngates);
+            for (uint32_t i = 0; i < ngates; i++) {
+                gw[3 * (size_t)i] = gates[i].in0;
+                gw[3 * (size_t)i + 1] = gates[i].in1;
+                gw[3 * (size_t)i + 2] = gates[i].out;
+            }
+            hipError_t e = hipMalloc((void **)&circ->d_gwires, gw.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(circ->d_gwires, gw.data(), gw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                gc_circ_free(circ);
+                return GC_E_HIP;
+            }
+            ent = cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
+            s->cache_gates += ent->cost;
         }
-        int stc = GC_OK;
-        circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &stc);
-        if (!circ) return stc;
-        std::vector<uint32_t> gw((size_t)3 * ngates);
-        for (uint32_t i = 0; i < ngates; i++) {
-            gw[3 * (size_t)i] = gates[i].in0;
-            gw[3 * (size_t)i + 1] = gates[i].in1;
-            gw[3 * (size_t)i + 2] = gates[i].out;
-        }
-        hipError_t e = hipMalloc((void **)&circ->d_gwires, gw.size() * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(circ->d_gwires, gw.data(), gw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            gc_circ_free(circ);
-            return GC_E_HIP;
-        }
-        cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
+        ent->last_use = ++s->tick;
     }
     tr.lap("alias + hash + cache");
-    const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
 
-    // (1) this call's wire maps on the device: in[], out[], and out[] with "no store" marks for the scatter (an output
-    //     wire that is an input wire has no gate: no Set); host-set labels of the store are uploaded
-    s->io_host.resize((size_t)nin + 2 * (size_t)nout + 1);
-    for (uint32_t i = 0; i < nin; i++) s->io_host[i] = in[i];
-    for (uint32_t j = 0; j < nout; j++) {
-        s->io_host[nin + j] = out[j];
-        s->io_host[nin + nout + j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
+    // out[] with "no store" marks (an output wire that is an input wire has no gate: no Set)
+    s->skip_scratch.resize(nout);
+    for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
+
+    // ---- a small step joins the open group --------------------------------------------------------------------
+    if (ngates && entry_is_small(ent)) {
+        s->stamps.ensure(s->store.host.size());
+        if (s->open >= 0) {
+            Slot &g = *s->slots[(size_t)s->open];
+            const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
+            if (g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes ||
+                s->stamps.conflicts(in, nin, s->skip_scratch.data(), nout)) {
+                int rcq = close_group(s);  // stream order carries the dependency to the next group
+                if (rcq != GC_OK) return rcq;
+            }
+        }
+        if (s->open < 0) {
+            uint32_t idx = 0;
+            Slot *ng = slot_new(s->slots, &idx);
+            if (!ng) return GC_E_NOMEM;
+            ng->reset();
+            ng->kind = Slot::kGroup;
+            s->open = (int)idx;
+        }
+        Slot &g = *s->slots[(size_t)s->open];
+        const size_t io_bytes = up16(((size_t)nin + 2 * (size_t)nout) * sizeof(uint32_t));
+        hipError_t e = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes);
+        if (e != hipSuccess) {
+            set_error("gc_stream_garble (pinned)", e);
+            return GC_E_NOMEM;
+        }
+        JobRec j;
+        j.ent = ent;
+        j.nin = nin, j.nout = nout, j.ngates = ngates, j.first_tmp = first_tmp, j.first_out = first_out;
+        g.up_used = up16(g.up_used);
+        j.off_io = g.up_used;
+        uint32_t *io = (uint32_t *)(g.h_up + g.up_used);
+        if (nin) std::memcpy(io, in, (size_t)nin * sizeof(uint32_t));
+        if (nout) {
+            std::memcpy(io + nin, out, (size_t)nout * sizeof(uint32_t));
+            std::memcpy(io + nin + nout, s->skip_scratch.data(), (size_t)nout * sizeof(uint32_t));
+        }
+        g.up_used += io_bytes;
+        j.off_w = g.arena_used;
+        g.arena_used += up256((size_t)ent->job.w_tile * 16);
+        j.off_t = g.arena_used;
+        g.arena_used += up256((size_t)ent->job.t_tile * 16);
+        j.off_bytes = g.down_used;
+        g.down_used += up16((size_t)ent->ser_long);
+        g.lds = std::max(g.lds, ent->lds);
+        g.has_or = g.has_or || ent->has_or;
+        g.jobs.push_back(j);
+        s->stamps.mark(in, nin, s->skip_scratch.data(), nout);
+        // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
+        // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it)
+        if (!s->store.dirty.empty()) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            int rcs = s->store.flush(ctx);
+            if (rcs != GC_OK) return rcs;
+        }
+        for (uint32_t k = 0; k < nout; k++)
+            if (s->skip_scratch[k] != 0xffffffffu) s->store.on_dev[out[k]] = 1;
+        s->queue.push_back(StepRef{(uint32_t)s->open, (uint32_t)g.jobs.size() - 1});
+        tr.lap("queued in group");
+        return GC_OK;
     }
+
+    // ---- a big (or empty) step: its own launch sequence, behind everything queued ------------------------------
+    {
+        int rcq = close_group(s);
+        if (rcq != GC_OK) return rcq;
+    }
+    uint32_t idx = 0;
+    Slot *bg = slot_new(s->slots, &idx);
+    if (!bg) return GC_E_NOMEM;
+    bg->reset();
+    Slot &b = *bg;
+    if (!b.need) GC_HIP(hipHostMalloc((void **)&b.need, sizeof(uint64_t), hipHostMallocDefault));
+    if (ngates == 0) {  // nothing on the wire
+        *b.need = 0;
+        GC_HIP(hipEventRecord(b.done, st));
+        b.kind = Slot::kBig;
+        b.launched = true;
+        s->queue.push_back(StepRef{idx, 0});
+        return GC_OK;
+    }
+    gc_circ *circ = ent->circ;
+    const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
+    // (1) this call's wire maps on the device: in[], out[], and out[] with "no store" marks for the scatter; host-set
+    //     labels of the store are uploaded.  The maps go up from the slot's own PINNED staging: a true asynchronous copy
+    //     that no later call can overwrite (every step in flight has its own slot).
+    const size_t io_words = (size_t)nin + 2 * (size_t)nout + 1;
     SerArgs a{};
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         int rcs = s->store.flush(ctx);
         if (rcs != GC_OK) return rcs;
-        hipError_t e = grow(&s->d_io, &s->io_cap, s->io_host.size());
-        if (e == hipSuccess) e = grow(&s->d_boff, &s->boff_cap, (size_t)nblocks + 1);
+        hipError_t e = hipSuccess;
+        if (b.h_io_cap < io_words) {
+            if (b.h_io) (void)hipHostFree(b.h_io);
+            b.h_io = nullptr;
+            b.h_io_cap = 0;
+            e = hipHostMalloc((void **)&b.h_io, (io_words + io_words / 2) * sizeof(uint32_t), hipHostMallocDefault);
+            if (e == hipSuccess) b.h_io_cap = io_words + io_words / 2;
+        }
+        if (e == hipSuccess) e = grow(&b.d_io, &b.io_cap, io_words);
+        if (e == hipSuccess) e = grow(&b.d_boff, &b.boff_cap, (size_t)nblocks + 1);
         // the bytes of this step: 13 header bytes + 3 rows per gate at most
-        if (e == hipSuccess) e = grow(&s->d_bytes[slot], &s->bytes_cap[slot], (size_t)ngates * 61 + 16);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(s->d_io, s->io_host.data(), s->io_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = grow(&b.d_bytes, &b.bytes_cap, (size_t)ngates * 61 + 16);
+        if (e == hipSuccess) {
+            for (uint32_t i = 0; i < nin; i++) b.h_io[i] = in[i];
+            for (uint32_t j = 0; j < nout; j++) {
+                b.h_io[nin + j] = out[j];
+                b.h_io[nin + nout + j] = s->skip_scratch[j];
+            }
+            e = hipMemcpyAsync(b.d_io, b.h_io, (io_words - 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        }
         if (e != hipSuccess) {
             set_error("gc_stream_garble", e);
             return e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -590,36 +1079,41 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
         a.gw = circ->d_gwires;
         a.ops = circ->d_ops;
         a.row_of_gate = circ->d_row_of_gate;
-        a.in = s->d_io;
-        a.out = s->d_io + nin;
+        a.in = b.d_io;
+        a.out = b.d_io + nin;
         a.ngates = ngates;
         a.first_tmp = first_tmp;
         a.first_out = first_out;
         // (2) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form)
-        hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff);
-        hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, st, s->d_boff, nblocks);
-        GC_HIP(hipMemcpyAsync(&s->need_host[slot], s->d_boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, st, a, b.d_boff);
+        hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, st, b.d_boff, nblocks);
+        GC_HIP(hipMemcpyAsync(b.need, b.d_boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }
     tr.lap("uploads + sizes");
     // (3) input labels through in[] (Get, :131-141), garble, outputs into the store (Set, :143-157) — all on the device
-    gc_batch *b = nullptr;
-    int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, s->d_io, s->d_io + nin + nout, nullptr, 0, &b);
+    gc_batch *bt = nullptr;
+    int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, b.d_io, b.d_io + nin + nout, nullptr, 0, &bt);
     if (rc != GC_OK) return rc;
     for (uint32_t j = 0; j < nout; j++)
         if (first_out + j >= first_tmp) s->store.on_dev[out[j]] = 1;
     // (4) wire format (:391-446) written by the device at the scanned offsets
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, s->d_boff, b->d_T, b->g.lt, s->d_bytes[slot]);
+        hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, b.d_boff, bt->d_T, bt->g.lt, b.d_bytes);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(s->done[slot], st);
+        if (e == hipSuccess) e = hipEventRecord(b.done, st);
         if (e != hipSuccess) {
             set_error("gc_stream_garble", e);
             rc = GC_E_HIP;
         }
     }
-    gc_circ_release_batch(circ, b);  // later passes on the same stream may reuse it: stream order protects the tables
-    if (rc == GC_OK) s->pending++;
+    gc_circ_release_batch(circ, bt);  // later passes on the same stream may reuse it: stream order protects the tables
+    if (rc == GC_OK) {
+        b.kind = Slot::kBig;
+        b.launched = true;
+        s->queue.push_back(StepRef{idx, 0});
+        s->n_big_steps++;
+    }
     tr.lap("enqueue pass + serialiser");
     return rc;
 } catch (...) {
@@ -627,30 +1121,63 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
 }
 
 int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
-    if (!s || !buf || !written || s->pending == 0) return GC_E_ARG;
+    if (!s || !buf || !written || s->queue.empty()) return GC_E_ARG;
     StreamTrace tr;
-    const uint32_t slot = s->head;
-    s->head ^= 1u;
-    s->pending--;
+    const StepRef ref = s->queue.front();
+    Slot &g = *s->slots[ref.slot];
+    if (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in the open group: launch it now
+        int rc = close_group(s);
+        if (rc != GC_OK && g.error == GC_OK) g.error = rc;
+    }
+    s->queue.pop_front();
     gc_ctx *ctx = s->ctx;
     GC_HIP(hipSetDevice(ctx->device));
-    GC_HIP(hipEventSynchronize(s->done[slot]));
-    const uint64_t need = s->need_host[slot];
-    *written = (size_t)need;
-    if (need > cap) return GC_E_ARG;
-    if (need) {  // on its own stream: the next circuit's kernels are already queued on the ctx stream
-        GC_HIP(hipMemcpyAsync(buf, s->d_bytes[slot], (size_t)need, hipMemcpyDeviceToHost, s->copy_stream));
-        GC_HIP(hipStreamSynchronize(s->copy_stream));
+    int rc = g.error;
+    if (rc == GC_OK && !g.synced) {
+        hipError_t e = hipEventSynchronize(g.done);
+        if (e != hipSuccess) {
+            set_error("gc_stream_garble_finish", e);
+            rc = GC_E_HIP;
+        }
+        g.synced = true;
     }
+    if (g.kind == Slot::kGroup) {
+        if (rc == GC_OK) {
+            const JobRec &j = g.jobs[ref.job];
+            const size_t sizes_bytes = up256(g.jobs.size() * sizeof(uint32_t));
+            const uint32_t need = ((const uint32_t *)g.h_down)[ref.job];
+            *written = need;
+            if (need > cap) rc = GC_E_ARG;
+            else if (need) std::memcpy(buf, g.h_down + sizes_bytes + j.off_bytes, need);
+        }
+        if (++g.handed == g.jobs.size()) g.reset();
+        tr.lap("wait + copy out");
+        return rc;
+    }
+    // a big step: its bytes come straight into the caller's buffer
+    if (rc == GC_OK) {
+        const uint64_t need = *g.need;
+        *written = (size_t)need;
+        if (need > cap) rc = GC_E_ARG;
+        else if (need) {  // on its own stream: the next circuit's kernels are already queued on the ctx stream
+            hipError_t e = hipMemcpyAsync(buf, g.d_bytes, (size_t)need, hipMemcpyDeviceToHost, s->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->copy_stream);
+            if (e != hipSuccess) {
+                set_error("gc_stream_garble_finish", e);
+                rc = GC_E_HIP;
+            }
+        }
+    }
+    g.reset();
     tr.lap("wait + d2h");
-    return GC_OK;
+    return rc;
 } catch (...) {
     return gc::on_exception();
 }
 
 int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                      uint32_t nin, const uint32_t *out, uint32_t nout, uint8_t *buf, size_t cap, size_t *written) {
-    if (!s || !buf || !written || s->pending) return GC_E_ARG;
+    if (!s || !buf || !written || !s->queue.empty()) return GC_E_ARG;
     int rc = gc_stream_garble_begin(s, gates, ngates, nwires, in, nin, out, nout);
     if (rc != GC_OK) return rc;
     return gc_stream_garble_finish(s, buf, cap, written);
@@ -673,7 +1200,7 @@ struct EvalSkel {
     };
     size_t nbytes = 0;
     uint32_t nrows = 0, nin = 0, nout = 0;
-    gc_circ *circ = nullptr;                 // owned by the stream's circuit cache
+    CircEntry *ent = nullptr;                // owned by the stream's circuit cache (dropped with it on eviction)
     std::vector<uint8_t> bytes;              // the reference block
     std::vector<Chunk> chunks;
     std::vector<uint32_t> gf_off;            // global id fields in stream order: byte offset | 1 << 31 for 4-byte ids
@@ -685,8 +1212,18 @@ struct EvalSkel {
 struct gc_stream_eval {
     gc_ctx *ctx = nullptr;
     std::vector<uint8_t> key;
+    int rounds = 0;
+    uint32_t *d_rk = nullptr;  // expanded key on the device (step groups)
     DevStore store;  // StreamEval.wires (global store), device-resident
     CircCache cache;
+    size_t cache_gates = 0, cache_budget = kCacheGatesDefault;
+    uint64_t tick = 0;
+    // step groups (see the head of this file): small blocks that share no global wire are evaluated by ONE launch sequence
+    std::vector<std::unique_ptr<Slot>> slots;
+    int open = -1;
+    ConflictStamps stamps;
+    std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
+    uint64_t n_groups = 0, n_group_blocks = 0;
     std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
     uint32_t *d_io = nullptr;
     size_t io_cap = 0;
@@ -711,6 +1248,43 @@ struct gc_stream_eval {
     uint32_t slab_turn = 0;
 };
 
+namespace {
+
+int eval_close_group(gc_stream_eval *e) {
+    if (e->open < 0) return GC_OK;
+    Slot &g = *e->slots[(size_t)e->open];
+    e->open = -1;
+    e->stamps.next_group();
+    e->n_groups++;
+    e->n_group_blocks += g.jobs.size();
+    return launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr);
+}
+
+// a slot for a new group of blocks: nothing comes back from an evaluator group, so a launched group's slot is free as
+// soon as its kernels have run; at most eight groups in flight, then the oldest is waited for
+Slot *eval_slot(gc_stream_eval *e, uint32_t *index) {
+    for (uint32_t i = 0; i < e->slots.size(); i++) {
+        Slot &sl = *e->slots[i];
+        if (sl.kind == Slot::kGroup && sl.launched && (sl.error != GC_OK || hipEventQuery(sl.done) == hipSuccess)) sl.reset();
+    }
+    (void)hipGetLastError();  // hipErrorNotReady of the queries
+    if (e->slots.size() >= 8) {
+        bool any_free = false;
+        for (auto &sl : e->slots) any_free = any_free || sl->kind == Slot::kFree;
+        if (!any_free) {
+            for (auto &sl : e->slots)
+                if (sl->kind == Slot::kGroup && sl->launched) {
+                    (void)hipEventSynchronize(sl->done);
+                    sl->reset();
+                    break;
+                }
+        }
+    }
+    return slot_new(e->slots, index);
+}
+
+}  // namespace
+
 extern "C" {
 
 gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, int *status) try {
@@ -723,7 +1297,18 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
     if (e) {
         e->ctx = ctx;
         e->key.assign(key, key + keylen);
+        e->rounds = k.rounds;
+        e->cache_budget = cache_budget_from_env();
         e->use_skels = std::getenv("GC_STREAM_NO_SKELETON") == nullptr;
+        hipError_t er = hipSetDevice(ctx->device);
+        if (er == hipSuccess) er = hipMalloc((void **)&e->d_rk, sizeof k.w);
+        if (er == hipSuccess) er = hipMemcpy(e->d_rk, k.w, sizeof k.w, hipMemcpyHostToDevice);
+        if (er != hipSuccess) {
+            set_error("gc_stream_eval_create", er);
+            rc = GC_E_HIP;
+            gc_stream_eval_free(e);
+            e = nullptr;
+        }
     }
     if (status) *status = rc;
     return e;
@@ -740,6 +1325,8 @@ void gc_stream_eval_free(gc_stream_eval *e) {
         (void)hipStreamSynchronize(e->ctx->stream);
     }
     for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
+    for (auto &sl : e->slots) sl->release();
+    if (e->d_rk) (void)hipFree(e->d_rk);
     if (e->d_io) (void)hipFree(e->d_io);
     for (int i = 0; i < 2; i++) {
         if (e->slab_pin[i]) (void)hipHostFree(e->slab_pin[i]);
@@ -751,6 +1338,8 @@ void gc_stream_eval_free(gc_stream_eval *e) {
 
 int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) try {
     if (!e || !l) return GC_E_ARG;
+    int rc = eval_close_group(e);  // a queued block reads the wire's OLD label (the reference runs in program order)
+    if (rc != GC_OK) return rc;
     e->store.set(w, *l);
     return GC_OK;
 } catch (...) {
@@ -764,9 +1353,13 @@ int gc_stream_eval_stats(const gc_stream_eval *e, uint64_t *parsed, uint64_t *ma
     return GC_OK;
 }
 
-int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) {
+int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
     if (!e || !l) return GC_E_ARG;
+    int rc = eval_close_group(e);  // a queued block may be the one that writes the wire
+    if (rc != GC_OK) return rc;
     return e->store.get(e->ctx, w, l);
+} catch (...) {
+    return gc::on_exception();
 }
 
 int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
@@ -793,9 +1386,15 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         e->last_t.resize(ntmp, 0);
     }
     std::vector<CircKey> &gates = e->keys;
+    // a small block (candidate for a step group) parses its rows into plain host scratch: they are copied into the
+    // group's pinned upload region when the block is queued; a big block uses the double-buffered pinned slab
+    const bool small_block = ngates <= kSmallGates;
     const uint32_t sb = e->slab_turn & 1u;
-    e->slab_turn++;
-    {
+    if (small_block) {
+        if (e->rows_scratch.size() < (size_t)ngates * 3 + 1) e->rows_scratch.resize((size_t)ngates * 3 + 1);
+        GC_HIP(hipSetDevice(e->ctx->device));
+    } else {
+        e->slab_turn++;
         GC_HIP(hipSetDevice(e->ctx->device));
         if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
         else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the H2D of the block two calls ago (long done)
@@ -808,7 +1407,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             e->slab_cap[sb] = want + want / 2;
         }
     }
-    gc_label *slab = e->slab_pin[sb];
+    gc_label *slab = small_block ? e->rows_scratch.data() : e->slab_pin[sb];
     size_t nrows = 0;
     tr.lap("eval: row buffer free");
     auto load_be64 = [](const uint8_t *p) {
@@ -846,7 +1445,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         }
         return true;
     };
-    gc_circ *circ = nullptr;
+    CircEntry *ent = nullptr;
     uint32_t nin = 0, nout = 0;
     size_t pos = 0;
     std::vector<uint32_t> &gf_ids = e->gf_ids, &wr_ids = e->wr_ids;
@@ -888,7 +1487,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                     q += 16u * c.nrows;
                 }
                 if (!same || !canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) continue;
-                circ = sk.circ;
+                ent = sk.ent;
                 nin = sk.nin, nout = sk.nout;
                 nrows = nr;
                 pos = sk.nbytes;
@@ -902,11 +1501,11 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                 break;
             }
     }
-    if (circ) {
+    if (ent) {
         e->n_matched++;
         tr.lap("eval: skeleton match");
     }
-    if (!circ) {
+    if (!ent) {
     if (++e->gen == 0) {  // stamp wrap-around
         std::fill(e->last_t.begin(), e->last_t.end(), 0);
         std::fill(e->last_w.begin(), e->last_w.end(), 0);
@@ -1014,8 +1613,29 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     const uint32_t cw = nin + ngates;
     const uint64_t h = ((ph.done() ^ nin) * CircuitHash::kPrime ^ nout) * CircuitHash::kPrime;
     // device circuit, cached by content
-    circ = cache_find_keys(e->cache, h, gates, cw, nin, nout);
-    if (!circ) {
+    ent = cache_find_keys(e->cache, h, gates, cw, nin, nout);
+    if (!ent) {
+        if (e->cache_gates + ngates + 1 > e->cache_budget && !e->cache.empty()) {
+            // The cache is bounded (the blocks are the peer's data: a stream of ever new circuits must not grow host and
+            // device memory without limit; the reference evaluator holds one block).  Least recently used circuits go,
+            // with the byte skeletons that point at them; nothing may refer to them any more: launch what is queued and
+            // drain the stream first (rare: once per budget's worth of NEW circuits).
+            int rcq = eval_close_group(e);
+            if (rcq != GC_OK) return rcq;
+            GC_HIP(hipStreamSynchronize(e->ctx->stream));
+            for (auto &sl : e->slots)
+                if (sl->kind == Slot::kGroup && sl->launched) sl->reset();
+            cache_make_room(e->cache, &e->cache_gates, e->cache_budget, (size_t)ngates + 1, [&](gc_circ *gone) {
+                for (auto &kv : e->skels) {
+                    std::vector<EvalSkel> &v = kv.second;
+                    for (size_t i = v.size(); i-- > 0;)
+                        if (v[i].ent && v[i].ent->circ == gone) {
+                            e->skel_bytes -= std::min(e->skel_bytes, v[i].bytes.size());
+                            v.erase(v.begin() + (long)i);
+                        }
+                }
+            });
+        }
         // wire ids of the device circuit: inputs, then the tmp-writing gates, then the global-writing gates
         int st = GC_OK;
         std::vector<uint32_t> &id_of = e->id_of;
@@ -1031,9 +1651,10 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             full[g].out = id_of[g];
             full[g].op = (uint8_t)gates[g].op;
         }
-        circ = gc_circ_load(e->ctx, full.data(), ngates, cw, nin, nout, &st);
-        if (!circ) return st;
-        cache_put_keys(e->cache, h, circ, gates, cw, nin, nout);
+        gc_circ *nc = gc_circ_load(e->ctx, full.data(), ngates, cw, nin, nout, &st);
+        if (!nc) return st;
+        ent = cache_put_keys(e->cache, h, nc, gates, cw, nin, nout);
+        e->cache_gates += ent->cost;
     }
     tr.lap("eval: hash + cache");
     // Input labels are gathered from, output labels scattered into, the device-resident store: nothing waits for the
@@ -1061,7 +1682,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         EvalSkel sk;
         sk.nbytes = pos;
         sk.nrows = (uint32_t)nrows, sk.nin = nin, sk.nout = nout;
-        sk.circ = circ;
+        sk.ent = ent;
         sk.bytes.assign(buf, buf + pos);
         sk.chunks = rec.chunks;
         sk.gf_off = rec.gf_off;
@@ -1072,7 +1693,67 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         }
     }
     }  // parsed
+    ent->last_use = ++e->tick;
     gc_ctx *ctx = e->ctx;
+    // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence -------
+    if (small_block && entry_is_small(ent)) {
+        e->stamps.ensure(e->store.host.size());
+        const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
+        if (e->open >= 0) {
+            Slot &g = *e->slots[(size_t)e->open];
+            if (g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes ||
+                e->stamps.conflicts(e->io_host.data(), nin, wr_ids.data(), nout)) {
+                int rcq = eval_close_group(e);  // stream order carries the dependency to the next group
+                if (rcq != GC_OK) return rcq;
+            }
+        }
+        if (e->open < 0) {
+            uint32_t idx = 0;
+            Slot *ng = eval_slot(e, &idx);
+            if (!ng) return GC_E_NOMEM;
+            ng->reset();
+            ng->kind = Slot::kGroup;
+            e->open = (int)idx;
+        }
+        Slot &g = *e->slots[(size_t)e->open];
+        const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = up16(nrows * sizeof(gc_label));
+        hipError_t er = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes + row_bytes + 16);
+        if (er != hipSuccess) {
+            set_error("gc_stream_eval_circuit (pinned)", er);
+            return GC_E_NOMEM;
+        }
+        JobRec j;
+        j.ent = ent;
+        j.nin = nin, j.nout = nout;
+        g.up_used = up16(g.up_used);
+        j.off_io = g.up_used;
+        if (nin + nout) std::memcpy(g.h_up + g.up_used, e->io_host.data(), ((size_t)nin + nout) * sizeof(uint32_t));
+        g.up_used += io_bytes;
+        j.off_rows = g.up_used;
+        if (nrows) std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
+        g.up_used += row_bytes;
+        j.off_w = g.arena_used;
+        g.arena_used += wbytes;
+        g.lds = std::max(g.lds, ent->lds);
+        g.has_or = g.has_or || ent->has_or;
+        g.jobs.push_back(j);
+        e->stamps.mark(e->io_host.data(), nin, wr_ids.data(), nout);
+        if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            int rcs = e->store.flush(ctx);
+            if (rcs != GC_OK) return rcs;
+        }
+        for (uint32_t k = 0; k < nout; k++) e->store.on_dev[wr_ids[k]] = 1;
+        tr.lap("eval: queued in group");
+        *consumed = pos;
+        return GC_OK;
+    }
+    // ---- a big block: its own launch sequence, behind everything queued -------------------------------------------
+    {
+        int rcq = eval_close_group(e);
+        if (rcq != GC_OK) return rcq;
+    }
+    gc_circ *circ = ent->circ;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         GC_HIP(hipSetDevice(ctx->device));
@@ -1088,8 +1769,11 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }
     gc_batch *b = nullptr;
     int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, e->d_io, e->d_io + nin, slab, nrows, &b);
+    // the pinned slab may be overwritten once what was enqueued from it has run: also when the pass failed half-way
+    // (an H2D copy from the slab may already be in flight)
+    if (!small_block) (void)hipEventRecord(e->slab_ev[sb], ctx->stream);
+    else (void)hipStreamSynchronize(ctx->stream);  // rows in plain host scratch (a small block without an LDS plan: rare)
     if (rc != GC_OK) return rc;
-    GC_HIP(hipEventRecord(e->slab_ev[sb], ctx->stream));
     gc_circ_release_batch(circ, b);
     for (uint32_t k = 0; k < nout; k++) e->store.on_dev[e->wr_ids[k]] = 1;
     tr.lap("eval: enqueue");

@@ -88,6 +88,8 @@ def lib():
         "gc_stream_garble": (i32, [vp, vp, u32, u32, vp, u32, vp, u32, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_stream_garble_begin": (i32, [vp, vp, u32, u32, vp, u32, vp, u32]),
         "gc_stream_garble_finish": (i32, [vp, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_garble_flush": (i32, [vp]),
+        "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
         "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
@@ -644,8 +646,19 @@ class Stream:
                                       C.byref(n)), "gc_stream_garble")
         return buf[: n.value].tobytes()
 
+    def flush(self):
+        """gc_stream_garble_flush: launch the queued group without waiting"""
+        _check(lib().gc_stream_garble_flush(self.h), "gc_stream_garble_flush")
+
+    def stats(self):
+        """(groups launched, steps that ran in groups, steps with a launch sequence of their own)"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().gc_stream_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "gc_stream_stats")
+        return a.value, b.value, c.value
+
     def garble_begin(self, gates, nwires, in_, out_):
-        """gc_stream_garble_begin: enqueue one circuit, do not wait (at most two in flight)"""
+        """gc_stream_garble_begin: queue one circuit, do not wait (up to 4 096 in flight; small independent circuits
+        share a launch sequence)"""
         g = np.ascontiguousarray(gates, dtype=GATE)
         i = np.ascontiguousarray(in_, dtype=np.uint32)
         o = np.ascontiguousarray(out_, dtype=np.uint32)

@@ -1,126 +1,299 @@
 #!/usr/bin/env python3
-"""Config-5-shaped streaming garbler throughput (circuit/stream_garble.go path): a program of large per-step circuits
-(each step consumes the previous step's outputs through global wire ids) through gc_stream_garble.  A single serial
-instance: one launch sequence per step.  Prints one JSON line: gates/s, AND/s, stream bytes/s and the SHA-256 of the
-byte stream (tests/test_gpu_stream.py checks the same construction against the CPU restatement at a smaller size)."""
+"""Config-5-shaped streaming throughput (circuit/stream_garble.go path; compiler/ssa/streamer.go:412-524 garbles one
+circuit per SSA instruction).  ONE serial instance; three kinds of programs through gc_stream_garble_begin / _finish
+(garbler, a window of steps queued ahead) and gc_stream_eval_circuit (evaluator, over the produced bytes):
+
+  big      chained 131 072-gate steps (64 levels x 2 048): every step its own launch sequence, the engine's best case
+  uniform  small steps of one shape (512 or 4 096 gates) in `chains` interleaved dependency chains: step k reads the
+           outputs of step k - chains, so `chains` independent steps are always available
+  mixed    70 % 64-bit adders, 25 % 64 x 64 multipliers, 5 % 131 072-gate steps; operands are drawn mostly from the
+           values of the last few steps (dependency chains as SSA code has them), results go to fresh wires or overwrite
+           an old variable (wire re-use)
+
+Prints one JSON line per program: gates/s of both sides, launch sequences used, SHA-256 of the byte stream.  The SHA-256s
+of the programs bench.py runs are pinned by the ORACLE (tests/golden/stream_bench_golden.json, written by
+tests/golden/make_stream_bench_golden.py in the build container) and checked here."""
+import ctypes as C
 import hashlib
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 
 from mpc_amd import engine
-from mpc_amd.circuit import synthetic_levelised
+from mpc_amd.circuit import GATE, adder, multiplier, synthetic_levelised
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "stream_bench_golden.json")
 
 
-def make_steps(nsteps, levels, width, and_frac, nin=256):
-    """step k reads global wires [k*nin, (k+1)*nin) and writes [(k+1)*nin, (k+2)*nin)"""
+# ---- programs: lists of (circuit, in wire ids, out wire ids) + the primary input wires ---------------------------------
+
+def program_big(total_gates=20_000_000, levels=64, width=2048, and_frac=0.25, nin=256):
+    """step k reads global wires [k*nin, (k+1)*nin) and writes [(k+1)*nin, (k+1)*nin + nout)"""
+    nsteps = max(1, total_gates // (levels * width))
     steps = []
     for k in range(nsteps):
         c = synthetic_levelised(levels, width, and_frac, seed=900 + (k % 4), ninputs=nin, inv_frac=0.05)
-        # the generator emits min(width, 128) outputs; chain them (repeated) into the next step's nin inputs
-        nout = c.num_outputs
-        in_ = [k * nin + i for i in range(nin)]
-        out_ = [(k + 1) * nin + i for i in range(nout)]
-        steps.append((c, in_, out_))
-    return steps
-
-
-def run(total_gates=10_000_000, levels=64, width=2048, and_frac=0.25, key=bytes(range(32)), ctx=None, evaluate=True):
-    per = levels * width
-    nsteps = max(1, total_gates // per)
-    nin = 256
-    steps = make_steps(nsteps, levels, width, and_frac, nin)
+        steps.append((c, [k * nin + i for i in range(nin)], [(k + 1) * nin + i for i in range(c.num_outputs)]))
     prim = list(range(nin))
     # later steps read wires the previous step did not write (nout < nin): declare those as primary inputs as well
     for k in range(1, nsteps):
         prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
-    rnd = hashlib.shake_256(b"stream-bench").digest(16 * (len(prim) + 1))
+    return steps, prim
+
+
+def make_steps(nsteps, levels, width, and_frac, nin=256):
+    """the big-step construction at a chosen size (tests/test_gpu_stream.py)"""
+    steps = []
+    for k in range(nsteps):
+        c = synthetic_levelised(levels, width, and_frac, seed=900 + (k % 4), ninputs=nin, inv_frac=0.05)
+        steps.append((c, [k * nin + i for i in range(nin)], [(k + 1) * nin + i for i in range(c.num_outputs)]))
+    return steps
+
+
+def program_uniform(gates=512, nsteps=4000, chains=8):
+    """`chains` interleaved chains of one small shape: step k reads what step k - chains wrote"""
+    levels, width = {512: (8, 64), 4096: (16, 256)}[gates]
+    nin = 64
+    shapes = [synthetic_levelised(levels, width, 0.25, seed=700 + v, ninputs=nin, inv_frac=0.05) for v in range(4)]
+    nout = shapes[0].num_outputs  # = min(width, 128) >= nin
+    prim = list(range(chains * nin))
+    steps = []
+    base = 0x11000  # 32-bit wire ids, as a program of this length has
+    for k in range(nsteps):
+        c = shapes[k % 4]
+        src = prim[(k % chains) * nin:(k % chains + 1) * nin] if k < chains else steps[k - chains][2][:nin]
+        steps.append((c, list(src), [base + k * nout + i for i in range(nout)]))
+    return steps, prim
+
+
+def program_mixed(nsteps=3000, seed=5, big_every=20):
+    rng = np.random.default_rng(seed)
+    add, mul = adder(64), multiplier(64)
+    bigs = [synthetic_levelised(64, 2048, 0.25, seed=900 + v, ninputs=256, inv_frac=0.05) for v in range(2)]
+    nvals = 64
+    prim = list(range(64 * nvals))
+    vals = [prim[64 * v:64 * (v + 1)] for v in range(nvals)]  # the program's live 64-bit values
+    recent = []
+    nxt = 0x20000
+    steps = []
+
+    def operand():
+        if recent and rng.random() < 0.6:  # the value of one of the last eight steps: a dependency chain
+            return recent[int(rng.integers(max(0, len(recent) - 8), len(recent)))]
+        return vals[int(rng.integers(0, len(vals)))]
+
+    for k in range(nsteps):
+        u = rng.random()
+        if big_every and k % big_every == big_every - 1:
+            c = bigs[(k // big_every) % 2]
+            in_ = operand() + operand() + operand() + operand()
+            nres = 2
+        else:
+            c = add if u < 0.7368 else mul  # 70 : 25 among the small steps
+            in_ = operand() + operand()
+            nres = 1
+        if rng.random() < 0.3:  # overwrite old variables (the allocator recycles wires)
+            tgt = [int(rng.integers(0, len(vals))) for _ in range(nres)]
+            while len(set(tgt)) < nres:
+                tgt = [int(rng.integers(0, len(vals))) for _ in range(nres)]
+            out_ = sum((vals[t] for t in tgt), [])
+            if set(out_) & set(in_):  # an in-place update is legal but rare: keep it out of the common path
+                out_ = list(range(nxt, nxt + 64 * nres))
+                nxt += 64 * nres
+                tgt = None
+        else:
+            out_ = list(range(nxt, nxt + 64 * nres))
+            nxt += 64 * nres
+            tgt = None
+        steps.append((c, in_, out_))
+        for r in range(nres):
+            v = out_[64 * r:64 * (r + 1)]
+            recent.append(v)
+            if tgt is None:
+                vals[int(rng.integers(0, len(vals)))] = v  # the new value replaces a dead one in the pool
+    return steps, prim
+
+
+PROGRAMS = {
+    "big": lambda: program_big(20_000_000),
+    "big130": lambda: program_big(130_000_000),
+    "uniform512": lambda: program_uniform(512, 4000, 8),
+    "uniform4096": lambda: program_uniform(4096, 1500, 8),
+    "uniform512x64": lambda: program_uniform(512, 8000, 64),
+    "mixed": lambda: program_mixed(3000),
+}
+
+
+def stream_rnd(name, nprim):
+    return hashlib.shake_256(b"stream-bench/" + name.encode()).digest(16 * (nprim + 1))
+
+
+# ---- lean drivers: one ctypes call per step, arguments converted once -------------------------------------------------
+
+class _Args:
+    def __init__(self, steps):
+        self.keep = []
+        self.begin = []
+        circs = {}
+        for c, in_, out_ in steps:
+            if id(c) not in circs:
+                g = np.ascontiguousarray(c.Gates, dtype=GATE)
+                circs[id(c)] = (g, g.ctypes.data_as(C.c_void_p))
+            g, pg = circs[id(c)]
+            i = np.asarray(in_, np.uint32)
+            o = np.asarray(out_, np.uint32)
+            self.keep.append((g, i, o))
+            self.begin.append((pg, len(g), c.NumWires, i.ctypes.data_as(C.c_void_p), len(i), o.ctypes.data_as(C.c_void_p), len(o)))
+
+
+def garble_program(ctx, key, steps, prim, rnd, window=64):
+    """returns (stream bytes as one array, per-step byte counts, seconds, stats, the Stream — still open); g.inputs0 =
+    the zero labels of the primary inputs as they were BEFORE the program ran (a program may overwrite its inputs)"""
+    L = engine.lib()
+    g = engine.Stream(ctx, key, rnd, prim)
+    g.inputs0 = [g.get(w)["l0"].copy() for w in prim]
+    a = _Args(steps)
+    n = len(steps)
+    cap = sum(c.NumGates * 13 + c.slab_rows() * 16 for c, _, _ in steps) + 64
+    out = np.empty(cap, np.uint8)
+    base = out.ctypes.data
+    sizes = np.zeros(n, np.int64)
+    nb = C.c_size_t(0)
+    pnb = C.byref(nb)
+    begin, finish, h = L.gc_stream_garble_begin, L.gc_stream_garble_finish, g.h
+    off = 0
+    issued = 0
+    t0 = time.perf_counter()
+    for k in range(n):
+        lim = min(n, k + window)
+        while issued < lim:
+            rc = begin(h, *a.begin[issued])
+            if rc:
+                raise engine.EngineError(rc, "gc_stream_garble_begin(step %d)" % issued)
+            issued += 1
+        rc = finish(h, C.c_void_p(base + off), cap - off, pnb)
+        if rc:
+            raise engine.EngineError(rc, "gc_stream_garble_finish(step %d)" % k)
+        sizes[k] = nb.value
+        off += nb.value
+    dt = time.perf_counter() - t0
+    return out[:off], sizes, dt, g.stats(), g
+
+
+def eval_program(ctx, key, steps, prim, g, stream, sizes):
+    """the evaluator alone over the produced bytes (all-zero inputs); returns seconds and checks the last outputs"""
+    L = engine.lib()
+    ev = engine.StreamEval(ctx, key)
+    for w, l0 in zip(prim, g.inputs0):
+        ev.set(w, (int(l0["d0"]), int(l0["d1"])))
+    n = len(steps)
+    call = L.gc_stream_eval_circuit
+    used = C.c_size_t(0)
+    pu = C.byref(used)
+    base = stream.ctypes.data
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    args = [(c.NumGates, c.NumWires, max(max(i), max(o)) + 1) for c, i, o in steps]
+    h = ev.h
+    t0 = time.perf_counter()
+    for k in range(n):
+        rc = call(h, args[k][0], args[k][1], args[k][2], C.c_void_p(base + int(offs[k])), int(sizes[k]), pu)
+        if rc:
+            raise engine.EngineError(rc, "gc_stream_eval_circuit(step %d)" % k)
+        if used.value != sizes[k]:
+            raise RuntimeError("evaluator consumed %d of %d bytes of step %d" % (used.value, sizes[k], k))
+    outs = steps[-1][2][:8]
+    got = [ev.get(o) for o in outs]  # waits for everything
+    dt = time.perf_counter() - t0
+    for o, lab in zip(outs, got):  # valid labels of the garbler's wires
+        wire = g.get(o)
+        assert lab in ((int(wire["l0"]["d0"]), int(wire["l0"]["d1"])), (int(wire["l1"]["d0"]), int(wire["l1"]["d1"]))), o
+    st = ev.stats()
+    ev.close()
+    return dt, st
+
+
+def golden_sha(name, key):
+    try:
+        with open(GOLDEN) as f:
+            return json.load(f).get("%s/key%d" % (name, len(key)))
+    except (OSError, ValueError):
+        return None
+
+
+def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, repeats=2):
+    steps, prim = PROGRAMS[name]()
+    rnd = stream_rnd(name, len(prim))
     own = ctx is None
     if own:
         ctx = engine.Context(0)
-    g = engine.Stream(ctx, key, rnd, prim)
-    ev = engine.StreamEval(ctx, key) if evaluate else None
-    if ev is not None:  # the evaluator's input labels: all-zero inputs
-        for w in prim:
-            wire = g.get(w)
-            ev.set(w, (int(wire["l0"]["d0"]), int(wire["l0"]["d1"])))
-    etimes = []
-    h = hashlib.sha256()
-    nbytes = 0
-    # The clock runs around the garbler's calls only (hashing the stream for the parity check is not part of the path).
-    # Steps are pipelined the way a driver would: gc_stream_garble_begin(k + 1) before gc_stream_garble_finish(k) — the
-    # bytes leave in order, the host's share of a step overlaps the GPU's share of the step before.  The first use of a
-    # circuit builds and caches its plan: reported separately from the steady state.
-    times = []
-    keep = []  # the blocks of the first steps, for the evaluator pass
-    neval = min(nsteps, 150) if evaluate else 0
-    t_prev = time.perf_counter()
-    g.garble_begin(steps[0][0].Gates, steps[0][0].NumWires, steps[0][1], steps[0][2])
-    for k in range(nsteps):
-        if k + 1 < nsteps:
-            c1, in1, out1 = steps[k + 1]
-            g.garble_begin(c1.Gates, c1.NumWires, in1, out1)
-        data = g.garble_finish()
-        now = time.perf_counter()
-        times.append(now - t_prev)
-        h.update(data)
-        nbytes += len(data)
-        if k < neval:
-            keep.append(data)
-        t_prev = time.perf_counter()
-    if ev is not None:
-        # evaluator alone over the stored blocks: a call returns when the block is parsed and its kernels are enqueued, so
-        # the clock stops after the final read-back (which waits for everything)
-        marks = []
-        for k in range(neval):
-            c, in_, out_ = steps[k]
-            nw = max(max(in_), max(out_)) + 1
-            t0 = time.perf_counter()
-            used = ev.circuit(c.NumGates, c.NumWires, nw, keep[k])
-            etimes.append(time.perf_counter() - t0)
-            assert used == len(keep[k])
-            marks.append(time.perf_counter())
-        t0 = time.perf_counter()
-        outs = steps[neval - 1][2][:8]
-        got_all = [ev.get(o) for o in outs]  # the last step's outputs must be valid labels of the garbler's wires
-        etimes[-1] += time.perf_counter() - t0
-        for o, got in zip(outs, got_all):
-            wire = g.get(o)
-            assert got in ((int(wire["l0"]["d0"]), int(wire["l0"]["d1"])), (int(wire["l1"]["d0"]), int(wire["l1"]["d1"])))
-        ev.close()
     gates = sum(c.NumGates for c, _, _ in steps)
     ands = sum(c.stats()["AND"] for c, _, _ in steps)
-    g.close()
+    best = None
+    for rep in range(repeats):  # the first pass builds and caches the plans: report the second as the steady state
+        stream, sizes, dt, stats, g = garble_program(ctx, key, steps, prim, rnd, window)
+        sha = hashlib.sha256(stream.tobytes() if len(stream) < (1 << 30) else memoryview(stream)).hexdigest()
+        res = {"program": name, "steps": len(steps), "gates": gates, "and": ands, "window": window,
+               "garble_s": dt, "garble_gates_per_s": gates / dt, "garble_us_per_step": dt / len(steps) * 1e6,
+               "stream_bytes": int(len(stream)), "launch_groups": stats[0], "grouped_steps": stats[1], "big_steps": stats[2],
+               "sha256": sha}
+        if rep == 0:
+            res["first_pass_s"] = dt
+            first = dt
+        else:
+            res["first_pass_s"] = first
+        want = golden_sha(name, key)
+        if want is not None and want != sha:
+            raise AssertionError("%s: stream SHA-256 %s != oracle's %s" % (name, sha, want))
+        if evaluate and rep == repeats - 1:
+            edt, est = eval_program(ctx, key, steps, prim, g, stream, sizes)
+            res.update({"eval_s": edt, "eval_gates_per_s": gates / edt, "eval_us_per_step": edt / len(steps) * 1e6,
+                        "eval_blocks_parsed": est[0], "eval_blocks_matched": est[1]})
+        g.close()
+        best = res
+    want = golden_sha(name, key)
+    best["sha256_golden"] = want
+    best["sha256_ok"] = None if want is None else bool(want == best["sha256"])
+    if want is not None and want != best["sha256"]:
+        raise AssertionError("%s: stream SHA-256 %s != oracle's %s" % (name, best["sha256"], want))
     if own:
         ctx.close()
-    dt = sum(times)
-    ndistinct = min(4, nsteps)
-    steady = times[ndistinct:]
-    per_step_gates = gates / nsteps
-    res = {"steps": nsteps, "gates": gates, "and": ands, "seconds": dt, "gates_per_s": gates / dt,
-           "and_per_s": ands / dt, "stream_bytes": nbytes, "stream_MBps": nbytes / dt / 1e6, "sha256": h.hexdigest()}
-    if steady:
-        sdt = sum(steady)
-        res["steady_ms_per_step"] = sdt / len(steady) * 1e3
-        res["steady_gates_per_s"] = per_step_gates * len(steady) / sdt
-        res["first_use_ms_per_circuit"] = sum(times[:ndistinct]) / ndistinct * 1e3
-    if etimes[ndistinct:]:
-        sdt = sum(etimes[ndistinct:])
-        res["eval_steady_ms_per_step"] = sdt / len(etimes[ndistinct:]) * 1e3
-        res["eval_steady_gates_per_s"] = per_step_gates * len(etimes[ndistinct:]) / sdt
-    return res
+    return best
 
 
 def run_for_line(key=bytes(range(32)), ctx=None):
-    """the `stream` object of bench.py's line: a bounded sample of the big-step program (152 chained 131 072-gate steps)"""
-    st = run(20_000_000, key=key, ctx=ctx)
-    return {k: st[k] for k in ("steps", "gates", "steady_ms_per_step", "steady_gates_per_s", "eval_steady_ms_per_step",
-                               "eval_steady_gates_per_s", "first_use_ms_per_circuit", "sha256") if k in st}
+    """the `stream` object of bench.py's line: the big-step program (bounded sample: 152 steps), the two uniform
+    small-step programs and the mixed program; every SHA-256 checked against the oracle's"""
+    out = {}
+    b = run_program("big", key, ctx, window=2)
+    out.update({"steps": b["steps"], "gates": b["gates"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
+                "steady_gates_per_s": b["garble_gates_per_s"], "eval_steady_ms_per_step": b["eval_us_per_step"] / 1e3,
+                "eval_steady_gates_per_s": b["eval_gates_per_s"], "first_pass_s": b["first_pass_s"], "sha256": b["sha256"],
+                "sha256_ok": b["sha256_ok"]})
+    for name in ("uniform512", "uniform4096", "mixed"):
+        r = run_program(name, key, ctx)
+        out[name] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
+                                       "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
+    out["published_reference"] = "1.4e7 gates/s, Go, i5-8257U (benchmarks.md:677-704: Ed25519 sign.mpcl streamed)"
+    return out
+
+
+def run(total_gates=10_000_000, key=bytes(range(32)), ctx=None, evaluate=True):
+    """compatibility with round 2's callers: the big-step program of `total_gates` gates"""
+    PROGRAMS["_big"] = lambda: program_big(total_gates)
+    r = run_program("_big", key, ctx, window=2, evaluate=evaluate)
+    return r
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000)))
+    names = sys.argv[1:] or ["big", "uniform512", "uniform4096", "mixed"]
+    for nm in names:
+        win = 64
+        if ":" in nm:
+            nm, w = nm.split(":")
+            win = int(w)
+        print(json.dumps(run_program(nm, window=2 if nm.startswith("big") and win == 64 else win)), flush=True)
