@@ -52,8 +52,8 @@ const char *gc_strerror(int status);
 /* thread-local detail of the last GC_E_HIP / GC_E_NOMEM on this thread ("" if none) */
 const char *gc_last_error(void);
 /* ABI version of this header (checked by the bindings).  2: + gc_dev_* (device memory for hosts without a HIP
- * allocator), gc_rot_* (ot/rot.go), gc_stream_garble_flush / gc_stream_stats and up to 4 096 circuits in flight per
- * stream (step groups); every v1 entry point is unchanged. */
+ * allocator), gc_rot_* (ot/rot.go), gc_stream_garble_flush / gc_stream_stats / gc_stream_intern / gc_stream_garble_begin_h and up
+ * to 4 096 circuits in flight per stream (step groups); every v1 entry point is unchanged. */
 #define GC_ABI_VERSION 2
 int gc_abi_version(void);
 
@@ -262,6 +262,15 @@ int gc_stream_garble_begin(gc_stream *, const gc_gate *gates, uint32_t ngates, u
                            uint32_t nin, const uint32_t *out, uint32_t nout);
 int gc_stream_garble_finish(gc_stream *, uint8_t *buf, size_t cap, size_t *written);
 int gc_stream_garble_flush(gc_stream *);
+/* A driver garbles the same few circuits over and over (the streamer keeps one compiled circuit per SSA instruction
+ * shape: 23 for Ed25519 sign.mpcl, benchmarks.md:698), and gc_stream_garble_begin has to recognise the gate list by
+ * content on every call (a hash and a gate-by-gate comparison: most of the host's share of a small step).
+ * gc_stream_intern does that ONCE and returns a handle for the stream's lifetime (the Go shim keeps a
+ * map[*Circuit]handle; interned circuits are exempt from cache eviction); gc_stream_garble_begin_h is
+ * gc_stream_garble_begin for an interned circuit: in[] / out[] have the circuit's ninputs / noutputs entries. */
+int gc_stream_intern(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                     uint32_t noutputs, uint32_t *handle);
+int gc_stream_garble_begin_h(gc_stream *, uint32_t handle, const uint32_t *in, const uint32_t *out);
 /* launch sequences so far: groups of small circuits, circuits that ran in them, circuits with a sequence of their own
  * (any pointer may be NULL) */
 int gc_stream_stats(const gc_stream *, uint64_t *groups, uint64_t *grouped_steps, uint64_t *big_steps);

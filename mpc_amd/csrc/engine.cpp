@@ -517,6 +517,7 @@ gc_batch *gc_batch_create(gc_circ *circ, uint32_t batch, int *status) try {
     if (rc == GC_OK) {
         b->circ = circ;
         b->g.batch = batch;
+        b->use_graph = std::getenv("GC_NO_GRAPH") == nullptr;  // developer aid: profilers that choke on graph launches
         hipError_t e = hipSetDevice(circ->ctx->device);
         if (e == hipSuccess) e = alloc_buffers(b);
         if (e == hipSuccess) e = hipMalloc((void **)&b->d_rk, 60 * sizeof(uint32_t));

@@ -593,6 +593,15 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
         un = unn_v;
     }
     GC_FPROF_EPILOGUE()
+    if constexpr (MULTI) {
+        // Set through out[] (stream_garble.go:143-157): the job's output labels go back into the wire store.  They were
+        // written to W by other waves of this workgroup: the barrier (with its vmcnt(0)) makes them visible.
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
+            const uint32_t idx = a.out_idx[k];
+            if (idx != 0xffffffffu) a.store[idx] = Wt[a.out_slots[k]];
+        }
+    }
 }
 
 template <int NR, bool PROF, bool HAS_OR>
@@ -686,6 +695,15 @@ __device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
         un = unn_v;
     }
     GC_FPROF_EPILOGUE()
+    if constexpr (MULTI) {
+        // Set through out[] (stream_garble.go:143-157): the job's output labels go back into the wire store.  They were
+        // written to W by other waves of this workgroup: the barrier (with its vmcnt(0)) makes them visible.
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
+            const uint32_t idx = a.out_idx[k];
+            if (idx != 0xffffffffu) a.store[idx] = Wt[a.out_slots[k]];
+        }
+    }
 }
 
 template <int NR, bool PROF, bool HAS_OR>

@@ -145,8 +145,11 @@ struct FlatJob {
     uint4 *Rout;       // garbler only: R of every instance, for the later passes of the pipeline
     uint32_t batch;
     uint32_t pad_;
-    const uint4 *store;       // job launches: the stream's wire store ...
-    const uint32_t *in_idx;   // ... and the store index of every input wire
+    uint4 *store;                // job launches: the stream's wire store ...
+    const uint32_t *in_idx;      // ... the store index of every input wire (Get through in[]) ...
+    const uint32_t *out_slots;   // ... and, for output k, its wire slot in W and its store index (Set through out[];
+    const uint32_t *out_idx;     //     0xffffffff: not stored), written back by the workgroup itself when it is done
+    uint32_t nout, pad2_;
 };
 // d_jobs: device array of njobs records (ti_log2 = 0, batch = 1, rnd = prof = nullptr); lds_bytes = the largest
 // fused_flat_bytes(nls, 0, ustride) of the group; has_or: some job's circuit has an OR gate; rounds: 10 / 12 / 14 (one

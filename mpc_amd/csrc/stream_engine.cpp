@@ -71,6 +71,7 @@ struct CircEntry {
     bool has_or = false;
     uint32_t ser_long = 0;  // bytes of the serialised gates with every id in the 4-byte form (an upper bound)
     uint64_t last_use = 0;  // LRU stamp (cache eviction)
+    bool pinned = false;    // interned by the caller (gc_stream_intern): never evicted
     size_t cost = 0;        // gates held (host copy + device plan): what the cache budget counts
 };
 using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
@@ -253,37 +254,56 @@ static hipError_t grow_pin(uint8_t **p, size_t *cap, size_t need) {
     return e;
 }
 
-// which global wires the OPEN group reads / writes: a stamp per wire, valid while it equals the group's generation
-struct ConflictStamps {
-    std::vector<uint32_t> rd, wr;
-    uint32_t gen = 1;
-    void next_group() {
-        if (++gen == 0) {
-            std::fill(rd.begin(), rd.end(), 0);
-            std::fill(wr.begin(), wr.end(), 0);
-            gen = 1;
-        }
-    }
+// The open groups of a stream, oldest first: a small window of launch sequences that have not been launched yet, filled
+// by list scheduling.  Group i of the window carries sequence number first_seq + i; per global wire the window remembers
+// the sequence number of the latest open group that reads / writes it.  A new step (later in program order than
+// everything queued) may join group i only if it conflicts with no step of groups i .. last (it then runs before the
+// groups behind i, beside the steps of group i): the earliest such group is one past the latest group it has a
+// read-after-write, write-after-write or write-after-read relation with.  Groups are launched in sequence order on one
+// HIP stream, so "later group" = "later in time".
+constexpr uint32_t kOpenGroups = 4;
+struct GroupWindow {
+    std::deque<uint32_t> open;      // slots of the open groups, oldest first
+    uint32_t first_seq = 1;         // sequence number of open.front()
+    std::vector<uint32_t> rd, wr;   // per wire: sequence number of the latest group that reads / writes it (stale if < first_seq)
     void ensure(size_t n) {
         if (rd.size() < n) {
             rd.resize(n, 0);
             wr.resize(n, 0);
         }
     }
-    // would a step with these reads / writes have to see, or be seen by, a step already in the open group?
-    bool conflicts(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
-        for (uint32_t i = 0; i < nr; i++)
-            if (wr[reads[i]] == gen) return true;  // read after write
+    // index into `open` of the earliest group the step may join (== open.size(): it needs a new group)
+    uint32_t place(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        uint32_t lo = first_seq;
+        for (uint32_t i = 0; i < nr; i++) {
+            const uint32_t w = wr[reads[i]];
+            if (w >= lo) lo = w + 1;  // read after write
+        }
         for (uint32_t j = 0; j < nw; j++) {
             if (writes[j] == 0xffffffffu) continue;
-            if (wr[writes[j]] == gen || rd[writes[j]] == gen) return true;  // write after write / write after read
+            const uint32_t w = wr[writes[j]], r = rd[writes[j]];
+            if (w >= lo) lo = w + 1;  // write after write
+            if (r >= lo) lo = r + 1;  // write after read
         }
-        return false;
+        return lo - first_seq;
     }
-    void mark(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
-        for (uint32_t i = 0; i < nr; i++) rd[reads[i]] = gen;
+    void mark(uint32_t index, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        const uint32_t seq = first_seq + index;
+        for (uint32_t i = 0; i < nr; i++)
+            if (rd[reads[i]] < seq) rd[reads[i]] = seq;
         for (uint32_t j = 0; j < nw; j++)
-            if (writes[j] != 0xffffffffu) wr[writes[j]] = gen;
+            if (writes[j] != 0xffffffffu) wr[writes[j]] = seq;
+    }
+    // the oldest group leaves the window (it is being launched)
+    uint32_t pop() {
+        const uint32_t slot = open.front();
+        open.pop_front();
+        if (++first_seq >= 0xfffffff0u && open.empty()) {  // sequence numbers wrap after 4e9 groups: start over
+            std::fill(rd.begin(), rd.end(), 0);
+            std::fill(wr.begin(), wr.end(), 0);
+            first_seq = 1;
+        }
+        return slot;
     }
 };
 
@@ -309,8 +329,8 @@ struct gc_stream {
     // circuits in flight (gc_stream_garble_begin / _finish), oldest first, and the slots that hold them
     std::vector<std::unique_ptr<Slot>> slots;
     std::deque<StepRef> queue;
-    int open = -1;                // slot of the group still accepting steps
-    ConflictStamps stamps;
+    GroupWindow win;              // the groups still accepting steps
+    std::vector<CircEntry *> handles;  // gc_stream_intern
     hipStream_t copy_stream = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
 };
@@ -454,26 +474,19 @@ __global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint
     }
 }
 
-// ---- the closing kernel of a step group: workgroup j = job j ---------------------------------------------------
-// Set through out[] (stream_garble.go:143-157; streaming.Set on the evaluator's side): store[out_idx[k]] = W[out_slots[k]];
-// then (garbler) the job's gates in the wire format, gate order, into the job's byte slot, the byte count into *size_out.
+// ---- the serialiser of a step group (garbler): workgroup j = job j ------------------------------------------------
+// The job's gates in the wire format (stream_garble.go:391-446), gate order, into the job's byte slot; the byte count
+// into *size_out.  Runs on the copy stream behind the group's garbling kernel, beside the NEXT group's garbling (the
+// output labels went back into the wire store in the garbling kernel's own epilogue).
 struct FinJob {
-    SerArgs a;                 // a.ngates == 0: nothing to serialise (evaluator)
-    const uint4 *W, *T;
-    const uint32_t *out_slots; // wire slot of output k in W
-    const uint32_t *out_idx;   // store index of output k, 0xffffffff: not stored
-    uint32_t nout, pad_;
+    SerArgs a;
+    const uint4 *T;
     uint8_t *bytes;
     uint32_t *size_out;
 };
 constexpr uint32_t kFinThreads = 1024;
-__global__ __launch_bounds__(kFinThreads) void k_stream_finish(const FinJob *jobs, uint4 *store) {
+__global__ __launch_bounds__(kFinThreads) void k_stream_serialise(const FinJob *jobs) {
     const FinJob j = jobs[blockIdx.x];
-    for (uint32_t k = threadIdx.x; k < j.nout; k += kFinThreads) {
-        const uint32_t idx = j.out_idx[k];
-        if (idx != 0xffffffffu) store[idx] = j.W[j.out_slots[k]];
-    }
-    if (j.a.ngates == 0) return;
     __shared__ uint32_t wsum[kFinThreads / 64];
     const uint32_t per = (j.a.ngates + kFinThreads - 1) / kFinThreads;  // consecutive gates per thread: byte order = gate order
     const uint32_t lo = min(threadIdx.x * per, j.a.ngates), hi = min(lo + per, j.a.ngates);
@@ -623,9 +636,10 @@ CircEntry *cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate 
 template <typename F>
 void cache_make_room(CircCache &cache, size_t *held, size_t budget, size_t cost, F dropped) {
     while (!cache.empty() && *held + cost > budget) {
-        auto victim = cache.begin();
+        auto victim = cache.end();
         for (auto it = cache.begin(); it != cache.end(); ++it)
-            if (it->second.last_use < victim->second.last_use) victim = it;
+            if (!it->second.pinned && (victim == cache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+        if (victim == cache.end()) break;  // only interned circuits left
         *held -= std::min(*held, victim->second.cost);
         dropped(victim->second.circ);
         gc_circ_free(victim->second.circ);
@@ -711,6 +725,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         f.rk = d_rk;
         f.store = store.d;
         f.in_idx = d_io;
+        f.out_slots = j.ent->circ->d_out_slots;
+        f.out_idx = eval ? d_io + j.nin : d_io + j.nin + j.nout;
+        f.nout = j.nout;
         fj[k] = f;
         FinJob q{};
         if (!eval) {
@@ -725,23 +742,19 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
             q.bytes = g.d_down + sizes_bytes + j.off_bytes;
             q.size_out = (uint32_t *)g.d_down + k;
         }
-        q.W = f.W;
         q.T = f.T;
-        q.out_slots = j.ent->circ->d_out_slots;
-        q.out_idx = eval ? d_io + j.nin : d_io + j.nin + j.nout;
-        q.nout = j.nout;
         fin[k] = q;
     }
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
     if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_stream_finish, dim3(n), dim3(kFinThreads), 0, st, (const FinJob *)(g.d_up + off_fin), store.d);
-        e = hipGetLastError();
-    }
     if (e == hipSuccess && !eval) {
-        // the bytes travel on the copy stream: the next group's kernels need not wait for them
+        // serialiser and bytes on the copy stream: the next group's garbling need not wait for either
         e = hipEventRecord(g.kdone, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_stream_serialise, dim3(n), dim3(kFinThreads), 0, copy_stream, (const FinJob *)(g.d_up + off_fin));
+            e = hipGetLastError();
+        }
         if (e == hipSuccess)
             e = hipMemcpyAsync(g.h_down, g.d_down, sizes_bytes + g.down_used, hipMemcpyDeviceToHost, copy_stream);
         if (e == hipSuccess) e = hipEventRecord(g.done, copy_stream);
@@ -752,15 +765,73 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     return GC_OK;
 }
 
-int close_group(gc_stream *s) {
-    if (s->open < 0) return GC_OK;
-    Slot &g = *s->slots[(size_t)s->open];
-    s->open = -1;
-    s->stamps.next_group();
+// the oldest open group leaves the window and is launched
+int launch_oldest(gc_stream *s) {
+    if (s->win.open.empty()) return GC_OK;
+    Slot &g = *s->slots[s->win.pop()];
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
     return launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream);
 }
+// everything queued is launched, in order (a read-back, a big step or the caller's flush follows)
+int close_group(gc_stream *s) {
+    int rc = GC_OK;
+    while (!s->win.open.empty()) {
+        const int r = launch_oldest(s);
+        if (rc == GC_OK) rc = r;
+    }
+    return rc;
+}
+
+// the stream's cached device circuit for this gate list (cached by content; a new circuit is validated once:
+// garbleGate's checks, stream_garble.go:195-210)
+int stream_find_or_load(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout,
+                        CircEntry **out_ent) {
+    const uint32_t first_tmp = nin;
+    hipStream_t st = s->ctx->stream;
+    CircEntry *ent = nullptr;
+    {
+        const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
+        ent = cache_find(s->cache, h, gates, ngates, nwires, nin, nout);
+        if (!ent) {
+            for (uint32_t i = 0; i < ngates; i++) {
+                if (gates[i].op > GC_INV) return GC_E_GATE;
+                if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
+            }
+            if (s->cache_gates + ngates + 1 > s->cache_budget && !s->cache.empty()) {
+                // over budget: least recently used circuits go.  Nothing may refer to them any more: launch what is queued
+                // and drain both streams first (rare: once per budget's worth of NEW circuits)
+                int rcq = close_group(s);
+                if (rcq != GC_OK) return rcq;
+                GC_HIP(hipStreamSynchronize(st));
+                GC_HIP(hipStreamSynchronize(s->copy_stream));
+                cache_make_room(s->cache, &s->cache_gates, s->cache_budget, (size_t)ngates + 1, [](gc_circ *) {});
+            }
+            int stc = GC_OK;
+            gc_circ *circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &stc);
+            if (!circ) return stc;
+            std::vector<uint32_t> gw((size_t)3 * ngates);
+            for (uint32_t i = 0; i < ngates; i++) {
+                gw[3 * (size_t)i] = gates[i].in0;
+                gw[3 * (size_t)i + 1] = gates[i].in1;
+                gw[3 * (size_t)i + 2] = gates[i].out;
+            }
+            hipError_t e = hipMalloc((void **)&circ->d_gwires, gw.size() * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemcpy(circ->d_gwires, gw.data(), gw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                gc_circ_free(circ);
+                return GC_E_HIP;
+            }
+            ent = cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
+            s->cache_gates += ent->cost;
+        }
+    }
+    *out_ent = ent;
+    return GC_OK;
+}
+
+int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in, uint32_t nin,
+                 const uint32_t *out, uint32_t nout, CircEntry *known);
 
 }  // namespace
 
@@ -826,6 +897,36 @@ void gc_stream_free(gc_stream *s) {
     delete s;
 }
 
+// gc_stream_intern: the circuit is looked up (or loaded) once and named by a handle; gc_stream_garble_begin_h then
+// skips the per-call content hash and gate-by-gate comparison — for a 4 096-gate SSA-step circuit that is most of the
+// host's share of a step.  Interned circuits are never evicted from the cache.
+int gc_stream_intern(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout,
+                     uint32_t *handle) try {
+    if (!s || !handle || (!gates && ngates) || ngates == 0 || nin > nwires || nout > nwires) return GC_E_ARG;
+    CircEntry *ent = nullptr;
+    int rc = stream_find_or_load(s, gates, ngates, nwires, nin, nout, &ent);
+    if (rc != GC_OK) return rc;
+    ent->pinned = true;
+    for (uint32_t i = 0; i < s->handles.size(); i++)
+        if (s->handles[i] == ent) {
+            *handle = i;
+            return GC_OK;
+        }
+    s->handles.push_back(ent);
+    *handle = (uint32_t)s->handles.size() - 1;
+    return GC_OK;
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_garble_begin_h(gc_stream *s, uint32_t handle, const uint32_t *in, const uint32_t *out) try {
+    if (!s || handle >= s->handles.size()) return GC_E_ARG;
+    CircEntry *ent = s->handles[handle];
+    return stream_begin(s, nullptr, (uint32_t)ent->gates.size(), ent->nwires, in, ent->nin, out, ent->nout, ent);
+} catch (...) {
+    return gc::on_exception();
+}
+
 int gc_stream_garble_flush(gc_stream *s) try {
     if (!s) return GC_E_ARG;
     return close_group(s);
@@ -861,7 +962,19 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streami
 // this file): the bytes still leave in order.  At most kMaxPending circuits in flight.
 int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                            uint32_t nin, const uint32_t *out, uint32_t nout) try {
-    if (!s || (!gates && ngates) || (nin && !in) || (nout && !out)) return GC_E_ARG;
+    if (!s || (!gates && ngates)) return GC_E_ARG;
+    return stream_begin(s, gates, ngates, nwires, in, nin, out, nout, nullptr);
+} catch (...) {
+    return gc::on_exception();
+}
+
+// known: the interned circuit of gc_stream_garble_begin_h (gates == nullptr then)
+}  // extern "C"
+
+namespace {
+int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
+                 uint32_t nin, const uint32_t *out, uint32_t nout, CircEntry *known) {
+    if (!s || (nin && !in) || (nout && !out)) return GC_E_ARG;
     if (s->queue.size() >= kMaxPending) return GC_E_ARG;
     // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
     // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
@@ -899,7 +1012,17 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
         for (uint32_t i = 0; i < nin && !aliased; i++) aliased = s->alias_gen[in[i]] == s->gen;
         if (aliased) {
             std::vector<uint8_t> set(nout, 0);
-            s->rewritten.assign(gates, gates + ngates);
+            if (known) {  // an interned circuit bound so that an output updates one of its inputs in place: rare, general path
+                s->rewritten.assign(ngates, gc_gate{});
+                for (uint32_t g = 0; g < ngates; g++) {
+                    const CircKey &k = known->gates[g];
+                    s->rewritten[g].in0 = k.in0, s->rewritten[g].in1 = k.in1, s->rewritten[g].out = k.out;
+                    s->rewritten[g].op = (uint8_t)k.op;
+                }
+                known = nullptr;
+            } else {
+                s->rewritten.assign(gates, gates + ngates);
+            }
             for (uint32_t g = 0; g < ngates; g++) {
                 gc_gate &q = s->rewritten[g];
                 auto redirect = [&](uint32_t w) {
@@ -915,71 +1038,42 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
     }
 
     // device circuit (cached by content); a new circuit is validated once (garbleGate's checks, :195-210)
-    CircEntry *ent = nullptr;
-    if (ngates) {
-        const uint64_t h = circuit_hash(gates, ngates, nwires, nin, nout);
-        ent = cache_find(s->cache, h, gates, ngates, nwires, nin, nout);
-        if (!ent) {
-            for (uint32_t i = 0; i < ngates; i++) {
-                if (gates[i].op > GC_INV) return GC_E_GATE;
-                if (gates[i].out < first_tmp) return GC_E_ARG;  // a gate writing an input-mapped wire: not produced by the compiler
-            }
-            if (s->cache_gates + ngates + 1 > s->cache_budget && !s->cache.empty()) {
-                // over budget: least recently used circuits go.  Nothing may refer to them any more: launch what is queued
-                // and drain both streams first (rare: once per budget's worth of NEW circuits)
-                int rcq = close_group(s);
-                if (rcq != GC_OK) return rcq;
-                GC_HIP(hipStreamSynchronize(st));
-                GC_HIP(hipStreamSynchronize(s->copy_stream));
-                cache_make_room(s->cache, &s->cache_gates, s->cache_budget, (size_t)ngates + 1, [](gc_circ *) {});
-            }
-            int stc = GC_OK;
-            gc_circ *circ = gc_circ_load(s->ctx, gates, ngates, nwires, nin, nout, &stc);
-            if (!circ) return stc;
-            std::vector<uint32_t> gw((size_t)3 * ngates);
-            for (uint32_t i = 0; i < ngates; i++) {
-                gw[3 * (size_t)i] = gates[i].in0;
-                gw[3 * (size_t)i + 1] = gates[i].in1;
-                gw[3 * (size_t)i + 2] = gates[i].out;
-            }
-            hipError_t e = hipMalloc((void **)&circ->d_gwires, gw.size() * sizeof(uint32_t));
-            if (e == hipSuccess) e = hipMemcpy(circ->d_gwires, gw.data(), gw.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                gc_circ_free(circ);
-                return GC_E_HIP;
-            }
-            ent = cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
-            s->cache_gates += ent->cost;
-        }
-        ent->last_use = ++s->tick;
+    CircEntry *ent = known;
+    if (ngates && !ent) {
+        int rcl = stream_find_or_load(s, gates, ngates, nwires, nin, nout, &ent);
+        if (rcl != GC_OK) return rcl;
     }
+    if (ent) ent->last_use = ++s->tick;
     tr.lap("alias + hash + cache");
 
     // out[] with "no store" marks (an output wire that is an input wire has no gate: no Set)
     s->skip_scratch.resize(nout);
     for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
 
-    // ---- a small step joins the open group --------------------------------------------------------------------
+    // ---- a small step joins the earliest open group it has no dependency on (or behind) --------------------------
     if (ngates && entry_is_small(ent)) {
-        s->stamps.ensure(s->store.host.size());
-        if (s->open >= 0) {
-            Slot &g = *s->slots[(size_t)s->open];
-            const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
-            if (g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes ||
-                s->stamps.conflicts(in, nin, s->skip_scratch.data(), nout)) {
-                int rcq = close_group(s);  // stream order carries the dependency to the next group
+        s->win.ensure(s->store.host.size());
+        const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
+        uint32_t gi = s->win.place(in, nin, s->skip_scratch.data(), nout);
+        auto full = [&](const Slot &g) {
+            return g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
+        };
+        while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
+        if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
+            if (s->win.open.size() >= kOpenGroups) {
+                int rcq = launch_oldest(s);
                 if (rcq != GC_OK) return rcq;
+                gi--;
             }
-        }
-        if (s->open < 0) {
             uint32_t idx = 0;
             Slot *ng = slot_new(s->slots, &idx);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            s->open = (int)idx;
+            s->win.open.push_back(idx);
         }
-        Slot &g = *s->slots[(size_t)s->open];
+        const uint32_t slot_idx = s->win.open[gi];
+        Slot &g = *s->slots[slot_idx];
         const size_t io_bytes = up16(((size_t)nin + 2 * (size_t)nout) * sizeof(uint32_t));
         hipError_t e = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes);
         if (e != hipSuccess) {
@@ -1007,7 +1101,7 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
         g.jobs.push_back(j);
-        s->stamps.mark(in, nin, s->skip_scratch.data(), nout);
+        s->win.mark(gi, in, nin, s->skip_scratch.data(), nout);
         // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
         // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it)
         if (!s->store.dirty.empty()) {
@@ -1017,7 +1111,7 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
         }
         for (uint32_t k = 0; k < nout; k++)
             if (s->skip_scratch[k] != 0xffffffffu) s->store.on_dev[out[k]] = 1;
-        s->queue.push_back(StepRef{(uint32_t)s->open, (uint32_t)g.jobs.size() - 1});
+        s->queue.push_back(StepRef{slot_idx, (uint32_t)g.jobs.size() - 1});
         tr.lap("queued in group");
         return GC_OK;
     }
@@ -1116,18 +1210,20 @@ int gc_stream_garble_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, 
     }
     tr.lap("enqueue pass + serialiser");
     return rc;
-} catch (...) {
-    return gc::on_exception();
 }
+}  // namespace
+
+extern "C" {
 
 int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
     if (!s || !buf || !written || s->queue.empty()) return GC_E_ARG;
     StreamTrace tr;
     const StepRef ref = s->queue.front();
     Slot &g = *s->slots[ref.slot];
-    if (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in the open group: launch it now
-        int rc = close_group(s);
-        if (rc != GC_OK && g.error == GC_OK) g.error = rc;
+    while (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in an open group: launch up to that one
+        int rc = launch_oldest(s);
+        if (rc != GC_OK && g.error == GC_OK && g.launched) g.error = rc;
+        if (s->win.open.empty()) break;
     }
     s->queue.pop_front();
     gc_ctx *ctx = s->ctx;
@@ -1220,8 +1316,7 @@ struct gc_stream_eval {
     uint64_t tick = 0;
     // step groups (see the head of this file): small blocks that share no global wire are evaluated by ONE launch sequence
     std::vector<std::unique_ptr<Slot>> slots;
-    int open = -1;
-    ConflictStamps stamps;
+    GroupWindow win;
     std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
     uint64_t n_groups = 0, n_group_blocks = 0;
     std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
@@ -1250,14 +1345,20 @@ struct gc_stream_eval {
 
 namespace {
 
-int eval_close_group(gc_stream_eval *e) {
-    if (e->open < 0) return GC_OK;
-    Slot &g = *e->slots[(size_t)e->open];
-    e->open = -1;
-    e->stamps.next_group();
+int eval_launch_oldest(gc_stream_eval *e) {
+    if (e->win.open.empty()) return GC_OK;
+    Slot &g = *e->slots[e->win.pop()];
     e->n_groups++;
     e->n_group_blocks += g.jobs.size();
     return launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr);
+}
+int eval_close_group(gc_stream_eval *e) {
+    int rc = GC_OK;
+    while (!e->win.open.empty()) {
+        const int r = eval_launch_oldest(e);
+        if (rc == GC_OK) rc = r;
+    }
+    return rc;
 }
 
 // a slot for a new group of blocks: nothing comes back from an evaluator group, so a launched group's slot is free as
@@ -1697,25 +1798,27 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     gc_ctx *ctx = e->ctx;
     // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence -------
     if (small_block && entry_is_small(ent)) {
-        e->stamps.ensure(e->store.host.size());
+        e->win.ensure(e->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
-        if (e->open >= 0) {
-            Slot &g = *e->slots[(size_t)e->open];
-            if (g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes ||
-                e->stamps.conflicts(e->io_host.data(), nin, wr_ids.data(), nout)) {
-                int rcq = eval_close_group(e);  // stream order carries the dependency to the next group
+        uint32_t gi = e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
+        auto full = [&](const Slot &g) {
+            return g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes;
+        };
+        while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
+        if (gi == e->win.open.size()) {
+            if (e->win.open.size() >= kOpenGroups) {
+                int rcq = eval_launch_oldest(e);
                 if (rcq != GC_OK) return rcq;
+                gi--;
             }
-        }
-        if (e->open < 0) {
             uint32_t idx = 0;
             Slot *ng = eval_slot(e, &idx);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            e->open = (int)idx;
+            e->win.open.push_back(idx);
         }
-        Slot &g = *e->slots[(size_t)e->open];
+        Slot &g = *e->slots[e->win.open[gi]];
         const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = up16(nrows * sizeof(gc_label));
         hipError_t er = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes + row_bytes + 16);
         if (er != hipSuccess) {
@@ -1737,7 +1840,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
         g.jobs.push_back(j);
-        e->stamps.mark(e->io_host.data(), nin, wr_ids.data(), nout);
+        e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout);
         if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned
             std::lock_guard<std::mutex> lk(ctx->mu);
             int rcs = e->store.flush(ctx);

@@ -89,6 +89,8 @@ def lib():
         "gc_stream_garble_begin": (i32, [vp, vp, u32, u32, vp, u32, vp, u32]),
         "gc_stream_garble_finish": (i32, [vp, vp, sz, C.POINTER(C.c_size_t)]),
         "gc_stream_garble_flush": (i32, [vp]),
+        "gc_stream_intern": (i32, [vp, vp, u32, u32, u32, u32, C.POINTER(C.c_uint32)]),
+        "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
@@ -645,6 +647,23 @@ class Stream:
         _check(lib().gc_stream_garble(self.h, _p(g), len(g), nwires, _p(i), len(i), _p(o), len(o), _p(buf), len(buf),
                                       C.byref(n)), "gc_stream_garble")
         return buf[: n.value].tobytes()
+
+    def intern(self, gates, nwires, nin, nout):
+        """gc_stream_intern: handle of a circuit (looked up by content once)"""
+        g = np.ascontiguousarray(gates, dtype=GATE)
+        h = C.c_uint32(0)
+        _check(lib().gc_stream_intern(self.h, _p(g), len(g), nwires, nin, nout, C.byref(h)), "gc_stream_intern")
+        need = len(g) * 61 + 16  # the buffer garble_finish fills must hold the largest circuit in flight
+        buf = getattr(self, "_buf", None)
+        if buf is None or len(buf) < need:
+            self._buf = np.empty(need + need // 2, np.uint8)
+        return h.value
+
+    def garble_begin_h(self, handle, in_, out_):
+        """gc_stream_garble_begin_h: queue an interned circuit"""
+        i = np.ascontiguousarray(in_, dtype=np.uint32)
+        o = np.ascontiguousarray(out_, dtype=np.uint32)
+        _check(lib().gc_stream_garble_begin_h(self.h, handle, _p(i), _p(o)), "gc_stream_garble_begin_h")
 
     def flush(self):
         """gc_stream_garble_flush: launch the queued group without waiting"""

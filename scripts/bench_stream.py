@@ -147,11 +147,20 @@ class _Args:
             g, pg = circs[id(c)]
             i = np.asarray(in_, np.uint32)
             o = np.asarray(out_, np.uint32)
-            self.keep.append((g, i, o))
+            self.keep.append((g, i, o, c))
             self.begin.append((pg, len(g), c.NumWires, i.ctypes.data_as(C.c_void_p), len(i), o.ctypes.data_as(C.c_void_p), len(o)))
 
+    def interned(self, stream):
+        """the same steps as (handle, in, out) for gc_stream_garble_begin_h: what a Go host with a map[*Circuit]handle passes"""
+        handles, out = {}, []
+        for (g, i, o, c), b in zip(self.keep, self.begin):
+            if id(c) not in handles:
+                handles[id(c)] = stream.intern(g, c.NumWires, len(i), len(o))
+            out.append((handles[id(c)], b[3], b[5]))
+        return out
 
-def garble_program(ctx, key, steps, prim, rnd, window=64):
+
+def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True):
     """returns (stream bytes as one array, per-step byte counts, seconds, stats, the Stream — still open); g.inputs0 =
     the zero labels of the primary inputs as they were BEFORE the program ran (a program may overwrite its inputs)"""
     L = engine.lib()
@@ -166,13 +175,16 @@ def garble_program(ctx, key, steps, prim, rnd, window=64):
     nb = C.c_size_t(0)
     pnb = C.byref(nb)
     begin, finish, h = L.gc_stream_garble_begin, L.gc_stream_garble_finish, g.h
+    bargs = a.begin
+    if intern:  # circuits named by handle (gc_stream_intern, once per circuit): no per-step content hash
+        begin, bargs = L.gc_stream_garble_begin_h, a.interned(g)
     off = 0
     issued = 0
     t0 = time.perf_counter()
     for k in range(n):
         lim = min(n, k + window)
         while issued < lim:
-            rc = begin(h, *a.begin[issued])
+            rc = begin(h, *bargs[issued])
             if rc:
                 raise engine.EngineError(rc, "gc_stream_garble_begin(step %d)" % issued)
             issued += 1
@@ -225,7 +237,7 @@ def golden_sha(name, key):
         return None
 
 
-def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, repeats=2):
+def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, repeats=2, intern=True):
     steps, prim = PROGRAMS[name]()
     rnd = stream_rnd(name, len(prim))
     own = ctx is None
@@ -235,9 +247,9 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
     ands = sum(c.stats()["AND"] for c, _, _ in steps)
     best = None
     for rep in range(repeats):  # the first pass builds and caches the plans: report the second as the steady state
-        stream, sizes, dt, stats, g = garble_program(ctx, key, steps, prim, rnd, window)
+        stream, sizes, dt, stats, g = garble_program(ctx, key, steps, prim, rnd, window, intern)
         sha = hashlib.sha256(stream.tobytes() if len(stream) < (1 << 30) else memoryview(stream)).hexdigest()
-        res = {"program": name, "steps": len(steps), "gates": gates, "and": ands, "window": window,
+        res = {"program": name, "steps": len(steps), "gates": gates, "and": ands, "window": window, "interned": intern,
                "garble_s": dt, "garble_gates_per_s": gates / dt, "garble_us_per_step": dt / len(steps) * 1e6,
                "stream_bytes": int(len(stream)), "launch_groups": stats[0], "grouped_steps": stats[1], "big_steps": stats[2],
                "sha256": sha}
@@ -291,9 +303,9 @@ def run(total_gates=10_000_000, key=bytes(range(32)), ctx=None, evaluate=True):
 
 if __name__ == "__main__":
     names = sys.argv[1:] or ["big", "uniform512", "uniform4096", "mixed"]
-    for nm in names:
-        win = 64
-        if ":" in nm:
-            nm, w = nm.split(":")
-            win = int(w)
-        print(json.dumps(run_program(nm, window=2 if nm.startswith("big") and win == 64 else win)), flush=True)
+    for nm in names:  # name[:window[:noh]]   noh: per-step content look-up (gc_stream_garble_begin) instead of handles
+        parts = nm.split(":")
+        nm = parts[0]
+        win = int(parts[1]) if len(parts) > 1 else 64
+        print(json.dumps(run_program(nm, window=2 if nm.startswith("big") and win == 64 else win,
+                                     intern=not (len(parts) > 2 and parts[2] == "noh"))), flush=True)
