@@ -119,12 +119,15 @@ func (stream *StreamEval) evalBlock(conn *p2p.Conn, numGates, numTmpWires, numWi
 			return err
 		}
 	}
-	if numGates == 0 {
-		return nil
-	}
+	// also for a block without gates: the call is InitCircuit(numWires, numTmpWires) (stream_evaluator.go:269) — it sizes
+	// the wire store, so that a later Get of a wire this block announced does not go out of range
 	var consumed C.size_t
+	var blkPtr *C.uint8_t
+	if len(stream.blk) > 0 {
+		blkPtr = (*C.uint8_t)(unsafe.Pointer(&stream.blk[0]))
+	}
 	st := C.gc_stream_eval_circuit(stream.h, C.uint32_t(numGates), C.uint32_t(numTmpWires), C.uint32_t(numWires),
-		(*C.uint8_t)(unsafe.Pointer(&stream.blk[0])), C.size_t(len(stream.blk)), &consumed)
+		blkPtr, C.size_t(len(stream.blk)), &consumed)
 	if st != C.GC_OK {
 		return statusError(st)
 	}

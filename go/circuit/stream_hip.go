@@ -26,10 +26,12 @@ import (
 
 // Streaming is a streaming garbled circuit garbler (device twin of stream_garble.go:27-38).
 type Streaming struct {
-	conn *p2p.Conn
-	ctx  *C.gc_ctx
-	h    *C.gc_stream
-	buf  []byte // serialised gates of one Garble call
+	conn    *p2p.Conn
+	ctx     *C.gc_ctx
+	h       *C.gc_stream
+	buf     []byte              // serialised gates of one circuit
+	handles map[*Circuit]uint32 // gc_stream_intern: a compiled circuit is recognised by content once, not per call
+	pending []int               // gate counts of the circuits queued by Begin and not yet written out by Finish
 }
 
 // NewStreaming creates a new streaming garbled circuit garbler (stream_garble.go:41-75).  The random stream is
@@ -85,15 +87,49 @@ func (stream *Streaming) GetInputs(offset, count int) []ot.Wire {
 // Garble garbles the circuit and streams the garbled tables into the stream (stream_garble.go:161-192): the
 // gates' bytes — op|flags, 16/32-bit wire ids, table rows, exactly as garbleGate writes them (:391-446) — come
 // back from the device in one piece and go through conn.WriteBuf / NeedSpace like the per-gate loop's output.
+// Same contract as the reference: when it returns, the circuit's bytes are in the connection's buffer and its output
+// wires are set.  It is Begin followed by Finish; everything queued before is written out first, in order.
 func (stream *Streaming) Garble(c *Circuit, in, out []Wire) (time.Duration, time.Duration, error) {
 	start := time.Now()
-	need := 61*len(c.Gates) + 16 // upper bound: 13 header bytes + 3 rows per gate
-	if len(stream.buf) < need {
-		stream.buf = make([]byte, need+need/2)
+	if err := stream.Begin(c, in, out); err != nil {
+		return 0, 0, err
 	}
 	mid := time.Now()
+	for len(stream.pending) > 0 {
+		if err := stream.Finish(); err != nil {
+			return 0, 0, err
+		}
+	}
+	return mid.Sub(start), time.Since(mid), nil
+}
+
+// Begin QUEUES a circuit (additive; gc_stream_garble_begin_h) and returns without waiting for the GPU.  A driver that
+// keeps a window of instructions queued ahead — compiler/ssa's streamer loop (streamer.go:412-524) calling Begin for
+// instruction k + d before Finish for instruction k — gives the engine step-level parallelism: queued circuits that
+// share no wire through in / out are garbled side by side in one launch (include/gcengine.h).  The bytes leave in
+// program order through Finish, so the peer sees exactly the stream the reference produces.  in / out must stay
+// unchanged until the call returns only (they are copied).
+func (stream *Streaming) Begin(c *Circuit, in, out []Wire) error {
 	if len(c.Gates) == 0 {
-		return mid.Sub(start), time.Since(mid), nil
+		stream.pending = append(stream.pending, 0)
+		return nil
+	}
+	h, ok := stream.handles[c]
+	if !ok {
+		var ch C.uint32_t
+		st := C.gc_stream_intern(stream.h, (*C.gc_gate)(unsafe.Pointer(&c.Gates[0])), C.uint32_t(len(c.Gates)),
+			C.uint32_t(c.NumWires), C.uint32_t(len(in)), C.uint32_t(len(out)), &ch)
+		if st != C.GC_OK {
+			if st == C.GC_E_GATE {
+				return fmt.Errorf("invalid operation") // garbleGate's default case
+			}
+			return statusError(st)
+		}
+		if stream.handles == nil {
+			stream.handles = make(map[*Circuit]uint32)
+		}
+		h = uint32(ch)
+		stream.handles[c] = h
 	}
 	var inPtr, outPtr *C.uint32_t
 	if len(in) > 0 {
@@ -102,26 +138,45 @@ func (stream *Streaming) Garble(c *Circuit, in, out []Wire) (time.Duration, time
 	if len(out) > 0 {
 		outPtr = (*C.uint32_t)(unsafe.Pointer(&out[0]))
 	}
+	if st := C.gc_stream_garble_begin_h(stream.h, C.uint32_t(h), inPtr, outPtr); st != C.GC_OK {
+		return statusError(st)
+	}
+	stream.pending = append(stream.pending, len(c.Gates))
+	return nil
+}
+
+// Pending is the number of circuits queued by Begin whose bytes Finish has not written out yet.
+func (stream *Streaming) Pending() int { return len(stream.pending) }
+
+// Finish writes the bytes of the OLDEST queued circuit into the connection (additive; gc_stream_garble_finish).
+func (stream *Streaming) Finish() error {
+	if len(stream.pending) == 0 {
+		return fmt.Errorf("Streaming.Finish: nothing queued")
+	}
+	ngates := stream.pending[0]
+	stream.pending = stream.pending[1:]
+	if ngates == 0 {
+		return nil
+	}
+	need := 61*ngates + 16 // upper bound: 13 header bytes + 3 rows per gate
+	if len(stream.buf) < need {
+		stream.buf = make([]byte, need+need/2)
+	}
 	var written C.size_t
-	st := C.gc_stream_garble(stream.h, (*C.gc_gate)(unsafe.Pointer(&c.Gates[0])), C.uint32_t(len(c.Gates)),
-		C.uint32_t(c.NumWires), inPtr, C.uint32_t(len(in)), outPtr, C.uint32_t(len(out)),
-		(*C.uint8_t)(unsafe.Pointer(&stream.buf[0])), C.size_t(len(stream.buf)), &written)
+	st := C.gc_stream_garble_finish(stream.h, (*C.uint8_t)(unsafe.Pointer(&stream.buf[0])), C.size_t(len(stream.buf)), &written)
 	if st != C.GC_OK {
-		if st == C.GC_E_GATE {
-			return 0, 0, fmt.Errorf("invalid operation") // garbleGate's default case
-		}
-		return 0, 0, statusError(st)
+		return statusError(st)
 	}
 	data := stream.buf[:int(written)]
 	for len(data) > 0 { // conn.NeedSpace(512) + direct writes into conn.WriteBuf in the reference (:177-185)
 		if err := stream.conn.NeedSpace(512); err != nil {
-			return 0, 0, err
+			return err
 		}
 		k := copy(stream.conn.WriteBuf[stream.conn.WritePos:], data)
 		stream.conn.WritePos += k
 		data = data[k:]
 	}
-	return mid.Sub(start), time.Since(mid), nil
+	return nil
 }
 
 // Close releases the device state (additive: the reference's Streaming is garbage collected).

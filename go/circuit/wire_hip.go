@@ -82,15 +82,54 @@ func (c *Circuit) evalFromConn(conn *p2p.Conn, key []byte, wires []ot.Label) err
 	n := int(C.gc_tables_wire_bytes(h.circ))
 	stride := (n + 3) &^ 3
 	wire := make([]byte, stride)
-	for ofs := 0; ofs < n; { // conn.Fill / ReadBuf are the connection's own read path (p2p/protocol.go:150)
-		if conn.ReadStart == conn.ReadEnd {
-			if err := conn.Fill(1); err != nil {
-				return err
+	ofs := 0
+	fill := func(upto int) error { // conn.Fill / ReadBuf are the connection's own read path (p2p/protocol.go:150)
+		for ofs < upto {
+			if conn.ReadStart == conn.ReadEnd {
+				if err := conn.Fill(1); err != nil {
+					return err
+				}
 			}
+			k := copy(wire[ofs:upto], conn.ReadBuf[conn.ReadStart:conn.ReadEnd])
+			conn.ReadStart += k
+			ofs += k
 		}
-		k := copy(wire[ofs:n], conn.ReadBuf[conn.ReadStart:conn.ReadEnd])
-		conn.ReadStart += k
-		ofs += k
+		return nil
+	}
+	be32 := func(p int) int {
+		return int(uint32(wire[p])<<24 | uint32(wire[p+1])<<16 | uint32(wire[p+2])<<8 | uint32(wire[p+3]))
+	}
+	// The peer's headers are checked as they arrive, like the reference does (evaluator.go:44-47 right after the 4-byte
+	// gate count; eval.go:54-56,86-89 for the row counts): a peer that announces another circuit gets the reference's
+	// error at once instead of the evaluator blocking on bytes that will never come.
+	if err := fill(4); err != nil {
+		return err
+	}
+	if got := be32(0); got != c.NumGates {
+		return fmt.Errorf("wrong number of gates: got %d, expected %d", got, c.NumGates)
+	}
+	for i := range c.Gates {
+		if err := fill(ofs + 4); err != nil {
+			return err
+		}
+		want := 0
+		switch c.Gates[i].Op {
+		case AND:
+			want = 2
+		case OR:
+			want = 3
+		case INV:
+			want = 1
+		}
+		if got := be32(ofs - 4); got != want {
+			if c.Gates[i].Op == AND {
+				return fmt.Errorf("corrupted ciruit: AND row length: %d", got) // eval.go:54-56
+			}
+			return fmt.Errorf("corrupted circuit: gate %d: %d rows, expected %d", i, got, want) // eval.go:86-89,101-104
+		}
+		if err := fill(ofs + 16*want); err != nil {
+			return err
+		}
 	}
 	nin, nout := c.Inputs.Size(), c.Outputs.Size()
 	var bad C.uint32_t

@@ -483,6 +483,17 @@ int gc_cot_receive_unpad_dev(gc_ctx *, const gc_label *seed, const void *d_flags
 int gc_cot_receive_unpad(gc_ctx *, const gc_label *seed, const uint8_t *flags, const gc_label *sent,
                          gc_label *result, size_t n);
 
+/* ROT (ot/rot.go:132-202).  Replaces the pad loop of ROT.Send (rot.go:156-172): data = the sender's IKNP
+ * labels (IKNPSender.Send), wires_out[j] = {H_j(data_j), H_j(data_j ^ delta)} — the sender's wire labels are OVERWRITTEN
+ * with the two hashed pads (rot.go:168-171), nothing but the seed travels — and the loop of ROT.Receive (rot.go:194-199):
+ * result[j] = H_j(result[j]) in place (result in = IKNPReceiver.Receive's labels).  H_j(x) = x ^ AES_{key_j}(x), key_j =
+ * BE(Label{D0: j, D1: 0} ^ seed), a fresh MITCCRH per call (rot.go:143,191).  The receiver's result[j] equals
+ * wires_out[j].L{flag_j} of the sender.  _dev: device pointers, asynchronous on the ctx stream. */
+int gc_rot_send(gc_ctx *, const gc_label *seed, const gc_label *delta, const gc_label *data, size_t n, gc_wire *wires_out);
+int gc_rot_receive(gc_ctx *, const gc_label *seed, gc_label *result, size_t n);
+int gc_rot_send_dev(gc_ctx *, const gc_label *seed, const gc_label *delta, const void *d_data, size_t n, void *d_wires_out);
+int gc_rot_receive_dev(gc_ctx *, const gc_label *seed, void *d_result, size_t n);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU (BASELINE config 4: 65 536 instances, 8 192 per GPU): instances are independent
  * (fresh R and labels per Garble call, circuit/garble.go:253-278), so each device garbles / evaluates a contiguous

@@ -560,4 +560,51 @@ int gc_cot_receive_unpad_dev(gc_ctx *ctx, const gc_label *seed, const void *d_fl
     return GC_OK;
 }
 
+// ---- ROT (ot/rot.go:132-202): the pad loops of ROT.Send / ROT.Receive --------------------------------------------
+// Sender: wires[j] = {H_j(data_j), H_j(data_j ^ Delta)} with H_j(x) = x ^ AES_{key_j}(x), key_j = BE(Label{j, 0} ^ seed)
+// (mitccrh.go:70-89, a fresh MITCCRH per Send: rot.go:143).  Receiver: result[j] = H_j(result[j]).  The same kernels as
+// the COT pads (k_cot_dual: one lane = one OT, the per-OT key schedule running one round ahead of the state).
+int gc_rot_send_dev(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, const void *d_data, size_t n,
+                    void *d_wires_out) {
+    if (!ctx || !seed || !delta || (n && (!d_data || !d_wires_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_cot_send(to_u4(*seed), to_u4(*delta), (const uint4 *)d_data, nullptr, n, (uint4 *)d_wires_out, ctx->d_te0,
+                    ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_rot_receive_dev(gc_ctx *ctx, const gc_label *seed, void *d_result, size_t n) {
+    if (!ctx || !seed || (n && !d_result)) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    GC_HIP(hipSetDevice(ctx->device));
+    launch_mitccrh(to_u4(*seed), 0, (uint4 *)d_result, n, 1, ctx->d_te0, ctx->stream);
+    GC_HIP(hipGetLastError());
+    return GC_OK;
+}
+
+int gc_rot_send(gc_ctx *ctx, const gc_label *seed, const gc_label *delta, const gc_label *data, size_t n,
+                gc_wire *wires_out) try {
+    if (!ctx || !seed || !delta || (n && (!data || !wires_out))) return GC_E_ARG;
+    if (n == 0) return GC_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    GC_HIP(hipSetDevice(ctx->device));
+    DevBuf d_data, d_out;
+    GC_HIP(d_data.alloc(n * 16));
+    GC_HIP(d_out.alloc(n * 32));
+    GC_HIP(hipMemcpyAsync(d_data.p, data, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    launch_cot_send(to_u4(*seed), to_u4(*delta), (const uint4 *)d_data.p, nullptr, n, (uint4 *)d_out.p, ctx->d_te0, ctx->stream);
+    GC_HIP(hipGetLastError());
+    GC_HIP(hipMemcpyAsync(wires_out, d_out.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    GC_HIP(hipStreamSynchronize(ctx->stream));
+    return GC_OK;
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_rot_receive(gc_ctx *ctx, const gc_label *seed, gc_label *result, size_t n) {
+    return gc_mitccrh_hash(ctx, seed, 0, result, n, 1);
+}
+
 }  // extern "C"

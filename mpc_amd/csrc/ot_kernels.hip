@@ -152,8 +152,9 @@ __global__ __launch_bounds__(256) void k_cot_send(uint4 seed, uint4 delta, const
     mitccrh_key(seed, j, k);
     uint4 x[2] = {data[j], lxor(data[j], delta)};
     mitccrh_hash_n<2>(x, k, te);
-    out[2 * j] = lxor(x[0], wires[2 * j]);
-    out[2 * j + 1] = lxor(x[1], wires[2 * j + 1]);
+    const uint4 z = make_uint4(0, 0, 0, 0);  // wires == nullptr: ROT (rot.go:168-171), the hashed pads themselves
+    out[2 * j] = lxor(x[0], wires ? wires[2 * j] : z);
+    out[2 * j + 1] = lxor(x[1], wires ? wires[2 * j + 1] : z);
 }
 
 void launch_cot_send_classic(uint4 seed, uint4 delta, const uint4 *data, const uint4 *wires, size_t n, uint4 *out,
@@ -264,7 +265,8 @@ __device__ __forceinline__ void aes128_otf_dual(uint32_t (&s)[N][4], uint32_t (&
 }
 
 // MODE 0: blks[j*h + t] ^= AES_key(j)(blks[j*h + t]), h = 1 or 2 (mitccrh.go:107-127)
-// MODE 1: COT.Send pads   (cot.go:160-181): out[2j] = H_j(x_j) ^ L0_j, out[2j+1] = H_j(x_j ^ delta) ^ L1_j
+// MODE 1: COT.Send pads   (cot.go:160-181): out[2j] = H_j(x_j) ^ L0_j, out[2j+1] = H_j(x_j ^ delta) ^ L1_j;
+//         without wires: ROT.Send (rot.go:156-172): out[2j], out[2j+1] = the hashed pads = the sender's wire j
 // MODE 2: COT.Receive     (cot.go:203-232): result[j] = sent[2j + flag_j] ^ H_j(result[j])
 template <int MODE, int NB>
 __global__ __launch_bounds__(kCotThreads) void k_cot_dual(uint4 seed, uint4 delta, uint64_t gid0, const uint4 *__restrict__ data,
@@ -289,9 +291,10 @@ __global__ __launch_bounds__(kCotThreads) void k_cot_dual(uint4 seed, uint4 delt
             x[0] = out[j];
         }
         uint4 pad[NB];
-        if (MODE == 1) {
-            pad[0] = wires[2 * j];
-            if (NB > 1) pad[NB - 1] = wires[2 * j + 1];
+        if (MODE == 1) {  // wires == nullptr: ROT.Send (rot.go:156-172) — the hashed pads ARE the sender's new wire labels
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            pad[0] = wires ? wires[2 * j] : z;
+            if (NB > 1) pad[NB - 1] = wires ? wires[2 * j + 1] : z;
         } else if (MODE == 2) {
             pad[0] = data[2 * j + (flags[j] ? 1 : 0)];  // data = the 2n labels received
         }

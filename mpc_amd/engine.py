@@ -157,6 +157,10 @@ def lib():
         "gc_mitccrh_hash": (i32, [vp, vp, C.c_uint64, vp, sz, u32]),
         "gc_cot_send_pads": (i32, [vp, vp, vp, vp, vp, sz, vp]),
         "gc_cot_receive_unpad": (i32, [vp, vp, vp, vp, vp, sz]),
+        "gc_rot_send": (i32, [vp, vp, vp, vp, sz, vp]),
+        "gc_rot_receive": (i32, [vp, vp, vp, sz]),
+        "gc_rot_send_dev": (i32, [vp, vp, vp, vp, sz, vp]),
+        "gc_rot_receive_dev": (i32, [vp, vp, vp, sz]),
         "gc_garble_wire": (i32, [vp, vp, sz, vp, sz, u32, vp, vp, vp, sz]),
         "gc_eval_wire": (i32, [vp, vp, sz, u32, vp, vp, sz, vp, vp]),
         "gc_dev_alloc": (vp, [vp, sz, ip]),
@@ -933,6 +937,30 @@ def cot_send_pads_dev(ctx, seed, delta, d_data, d_wires, n, d_out):
 def cot_receive_unpad_dev(ctx, seed, d_flags, d_sent, d_result, n):
     _check(lib().gc_cot_receive_unpad_dev(ctx.h, _p(_lab1(seed)), _dp(d_flags), _dp(d_sent),
                                           _dp(d_result), n), "gc_cot_receive_unpad_dev")
+
+
+def rot_send(ctx, seed, delta, data):
+    """gc_rot_send: ROT.Send's pad loop (ot/rot.go:156-172) -> WIRE[n]"""
+    d = np.ascontiguousarray(data, dtype=LABEL)
+    out = np.zeros(max(len(d), 1), WIRE)
+    _check(lib().gc_rot_send(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), _p(d) if len(d) else None, len(d), _p(out)),
+           "gc_rot_send")
+    return out[: len(d)]
+
+
+def rot_receive(ctx, seed, result):
+    """gc_rot_receive: ROT.Receive's pad loop (ot/rot.go:194-199)"""
+    r = np.ascontiguousarray(result, dtype=LABEL).copy()
+    _check(lib().gc_rot_receive(ctx.h, _p(_lab1(seed)), _p(r) if len(r) else None, len(r)), "gc_rot_receive")
+    return r
+
+
+def rot_send_dev(ctx, seed, delta, d_data, n, d_wires_out):
+    _check(lib().gc_rot_send_dev(ctx.h, _p(_lab1(seed)), _p(_lab1(delta)), _dp(d_data), n, _dp(d_wires_out)), "gc_rot_send_dev")
+
+
+def rot_receive_dev(ctx, seed, d_result, n):
+    _check(lib().gc_rot_receive_dev(ctx.h, _p(_lab1(seed)), _dp(d_result), n), "gc_rot_receive_dev")
 
 
 def cot_receive_unpad(ctx, seed, flags, sent, result):

@@ -365,6 +365,22 @@ def cot_send_pads(seed, delta, data, wires):
     return out[: 2 * n]
 
 
+def rot_send(seed, delta, data):
+    """ROT.Send pad loop (ot/rot.go:156-172): WIRE[n] = {H_j(data_j), H_j(data_j ^ delta)}"""
+    d = np.ascontiguousarray(data, dtype=LABEL)
+    n = len(d)
+    out = np.zeros(max(n, 1), WIRE)
+    lib().orc_rot_send(_lab(seed), _lab(delta), _p(d), C.c_size_t(n), _p(out))
+    return out[:n]
+
+
+def rot_receive(seed, result):
+    """ROT.Receive pad loop (ot/rot.go:194-199): the hashed pads of the labels IKNP delivered"""
+    r = np.ascontiguousarray(result, dtype=LABEL).copy()
+    lib().orc_rot_receive(_lab(seed), _p(r), C.c_size_t(len(r)))
+    return r
+
+
 def cot_receive_unpad(seed, flags, sent, result):
     f = np.ascontiguousarray(flags, dtype=np.uint8)
     s = np.ascontiguousarray(sent, dtype=LABEL)

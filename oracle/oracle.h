@@ -157,6 +157,9 @@ void orc_mitccrh_hash(orc_mitccrh *m, orc_label *blks, int k, int h);
 void orc_cot_send_pads(orc_label seed, orc_label delta, const orc_label *data, const orc_wire *wires, size_t n, orc_label *out);
 /* result[n] in: IKNP receive output; out: chosen labels */
 void orc_cot_receive_unpad(orc_label seed, const uint8_t *flags, const orc_label *sent /*2n*/, orc_label *result, size_t n);
+/* ROT pad loops: ot/rot.go:156-172 (sender: wires[j] = the two hashed pads) and :194-199 (receiver: in place) */
+void orc_rot_send(orc_label seed, orc_label delta, const orc_label *data, size_t n, orc_wire *wires);
+void orc_rot_receive(orc_label seed, orc_label *result, size_t n);
 
 /* ---- GF(2^128): ot/mul128_generic.go, ot/gf128.go ---------------------- */
 void orc_mul128(orc_label a, orc_label b, orc_label *lo, orc_label *hi);

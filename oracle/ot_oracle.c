@@ -217,6 +217,48 @@ void orc_cot_send_pads(orc_label seed, orc_label delta, const orc_label *data, c
     }
 }
 
+/* ---- ROT pads: rot.go:132-202 --------------------------------------------- */
+
+/* ROT.Send (rot.go:156-172): the sender OVERWRITES wires[j] with the two hashed pads of OT j:
+ * pad = [data_j, data_j ^ Delta]; mitccrh.Hash(pad, otBatchSize, 2); wires[j] = {pad[0], pad[1]}.  Nothing but the seed
+ * travels (rot.go:145-153). */
+void orc_rot_send(orc_label seed, orc_label delta, const orc_label *data, size_t n, orc_wire *wires) {
+    orc_mitccrh m;
+    orc_mitccrh_init(&m, seed, 8);
+    orc_label pad[16];
+    memset(pad, 0, sizeof pad);
+    for (size_t i = 0; i < n; i += 8) { /* rot.go:157-172 */
+        size_t end = i + 8;
+        if (end > n) end = n;
+        for (size_t j = i; j < end; j++) {
+            pad[2 * (j - i)] = data[j];
+            pad[2 * (j - i) + 1] = data[j];
+            pad[2 * (j - i) + 1].d0 ^= delta.d0;
+            pad[2 * (j - i) + 1].d1 ^= delta.d1;
+        }
+        orc_mitccrh_hash(&m, pad, 8, 2);
+        for (size_t j = i; j < end; j++) {
+            wires[j].l0 = pad[2 * (j - i)];
+            wires[j].l1 = pad[2 * (j - i) + 1];
+        }
+    }
+}
+
+/* ROT.Receive (rot.go:194-199): result[j] = the hashed pad of the label IKNP delivered, in place */
+void orc_rot_receive(orc_label seed, orc_label *result, size_t n) {
+    orc_mitccrh m;
+    orc_mitccrh_init(&m, seed, 8);
+    orc_label pad[8];
+    memset(pad, 0, sizeof pad);
+    for (size_t i = 0; i < n; i += 8) {
+        size_t end = 8;
+        if (end > n - i) end = n - i;
+        for (size_t j = 0; j < end; j++) pad[j] = result[i + j]; /* copy(pad, result[i:]) */
+        orc_mitccrh_hash(&m, pad, 8, 1);
+        for (size_t j = 0; j < end; j++) result[i + j] = pad[j]; /* copy(result[i:], pad) */
+    }
+}
+
 void orc_cot_receive_unpad(orc_label seed, const uint8_t *flags, const orc_label *sent, orc_label *result, size_t n) {
     orc_mitccrh m;
     orc_mitccrh_init(&m, seed, 8);

@@ -198,12 +198,13 @@ def test_go_shim_names_only_declared_entry_points_and_covers_the_table():
         used |= set(re.findall(r"\bC\.(gc_[a-z0-9_]+)\(", text))
     assert used and used <= names, sorted(used - names)
     must = {"gc_ctx_create", "gc_circ_load", "gc_garble", "gc_eval", "gc_garble_wire", "gc_eval_wire", "gc_stream_create",
-            "gc_stream_get_wire", "gc_stream_garble", "gc_stream_eval_create", "gc_stream_eval_set_wire",
+            "gc_stream_get_wire", "gc_stream_intern", "gc_stream_garble_begin_h", "gc_stream_garble_finish",
+            "gc_stream_eval_create", "gc_stream_eval_set_wire",
             "gc_stream_eval_get_wire", "gc_stream_eval_circuit", "gc_iknp_receiver_create", "gc_iknp_sender_create",
             "gc_iknp_receive", "gc_iknp_send", "gc_iknp_receive_bits", "gc_iknp_send_bits", "gc_kos_receiver_tags",
             "gc_kos_sender_check", "gc_mitccrh_hash", "gc_cot_send_pads", "gc_cot_receive_unpad", "gc_host_alloc",
             "gc_comm_init_all", "gc_comm_init_rank", "gc_comm_get_unique_id", "gc_comm_allgather_all",
-            "gc_comm_allgather",
+            "gc_comm_allgather", "gc_rot_send", "gc_rot_receive",
             # the device-resident pipeline must be reachable from Go (go/circuit/batch_hip.go): device memory through
             # the ABI and the batch calls themselves
             "gc_dev_alloc", "gc_dev_free", "gc_dev_upload", "gc_dev_download", "gc_dev_memset", "gc_batch_create",

@@ -279,3 +279,46 @@ def test_cot_tuned_and_classic_kernels_agree(ctx, monkeypatch):
     b = subprocess.run([sys.executable, "-c", code], env=dict(env, GC_COT_CLASSIC="1"), capture_output=True, text=True, timeout=300)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     assert a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1]
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, 4097])
+def test_rot_pads_match_oracle_and_pair_up(ctx, n):
+    """ROT (ot/rot.go:132-202): the sender's wires[j] become the two hashed pads, the receiver's result[j] the hashed pad of
+    the label IKNP delivered; result[j] == wires[j].L{flag_j}; bytes == the oracle's restatement of both loops; the
+    device-resident forms (labels straight from gc_iknp_*_dev) agree"""
+    rng = np.random.default_rng(1000 + n)
+    lab = lambda: (int(rng.integers(0, 1 << 63)), int(rng.integers(0, 1 << 63)))
+    seed, delta = lab(), lab()
+    data = np.zeros(n, LABEL)
+    data["d0"] = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    data["d1"] = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    flags = rng.integers(0, 2, n).astype(bool)
+    # what IKNP hands the receiver: the sender's label, ^ delta where the choice bit is set (iknp_test.go:98-113)
+    recv = data.copy()
+    recv["d0"][flags] ^= np.uint64(delta[0])
+    recv["d1"][flags] ^= np.uint64(delta[1])
+    wires = engine.rot_send(ctx, seed, delta, data)
+    res = engine.rot_receive(ctx, seed, recv)
+    assert wires.tobytes() == oracle.rot_send(seed, delta, data).tobytes()
+    assert res.tobytes() == oracle.rot_receive(seed, recv).tobytes()
+    want = np.where(flags, wires["l1"], wires["l0"]) if n else res
+    assert (res == want).all(), "the receiver's pad is the sender's wires[j].L{flag}"
+    if n:
+        d_data, d_recv = ctx.to_device(data.view(np.uint8)), ctx.to_device(recv.view(np.uint8))
+        d_w = ctx.zeros((n, 32))
+        engine.rot_send_dev(ctx, seed, delta, d_data, n, d_w)
+        engine.rot_receive_dev(ctx, seed, d_recv, n)
+        assert d_w.numpy().tobytes() == wires.tobytes()
+        assert d_recv.numpy().tobytes() == res.tobytes()
+
+
+def test_rot_uses_the_reference_mitccrh_vectors(ctx):
+    """the 8 vectors of ot/mitccrh_test.go:23-30 (seed 0, zero blocks, keys 0..7) through the ROT paths: a sender with zero
+    IKNP labels and Delta = 0 gets them as both pads of wire j, a receiver with zero labels as result[j]"""
+    z = np.zeros(8, LABEL)
+    wires = engine.rot_send(ctx, (0, 0), (0, 0), z)
+    res = engine.rot_receive(ctx, (0, 0), z)
+    for i in range(8):
+        assert oracle.label_to_bytes(wires[i]["l0"]).hex() == MITCCRH_BLOCKS[i]
+        assert oracle.label_to_bytes(wires[i]["l1"]).hex() == MITCCRH_BLOCKS[i]
+        assert oracle.label_to_bytes(res[i]).hex() == MITCCRH_BLOCKS[i]

@@ -119,3 +119,37 @@ def test_bitcot_correlation():
     s = oracle.iknp_send_bits(snd, u, n)
     d0 = np.uint64(0xFFFFFFFFFFFFFFFF) if oracle.label_bit(delta, 0) else np.uint64(0)
     assert ((s ^ r) == (choices & d0)).all()
+
+
+def test_rot_pads_pair_up_and_hit_the_reference_vectors():
+    """oracle restatement of ot/rot.go:156-172,194-199: result[j] == wires[j].L{flag_j}; with zero labels, zero Delta and
+    seed 0 both loops reproduce ot/mitccrh_test.go:23-30"""
+    import numpy as np
+    from tests.test_oracle_kat import MITCCRH_BLOCKS
+    rng = np.random.default_rng(5)
+    for n in (1, 8, 9, 100):
+        seed = (int(rng.integers(0, 1 << 63)), int(rng.integers(0, 1 << 63)))
+        delta = (int(rng.integers(0, 1 << 63)), int(rng.integers(0, 1 << 63)))
+        data = np.zeros(n, oracle.LABEL)
+        data["d0"] = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+        data["d1"] = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+        flags = rng.integers(0, 2, n).astype(bool)
+        recv = data.copy()
+        recv["d0"][flags] ^= np.uint64(delta[0])
+        recv["d1"][flags] ^= np.uint64(delta[1])
+        wires = oracle.rot_send(seed, delta, data)
+        res = oracle.rot_receive(seed, recv)
+        assert (res == np.where(flags, wires["l1"], wires["l0"])).all()
+        # the same through the MITCCRH object directly (mitccrh.go:93-128): OT j under key index j
+        m = oracle.MITCCRH(seed, 8)
+        for i in range(0, n, 8):
+            k = min(8, n - i)
+            pad = np.zeros(8, oracle.LABEL)
+            pad[:k] = recv[i:i + k]
+            m.hash(pad, 8, 1)
+            assert (pad[:k] == res[i:i + k]).all()
+    z = np.zeros(8, oracle.LABEL)
+    w = oracle.rot_send((0, 0), (0, 0), z)
+    r = oracle.rot_receive((0, 0), z)
+    for i in range(8):
+        assert oracle.label_to_bytes(w[i]["l0"]).hex() == MITCCRH_BLOCKS[i] == oracle.label_to_bytes(r[i]).hex()
