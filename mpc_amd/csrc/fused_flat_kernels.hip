@@ -477,6 +477,9 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
     /* only made wave-uniform when it becomes the current one; headers run two units ahead                   */ \
     FUnit un = load_unit(a.units, 1, vz);                                                          \
     if (threadIdx.x < u.n16) stage[threadIdx.x] = a.prog[u.off16 + threadIdx.x];                             \
+    /* unit images run TWO units ahead: the image committed to LDS at the end of unit ui was fetched during unit */ \
+    /* ui - 1 (a whole unit of slack: on narrow circuits a unit is shorter than an HBM round trip)            */ \
+    uint4 pre_cur = a.prog[un.off16 + threadIdx.x];                                                          \
     __syncthreads();                                                                                         \
     const uint32_t lo = te_lane_off();                                                                       \
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);                           \
@@ -580,17 +583,20 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
         // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
         // during the barrier and the XOR part.
         const FUnit unn_v = load_unit(a.units, ui + 2, vz);
-        const uint4 pre = a.prog[un.off16 + threadIdx.x];  // past the image's end: the next image or padding
+        // image of unit ui + 2 (images are contiguous: it starts where unit ui + 1's ends); past the image's end: the next
+        // image or padding
+        const uint4 pre_next = a.prog[un.off16 + un.n16 + threadIdx.x];
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<true>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
         GC_FPROF(4)
-        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre;
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre_cur;
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
         u = uniform_unit(un);
         un = unn_v;
+        pre_cur = pre_next;
     }
     GC_FPROF_EPILOGUE()
     if constexpr (MULTI) {
@@ -604,6 +610,21 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
     }
 }
 
+// this workgroup's job record, word by word through v_readfirstlane: wave-uniform values the compiler keeps in SGPRs
+// (a plain struct copy from global memory lands in VGPRs — the kernel has stores it cannot prove disjoint — and with
+// them the 128-VGPR budget of a 1024-thread workgroup spills)
+__device__ __forceinline__ FlArgs load_job(const FlArgs *jobs) {
+    constexpr int kWords = sizeof(FlArgs) / 4;
+    static_assert(sizeof(FlArgs) % 4 == 0, "FlatJob is a whole number of dwords");
+    const uint32_t *p = (const uint32_t *)(jobs + blockIdx.x);
+    uint32_t w[kWords];
+#pragma unroll
+    for (int i = 0; i < kWords; i++) w[i] = __builtin_amdgcn_readfirstlane(p[i]);
+    FlArgs a;
+    __builtin_memcpy(&a, w, sizeof a);
+    return a;
+}
+
 template <int NR, bool PROF, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     garble_flat_body<NR, PROF, HAS_OR, false>(a);
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
 // step groups of the streaming engine: workgroup j = job j (a whole, independent one-instance circuit)
 template <int NR, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs) {
-    const FlArgs a = jobs[blockIdx.x];
+    const FlArgs a = load_job(jobs);
     garble_flat_body<NR, false, HAS_OR, true>(a);
 }
 
@@ -682,17 +703,20 @@ __device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
         // compiler guards with vmcnt(0)) would otherwise stall on these loads right after they were issued.  They land
         // during the barrier and the XOR part.
         const FUnit unn_v = load_unit(a.units, ui + 2, vz);
-        const uint4 pre = a.prog[un.off16 + threadIdx.x];  // past the image's end: the next image or padding
+        // image of unit ui + 2 (images are contiguous: it starts where unit ui + 1's ends); past the image's end: the next
+        // image or padding
+        const uint4 pre_next = a.prog[un.off16 + un.n16 + threadIdx.x];
         if (nh && u.nout) lds_barrier();
         GC_FPROF(2)
         if (u.nout) xor_part<false>(buf, u, a.ogslot, wl, rl, Wt, ti_log2, tim);
         GC_FPROF(4)
-        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre;
+        if (threadIdx.x < un.n16) stage[((ui + 1) & 1u) * ustride + threadIdx.x] = pre_cur;
         GC_FPROF(3)
         lds_barrier();
         GC_FPROF(5)
         u = uniform_unit(un);
         un = unn_v;
+        pre_cur = pre_next;
     }
     GC_FPROF_EPILOGUE()
     if constexpr (MULTI) {
@@ -712,7 +736,7 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
 }
 template <int NR, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs) {
-    const FlArgs a = jobs[blockIdx.x];
+    const FlArgs a = load_job(jobs);
     eval_flat_body<NR, false, HAS_OR, true>(a);
 }
 
