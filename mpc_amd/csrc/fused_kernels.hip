@@ -107,7 +107,8 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
                                              const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
                                              uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
                                              uint4 *Tt, const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)],
-                                             const uint32_t *te, uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast) {
+                                             const uint32_t *te, uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast,
+                                             const uint32_t lane_limit = kFusedThreads) {
     LanePos lp[G];
     GateDesc d[G];
     uint4 va[G], vb[G];
@@ -117,7 +118,8 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
             lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
             d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
         } else {
-            lp[p] = classify<2, 2, 1>(st, t0 + p * kFusedThreads + threadIdx.x, ti_log2, tim);
+            // lane_limit (level launches of ONE instance): only the first lanes of the workgroup carry work
+            lp[p] = classify<2, 2, 1>(st, threadIdx.x < lane_limit ? t0 + p * kFusedThreads + threadIdx.x : 0xffffffffu, ti_log2, tim);
             d[p] = lp[p].kind ? descs[st.first + lp[p].g] : GateDesc{0, 0, 0, 0};
         }
     }
@@ -213,7 +215,8 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
                                            const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
                                            uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
                                            const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
-                                           uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast) {
+                                           uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast,
+                                           const uint32_t lane_limit = kFusedThreads) {
     LanePos lp[G];
     GateDesc d[G];
     uint4 va[G], vb[G], tab[G];
@@ -223,7 +226,7 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
             lp[p] = LanePos{n_kind, n_g, n_inst, n_q};
             d[p] = GateDesc{n_in0, n_in1, n_tweak, n_row_op};
         } else {
-            lp[p] = classify<1, 0, 0>(st, t0 + p * kFusedThreads + threadIdx.x, ti_log2, tim);
+            lp[p] = classify<1, 0, 0>(st, threadIdx.x < lane_limit ? t0 + p * kFusedThreads + threadIdx.x : 0xffffffffu, ti_log2, tim);
             d[p] = lp[p].kind ? descs[st.first + lp[p].g] : GateDesc{0, 0, 0, 0};
         }
     }
@@ -388,6 +391,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
 }
 
 // ---- ONE instance, one launch per level, lanes along the gates -------------------------------------------------------
+// Lanes of a level per workgroup.  A full workgroup of 1 024 hash lanes is 1 024 AES blocks on ONE CU: 4.4 us at the
+// core's 16-wave rate, while 250 CUs idle (a level of a 131 072-gate step has ~3 600 lanes).  256 lanes per workgroup
+// (4 waves, one per SIMD; the other 12 waves only help to build the table) spread the level over four times as many CUs:
+// the blocks of a workgroup take 2.2 us.
+constexpr uint32_t kLevelLanes = 64;
 // A single instance on the fused kernels is one workgroup on one CU: a streamed SSA-step circuit of 131 072 gates spends
 // 0.78 ms there, AES-bound on that CU.  When a level has several passes of work, the level's lanes are spread over
 // workgroups instead — pass k of the level is workgroup k — and the levels become launches (the kernel boundary is
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_level1(const GateDesc 
                                                                  const uint32_t *__restrict__ g_te0) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     uint32_t rkr[4 * (NR + 1)];
-    if (blockIdx.x * kFusedThreads < ((st.n_and + st.n_or) << 2) + (st.n_inv << 1)) {  // this pass has hash lanes
+    if (blockIdx.x * kLevelLanes < ((st.n_and + st.n_or) << 2) + (st.n_inv << 1)) {  // this pass has hash lanes
         load_te_dual(te, g_te0);
         load_round_keys<NR>(rkr, rk);
         __syncthreads();
@@ -409,8 +417,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_level1(const GateDesc 
         for (int i = 0; i < 4 * (NR + 1); i++) rkr[i] = 0;
     }
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
-    garble_group<NR, false, 1, false>(st, blockIdx.x * kFusedThreads, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W,
-                                      T, Rv, rkr, te, te_lane_off(), pacc, plast);
+    garble_group<NR, false, 1, false>(st, blockIdx.x * kLevelLanes, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W,
+                                      T, Rv, rkr, te, te_lane_off(), pacc, plast, kLevelLanes);
 }
 
 template <int NR>
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_level1(const GateDesc *_
                                                                const uint32_t *__restrict__ g_te0) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     uint32_t rkr[4 * (NR + 1)];
-    if (blockIdx.x * kFusedThreads < (st.n_and << 1) + st.n_or + st.n_inv) {
+    if (blockIdx.x * kLevelLanes < (st.n_and << 1) + st.n_or + st.n_inv) {
         load_te_dual(te, g_te0);
         load_round_keys<NR>(rkr, rk);
         __syncthreads();
@@ -429,22 +437,28 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_level1(const GateDesc *_
         for (int i = 0; i < 4 * (NR + 1); i++) rkr[i] = 0;
     }
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
-    eval_group<NR, false, 1, false>(st, blockIdx.x * kFusedThreads, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
-                                    rkr, te, te_lane_off(), pacc, plast);
+    eval_group<NR, false, 1, false>(st, blockIdx.x * kLevelLanes, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
+                                    rkr, te, te_lane_off(), pacc, plast, kLevelLanes);
 }
 
-// passes (1024-lane workgroups) of a level for one instance
+// passes (1024-lane workgroups) of a level for one instance: the measure of "wide" (plan.h: wide_for_one_instance)
 uint32_t level1_passes(const Step &st, bool eval) {
     const uint32_t lanes = eval ? (st.n_and << 1) + st.n_or + st.n_inv + (st.count - st.nonfree)
                                 : ((st.n_and + st.n_or) << 2) + (st.n_inv << 1) + (st.count - st.nonfree);
     return (lanes + kFusedThreads - 1) / kFusedThreads;
+}
+// workgroups of a level launch (kLevelLanes lanes each)
+static uint32_t level1_groups(const Step &st, bool eval) {
+    const uint32_t lanes = eval ? (st.n_and << 1) + st.n_or + st.n_inv + (st.count - st.nonfree)
+                                : ((st.n_and + st.n_or) << 2) + (st.n_inv << 1) + (st.count - st.nonfree);
+    return (lanes + kLevelLanes - 1) / kLevelLanes;
 }
 
 // one launch per level of `levels` (host copy of the device step array a.steps)
 void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream_t s) {
     for (uint32_t lv = 0; lv < a.nsteps; lv++) {
         const Step &st = levels[lv];
-        const uint32_t grid = level1_passes(st, eval);
+        const uint32_t grid = level1_groups(st, eval);
         if (grid == 0) continue;
 #define GC_L1(NR)                                                                                                      \
     if (eval)                                                                                                          \

@@ -100,6 +100,10 @@ def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4
     return rows
 
 
-if __name__ == "__main__":
-    for r in run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 131072):
+if __name__ == "__main__":  # [batch [gates [W:f,W:f,...]]]   e.g.  1024 131072 1024:0,1024:0.17
+    cases = None
+    if len(sys.argv) > 3:
+        cases = [(int(c.split(":")[0]), float(c.split(":")[1])) for c in sys.argv[3].split(",")]
+    for r in run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 131072,
+                 cases=cases, chain=0 if cases else 4096):
         print(json.dumps(r), flush=True)
