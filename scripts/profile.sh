@@ -9,12 +9,12 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-iknp $*"
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/bench_kt.log 2>&1
+ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-iknp --no-stream --no-config3 --no-host-api --no-synthetic $*"
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/bench_kt.log 2>&1
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/kt -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > '$OUT'/kernel_trace_head.csv' _ {} \;
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_r -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_r.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_w -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_w.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $OUT/pmc_r -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_r.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d $OUT/pmc_w -o pmc -- python $REPO/bench.py $ARGS > $OUT/bench_pmc_w.log 2>&1
 # batch / schedule / key bytes of this run (defaults of bench.py unless overridden in the arguments)
 B=1024; S=1; K=32
 set -- $ARGS
