@@ -42,7 +42,7 @@ if len(sys.argv) > 5:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_build_hash  # the counters describe THIS build of the kernels: bench.py drops them otherwise
     j = {"batch": batch, "schedule": schedule, "key_bytes": key_bytes, "kernel_build_hash": kernel_build_hash(),
-         "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+         "source": "profiles/%s_flat_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                    "FETCH_SIZE x2 per MI355X_MICROARCH.md)" % tag_name}
     for nm in ("garble", "eval"):
         r, w = pick("pmc_r", "k_%s_" % nm), pick("pmc_w", "k_%s_" % nm)
