@@ -18,24 +18,8 @@
 // All hash lanes of all gate types share one AES code path, so mixed waves never run it twice.
 #include "aes_device.h"
 #include "kernels.h"
-#include <cstdlib>
 
 namespace gc {
-
-// timing experiments only (-DGC_EXP=n builds a library with WRONG results): 1 = no AES, 2 = no operand / row loads,
-// 3 = no stores
-#ifndef GC_EXP
-#define GC_EXP 0
-#endif
-template <int NR>
-__device__ __forceinline__ uint4 exp_hash(const uint32_t (&k)[4], const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
-                                          uint32_t lo) {
-#if GC_EXP == 1
-    return make_uint4(k[0], k[1], k[2], k[3]);
-#else
-    return hash_dual<NR>(k, rkr, te, lo);
-#endif
-}
 
 constexpr int kFusedThreads = 1024;
 constexpr int kGroup = 4;  // passes of a level whose loads are issued together (see k_garble_fused)
@@ -117,14 +101,6 @@ enum LaneKind { K_NONE = 0, K_AND = 1, K_OR = 2, K_INV = 3, K_FREE = 4 };
         plast = now__;                                                 \
     }
 
-// the same without the drain: where a wave IS at this point of the pipelined level loop
-#define GC_PROF_LITE(slot)                                             \
-    if constexpr (PROF) {                                              \
-        const uint64_t now__ = __builtin_amdgcn_s_memtime();           \
-        pacc[slot] += now__ - plast;                                   \
-        plast = now__;                                                 \
-    }
-
 template <int NR, bool PROF, int G, bool PRE = true>
 __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                              const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
@@ -132,8 +108,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
                                              uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
                                              uint4 *Tt, const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)],
                                              const uint32_t *te, uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast,
-                                             const uint32_t lane_limit = kFusedThreads, const uint32_t wl2_ = 0xffffffffu) {
-    const uint32_t wl2 = wl2_ == 0xffffffffu ? ti_log2 : wl2_;  // log2 of a wire row (paired tiles: 2 * TI labels)
+                                             const uint32_t lane_limit = kFusedThreads) {
     LanePos lp[G];
     GateDesc d[G];
     uint4 va[G], vb[G];
@@ -155,8 +130,8 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
         if (lp[p].kind == K_NONE) continue;
         // AND lanes 2,3 hash operand b; OR and XOR lanes need both operands
         const bool second = lp[p].kind == K_AND && (lp[p].q & 2);
-        va[p] = Wt[((size_t)(second ? d[p].in1 : d[p].in0) << wl2) + lp[p].inst];
-        if (lp[p].kind == K_FREE || lp[p].kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << wl2) + lp[p].inst];
+        va[p] = Wt[((size_t)(second ? d[p].in1 : d[p].in0) << ti_log2) + lp[p].inst];
+        if (lp[p].kind == K_FREE || lp[p].kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + lp[p].inst];
     }
     GC_PROF_MARK(1)
 #pragma unroll
@@ -164,7 +139,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
         const int kind = lp[p].kind;
         const uint32_t g = lp[p].g, inst = lp[p].inst, q = lp[p].q;
         if (kind == K_NONE) continue;
-        const size_t o_out = ((size_t)(ninputs + st.first + g) << wl2) + inst;
+        const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
         if (kind == K_FREE) {
             uint4 v = lxor(va[p], vb[p]);
             if ((d[p].row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
@@ -186,7 +161,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
             const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
             make_k_half(x, d[p].tweak + (second ? 1u : 0u), k);
         }
-        const uint4 h = exp_hash<NR>(k, rkr, te, lo);
+        const uint4 h = hash_dual<NR>(k, rkr, te, lo);
         uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
 
         if (kind == K_AND) {  // garble.go:353-395
@@ -241,8 +216,7 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
                                            uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
                                            const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
                                            uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast,
-                                           const uint32_t lane_limit = kFusedThreads, const uint32_t wl2_ = 0xffffffffu) {
-    const uint32_t wl2 = wl2_ == 0xffffffffu ? ti_log2 : wl2_;
+                                           const uint32_t lane_limit = kFusedThreads) {
     LanePos lp[G];
     GateDesc d[G];
     uint4 va[G], vb[G], tab[G];
@@ -264,8 +238,8 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
         if (kind == K_NONE) continue;
         const uint32_t inst = lp[p].inst, q = lp[p].q;
         // AND lane 1 hashes operand b; OR and XOR lanes need both operands
-        va[p] = Wt[((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << wl2) + inst];
-        if (kind == K_FREE || kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << wl2) + inst];
+        va[p] = Wt[((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << ti_log2) + inst];
+        if (kind == K_FREE || kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + inst];
         const uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
         if (kind == K_AND) tab[p] = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
         else if (kind == K_INV) tab[p] = row[0];
@@ -276,7 +250,7 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
         const int kind = lp[p].kind;
         const uint32_t g = lp[p].g, inst = lp[p].inst, q = lp[p].q;
         if (kind == K_NONE) continue;
-        const size_t o_out = ((size_t)(ninputs + st.first + g) << wl2) + inst;
+        const size_t o_out = ((size_t)(ninputs + st.first + g) << ti_log2) + inst;
         if (kind == K_FREE) {  // eval.go:49-51
             Wt[o_out] = lxor(va[p], vb[p]);
             continue;
@@ -286,7 +260,7 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
         if (kind == K_AND) make_k_half(x, d[p].tweak + q, k);
         else if (kind == K_INV) make_k_half(x, d[p].tweak, k);
         else make_k(va[p], vb[p], d[p].tweak, k);
-        const uint4 h = exp_hash<NR>(k, rkr, te, lo);
+        const uint4 h = hash_dual<NR>(k, rkr, te, lo);
         if (kind == K_AND) {  // eval.go:53-78
             const uint4 a = dpp128<DPP_PAIR0>(x);
             uint4 v;
@@ -306,373 +280,25 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
     GC_PROF_MARK(2)
 }
 
-// ---- wide levels: passes of a level as a software pipeline ------------------------------------------------------------
-// A level of several passes (1024 lanes each) used to run as load -> wait -> hash -> store per group of four passes, all
-// sixteen waves in step: the label traffic of a group (descriptor round trip, operand round trip, store drain) and its AES
-// time added up (synthetic W = 1 024, f = 0.17: 11 us + 12 us per level and tile).  Here a level is a pipeline over GROUPS
-// of kPipe passes:
-//     iteration g:  issue operand loads of group g+1 | issue descriptor loads of group g+2 | hash group g (results stay in
-//                   registers) | s_waitcnt vmcnt(0) | stores of group g
-// so every wait on vector memory sits at the END of a hash part — what it waits for (the loads above and the stores of group
-// g-1) had the whole AES time to complete — and the stores of group g drain under the hashes of group g+1.  (Loads and
-// stores share vmcnt on gfx9, so a wait for a load issued before a store is only cheap when the store count after it is
-// known; with the explicit wait in front of the stores the compiler never has to wait across them.)  The passes are taken in
-// the order first, last, second, last but one, ...: hash lanes fill the first passes of a level and free lanes the last
-// ones, so every group pairs a pass that hashes with one that only moves labels.
-constexpr int kPipe = 2;
-
-// lane position packed into one register (the pipeline keeps five of these alive): kind | q << 3 | inst << 8
-__device__ __forceinline__ uint32_t pos_pack(const LanePos &lp) { return (uint32_t)lp.kind | (lp.q << 3) | (lp.inst << 8); }
-__device__ __forceinline__ int pos_kind(uint32_t pos) { return (int)(pos & 7u); }
-__device__ __forceinline__ uint32_t pos_q(uint32_t pos) { return (pos >> 3) & 3u; }
-__device__ __forceinline__ uint32_t pos_inst(uint32_t pos) { return pos >> 8; }
-
-struct PassDesc {
-    uint32_t pos, g;
-    GateDesc d;
-};
-struct PassIn {
-    uint32_t pos, g, tweak, row_op;
-    uint4 va, vb, tab;  // tab: evaluator only
-};
-struct PassOut {
-    uint4 w, t;
-    uint32_t w_idx, t_idx;  // index into the tile's wire / table array, ~0u: nothing to store
-};
-
-__device__ __forceinline__ uint32_t piped_pass_t0(uint32_t i, uint32_t P, uint32_t mode = 0) {
-    if (i >= P) return 0xffffffffu;
-    if (mode == 2) return (((threadIdx.x >> 8) & 1) ? P - 1 - i : i) * kFusedThreads;  // EXPERIMENT
-    if (mode == 4) return ((i + (threadIdx.x >> 6)) % P) * kFusedThreads;               // EXPERIMENT
-    if (mode == 5) return ((i + (threadIdx.x >> 8)) % P) * kFusedThreads;               // EXPERIMENT
-    return ((i & 1) ? P - 1 - (i >> 1) : (i >> 1)) * kFusedThreads;
-}
-
-template <int LQA, int LQO, int LQI>
-__device__ __forceinline__ void piped_fetch_desc(PassDesc &o, const Step &st, uint32_t t0, const GateDesc *__restrict__ descs,
-                                                 uint32_t ti_log2, uint32_t tim) {
-    const LanePos lp = classify<LQA, LQO, LQI>(st, t0 == 0xffffffffu ? t0 : t0 + threadIdx.x, ti_log2, tim);
-    o.pos = pos_pack(lp);
-    o.g = lp.g;
-    // unconditional (an idle lane re-reads the level's first descriptor): a load under a condition is a load followed by a
-    // register copy at the join, and the copy would wait for it on the spot
-    o.d = descs[st.first + lp.g];
-}
-
-__device__ __forceinline__ void garble_issue_labels(PassIn &o, const PassDesc &pd, uint32_t wl2, const uint4 *Wt) {
-    o.pos = pd.pos;
-    o.g = pd.g;
-    o.tweak = pd.d.tweak;
-    o.row_op = pd.d.row_op;
-    const int kind = pos_kind(pd.pos);
-    // (fields first, selection after: a select between two struct fields becomes a select between two addresses and
-    // sends the whole descriptor set to scratch)
-    const uint32_t in0 = pd.d.in0, in1 = pd.d.in1, inst = pos_inst(pd.pos);
-    const bool second = kind == K_AND && (pos_q(pd.pos) & 2);
-    const uint32_t ia = second ? in1 : in0;
-    // va of every lane (idle lanes: operand 0 of the level's first gate), vb where it is used and left undefined elsewhere —
-    // no zero-fill: a merge of {0, loaded} is again a copy that waits
-#if GC_EXP == 2
-    o.va = o.vb = make_uint4(ia, in1, inst, 7u);
-#else
-    o.va = Wt[((size_t)ia << wl2) + inst];
-    if (kind == K_FREE || kind == K_OR) o.vb = Wt[((size_t)in1 << wl2) + inst];
-#endif
-}
-
-__device__ __forceinline__ void eval_issue_labels(PassIn &o, const PassDesc &pd, uint32_t ti_log2, uint32_t wl2, uint32_t TI, const uint4 *Wt,
-                                                  const uint4 *Tt) {
-    o.pos = pd.pos;
-    o.g = pd.g;
-    o.tweak = pd.d.tweak;
-    o.row_op = pd.d.row_op;
-    const int kind = pos_kind(pd.pos);
-    const uint32_t inst = pos_inst(pd.pos), q = pos_q(pd.pos), in0 = pd.d.in0, in1 = pd.d.in1;
-    const uint32_t ia = (kind == K_AND && q) ? in1 : in0;
-    const uint32_t row = ((pd.d.row_op & kRowMask) << ti_log2) + inst + ((kind == K_AND && q) ? TI : 0u);
-#if GC_EXP == 2
-    o.va = o.vb = o.tab = make_uint4(ia, in1, row, 7u);
-#else
-    o.va = Wt[((size_t)ia << wl2) + inst];
-    if (kind == K_FREE || kind == K_OR) o.vb = Wt[((size_t)in1 << wl2) + inst];
-    if (kind == K_AND || kind == K_INV) o.tab = Tt[row];  // AND lane 0: TG, lane 1: TE
-#endif
-}
-
-// one pass of the garbler: the same algebra as garble_group, results returned instead of stored
-template <int NR>
-__device__ __forceinline__ PassOut garble_pass(const Step &st, const PassIn &in, uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, uint32_t TI,
-                                               const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
-                                               uint32_t lo) {
-    PassOut o;
-    o.w = o.t = make_uint4(0, 0, 0, 0);
-    o.w_idx = o.t_idx = 0xffffffffu;
-    const int kind = pos_kind(in.pos);
-    const uint32_t g = in.g, inst = pos_inst(in.pos), q = pos_q(in.pos);
-    if (kind == K_NONE) return o;
-    const uint32_t o_out = ((ninputs + st.first + g) << wl2) + inst;
-    if (kind == K_FREE) {
-        uint4 v = lxor(in.va, in.vb);
-        if ((in.row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
-        o.w = v;
-        o.w_idx = o_out;
-        return o;
-    }
-    const uint4 R = Rt[inst];
-    uint4 base;
-    uint32_t k[4];
-    if (kind == K_OR) {  // garble.go:74-83
-        const uint4 a = lxor(in.va, land(R, (q & 2) ? ~0u : 0u));
-        const uint4 b = lxor(in.vb, land(R, (q & 1) ? ~0u : 0u));
-        base = make_uint4(a.y, b.y, 0, 0);
-        make_k(a, b, in.tweak, k);
-    } else {
-        const bool second = (kind == K_AND) && (q & 2);
-        base = in.va;
-        const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
-        make_k_half(x, in.tweak + (second ? 1u : 0u), k);
-    }
-    const uint4 h = exp_hash<NR>(k, rkr, te, lo);
-    const uint32_t row = ((in.row_op & kRowMask) << ti_log2) + inst;
-    if (kind == K_AND) {  // garble.go:353-395
-        const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));
-        const uint4 a0 = dpp128<DPP_BC0>(base);
-        const uint32_t pa = smask(a0);
-        const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
-        uint4 v, tab;
-        if (q & 2) {
-            tab = lxor(pp, a0);
-            v = lxor(h, land(lxor(tab, a0), pb));
-        } else {
-            tab = lxor(pp, land(R, pb));
-            v = lxor(h, land(tab, pa));
-        }
-        const uint4 other = dpp128<DPP_XOR2>(v);
-        if (q == 0) {
-            o.w = lxor(v, other);
-            o.w_idx = o_out;
-            o.t = tab;
-            o.t_idx = row;
-        } else if (q == 2) {
-            o.t = tab;
-            o.t_idx = row + TI;
-        }
-    } else if (kind == K_INV) {  // garble.go:446-474
-        const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));
-        if (q == 0) {
-            const bool sbit = lbit_s(base);
-            o.w = sbit ? lxor(pp, h) : lxor(h, R);
-            o.w_idx = o_out;
-            o.t = lxor(pp, R);
-            o.t_idx = row;
-        }
-    } else {  // K_OR: garble.go:412-444
-        const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
-        const uint32_t l0 = 2 * pa + pb;
-        const uint4 x1 = dpp128<DPP_XOR1>(h), x2 = dpp128<DPP_XOR2>(h), x3 = dpp128<DPP_XOR3>(h);
-        const uint4 tk = l0 == 0 ? h : l0 == 1 ? x1 : l0 == 2 ? x2 : x3;
-        const uint4 tz = dpp128<DPP_BC0>(tk);
-        const uint32_t m0 = l0 == 0 ? ~0u : 0u;
-        const uint4 c0 = lxor(tz, land(R, ~m0)), c1 = lxor(tz, land(R, m0));
-        if (q == 0) {
-            o.w = c0;
-            o.w_idx = o_out;
-        } else {
-            o.t = lxor(tk, q == l0 ? c0 : c1);
-            o.t_idx = row + ((q - 1) << ti_log2);
-        }
-    }
-    return o;
-}
-
-// one pass of the evaluator (eval_group's algebra)
-template <int NR>
-__device__ __forceinline__ PassOut eval_pass(const Step &st, const PassIn &in, uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, const uint4 *Tt,
-                                             const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te, uint32_t lo) {
-    PassOut o;
-    o.w = o.t = make_uint4(0, 0, 0, 0);
-    o.w_idx = o.t_idx = 0xffffffffu;
-    const int kind = pos_kind(in.pos);
-    const uint32_t g = in.g, inst = pos_inst(in.pos), q = pos_q(in.pos);
-    if (kind == K_NONE) return o;
-    const uint32_t o_out = ((ninputs + st.first + g) << wl2) + inst;
-    if (kind == K_FREE) {  // eval.go:49-51
-        o.w = lxor(in.va, in.vb);
-        o.w_idx = o_out;
-        return o;
-    }
-    uint32_t k[4];
-    const uint4 x = in.va;
-    if (kind == K_AND) make_k_half(x, in.tweak + q, k);
-    else if (kind == K_INV) make_k_half(x, in.tweak, k);
-    else make_k(in.va, in.vb, in.tweak, k);
-    const uint4 h = exp_hash<NR>(k, rkr, te, lo);
-    if (kind == K_AND) {  // eval.go:53-78
-        const uint4 a = dpp128<DPP_PAIR0>(x);
-        uint4 v;
-        if (q) v = lxor(h, land(lxor(in.tab, a), smask(x)));
-        else v = lxor(h, land(in.tab, smask(x)));
-        const uint4 other = dpp128<DPP_XOR1>(v);
-        if (q == 0) {
-            o.w = lxor(v, other);
-            o.w_idx = o_out;
-        }
-    } else if (kind == K_INV) {  // eval.go:96-109
-        o.w = lxor(h, land(in.tab, smask(x)));
-        o.w_idx = o_out;
-    } else {  // eval.go:80-94
-        const uint32_t index = (lbit_s(in.va) ? 2u : 0u) | (lbit_s(in.vb) ? 1u : 0u);
-        uint4 c = make_uint4(0, 0, 0, 0);
-        if (index > 0) c = (Tt + ((size_t)(in.row_op & kRowMask) << ti_log2) + inst)[(size_t)(index - 1) << ti_log2];
-        o.w = lxor(h, c);
-        o.w_idx = o_out;
-    }
-    return o;
-}
-
-// one group of the pipeline: `cur` holds the operands of group g (loads issued one group earlier), `nxt` receives those of
-// group g+1.  The level loops call this with two operand sets in alternation, so no register is ever copied between them —
-// a copy of a just-loaded register is a use, and a use in front of the hashes is a wait in front of the hashes.
-template <int NR, bool PROF>
-__device__ __forceinline__ void garble_piped_group(const Step &st, uint32_t g, uint32_t NG, uint32_t P, PassDesc (&dn)[kPipe],
-                                                   PassIn (&cur)[kPipe], PassIn (&nxt)[kPipe],
-                                                   const GateDesc *__restrict__ descs, uint32_t ninputs, uint32_t ti_log2, uint32_t wl2,
-                                                   uint32_t tim, uint32_t TI, uint4 *Wt, uint4 *Tt, const uint4 *Rt,
-                                                   const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te, uint32_t lo,
-                                                   uint64_t (&pacc)[4], uint64_t &plast, uint32_t mode = 0) {
-    // past the level's last group these are idle passes (every lane on the first descriptor / its operand 0): issued all the
-    // same, a conditional issue would again merge old and new registers
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) garble_issue_labels(nxt[p], dn[p], wl2, Wt);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<2, 2, 1>(dn[p], st, piped_pass_t0((g + 2) * kPipe + p, P, mode), descs, ti_log2, tim);
-    GC_PROF_LITE(0)
-    PassOut o[kPipe];
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) o[p] = garble_pass<NR>(st, cur[p], ninputs, ti_log2, wl2, TI, Rt, rkr, te, lo);
-    GC_PROF_LITE(1)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): loads of g+1 / g+2 and the stores of g-1, all one hash part old
-    GC_PROF_LITE(2)
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) {
-#if GC_EXP == 3
-        if (o[p].w_idx == 0xfffffffeu) Wt[o[p].w_idx] = lxor(o[p].w, o[p].t);
-#else
-        if (o[p].w_idx != 0xffffffffu) Wt[o[p].w_idx] = o[p].w;
-        if (o[p].t_idx != 0xffffffffu) Tt[o[p].t_idx] = o[p].t;
-#endif
-    }
-}
-
-template <int NR, bool PROF>
-__device__ __forceinline__ void garble_level_piped(const Step &st, uint32_t e_all, const GateDesc *__restrict__ descs,
-                                                   uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, uint32_t tim, uint32_t TI, uint4 *Wt,
-                                                   uint4 *Tt, const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)],
-                                                   const uint32_t *te, uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast, uint32_t mode = 0) {
-    const uint32_t P = (e_all + kFusedThreads - 1) / kFusedThreads, NG = (P + kPipe - 1) / kPipe;
-    PassDesc dn[kPipe];
-    PassIn A[kPipe], B[kPipe];
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<2, 2, 1>(dn[p], st, piped_pass_t0(p, P, mode), descs, ti_log2, tim);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) garble_issue_labels(A[p], dn[p], wl2, Wt);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<2, 2, 1>(dn[p], st, piped_pass_t0(kPipe + p, P, mode), descs, ti_log2, tim);
-    for (uint32_t g = 0; g < NG; g += 2) {
-        garble_piped_group<NR, PROF>(st, g, NG, P, dn, A, B, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast, mode);
-        if (g + 1 < NG) garble_piped_group<NR, PROF>(st, g + 1, NG, P, dn, B, A, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast, mode);
-    }
-}
-
-template <int NR, bool PROF>
-__device__ __forceinline__ void eval_piped_group(const Step &st, uint32_t g, uint32_t NG, uint32_t P, PassDesc (&dn)[kPipe],
-                                                 PassIn (&cur)[kPipe], PassIn (&nxt)[kPipe], const GateDesc *__restrict__ descs,
-                                                 uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, uint32_t tim, uint32_t TI, uint4 *Wt,
-                                                 const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
-                                                 uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast, uint32_t mode = 0) {
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) eval_issue_labels(nxt[p], dn[p], ti_log2, wl2, TI, Wt, Tt);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<1, 0, 0>(dn[p], st, piped_pass_t0((g + 2) * kPipe + p, P, mode), descs, ti_log2, tim);
-    GC_PROF_LITE(0)
-    PassOut o[kPipe];
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) o[p] = eval_pass<NR>(st, cur[p], ninputs, ti_log2, wl2, Tt, rkr, te, lo);
-    GC_PROF_LITE(1)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    GC_PROF_LITE(2)
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) {
-#if GC_EXP == 3
-        if (o[p].w_idx == 0xfffffffeu) Wt[o[p].w_idx] = o[p].w;
-#else
-        if (o[p].w_idx != 0xffffffffu) Wt[o[p].w_idx] = o[p].w;
-#endif
-    }
-}
-
-template <int NR, bool PROF>
-__device__ __forceinline__ void eval_level_piped(const Step &st, uint32_t e_all, const GateDesc *__restrict__ descs,
-                                                 uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, uint32_t tim, uint32_t TI, uint4 *Wt,
-                                                 const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
-                                                 uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast, uint32_t mode = 0) {
-    const uint32_t P = (e_all + kFusedThreads - 1) / kFusedThreads, NG = (P + kPipe - 1) / kPipe;
-    PassDesc dn[kPipe];
-    PassIn A[kPipe], B[kPipe];
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<1, 0, 0>(dn[p], st, piped_pass_t0(p, P, mode), descs, ti_log2, tim);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) eval_issue_labels(A[p], dn[p], ti_log2, wl2, TI, Wt, Tt);
-#pragma unroll
-    for (int p = 0; p < kPipe; p++) piped_fetch_desc<1, 0, 0>(dn[p], st, piped_pass_t0(kPipe + p, P, mode), descs, ti_log2, tim);
-    for (uint32_t g = 0; g < NG; g += 2) {
-        eval_piped_group<NR, PROF>(st, g, NG, P, dn, A, B, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast, mode);
-        if (g + 1 < NG) eval_piped_group<NR, PROF>(st, g + 1, NG, P, dn, B, A, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast, mode);
-    }
-}
-
-// Paired tiles: a wire row holds the labels of TWO tiles (2 * TI * 16 B = one 128-byte line at TI = 4), and the two tiles
-// of a pair run on the same XCD (workgroups go round-robin over the 8 XCDs, so blocks b and b + 8 share an L2): the line
-// one of them misses on is a hit for the other, and the halves they write merge in that L2.
-__device__ __forceinline__ uint32_t tile_of_block(bool paired) {
-    const uint32_t b = blockIdx.x;
-    return paired ? ((((b >> 4) << 3) + (b & 7)) << 1) + ((b >> 3) & 1) : b;
-}
-
-// EXPERIMENT: hold every other octet of workgroups back by `ticks` of s_memtime at the start, so that half of the CUs
-// are in their label-traffic phase while the other half hashes
-__device__ __forceinline__ void stagger_start(uint32_t ticks) {
-    if (ticks && ((blockIdx.x >> 3) & 1)) {
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-    }
-}
-
 template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *__restrict__ descs,
                                                                 const Step *__restrict__ steps, uint32_t nsteps,
-                                                                uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, size_t w_tile,
+                                                                uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
                                                                 size_t t_tile, uint4 *__restrict__ W,
                                                                 const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
                                                                 const uint32_t *__restrict__ rk,
                                                                 const uint32_t *__restrict__ g_te0,
-                                                                uint64_t *__restrict__ prof, uint32_t stagger) {
+                                                                uint64_t *__restrict__ prof) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, rk);
     __syncthreads();
-    const bool piped = stagger != 1 && stagger != 3;
     const uint32_t lo = te_lane_off();
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
-    const uint32_t tile = tile_of_block(wl2 != ti_log2);
-    uint4 *Wt = W + (wl2 != ti_log2 ? (size_t)(tile >> 1) * w_tile + (size_t)(tile & 1) * TI : (size_t)tile * w_tile);
-    uint4 *Tt = T + (size_t)tile * t_tile;
-    // the tile's offsets R live in LDS: a hash lane reads its R on the way into the AES, and a global load there would make
-    // that point wait for every vector load in flight (vmcnt), the prefetched operands of the next passes included
-    __shared__ uint4 Rt[64];
-    if (threadIdx.x < TI) Rt[threadIdx.x] = Rv[(size_t)tile * TI + threadIdx.x];
-    __syncthreads();
+    uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
+    uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
+    const uint4 *Rt = Rv + (size_t)blockIdx.x * TI;
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -695,11 +321,13 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
         const uint32_t e_all = level_lanes<2, 2, 1>(st, ti_log2);
         // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
         // zero-fill of empty passes on its critical path
-        if (e_all <= (uint32_t)kFusedThreads) garble_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast, kFusedThreads, wl2);
-        else if (piped) garble_level_piped<NR, PROF>(st, e_all, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast, stagger);
+        if (e_all <= (uint32_t)kFusedThreads) garble_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
         else
-            for (uint32_t tt = 0, ng_ = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng_; tt++)
-                garble_group<NR, PROF, kGroup, false>(st, ((stagger == 3 && ((threadIdx.x >> 8) & 1)) ? ng_ - 1 - tt : tt) * kGroup * kFusedThreads, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast, kFusedThreads, wl2);
+            // the groups of a level in opposite orders for the two halves of the workgroup's waves (quartets 0, 2 forwards;
+            // 1, 3 backwards): hash lanes fill the first passes of a level and free lanes the last ones, so while one half
+            // hashes the other half moves labels (+4 % on the wide synthetic rows; groups of a level are independent)
+            for (uint32_t tt = 0, ng = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng; tt++)
+                garble_group<NR, PROF, kGroup, false>(st, (((threadIdx.x >> 8) & 1) ? ng - 1 - tt : tt) * (kGroup * kFusedThreads), lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
         if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
@@ -710,30 +338,28 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
     }
     if constexpr (PROF) {
         if (threadIdx.x == 0 || threadIdx.x == kFusedThreads - 64)
-            for (int i = 0; i < 4; i++) prof[(size_t)tile * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
+            for (int i = 0; i < 4; i++) prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
     }
 }
 
 template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__restrict__ descs,
                                                               const Step *__restrict__ steps, uint32_t nsteps,
-                                                              uint32_t ninputs, uint32_t ti_log2, uint32_t wl2, size_t w_tile,
+                                                              uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
                                                               size_t t_tile, uint4 *__restrict__ W,
                                                               const uint4 *__restrict__ T,
                                                               const uint32_t *__restrict__ rk,
                                                               const uint32_t *__restrict__ g_te0,
-                                                              uint64_t *__restrict__ prof, uint32_t stagger) {
+                                                              uint64_t *__restrict__ prof) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, rk);
     __syncthreads();
-    const bool piped = stagger != 1 && stagger != 3;
     const uint32_t lo = te_lane_off();
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
-    const uint32_t tile = tile_of_block(wl2 != ti_log2);
-    uint4 *Wt = W + (wl2 != ti_log2 ? (size_t)(tile >> 1) * w_tile + (size_t)(tile & 1) * TI : (size_t)tile * w_tile);
-    const uint4 *Tt = T + (size_t)tile * t_tile;
+    uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
+    const uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -749,11 +375,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
         const uint32_t e_all = level_lanes<1, 0, 0>(st, ti_log2);
         // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
         // zero-fill of empty passes on its critical path
-        if (e_all <= (uint32_t)kFusedThreads) eval_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast, kFusedThreads, wl2);
-        else if (piped) eval_level_piped<NR, PROF>(st, e_all, descs, ninputs, ti_log2, wl2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast, stagger);
+        if (e_all <= (uint32_t)kFusedThreads) eval_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
         else
-            for (uint32_t tt = 0, ng_ = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng_; tt++)
-                eval_group<NR, PROF, kGroup, false>(st, ((stagger == 3 && ((threadIdx.x >> 8) & 1)) ? ng_ - 1 - tt : tt) * kGroup * kFusedThreads, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast, kFusedThreads, wl2);
+            for (uint32_t tt = 0, ng = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng; tt++)
+                eval_group<NR, PROF, kGroup, false>(st, (((threadIdx.x >> 8) & 1) ? ng - 1 - tt : tt) * (kGroup * kFusedThreads), lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
         if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
@@ -764,7 +389,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
     }
     if constexpr (PROF) {
         if (threadIdx.x == 0 || threadIdx.x == kFusedThreads - 64)
-            for (int i = 0; i < 4; i++) prof[(size_t)tile * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
+            for (int i = 0; i < 4; i++) prof[(size_t)blockIdx.x * 8 + (threadIdx.x ? 4 : 0) + i] = pacc[i];
     }
 }
 
@@ -854,21 +479,16 @@ void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream
     }
 }
 
-static uint32_t stagger_env() {
-    const char *e = getenv("GC_STAGGER");
-    return e ? (uint32_t)atoi(e) : 0u;
-}
-
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
 #define GC_GF(NR)                                                                                               \
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_garble_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,    \
-                           g.ti_log2, g.lw.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof, stagger_env());  \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof);  \
     else                                                                                                        \
         hipLaunchKernelGGL((k_garble_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,   \
-                           g.ti_log2, g.lw.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof, stagger_env())
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof)
     switch (a.rounds) {
     case 10: GC_GF(10); break;
     case 12: GC_GF(12); break;
@@ -883,12 +503,12 @@ void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
 #define GC_EF(NR)                                                                                               \
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_eval_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,      \
-                           g.ti_log2, g.lw.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
-                           a.prof, stagger_env());                                                                             \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
+                           a.prof);                                                                             \
     else                                                                                                        \
         hipLaunchKernelGGL((k_eval_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,     \
-                           g.ti_log2, g.lw.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
-                           a.prof, stagger_env())
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
+                           a.prof)
     switch (a.rounds) {
     case 10: GC_EF(10); break;
     case 12: GC_EF(12); break;

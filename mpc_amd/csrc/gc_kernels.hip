@@ -7,7 +7,6 @@
 // Arithmetic restated from circuit/garble.go:311-482 (garbleInto) and circuit/eval.go:28-112.
 #include "aes_device.h"
 #include "kernels.h"
-#include <cstdlib>
 
 namespace gc {
 
@@ -46,9 +45,6 @@ BatchGeom make_geom(uint32_t batch, int schedule, uint32_t nslots, uint32_t slab
         g.bstride = g.ntiles * ti;
         g.lw = Layout{t, ti - 1, ti, (size_t)nslots * ti};
         g.lt = Layout{t, ti - 1, ti, (size_t)(slab_rows ? slab_rows : 1) * ti};
-        // wires in HBM (fused_kernels.hip): the wire rows of two tiles share a row, so that a row of 2 * TI labels is a
-        // whole 128-byte line at TI = 4 (tile_of_block there)
-        if (!g.lds_wires && g.ntiles % 16 == 0 && !getenv("GC_NO_PAIR")) g.lw = Layout{t + 1, 2 * ti - 1, 2 * ti, (size_t)nslots * 2 * ti};
     }
     return g;
 }
