@@ -18,6 +18,7 @@
 // All hash lanes of all gate types share one AES code path, so mixed waves never run it twice.
 #include "aes_device.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace gc {
 
@@ -280,6 +281,347 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
     GC_PROF_MARK(2)
 }
 
+
+// ---- wide levels: hash waves and free waves ----------------------------------------------------------------------------
+// A level of several passes used to run as load -> wait -> hash -> store per group of four passes with all sixteen waves in
+// step, and the label traffic and the AES time of a level ADDED UP (profiles/r03_exp_hbm_wire_overlap.txt: the cost of the
+// traffic is the time the waves spend issuing it into a memory pipe that takes ~19 GB/s per CU of these 64-byte pieces, and a
+// wave that is stuck on a vector-memory instruction does not hash; pipelining the passes of ALL waves removed every wait for
+// data and not a microsecond).  So the two kinds of work go to different waves of the workgroup:
+//   hash waves (the first H)  walk the level's AND / OR / INV lanes, 64 H per pass, as a software pipeline of depth one —
+//                             operand loads of pass p+1 and the descriptor of p+2 in flight under the AES of pass p, the only
+//                             vmcnt(0) at the END of the hash (what it waits for is one AES old), stores behind it — their
+//                             few vector-memory instructions per pass never stall them for long;
+//   free waves (the other 16 - H) stream the XOR / XNOR lanes in groups of four passes, bound by the memory pipe alone.
+// Both finish at the level's barrier.  The two operand sets of the pipeline alternate (A, B): copying a just-loaded register
+// is a use, and a use in front of the hashes is a wait in front of the hashes; for the same reason every load of the pipeline
+// is unconditional (idle lanes re-read the level's first descriptor and its operand) and nothing is zero-filled.
+// lane position packed into one register (the pipeline keeps five of these alive): kind | q << 3 | inst << 8
+__device__ __forceinline__ uint32_t pos_pack(const LanePos &lp) { return (uint32_t)lp.kind | (lp.q << 3) | (lp.inst << 8); }
+__device__ __forceinline__ int pos_kind(uint32_t pos) { return (int)(pos & 7u); }
+__device__ __forceinline__ uint32_t pos_q(uint32_t pos) { return (pos >> 3) & 3u; }
+__device__ __forceinline__ uint32_t pos_inst(uint32_t pos) { return pos >> 8; }
+
+struct PassDesc {
+    uint32_t pos, g;
+    GateDesc d;
+};
+struct PassIn {
+    uint32_t pos, g, tweak, row_op;
+    uint4 va, vb, tab;  // tab: evaluator only
+};
+struct PassOut {
+    uint4 w, t;
+    uint32_t w_idx, t_idx;  // index into the tile's wire / table array, ~0u: nothing to store
+};
+
+__device__ __forceinline__ void garble_issue_labels(PassIn &o, const PassDesc &pd, uint32_t ti_log2, const uint4 *Wt) {
+    o.pos = pd.pos;
+    o.g = pd.g;
+    o.tweak = pd.d.tweak;
+    o.row_op = pd.d.row_op;
+    const int kind = pos_kind(pd.pos);
+    // (fields first, selection after: a select between two struct fields becomes a select between two addresses and
+    // sends the whole descriptor set to scratch)
+    const uint32_t in0 = pd.d.in0, in1 = pd.d.in1, inst = pos_inst(pd.pos);
+    const bool second = kind == K_AND && (pos_q(pd.pos) & 2);
+    const uint32_t ia = second ? in1 : in0;
+    // va of every lane (idle lanes: operand 0 of the level's first gate), vb where it is used and left undefined elsewhere —
+    // no zero-fill: a merge of {0, loaded} is again a copy that waits
+    o.va = Wt[((size_t)ia << ti_log2) + inst];
+    if (kind == K_FREE || kind == K_OR) o.vb = Wt[((size_t)in1 << ti_log2) + inst];
+}
+
+__device__ __forceinline__ void eval_issue_labels(PassIn &o, const PassDesc &pd, uint32_t ti_log2, uint32_t TI, const uint4 *Wt,
+                                                  const uint4 *Tt) {
+    o.pos = pd.pos;
+    o.g = pd.g;
+    o.tweak = pd.d.tweak;
+    o.row_op = pd.d.row_op;
+    const int kind = pos_kind(pd.pos);
+    const uint32_t inst = pos_inst(pd.pos), q = pos_q(pd.pos), in0 = pd.d.in0, in1 = pd.d.in1;
+    const uint32_t ia = (kind == K_AND && q) ? in1 : in0;
+    const uint32_t row = ((pd.d.row_op & kRowMask) << ti_log2) + inst + ((kind == K_AND && q) ? TI : 0u);
+    o.va = Wt[((size_t)ia << ti_log2) + inst];
+    if (kind == K_FREE || kind == K_OR) o.vb = Wt[((size_t)in1 << ti_log2) + inst];
+    if (kind == K_AND || kind == K_INV) o.tab = Tt[row];  // AND lane 0: TG, lane 1: TE
+}
+
+// one pass of the garbler: the same algebra as garble_group, results returned instead of stored
+template <int NR>
+__device__ __forceinline__ PassOut garble_pass(const Step &st, const PassIn &in, uint32_t ninputs, uint32_t ti_log2, uint32_t TI,
+                                               const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
+                                               uint32_t lo) {
+    PassOut o;
+    o.w = o.t = make_uint4(0, 0, 0, 0);
+    o.w_idx = o.t_idx = 0xffffffffu;
+    const int kind = pos_kind(in.pos);
+    const uint32_t g = in.g, inst = pos_inst(in.pos), q = pos_q(in.pos);
+    if (kind == K_NONE) return o;
+    const uint32_t o_out = ((ninputs + st.first + g) << ti_log2) + inst;
+    if (kind == K_FREE) {
+        uint4 v = lxor(in.va, in.vb);
+        if ((in.row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
+        o.w = v;
+        o.w_idx = o_out;
+        return o;
+    }
+    const uint4 R = Rt[inst];
+    uint4 base;
+    uint32_t k[4];
+    if (kind == K_OR) {  // garble.go:74-83
+        const uint4 a = lxor(in.va, land(R, (q & 2) ? ~0u : 0u));
+        const uint4 b = lxor(in.vb, land(R, (q & 1) ? ~0u : 0u));
+        base = make_uint4(a.y, b.y, 0, 0);
+        make_k(a, b, in.tweak, k);
+    } else {
+        const bool second = (kind == K_AND) && (q & 2);
+        base = in.va;
+        const uint4 x = lxor(base, land(R, (q & 1) ? ~0u : 0u));
+        make_k_half(x, in.tweak + (second ? 1u : 0u), k);
+    }
+    const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+    const uint32_t row = ((in.row_op & kRowMask) << ti_log2) + inst;
+    if (kind == K_AND) {  // garble.go:353-395
+        const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));
+        const uint4 a0 = dpp128<DPP_BC0>(base);
+        const uint32_t pa = smask(a0);
+        const uint32_t pb = (uint32_t)((int32_t)dpp32<DPP_BC2>(base.y) >> 31);
+        uint4 v, tab;
+        if (q & 2) {
+            tab = lxor(pp, a0);
+            v = lxor(h, land(lxor(tab, a0), pb));
+        } else {
+            tab = lxor(pp, land(R, pb));
+            v = lxor(h, land(tab, pa));
+        }
+        const uint4 other = dpp128<DPP_XOR2>(v);
+        if (q == 0) {
+            o.w = lxor(v, other);
+            o.w_idx = o_out;
+            o.t = tab;
+            o.t_idx = row;
+        } else if (q == 2) {
+            o.t = tab;
+            o.t_idx = row + TI;
+        }
+    } else if (kind == K_INV) {  // garble.go:446-474
+        const uint4 pp = lxor(h, dpp128<DPP_XOR1>(h));
+        if (q == 0) {
+            const bool sbit = lbit_s(base);
+            o.w = sbit ? lxor(pp, h) : lxor(h, R);
+            o.w_idx = o_out;
+            o.t = lxor(pp, R);
+            o.t_idx = row;
+        }
+    } else {  // K_OR: garble.go:412-444
+        const uint32_t pa = (base.x >> 31) ^ ((q >> 1) & 1), pb = (base.y >> 31) ^ (q & 1);
+        const uint32_t l0 = 2 * pa + pb;
+        const uint4 x1 = dpp128<DPP_XOR1>(h), x2 = dpp128<DPP_XOR2>(h), x3 = dpp128<DPP_XOR3>(h);
+        const uint4 tk = l0 == 0 ? h : l0 == 1 ? x1 : l0 == 2 ? x2 : x3;
+        const uint4 tz = dpp128<DPP_BC0>(tk);
+        const uint32_t m0 = l0 == 0 ? ~0u : 0u;
+        const uint4 c0 = lxor(tz, land(R, ~m0)), c1 = lxor(tz, land(R, m0));
+        if (q == 0) {
+            o.w = c0;
+            o.w_idx = o_out;
+        } else {
+            o.t = lxor(tk, q == l0 ? c0 : c1);
+            o.t_idx = row + ((q - 1) << ti_log2);
+        }
+    }
+    return o;
+}
+
+// one pass of the evaluator (eval_group's algebra)
+template <int NR>
+__device__ __forceinline__ PassOut eval_pass(const Step &st, const PassIn &in, uint32_t ninputs, uint32_t ti_log2, const uint4 *Tt,
+                                             const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te, uint32_t lo) {
+    PassOut o;
+    o.w = o.t = make_uint4(0, 0, 0, 0);
+    o.w_idx = o.t_idx = 0xffffffffu;
+    const int kind = pos_kind(in.pos);
+    const uint32_t g = in.g, inst = pos_inst(in.pos), q = pos_q(in.pos);
+    if (kind == K_NONE) return o;
+    const uint32_t o_out = ((ninputs + st.first + g) << ti_log2) + inst;
+    if (kind == K_FREE) {  // eval.go:49-51
+        o.w = lxor(in.va, in.vb);
+        o.w_idx = o_out;
+        return o;
+    }
+    uint32_t k[4];
+    const uint4 x = in.va;
+    if (kind == K_AND) make_k_half(x, in.tweak + q, k);
+    else if (kind == K_INV) make_k_half(x, in.tweak, k);
+    else make_k(in.va, in.vb, in.tweak, k);
+    const uint4 h = hash_dual<NR>(k, rkr, te, lo);
+    if (kind == K_AND) {  // eval.go:53-78
+        const uint4 a = dpp128<DPP_PAIR0>(x);
+        uint4 v;
+        if (q) v = lxor(h, land(lxor(in.tab, a), smask(x)));
+        else v = lxor(h, land(in.tab, smask(x)));
+        const uint4 other = dpp128<DPP_XOR1>(v);
+        if (q == 0) {
+            o.w = lxor(v, other);
+            o.w_idx = o_out;
+        }
+    } else if (kind == K_INV) {  // eval.go:96-109
+        o.w = lxor(h, land(in.tab, smask(x)));
+        o.w_idx = o_out;
+    } else {  // eval.go:80-94
+        const uint32_t index = (lbit_s(in.va) ? 2u : 0u) | (lbit_s(in.vb) ? 1u : 0u);
+        uint4 c = make_uint4(0, 0, 0, 0);
+        if (index > 0) c = (Tt + ((size_t)(in.row_op & kRowMask) << ti_log2) + inst)[(size_t)(index - 1) << ti_log2];
+        o.w = lxor(h, c);
+        o.w_idx = o_out;
+    }
+    return o;
+}
+
+// one group of the pipeline: `cur` holds the operands of group g (loads issued one group earlier), `nxt` receives those of
+// group g+1.  The level loops call this with two operand sets in alternation, so no register is ever copied between them —
+// a copy of a just-loaded register is a use, and a use in front of the hashes is a wait in front of the hashes.
+template <int LQA, int LQO, int LQI>
+__device__ __forceinline__ void role_fetch_desc(PassDesc &o, const Step &st, uint32_t t, uint32_t e_hash,
+                                                const GateDesc *__restrict__ descs, uint32_t ti_log2, uint32_t tim) {
+    const LanePos lp = classify<LQA, LQO, LQI>(st, t < e_hash ? t : 0xffffffffu, ti_log2, tim);
+    o.pos = pos_pack(lp);
+    o.g = lp.g;
+    o.d = descs[st.first + lp.g];
+}
+
+// one pass of the hash waves: cur holds the operands of this pass, nxt receives those of the next one
+template <int NR>
+__device__ __forceinline__ void garble_hash_step(const Step &st, uint32_t t_next2, uint32_t e_hash, PassDesc &dn, PassIn &cur,
+                                                 PassIn &nxt, const GateDesc *__restrict__ descs, uint32_t ninputs,
+                                                 uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt, uint4 *Tt,
+                                                 const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
+                                                 uint32_t lo) {
+    garble_issue_labels(nxt, dn, ti_log2, Wt);
+    role_fetch_desc<2, 2, 1>(dn, st, t_next2, e_hash, descs, ti_log2, tim);
+    const PassOut o = garble_pass<NR>(st, cur, ninputs, ti_log2, TI, Rt, rkr, te, lo);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above and the stores of the previous pass, one AES old
+    if (o.w_idx != 0xffffffffu) Wt[o.w_idx] = o.w;
+    if (o.t_idx != 0xffffffffu) Tt[o.t_idx] = o.t;
+}
+
+template <int NR>
+__device__ __forceinline__ void garble_hash_role(const Step &st, uint32_t e_hash, uint32_t H, const LanePos &lp0,
+                                                 const GateDesc &d0, const PassDesc &pre1, const GateDesc *__restrict__ descs,
+                                                 uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
+                                                 uint4 *Tt, const uint4 *Rt, const uint32_t (&rkr)[4 * (NR + 1)],
+                                                 const uint32_t *te, uint32_t lo) {
+    const uint32_t LP = H << 6, NP = (e_hash + LP - 1) / LP;
+    // the descriptors of the first two passes were fetched before the barrier of the previous level (pass 0 of a hash wave
+    // is the lane numbering of a whole-workgroup pass: lp0 / d0 are the kernel's prefetch for single-pass levels)
+    PassDesc dn;
+    PassIn A, B;
+    dn.pos = threadIdx.x < e_hash ? pos_pack(lp0) : 0u;
+    dn.g = threadIdx.x < e_hash ? lp0.g : 0u;
+    dn.d = d0;
+    garble_issue_labels(A, dn, ti_log2, Wt);
+    dn = pre1;
+    for (uint32_t p = 0; p < NP; p += 2) {
+        garble_hash_step<NR>(st, (p + 2) * LP + threadIdx.x, e_hash, dn, A, B, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo);
+        if (p + 1 < NP)
+            garble_hash_step<NR>(st, (p + 3) * LP + threadIdx.x, e_hash, dn, B, A, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo);
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void eval_hash_step(const Step &st, uint32_t t_next2, uint32_t e_hash, PassDesc &dn, PassIn &cur,
+                                               PassIn &nxt, const GateDesc *__restrict__ descs, uint32_t ninputs,
+                                               uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt, const uint4 *Tt,
+                                               const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te, uint32_t lo) {
+    eval_issue_labels(nxt, dn, ti_log2, TI, Wt, Tt);
+    role_fetch_desc<1, 0, 0>(dn, st, t_next2, e_hash, descs, ti_log2, tim);
+    const PassOut o = eval_pass<NR>(st, cur, ninputs, ti_log2, Tt, rkr, te, lo);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (o.w_idx != 0xffffffffu) Wt[o.w_idx] = o.w;
+}
+
+template <int NR>
+__device__ __forceinline__ void eval_hash_role(const Step &st, uint32_t e_hash, uint32_t H, const LanePos &lp0,
+                                               const GateDesc &d0, const PassDesc &pre1, const GateDesc *__restrict__ descs,
+                                               uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
+                                               const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
+                                               uint32_t lo) {
+    const uint32_t LP = H << 6, NP = (e_hash + LP - 1) / LP;
+    PassDesc dn;
+    PassIn A, B;
+    dn.pos = threadIdx.x < e_hash ? pos_pack(lp0) : 0u;
+    dn.g = threadIdx.x < e_hash ? lp0.g : 0u;
+    dn.d = d0;
+    eval_issue_labels(A, dn, ti_log2, TI, Wt, Tt);
+    dn = pre1;
+    for (uint32_t p = 0; p < NP; p += 2) {
+        eval_hash_step<NR>(st, (p + 2) * LP + threadIdx.x, e_hash, dn, A, B, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo);
+        if (p + 1 < NP)
+            eval_hash_step<NR>(st, (p + 3) * LP + threadIdx.x, e_hash, dn, B, A, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo);
+    }
+}
+
+// the free waves: XOR / XNOR lanes (the same for both sides but for the offset of an XNOR, garble.go:342-351 / eval.go:49-51),
+// groups of kGroup passes of 64 F lanes
+template <bool GARBLE>
+__device__ __forceinline__ void free_role(const Step &st, uint32_t n_free_lanes, uint32_t first_lane, uint32_t F,
+                                          const GateDesc *__restrict__ descs, uint32_t ninputs, uint32_t ti_log2, uint32_t tim,
+                                          uint4 *Wt, const uint4 *Rt) {
+    const uint32_t LP = F << 6, fl = threadIdx.x - first_lane;
+    for (uint32_t u0 = 0; u0 < n_free_lanes; u0 += kGroup * LP) {
+        uint32_t gate[kGroup], inst[kGroup];
+        bool on[kGroup];
+        GateDesc d[kGroup];
+        uint4 va[kGroup], vb[kGroup];
+#pragma unroll
+        for (int p = 0; p < kGroup; p++) {
+            const uint32_t u = u0 + p * LP + fl;
+            on[p] = u < n_free_lanes;
+            gate[p] = on[p] ? st.nonfree + (u >> ti_log2) : 0u;
+            inst[p] = u & tim;
+            d[p] = descs[st.first + gate[p]];
+        }
+#pragma unroll
+        for (int p = 0; p < kGroup; p++) {
+            va[p] = Wt[((size_t)d[p].in0 << ti_log2) + inst[p]];
+            vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + inst[p]];
+        }
+#pragma unroll
+        for (int p = 0; p < kGroup; p++) {
+            uint4 v = lxor(va[p], vb[p]);
+            if (GARBLE && (d[p].row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst[p]]);
+            if (on[p]) Wt[((size_t)(ninputs + st.first + gate[p]) << ti_log2) + inst[p]] = v;
+        }
+    }
+}
+
+// hash waves H of a level with e_hash hash lanes and n_free free lanes (the other F = 16 - H waves stream the free lanes):
+// as few free waves as finish under the hash role, from a cost model fitted to the synthetic sweep (W = 1 024 / 16 384,
+// f = 0.17 / 0.5, both sides, H = 6 .. 15; ns):
+//   hash role  T = 2 500 (descriptor + operand round trip at the head of the level) + 700 per pass (of ~768 lanes)
+//              + 290 per 64 hash lanes (the AES: bound by the LDS array whatever H >= 6 is)
+//   free role  48 B per lane at 19 GB/s x F / (F + 1.7) (the memory pipe fills with the waves that feed it)
+//              = 2.53 n_free (1 + 1.7 / F)  <=  T   <=>   F >= 1.7 / (T / (2.53 n_free) - 1)
+// (closed form on purpose: a search over H with its two integer divisions per candidate cost 2.4 us of scalar code per level.)
+// tune != 0: H fixed, for measurements.
+__device__ __forceinline__ uint32_t role_hash_waves(uint32_t e_hash, uint32_t n_free, uint32_t tune) {
+    if (n_free == 0) return 16;
+    if (e_hash == 0) return 0;
+    const uint32_t need = (e_hash + 63) >> 6;
+    if (tune) return need < tune ? need : tune;
+    // integers, thousandths of a ns: F = ceil(4.301 n_free / (T - 2.53 n_free)), at most 8 free waves
+    const uint32_t t_hash = 2500u + 58u * (need + 11u) + 290u * need;
+    const uint32_t num = 4301u * n_free, sub = 2530u * n_free, tt = 1000u * t_hash;
+    uint32_t F = 8;
+    if (tt > sub) {
+        const uint32_t den = tt - sub;
+        F = (num + den - 1) / den;
+        F = F < 1 ? 1 : F > 8 ? 8 : F;
+    }
+    const uint32_t H = 16 - F;
+    return need < H ? need : H;
+}
+
 template <int NR, bool PROF>
 __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *__restrict__ descs,
                                                                 const Step *__restrict__ steps, uint32_t nsteps,
@@ -288,7 +630,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
                                                                 const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
                                                                 const uint32_t *__restrict__ rk,
                                                                 const uint32_t *__restrict__ g_te0,
-                                                                uint64_t *__restrict__ prof) {
+                                                                uint64_t *__restrict__ prof, uint32_t tune) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
@@ -298,7 +640,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
     uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
     uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
-    const uint4 *Rt = Rv + (size_t)blockIdx.x * TI;
+    // the tile's offsets R live in LDS: a hash lane reads its R on the way into the AES, and a global load there would make
+    // that point wait for every vector load in flight (vmcnt), the prefetched operands of the next pass included
+    __shared__ uint4 Rt[64];
+    if (threadIdx.x < TI) Rt[threadIdx.x] = Rv[(size_t)blockIdx.x * TI + threadIdx.x];
+    __syncthreads();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -316,14 +663,23 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
     Step st_next = steps[0];
     LanePos lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    // wide levels (hash waves / free waves): the split of the next level and the hash waves' second descriptor
+    uint32_t e_hash_next = level_lanes<2, 2, 1>(st_next, ti_log2) - ((st_next.count - st_next.nonfree) << ti_log2);
+    uint32_t H_next = level_lanes<2, 2, 1>(st_next, ti_log2) > (uint32_t)kFusedThreads ? role_hash_waves(e_hash_next, level_lanes<2, 2, 1>(st_next, ti_log2) - e_hash_next, tune) : 0u;
+    PassDesc pre1;
+    if (!PROF && wave < H_next) role_fetch_desc<2, 2, 1>(pre1, st_next, (H_next << 6) + threadIdx.x, e_hash_next, descs, ti_log2, tim);
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t e_all = level_lanes<2, 2, 1>(st, ti_log2);
+        const uint32_t e_hash = e_hash_next, H = H_next;
         // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
         // zero-fill of empty passes on its critical path
         if (e_all <= (uint32_t)kFusedThreads) garble_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo, pacc, plast);
-        else
-            // the groups of a level in opposite orders for the two halves of the workgroup's waves (quartets 0, 2 forwards;
+        else if (!PROF) {
+            if (wave < H) garble_hash_role<NR>(st, e_hash, H, lp_next, d_next, pre1, descs, ninputs, ti_log2, tim, TI, Wt, Tt, Rt, rkr, te, lo);
+            else free_role<true>(st, e_all - e_hash, H << 6, 16 - H, descs, ninputs, ti_log2, tim, Wt, Rt);
+        } else
+            // (instrumented builds) the groups of a level in opposite orders for the two halves of the workgroup's waves (quartets 0, 2 forwards;
             // 1, 3 backwards): hash lanes fill the first passes of a level and free lanes the last ones, so while one half
             // hashes the other half moves labels (+4 % on the wide synthetic rows; groups of a level are independent)
             for (uint32_t tt = 0, ng = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng; tt++)
@@ -332,6 +688,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_garble_fused(const GateDesc *
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, threadIdx.x, ti_log2, tim);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+            e_hash_next = level_lanes<2, 2, 1>(st_next, ti_log2) - ((st_next.count - st_next.nonfree) << ti_log2);
+            H_next = level_lanes<2, 2, 1>(st_next, ti_log2) > (uint32_t)kFusedThreads ? role_hash_waves(e_hash_next, level_lanes<2, 2, 1>(st_next, ti_log2) - e_hash_next, tune) : 0u;
+            if (!PROF && wave < H_next) role_fetch_desc<2, 2, 1>(pre1, st_next, (H_next << 6) + threadIdx.x, e_hash_next, descs, ti_log2, tim);
         }
         __syncthreads();
         GC_PROF_MARK(3)
@@ -350,7 +709,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
                                                               const uint4 *__restrict__ T,
                                                               const uint32_t *__restrict__ rk,
                                                               const uint32_t *__restrict__ g_te0,
-                                                              uint64_t *__restrict__ prof) {
+                                                              uint64_t *__restrict__ prof, uint32_t tune) {
     __shared__ uint32_t te[kTeDualBytes / 4];
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
@@ -360,6 +719,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
     const uint32_t TI = 1u << ti_log2, tim = TI - 1;
     uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
     const uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     if constexpr (PROF) plast = __builtin_amdgcn_s_memtime();
 
@@ -370,19 +730,31 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_fused(const GateDesc *__
     Step st_next = steps[0];
     LanePos lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    // wide levels (hash waves / free waves): the split of the next level and the hash waves' second descriptor
+    uint32_t e_hash_next = level_lanes<1, 0, 0>(st_next, ti_log2) - ((st_next.count - st_next.nonfree) << ti_log2);
+    uint32_t H_next = level_lanes<1, 0, 0>(st_next, ti_log2) > (uint32_t)kFusedThreads ? role_hash_waves(e_hash_next, level_lanes<1, 0, 0>(st_next, ti_log2) - e_hash_next, tune) : 0u;
+    PassDesc pre1;
+    if (!PROF && wave < H_next) role_fetch_desc<1, 0, 0>(pre1, st_next, (H_next << 6) + threadIdx.x, e_hash_next, descs, ti_log2, tim);
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t e_all = level_lanes<1, 0, 0>(st, ti_log2);
+        const uint32_t e_hash = e_hash_next, H = H_next;
         // a level of one pass (narrow, deep circuits) takes the single-pass instantiation: no classification or
         // zero-fill of empty passes on its critical path
         if (e_all <= (uint32_t)kFusedThreads) eval_group<NR, PROF, 1>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
-        else
+        else if (!PROF) {
+            if (wave < H) eval_hash_role<NR>(st, e_hash, H, lp_next, d_next, pre1, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo);
+            else free_role<false>(st, e_all - e_hash, H << 6, 16 - H, descs, ninputs, ti_log2, tim, Wt, nullptr);
+        } else
             for (uint32_t tt = 0, ng = (e_all + kGroup * kFusedThreads - 1) / (kGroup * kFusedThreads); tt < ng; tt++)
                 eval_group<NR, PROF, kGroup, false>(st, (((threadIdx.x >> 8) & 1) ? ng - 1 - tt : tt) * (kGroup * kFusedThreads), lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1, d_next.tweak, d_next.row_op, descs, ninputs, ti_log2, tim, TI, Wt, Tt, rkr, te, lo, pacc, plast);
         if (lv + 1 < nsteps) {
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, threadIdx.x, ti_log2, tim);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+            e_hash_next = level_lanes<1, 0, 0>(st_next, ti_log2) - ((st_next.count - st_next.nonfree) << ti_log2);
+            H_next = level_lanes<1, 0, 0>(st_next, ti_log2) > (uint32_t)kFusedThreads ? role_hash_waves(e_hash_next, level_lanes<1, 0, 0>(st_next, ti_log2) - e_hash_next, tune) : 0u;
+            if (!PROF && wave < H_next) role_fetch_desc<1, 0, 0>(pre1, st_next, (H_next << 6) + threadIdx.x, e_hash_next, descs, ti_log2, tim);
         }
         __syncthreads();
         GC_PROF_MARK(3)
@@ -479,16 +851,21 @@ void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream
     }
 }
 
+static uint32_t tune_env() {
+    const char *e = getenv("GC_TUNE");
+    return e ? (uint32_t)atoi(e) : 0u;
+}
+
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
 #define GC_GF(NR)                                                                                               \
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_garble_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,    \
-                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof);  \
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof, tune_env());  \
     else                                                                                                        \
         hipLaunchKernelGGL((k_garble_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,   \
-                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof)
+                           g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0, a.prof, tune_env())
     switch (a.rounds) {
     case 10: GC_GF(10); break;
     case 12: GC_GF(12); break;
@@ -504,11 +881,11 @@ void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_eval_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,      \
                            g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
-                           a.prof);                                                                             \
+                           a.prof, tune_env());                                                                             \
     else                                                                                                        \
         hipLaunchKernelGGL((k_eval_fused<NR, false>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,     \
                            g.ti_log2, g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0, \
-                           a.prof)
+                           a.prof, tune_env())
     switch (a.rounds) {
     case 10: GC_EF(10); break;
     case 12: GC_EF(12); break;

@@ -455,6 +455,29 @@ def test_global_wire_kernels_on_a_circuit_that_exceeds_lds(ctx, batch):
         check_garble_eval(ctx, c, KEY128, batch, "glob1c", check_all_wires=False, schedule=1)
 
 
+def test_global_wire_kernels_hash_and_free_waves(ctx):
+    """wide levels split the workgroup into hash waves and free waves (fused_kernels.hip): besides mixed levels, levels
+    without a hashed gate (all sixteen waves stream), without a free gate (all sixteen hash), with a handful of ANDs (fewer
+    hash lanes than one wave) and with a handful of XORs; tile sizes 1 and 4; every wire compared"""
+    from mpc_amd.circuit import AND, XNOR, XOR, Circuit
+    base = synthetic_levelised(12, 2500, 0.3, seed=177, ninputs=64, or_frac=0.05, inv_frac=0.08, xnor_frac=0.1)
+    g = base.Gates.copy()
+    w = 2500
+    g["op"][2 * w:3 * w] = np.where(np.arange(w) % 7 == 0, XNOR, XOR)   # no hashed gate
+    g["op"][4 * w:5 * w] = AND                                          # no free gate
+    g["op"][6 * w:7 * w] = XOR
+    g["op"][6 * w + 11:6 * w + 16] = AND                                # five ANDs
+    g["op"][8 * w:9 * w] = AND
+    g["op"][8 * w + 100:8 * w + 105] = XOR                              # five XORs
+    c = Circuit(base.NumWires, base.Inputs, base.Outputs, g, "roles")
+    dc = engine.DeviceCircuit(ctx, c)
+    b = engine.Batch(dc, 5)
+    assert not b.lds_wires, "expected the HBM-wire kernels (live labels %d)" % dc.info.n_flat_slots
+    b.close(); dc.close()
+    check_garble_eval(ctx, c, KEY256, 5, "roles5", check_all_wires=True, schedule=1)
+    check_garble_eval(ctx, c, KEY128, 1027, "roles1027", check_all_wires=False, schedule=1, sample=[0, 3, 512, 1023, 1026])
+
+
 @pytest.mark.parametrize("batch", [2, 520])
 def test_global_wire_kernels_narrow_deep_circuit(ctx, batch):
     """the same kernels on levels of a single pass (their single-pass instantiation with the descriptor prefetched
