@@ -67,6 +67,40 @@ struct Trace {
 };
 }  // namespace
 
+// ---- cooperative one-launch passes of ONE instance (kernels.h: launch_coop) ------------------------------------------------
+// First use: allocate the barrier state and run the self-test (are the kCoopGroups workgroups on one XCD, do values stored
+// before the barrier arrive behind it); GC_NO_COOP keeps the level launches.  Called with ctx->mu held or from one thread.
+static bool coop_ready(gc_ctx *c) {
+    if (c->capturing) return false;  // (recorded pipelines keep the level launches)
+    if (c->coop_state != 0) return c->coop_state > 0;
+    c->coop_state = -1;
+    if (std::getenv("GC_NO_COOP")) return false;
+    if (hipMalloc((void **)&c->d_coop, sizeof(CoopCtl)) != hipSuccess) return false;
+    if (hipHostMalloc((void **)&c->h_coop_err, 256, hipHostMallocPortable) != hipSuccess) return false;
+    CoopCtl *h = (CoopCtl *)c->h_coop_err;  // the head of the control block after the self-test
+    std::memset(h, 0xff, 256);
+    launch_coop_selftest(c->d_coop, c->stream);
+    if (hipMemcpyAsync(h, c->d_coop, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    const bool ok = h->error == 0 && h->bad == 0 && h->count == 128u * kCoopGroups;
+    if (std::getenv("GC_TRACE"))
+        std::fprintf(stderr, "[gc trace] coop self-test: %s, error %u bad %u, 128 barriers in %u ticks\n", ok ? "passed" : "FAILED",
+                     h->error, h->bad, h->ticks);
+    *c->h_coop_err = 0;
+    if (ok) c->coop_state = 1;
+    return ok;
+}
+
+int gc_ctx_coop_check(gc_ctx *c) {
+    if (!c || !c->h_coop_err || *c->h_coop_err == 0) return GC_OK;
+    *c->h_coop_err = 0;
+    c->coop_state = -1;
+    (void)hipMemsetAsync(c->d_coop, 0, sizeof(CoopCtl), c->stream);
+    std::snprintf(gc::tls_error, sizeof gc::tls_error,
+                  "a cooperative one-instance pass lost a workgroup (barrier timeout); its results are invalid, level launches from here on");
+    return GC_E_HIP;
+}
+
 extern "C" {
 
 const char *gc_strerror(int status) {
@@ -131,6 +165,8 @@ void gc_ctx_destroy(gc_ctx *c) {
         (void)hipStreamDestroy(c->stream);
     }
     if (c->d_te0) (void)hipFree(c->d_te0);
+    if (c->d_coop) (void)hipFree(c->d_coop);
+    if (c->h_coop_err) (void)hipHostFree(c->h_coop_err);
     for (int b = 0; b < 2; b++) {
         if (c->stage[b]) (void)hipFree(c->stage[b]);
         if (c->ev_k[b]) (void)hipEventDestroy(c->ev_k[b]);
@@ -247,7 +283,7 @@ int gc_ctx_sync(gc_ctx *c) {
     if (!c) return GC_E_ARG;
     GC_HIP(hipSetDevice(c->device));
     GC_HIP(hipStreamSynchronize(c->stream));
-    return GC_OK;
+    return gc_ctx_coop_check(c);
 }
 
 void *gc_ctx_stream(gc_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -710,6 +746,16 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
             uint64_t passes = 0;
             for (const Step &st : p.levels) passes += level1_passes(st, eval);
             if (passes * 2 >= (uint64_t)a.nsteps * 5) {
+                if (coop_ready(b->circ->ctx)) {  // ONE launch: 32 workgroups of one XCD behind a barrier in its L2
+                    gc_ctx *cx = b->circ->ctx;
+                    launch_coop(eval, a, cx->d_coop, s);
+                    GC_HIP(hipGetLastError());
+                    // the flag stays up on the device once raised, so every later copy repeats it until gc_ctx_coop_check
+                    // (gc_ctx_sync, gc_pass_dev, the streaming calls that hand results out) has reported it
+                    GC_HIP(hipMemcpyAsync(cx->h_coop_err, &cx->d_coop->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    b->last_launches = 1;
+                    return GC_OK;
+                }
                 b->last_launches = a.nsteps;
                 const int kGraphKey = 3;  // distinct from the schedule-0 graphs of this batch
                 if (!b->use_graph || b->circ->ctx->capturing) {
@@ -1382,6 +1428,7 @@ int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const 
     do {
         hipError_t e = hipSetDevice(ctx->device);
         b->store_all = false;
+        if ((rc = gc_ctx_coop_check(ctx)) != GC_OK) break;
         if (e == hipSuccess && (rc = relayout(b)) != GC_OK) break;
         if (e == hipSuccess && !eval) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
         // one instance: a tile of one, the table array is the dense slab [row] and wire slot w is element w

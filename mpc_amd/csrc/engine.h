@@ -39,7 +39,15 @@ struct gc_ctx {
     hipEvent_t ev_c[2] = {nullptr, nullptr};  // copy from / to stage[b] done
     void *stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;
+    // ONE instance of a wide circuit as one cooperative launch (fused_kernels.hip: k_garble_coop): barrier state in device
+    // memory, the verdict of the self-test (0 not run, 1 passed, -1 off), and a pinned word the error flag of every such
+    // pass is copied to (checked when the next pass is enqueued and by gc_ctx_sync)
+    gc::CoopCtl *d_coop = nullptr;
+    int coop_state = 0;
+    uint32_t *h_coop_err = nullptr;
 };
+// internal: GC_E_HIP (and the cooperative passes switched off) if a cooperative pass of this ctx reported a lost workgroup
+int gc_ctx_coop_check(gc_ctx *c);
 
 struct gc_graph {
     gc_ctx *ctx = nullptr;

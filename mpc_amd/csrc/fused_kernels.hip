@@ -102,7 +102,21 @@ enum LaneKind { K_NONE = 0, K_AND = 1, K_OR = 2, K_INV = 3, K_FREE = 4 };
         plast = now__;                                                 \
     }
 
-template <int NR, bool PROF, int G, bool PRE = true>
+// a label from the wire array; COH: past this CU's L1 (two 64-bit loads of agent scope) — the cooperative one-instance kernels
+// read labels that OTHER CUs of the XCD wrote into lines this CU may still hold
+template <bool COH>
+__device__ __forceinline__ uint4 load_label(const uint4 *p) {
+    if constexpr (COH) {
+        const uint64_t *q = (const uint64_t *)p;
+        const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+    } else {
+        return *p;
+    }
+}
+
+template <int NR, bool PROF, int G, bool PRE = true, bool COH = false>
 __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                              const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
                                              const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
@@ -131,8 +145,8 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
         if (lp[p].kind == K_NONE) continue;
         // AND lanes 2,3 hash operand b; OR and XOR lanes need both operands
         const bool second = lp[p].kind == K_AND && (lp[p].q & 2);
-        va[p] = Wt[((size_t)(second ? d[p].in1 : d[p].in0) << ti_log2) + lp[p].inst];
-        if (lp[p].kind == K_FREE || lp[p].kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + lp[p].inst];
+        va[p] = load_label<COH>(Wt + ((size_t)(second ? d[p].in1 : d[p].in0) << ti_log2) + lp[p].inst);
+        if (lp[p].kind == K_FREE || lp[p].kind == K_OR) vb[p] = load_label<COH>(Wt + ((size_t)d[p].in1 << ti_log2) + lp[p].inst);
     }
     GC_PROF_MARK(1)
 #pragma unroll
@@ -210,7 +224,7 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
     GC_PROF_MARK(2)
 }
 
-template <int NR, bool PROF, int G, bool PRE = true>
+template <int NR, bool PROF, int G, bool PRE = true, bool COH = false>
 __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                            const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
                                            const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
@@ -239,8 +253,8 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
         if (kind == K_NONE) continue;
         const uint32_t inst = lp[p].inst, q = lp[p].q;
         // AND lane 1 hashes operand b; OR and XOR lanes need both operands
-        va[p] = Wt[((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << ti_log2) + inst];
-        if (kind == K_FREE || kind == K_OR) vb[p] = Wt[((size_t)d[p].in1 << ti_log2) + inst];
+        va[p] = load_label<COH>(Wt + ((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << ti_log2) + inst);
+        if (kind == K_FREE || kind == K_OR) vb[p] = load_label<COH>(Wt + ((size_t)d[p].in1 << ti_log2) + inst);
         const uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
         if (kind == K_AND) tab[p] = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
         else if (kind == K_INV) tab[p] = row[0];
@@ -814,6 +828,177 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_level1(const GateDesc *_
     uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
     eval_group<NR, false, 1, false>(st, blockIdx.x * kLevelLanes, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
                                     rkr, te, te_lane_off(), pacc, plast, kLevelLanes);
+}
+
+// ---- ONE instance, ONE launch: the levels behind a barrier in L2 ------------------------------------------------------------
+// A level launch costs 5.9 us for ~3 000 lanes of work (profiles/r03_stream_big_kernel_stats.csv): 2 - 2.5 us from one
+// kernel to the next one that depends on it, the 64 KiB table of every hashing workgroup built again, two dependent round
+// trips for descriptor and operand.  Here kCoopGroups workgroups of 256 threads stay resident for the whole pass (table
+// and round keys once) and meet at a counter between levels.  They are the workgroups 0, 8, 16, ... of the grid: workgroups
+// go round-robin over the 8 XCDs, so these sit on ONE XCD and share its L2 — a label is visible to the other CUs as soon as
+// its store is acknowledged (the vector L1 writes through), the counter lives in that L2, and the readers fetch labels
+// past their L1; no write-back or invalidate of L2, which an agent-scope release / acquire would cost at every level.
+// The placement is checked, not assumed: gc_ctx runs k_coop_selftest once (XCC_ID of every group, values handed round
+// through the barrier) and keeps the level launches if it fails; every wait is bounded (kCoopTimeout), a workgroup that
+// gives up raises ctl->error and the pass is reported as failed.
+constexpr uint32_t kCoopThreads = 256;
+constexpr uint64_t kCoopTimeout = 40u * 1000u * 1000u;  // s_memtime ticks (~1.1 GHz): ~36 ms
+
+// barrier number `gen` (1, 2, ... within one launch): one atomic add, then a plain load past the L1 until every group has
+// added.  Measured on one XCD: an atomic add takes 0.7 us to come back whatever its scope; 32 workgroups that poll the
+// counter with read-modify-writes queue at its L2 bank (5 - 6 us per barrier); per-group flags (a store, one load of all 32
+// flags per poll, no atomic at all) cost 2.3 us; this costs 1.9 us.  The error flag / the clock every 64th poll.
+__device__ __forceinline__ void coop_barrier(CoopCtl *ctl, uint32_t gen) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's stores are in L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t target = gen * kCoopGroups;
+        __hip_atomic_fetch_add(&ctl->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if ((++spins & 63u) == 0) {
+                if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (__builtin_amdgcn_s_memtime() - t0 > kCoopTimeout) {
+                    __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // no cache invalidate: buffer_inv sc1 walks the L2 (12 us measured); the labels are read past the L1 instead
+    // (load_label<true>), everything else the pass reads is constant
+}
+
+template <int NR>
+__global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
+                                                              uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
+                                                              const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
+                                                              const uint32_t *__restrict__ rk,
+                                                              const uint32_t *__restrict__ g_te0, CoopCtl *ctl) {
+    if (blockIdx.x & 7) return;
+    const uint32_t rank = blockIdx.x >> 3;
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    load_te_dual(te, g_te0);
+    uint32_t rkr[4 * (NR + 1)];
+    load_round_keys<NR>(rkr, rk);
+    __syncthreads();
+    const uint32_t lo = te_lane_off();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    // wave-sized chunks of a level's lanes, dealt round over the groups first: the hash lanes (the first ones of a level)
+    // spread over all CUs.  The descriptor of this wave's first chunk of the NEXT level is fetched before the barrier.
+    const uint32_t c0 = wave * kCoopGroups + rank, stride = (kCoopThreads / 64) * kCoopGroups;
+    const uint32_t t_first = (c0 << 6) + (threadIdx.x & 63u);
+    Step st_next = steps[0];
+    LanePos lp_next = classify<2, 2, 1>(st_next, t_first, 0u, 0u);
+    GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    for (uint32_t lv = 0; lv < nsteps; lv++) {
+        const Step st = st_next;
+        const uint32_t chunks = (level_lanes<2, 2, 1>(st, 0u) + 63u) >> 6;
+        if (c0 < chunks)
+            garble_group<NR, false, 1, true, true>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1,
+                                                   d_next.tweak, d_next.row_op, descs, ninputs, 0u, 0u, 1u, W, T, Rv, rkr, te, lo,
+                                                   pacc, plast, kCoopThreads);
+        for (uint32_t c = c0 + stride; c < chunks; c += stride)
+            garble_group<NR, false, 1, false, true>(st, (c - wave) << 6, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W,
+                                                    T, Rv, rkr, te, lo, pacc, plast, kCoopThreads);
+        if (lv + 1 < nsteps) {
+            st_next = steps[lv + 1];
+            lp_next = classify<2, 2, 1>(st_next, t_first, 0u, 0u);
+            if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+            coop_barrier(ctl, lv + 1);
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
+                                                            uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
+                                                            const uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
+                                                            const uint32_t *__restrict__ g_te0, CoopCtl *ctl) {
+    if (blockIdx.x & 7) return;
+    const uint32_t rank = blockIdx.x >> 3;
+    __shared__ uint32_t te[kTeDualBytes / 4];
+    load_te_dual(te, g_te0);
+    uint32_t rkr[4 * (NR + 1)];
+    load_round_keys<NR>(rkr, rk);
+    __syncthreads();
+    const uint32_t lo = te_lane_off();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint64_t pacc[4] = {0, 0, 0, 0}, plast = 0;
+    const uint32_t c0 = wave * kCoopGroups + rank, stride = (kCoopThreads / 64) * kCoopGroups;
+    const uint32_t t_first = (c0 << 6) + (threadIdx.x & 63u);
+    Step st_next = steps[0];
+    LanePos lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
+    GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    for (uint32_t lv = 0; lv < nsteps; lv++) {
+        const Step st = st_next;
+        const uint32_t chunks = (level_lanes<1, 0, 0>(st, 0u) + 63u) >> 6;
+        if (c0 < chunks)
+            eval_group<NR, false, 1, true, true>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1,
+                                                 d_next.tweak, d_next.row_op, descs, ninputs, 0u, 0u, 1u, W, T, rkr, te, lo, pacc,
+                                                 plast, kCoopThreads);
+        for (uint32_t c = c0 + stride; c < chunks; c += stride)
+            eval_group<NR, false, 1, false, true>(st, (c - wave) << 6, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
+                                                  rkr, te, lo, pacc, plast, kCoopThreads);
+        if (lv + 1 < nsteps) {
+            st_next = steps[lv + 1];
+            lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
+            if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+            coop_barrier(ctl, lv + 1);
+        }
+    }
+}
+
+// Are the kCoopGroups workgroups on one XCD, and does a value stored before the barrier arrive behind it?  64 rounds of:
+// every group writes a fresh value, barrier, reads its neighbour's, barrier.  ctl->bad counts what went wrong.
+__global__ __launch_bounds__(kCoopThreads) void k_coop_selftest(CoopCtl *ctl) {
+    if (blockIdx.x & 7) return;
+    const uint32_t rank = blockIdx.x >> 3;
+    uint32_t *scratch = ctl->scratch;  // written with plain stores and read past the L1, as the labels are
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID
+    if (threadIdx.x == 0) scratch[32 + rank] = xcc;
+    uint32_t bar = 0, bad = 0;
+    const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+    for (uint32_t it = 0; it < 64; it++) {
+        if (threadIdx.x == 0) scratch[rank] = it * 131u + rank;
+        coop_barrier(ctl, ++bar);
+        const uint32_t nb = (rank + 1 + it) % kCoopGroups;
+        if (threadIdx.x == 64 && __hip_atomic_load(&scratch[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it * 131u + nb) bad++;
+        coop_barrier(ctl, ++bar);
+    }
+    if (threadIdx.x == 0 && rank == 0) ctl->ticks = (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin);  // ticks of 128 barriers
+    if (threadIdx.x == 64) {
+        for (uint32_t r = 0; r < kCoopGroups; r++)
+            if (__hip_atomic_load(&scratch[32 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc) bad++;
+        if (bad) __hip_atomic_fetch_add(&ctl->bad, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+void launch_coop_selftest(CoopCtl *ctl, hipStream_t s) {
+    (void)hipMemsetAsync(ctl, 0, sizeof(CoopCtl), s);
+    hipLaunchKernelGGL(k_coop_selftest, dim3(8 * kCoopGroups), dim3(kCoopThreads), 0, s, ctl);
+}
+
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, hipStream_t s) {
+    if (a.nsteps == 0) return;
+    (void)hipMemsetAsync(ctl, 0, 4, s);  // count; error stays up once raised (gc_ctx_coop_check lowers it)
+    const dim3 grid(8 * kCoopGroups), block(kCoopThreads);
+#define GC_CO(NR)                                                                                                          \
+    if (eval)                                                                                                              \
+        hipLaunchKernelGGL((k_eval_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W,               \
+                           (const uint4 *)a.T, a.rk, a.te0, ctl);                                                         \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((k_garble_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W, a.R, a.T,   \
+                           a.rk, a.te0, ctl)
+    switch (a.rounds) {
+    case 10: GC_CO(10); break;
+    case 12: GC_CO(12); break;
+    default: GC_CO(14); break;
+    }
+#undef GC_CO
 }
 
 // passes (1024-lane workgroups) of a level for one instance: the measure of "wide" (plan.h: wide_for_one_instance)

@@ -80,6 +80,18 @@ void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 // levels = host copy of the step array
 uint32_t level1_passes(const Step &st, bool eval);
 void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream_t s);
+// the same walk as ONE launch: kCoopGroups workgroups of one XCD (one L2) walk the levels together, a counter in that L2
+// is the barrier between levels (fused_kernels.hip: k_garble_coop).  ctl lives in device memory and is zeroed by the launch.
+struct CoopCtl {
+    uint32_t count;        // arrivals, monotonic over the barriers of one launch (zeroed by every launch)
+    uint32_t error;        // a workgroup gave up waiting (never seen after a passed self-test; stays up until reported)
+    uint32_t bad;          // self-test: values that did not arrive, workgroups on another XCD
+    uint32_t ticks;        // self-test: s_memtime ticks of its 128 barriers
+    uint32_t scratch[64];  // self-test
+};
+constexpr uint32_t kCoopGroups = 32;
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, hipStream_t s);
+void launch_coop_selftest(CoopCtl *ctl, hipStream_t s);
 
 // Fused schedule with LDS-resident wires (fused_lds_kernels.hip)
 struct FusedLdsArgs {

@@ -1236,6 +1236,7 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
             rc = GC_E_HIP;
         }
         g.synced = true;
+        if (rc == GC_OK) rc = gc_ctx_coop_check(ctx);  // a big step as one cooperative launch: did every workgroup stay?
     }
     if (g.kind == Slot::kGroup) {
         if (rc == GC_OK) {
