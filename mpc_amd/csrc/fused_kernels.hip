@@ -848,12 +848,16 @@ constexpr uint64_t kCoopTimeout = 40u * 1000u * 1000u;  // s_memtime ticks (~1.1
 // added.  Measured on one XCD: an atomic add takes 0.7 us to come back whatever its scope; 32 workgroups that poll the
 // counter with read-modify-writes queue at its L2 bank (5 - 6 us per barrier); per-group flags (a store, one load of all 32
 // flags per poll, no atomic at all) cost 2.3 us; this costs 1.9 us.  The error flag / the clock every 64th poll.
-__device__ __forceinline__ void coop_barrier(CoopCtl *ctl, uint32_t gen) {
+// (in two halves, so that what does not depend on the level — the next level's descriptor — is fetched while the add travels)
+__device__ __forceinline__ void coop_arrive(CoopCtl *ctl) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's stores are in L2
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&ctl->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void coop_wait(CoopCtl *ctl, uint32_t gen) {
     if (threadIdx.x == 0) {
         const uint32_t target = gen * kCoopGroups;
-        __hip_atomic_fetch_add(&ctl->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         uint32_t spins = 0;
         while (__hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -869,6 +873,11 @@ __device__ __forceinline__ void coop_barrier(CoopCtl *ctl, uint32_t gen) {
     __syncthreads();
     // no cache invalidate: buffer_inv sc1 walks the L2 (12 us measured); the labels are read past the L1 instead
     // (load_label<true>), everything else the pass reads is constant
+}
+
+__device__ __forceinline__ void coop_barrier(CoopCtl *ctl, uint32_t gen) {
+    coop_arrive(ctl);
+    coop_wait(ctl, gen);
 }
 
 template <int NR>
@@ -905,10 +914,11 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
             garble_group<NR, false, 1, false, true>(st, (c - wave) << 6, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W,
                                                     T, Rv, rkr, te, lo, pacc, plast, kCoopThreads);
         if (lv + 1 < nsteps) {
+            coop_arrive(ctl);
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, t_first, 0u, 0u);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
-            coop_barrier(ctl, lv + 1);
+            coop_wait(ctl, lv + 1);
         }
     }
 }
@@ -944,10 +954,11 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
             eval_group<NR, false, 1, false, true>(st, (c - wave) << 6, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
                                                   rkr, te, lo, pacc, plast, kCoopThreads);
         if (lv + 1 < nsteps) {
+            coop_arrive(ctl);
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
-            coop_barrier(ctl, lv + 1);
+            coop_wait(ctl, lv + 1);
         }
     }
 }

@@ -22,10 +22,13 @@
 // still leave in program order through gc_stream_garble_finish.  Steps of more than kSmallGates gates keep the
 // per-step path (level launches spread over the chip).  The evaluator groups its blocks the same way.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <memory>
 #include <new>
+#include <thread>
 #include <unordered_map>
 
 #include <chrono>
@@ -1289,6 +1292,12 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
 // way every time: the same op / flag bytes and tmp ids at the same offsets, only the table rows and the global ids
 // differ.  A new block that equals a skeleton on every other byte, and whose global ids repeat in the same pattern, IS
 // that circuit: no gate is decoded, the rows are copied out, the global ids are read at their known offsets.
+static inline uint64_t skel_load_be64(const uint8_t *p) {
+    uint64_t v;
+    std::memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+
 struct EvalSkel {
     struct Chunk {
         uint32_t cmp;    // bytes that must equal the reference block
@@ -1304,6 +1313,139 @@ struct EvalSkel {
     std::vector<uint32_t> gf_canon;          // index of the first field that names the same wire (the repeat pattern)
     std::vector<uint32_t> in_gf, out_gf;     // field of input k (its first read) / of the k-th global write
     std::vector<uint8_t> out_live;           // 0: a later gate of the block writes the same wire (streaming.Set: last wins)
+    // the chunk list cut into segments of about equal length with their start positions, so that several threads can
+    // compare / copy side by side (SkelPool)
+    struct Seg {
+        uint32_t c0, c1;   // chunks [c0, c1)
+        size_t byte_off;   // where c0 starts in the block
+        uint32_t row_off;  // rows in front of c0
+    };
+    std::vector<Seg> segs;
+    void build_segs() {
+        segs.clear();
+        const uint32_t n = (uint32_t)chunks.size(), per = n / 8 >= 2048 ? n / 8 : n ? n : 1;
+        size_t off = 0;
+        uint32_t rows = 0;
+        for (uint32_t c = 0; c < n; c++) {
+            if (c % per == 0 && (segs.empty() || n - c >= per / 2)) {
+                if (!segs.empty()) segs.back().c1 = c;
+                segs.push_back(Seg{c, n, off, rows});
+            }
+            off += (size_t)chunks[c].cmp + chunks[c].skip + 16u * (size_t)chunks[c].nrows;
+            rows += chunks[c].nrows;
+        }
+        if (segs.empty()) segs.push_back(Seg{0, 0, 0, 0});
+    }
+    // chunks [c0, c1) of `buf` against the reference: equal outside the global ids and the rows?  rows -> slab
+    bool match_seg(const Seg &sg, const uint8_t *buf, gc_label *slab) const {
+        const uint8_t *p = buf + sg.byte_off, *q = bytes.data() + sg.byte_off;
+        size_t nr = sg.row_off;
+        for (uint32_t ci = sg.c0; ci < sg.c1; ci++) {
+            const Chunk &c = chunks[ci];
+            uint64_t acc = 0;
+            uint32_t i = 0;
+            for (; i + 8 <= c.cmp; i += 8) {
+                uint64_t x, y;
+                std::memcpy(&x, p + i, 8);
+                std::memcpy(&y, q + i, 8);
+                acc |= x ^ y;
+            }
+            if (i < c.cmp) {
+                if (c.cmp >= 8) {  // the last, partial word: re-read the run's final 8 bytes
+                    uint64_t x, y;
+                    std::memcpy(&x, p + c.cmp - 8, 8);
+                    std::memcpy(&y, q + c.cmp - 8, 8);
+                    acc |= x ^ y;
+                } else {
+                    for (; i < c.cmp; i++) acc |= (uint64_t)(p[i] ^ q[i]);
+                }
+            }
+            if (acc) return false;
+            p += c.cmp + c.skip;
+            q += c.cmp + c.skip;
+            for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
+            q += 16u * c.nrows;
+        }
+        return true;
+    }
+};
+
+// Helper threads for the skeleton match of a big block (a 131 072-gate block is ~33 000 compare runs and 43 000 rows: 0.42 ms
+// on one core, more than the GPU needs for the block).  Segments are handed out through a counter; the calling thread
+// takes its share.  GC_STREAM_THREADS = helpers (default 3, 0: none).
+struct SkelPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const EvalSkel *sk = nullptr;
+    const uint8_t *buf = nullptr;
+    gc_label *slab = nullptr;
+    uint64_t job = 0;
+    bool stop = false;
+    std::atomic<uint32_t> next{0}, done{0};
+    std::atomic<bool> same{true};
+    int helpers = -1;
+
+    void work() {
+        const uint32_t n = (uint32_t)sk->segs.size();
+        for (;;) {
+            const uint32_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) break;
+            if (same.load(std::memory_order_relaxed) && !sk->match_seg(sk->segs[i], buf, slab)) same.store(false, std::memory_order_relaxed);
+            if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+                std::lock_guard<std::mutex> lk(mu);
+                cv_done.notify_all();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || job != seen; });
+                if (stop) return;
+                seen = job;
+            }
+            work();
+        }
+    }
+    bool match(const EvalSkel &s, const uint8_t *b, gc_label *rows) {
+        if (helpers < 0) {
+            const char *v = std::getenv("GC_STREAM_THREADS");
+            helpers = v ? std::atoi(v) : 3;
+            helpers = helpers < 0 ? 0 : helpers > 15 ? 15 : helpers;
+        }
+        if (s.segs.size() < 2 || helpers == 0) {
+            for (const EvalSkel::Seg &sg : s.segs)
+                if (!s.match_seg(sg, b, rows)) return false;
+            return true;
+        }
+        if (th.empty())
+            for (int i = 0; i < helpers; i++) th.emplace_back([this] { loop(); });
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            sk = &s, buf = b, slab = rows;
+            next.store(0), done.store(0), same.store(true);
+            job++;
+        }
+        cv_work.notify_all();
+        work();
+        const uint32_t n = (uint32_t)s.segs.size();
+        if (done.load(std::memory_order_acquire) != n) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) == n; });
+        }
+        return same.load();
+    }
+    ~SkelPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th) t.join();
+    }
 };
 
 struct gc_stream_eval {
@@ -1334,6 +1476,7 @@ struct gc_stream_eval {
     std::vector<uint32_t> gf_ids, wr_ids;   // scratch: the block's global ids by field / the wires it writes
     EvalSkel rec;                           // skeleton of the block being parsed (kept when the parse succeeds)
     bool use_skels = true;                  // GC_STREAM_NO_SKELETON (read at creation): every block is parsed
+    SkelPool pool;                          // helper threads of the skeleton match (started by the first big block)
     uint64_t n_parsed = 0, n_matched = 0;
     size_t skel_bytes = 0;                  // reference bytes held by skels (capped: the blocks are the peer's data)
     // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
@@ -1557,37 +1700,8 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (e->use_skels && it != e->skels.end())
             for (const EvalSkel &sk : it->second) {
                 if (sk.nbytes > len) continue;
-                const uint8_t *p = buf, *q = sk.bytes.data();
-                size_t nr = 0;
-                bool same = true;
-                for (const EvalSkel::Chunk &c : sk.chunks) {
-                    uint64_t acc = 0;
-                    uint32_t i = 0;
-                    for (; i + 8 <= c.cmp; i += 8) {
-                        uint64_t x, y;
-                        std::memcpy(&x, p + i, 8);
-                        std::memcpy(&y, q + i, 8);
-                        acc |= x ^ y;
-                    }
-                    if (i < c.cmp) {
-                        if (c.cmp >= 8) {  // the last, partial word: re-read the run's final 8 bytes
-                            uint64_t x, y;
-                            std::memcpy(&x, p + c.cmp - 8, 8);
-                            std::memcpy(&y, q + c.cmp - 8, 8);
-                            acc |= x ^ y;
-                        } else {
-                            for (; i < c.cmp; i++) acc |= (uint64_t)(p[i] ^ q[i]);
-                        }
-                    }
-                    if (acc) {
-                        same = false;
-                        break;
-                    }
-                    p += c.cmp + c.skip;
-                    q += c.cmp + c.skip;
-                    for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{load_be64(p), load_be64(p + 8)};
-                    q += 16u * c.nrows;
-                }
+                const bool same = e->pool.match(sk, buf, slab);
+                const size_t nr = sk.nrows;
                 if (!same || !canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) continue;
                 ent = sk.ent;
                 nin = sk.nin, nout = sk.nout;
@@ -1787,6 +1901,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         sk.ent = ent;
         sk.bytes.assign(buf, buf + pos);
         sk.chunks = rec.chunks;
+        sk.build_segs();
         sk.gf_off = rec.gf_off;
         sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
         if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) {
