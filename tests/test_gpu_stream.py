@@ -154,6 +154,39 @@ def test_stream_large_chained_program_matches_oracle():
     ctx.close()
 
 
+def test_stream_big_steps_cooperative_and_level_launches_agree(monkeypatch):
+    """a big step runs as ONE cooperative launch (32 workgroups of one XCD behind a barrier in its L2, k_garble_coop /
+    k_eval_coop) when the context's self-test of that placement passes, and as one launch per level otherwise
+    (GC_NO_COOP): the same bytes and the same evaluated labels either way, equal to the oracle's"""
+    from scripts.bench_stream import make_steps
+    nin = 256
+    steps = make_steps(3, 24, 2048, 0.3, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("coopstream", 32)
+    rnd = drbg("coopstream-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    outs = []
+    for no_coop in (False, True):
+        if no_coop:
+            monkeypatch.setenv("GC_NO_COOP", "1")  # read when a context first meets a big step
+        ctx = engine.Context(0)
+        gg, ge = engine.Stream(ctx, key, rnd, prim), engine.StreamEval(ctx, key)
+        for w in prim:
+            ge.set(w, gg.get(w)["l0"])
+        for (c, in_, out_), wbytes in zip(steps, want):
+            got = gg.garble(c.Gates, c.NumWires, in_, out_)
+            assert got == wbytes, "cooperative" if not no_coop else "level launches"
+            nw = max(max(in_), max(out_)) + 1
+            assert ge.circuit(c.NumGates, c.NumWires, nw, got) == len(got)
+        outs.append([ge.get(o) for o in steps[-1][2]])
+        ctx.sync()  # reports a cooperative pass that lost a workgroup
+        gg.close(); ge.close(); ctx.close()
+    assert outs[0] == outs[1]
+
+
 def test_stream_million_gate_step_matches_oracle():
     """one step of more than 2^20 gates: the device serialiser's block scan then runs more than one block per
     thread (k_ser_scan), and the evaluator renames > 10^6 wires; wire ids above 0xffff (long form) and below mix"""
