@@ -187,6 +187,46 @@ def test_stream_big_steps_cooperative_and_level_launches_agree(monkeypatch):
     assert outs[0] == outs[1]
 
 
+def test_stream_concurrent_cooperative_passes():
+    """three garbler streams (three contexts, three threads) send big steps to the same GPU at once: their cooperative
+    passes share the XCD's resident slots; every stream's bytes are the oracle's and no pass reports a lost workgroup"""
+    import hashlib
+    import threading
+    from scripts.bench_stream import make_steps
+    nin = 256
+    steps = make_steps(12, 32, 2048, 0.25, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("cc", 32)
+    rnd = drbg("cc-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    want = hashlib.sha256()
+    for c, in_, out_ in steps:
+        want.update(og.garble(c.Gates, c.NumWires, in_, out_))
+    res = [None] * 3
+
+    def run(i):
+        try:
+            ctx = engine.Context(0)
+            gg = engine.Stream(ctx, key, rnd, prim)
+            h = hashlib.sha256()
+            for c, in_, out_ in steps:
+                h.update(gg.garble(c.Gates, c.NumWires, in_, out_))
+            ctx.sync()
+            res[i] = h.hexdigest()
+            gg.close(); ctx.close()
+        except Exception as e:  # noqa: BLE001 - reported through the assertion below
+            res[i] = "error: %s" % e
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert res == [want.hexdigest()] * 3
+
+
 def test_stream_million_gate_step_matches_oracle():
     """one step of more than 2^20 gates: the device serialiser's block scan then runs more than one block per
     thread (k_ser_scan), and the evaluator renames > 10^6 wires; wire ids above 0xffff (long form) and below mix"""
