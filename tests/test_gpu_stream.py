@@ -411,6 +411,58 @@ def test_stream_evaluator_recognises_repeated_blocks():
     gg.close(); ge.close(); gp.close(); ctx.close()
 
 
+@pytest.mark.parametrize("threads", ["3", "0"])
+def test_stream_evaluator_big_repeated_blocks_on_helper_threads(threads, monkeypatch):
+    """big blocks that match a byte skeleton are compared / copied in eight segments by the caller and helper threads
+    (SkelPool; GC_STREAM_THREADS = 0: the caller alone): four 49 152-gate blocks of one shape against the oracle's StreamEval,
+    then a block with one byte changed in its LAST segment (an XOR made XNOR) — it is not the skeleton's block and has to
+    take the gate-by-gate path"""
+    from scripts.bench_stream import make_steps
+    monkeypatch.setenv("GC_STREAM_THREADS", threads)
+    ctx = engine.Context(0)
+    nin = 256
+    steps = make_steps(4, 24, 2048, 0.4, nin)
+    steps = [(steps[0][0], i, o) for _, i, o in steps]  # one shape: blocks 2 .. 4 match block 1's skeleton
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("bigskel", 32)
+    rnd = drbg("bigskel-rnd", 16 * (len(prim) + 1))
+    gg = engine.Stream(ctx, key, rnd, prim)
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    for w in prim:
+        lab = gg.get(w)["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    datas = []
+    for c, in_, out_ in steps:
+        data = gg.garble(c.Gates, c.NumWires, in_, out_)
+        nw = max(max(in_), max(out_)) + 1
+        datas.append((c, data, nw, out_))
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        for o in out_[:16] + out_[-16:]:
+            assert ge.get(o) == oe.get(o)
+    assert ge.stats() == (1, 3)  # parsed, matched
+    c, data, nw, out_ = datas[-1]
+    raw = bytearray(data)
+    pos, last_xor = 0, None
+    for g in range(c.NumGates):  # walk the records (stream_garble.go:391-446): op byte, ids, rows
+        op = raw[pos] & 0x0f
+        z = 2 if raw[pos] & 0x10 else 4
+        if op == 0:
+            last_xor = pos
+        pos += 1 + z * (2 if op == 4 else 3) + 16 * {0: 0, 1: 0, 2: 2, 3: 3, 4: 1}[op]
+    assert pos == len(raw) and last_xor is not None and last_xor > len(raw) * 7 // 8
+    raw[last_xor] |= 1  # XOR -> XNOR
+    for ev in (ge, oe):
+        assert ev.circuit(c.NumGates, c.NumWires, nw, bytes(raw)) == len(raw)
+    assert ge.stats() == (2, 3)
+    for o in out_:
+        assert ge.get(o) == oe.get(o)
+    gg.close(); ge.close(); ctx.close()
+
+
 def _dependency_program(base):
     """A program of small SSA-step circuits with every kind of dependency between neighbours (global wires through
     in[] / out[]): runs of independent steps, read-after-write chains, two steps writing the same wire, a step
