@@ -277,6 +277,59 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
     return best
 
 
+NATIVE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stream_driver")
+
+
+def write_program(path, key, rnd, prim, steps, window):
+    """the program as tools/stream_driver.c reads it (see the format there)"""
+    import struct
+    circs, index = [], {}
+    for c, _, _ in steps:
+        if id(c) not in index:
+            index[id(c)] = len(circs)
+            circs.append(c)
+    with open(path, "wb") as f:
+        f.write(b"GCSP" + struct.pack("<I", 1))
+        f.write(struct.pack("<I", len(key)) + bytes(key))
+        f.write(struct.pack("<Q", len(rnd)) + bytes(rnd))
+        f.write(struct.pack("<I", len(prim)) + np.asarray(prim, np.uint32).tobytes())
+        f.write(struct.pack("<I", len(circs)))
+        for c in circs:
+            g = np.ascontiguousarray(c.Gates, dtype=GATE)
+            assert g.dtype.itemsize == 20
+            f.write(struct.pack("<IIII", len(g), c.NumWires, c.num_inputs, c.num_outputs) + g.tobytes())
+        f.write(struct.pack("<I", len(steps)))
+        for c, in_, out_ in steps:
+            f.write(struct.pack("<I", index[id(c)]) + np.asarray(in_, np.uint32).tobytes() + np.asarray(out_, np.uint32).tobytes())
+        f.write(struct.pack("<I", window))
+
+
+def run_native(name, key=bytes(range(32)), window=64):
+    """the same program driven by tools/stream_driver (plain C over the C ABI: what a cgo host sees, no interpreter
+    between the calls); the SHA-256 of its byte stream is checked against the oracle's like the Python-driven run's.
+    None if the driver has not been built."""
+    import subprocess
+    import tempfile
+    if not os.path.exists(NATIVE):
+        return None
+    steps, prim = PROGRAMS[name]()
+    rnd = stream_rnd(name, len(prim))
+    gates = sum(c.NumGates for c, _, _ in steps)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "program.bin")
+        write_program(path, key, rnd, prim, steps, window)
+        out = subprocess.run([NATIVE, path], check=True, capture_output=True, text=True, timeout=600).stdout
+    r = json.loads(out.strip().splitlines()[-1])
+    want = golden_sha(name, key)
+    if want is not None and want != r["sha256"]:
+        raise AssertionError("%s (native driver): stream SHA-256 %s != oracle's %s" % (name, r["sha256"], want))
+    return {"program": name, "host": "tools/stream_driver (C)", "steps": r["steps"], "window": window, "gates": gates,
+            "garble_gates_per_s": gates / r["garble_s"], "garble_us_per_step": r["garble_s"] / r["steps"] * 1e6,
+            "eval_gates_per_s": gates / r["eval_s"], "eval_us_per_step": r["eval_s"] / r["steps"] * 1e6,
+            "eval_blocks_matched": r["eval_blocks_matched"], "sha256": r["sha256"],
+            "sha256_ok": None if want is None else True}
+
+
 def run_for_line(key=bytes(range(32)), ctx=None):
     """the `stream` object of bench.py's line: the big-step program (bounded sample: 152 steps), the two uniform
     small-step programs and the mixed program; every SHA-256 checked against the oracle's"""
@@ -290,6 +343,18 @@ def run_for_line(key=bytes(range(32)), ctx=None):
         r = run_program(name, key, ctx)
         out[name] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
                                        "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
+    # the same programs with a C host in place of this interpreter (what a cgo caller gets)
+    native = {}
+    for name, win in (("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
+        try:
+            r = run_native(name, key, win)
+        except Exception as e:  # a side measurement: reported, never fatal for the bench line
+            r = {"error": str(e)[:200]}
+        if r is not None:
+            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
+                                                      "eval_us_per_step", "sha256_ok", "error")}
+    if native:
+        out["native_host"] = native
     out["published_reference"] = "1.4e7 gates/s, Go, i5-8257U (benchmarks.md:677-704: Ed25519 sign.mpcl streamed)"
     return out
 
@@ -307,5 +372,8 @@ if __name__ == "__main__":
         parts = nm.split(":")
         nm = parts[0]
         win = int(parts[1]) if len(parts) > 1 else 64
+        if len(parts) > 2 and parts[2] == "native":
+            print(json.dumps(run_native(nm, window=2 if nm.startswith("big") and win == 64 else win)), flush=True)
+            continue
         print(json.dumps(run_program(nm, window=2 if nm.startswith("big") and win == 64 else win,
                                      intern=not (len(parts) > 2 and parts[2] == "noh"))), flush=True)

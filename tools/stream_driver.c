@@ -1,0 +1,213 @@
+/* stream_driver.c — a streamed program driven through the C ABI from plain C, the way a cgo host would: no interpreter
+ * between the calls.  scripts/bench_stream.py writes the program (its circuits, its steps with their wire bindings, the
+ * key and the garbler's random stream) to a file, runs this, and reads back one line of timings and the SHA-256 of the
+ * garbler's bytes, which it compares with the oracle-made golden like its own runs.
+ *
+ * file format (little endian): "GCSP" u32 version=1 | u32 keylen, key | u64 rndlen, rnd | u32 nprim, prim ids |
+ *   u32 ncirc { u32 ngates u32 nwires u32 nin u32 nout, gates (gc_gate: 20 bytes each) } |
+ *   u32 nsteps { u32 circ, in[nin], out[nout] } | u32 window
+ * usage: stream_driver program.bin            -> {"garble_s": .., "eval_s": .., "bytes": .., "sha256": "..", ...}
+ *
+ * Build: gcc -O2 -I include tools/stream_driver.c -L mpc_amd/csrc -lgcengine -Wl,-rpath,... (oracle/Makefile-style recipe
+ * in __graft_entry__.build()). */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "gcengine.h"
+
+/* ---- SHA-256 (FIPS 180-4), for the byte stream ---- */
+typedef struct {
+    uint32_t h[8];
+    uint64_t len;
+    uint8_t buf[64];
+    size_t fill;
+} sha256_t;
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha_block(sha256_t *s, const uint8_t *p) {
+    uint32_t w[64], a, b, c, d, e, f, g, h;
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    a = s->h[0], b = s->h[1], c = s->h[2], d = s->h[3], e = s->h[4], f = s->h[5], g = s->h[6], h = s->h[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = h + (ROR(e, 6) ^ ROR(e, 11) ^ ROR(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+        const uint32_t t2 = (ROR(a, 2) ^ ROR(a, 13) ^ ROR(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    s->h[0] += a, s->h[1] += b, s->h[2] += c, s->h[3] += d, s->h[4] += e, s->h[5] += f, s->h[6] += g, s->h[7] += h;
+}
+static void sha_init(sha256_t *s) {
+    static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(s->h, iv, sizeof iv);
+    s->len = 0;
+    s->fill = 0;
+}
+static void sha_update(sha256_t *s, const uint8_t *p, size_t n) {
+    s->len += n;
+    if (s->fill) {
+        const size_t take = n < 64 - s->fill ? n : 64 - s->fill;
+        memcpy(s->buf + s->fill, p, take);
+        s->fill += take, p += take, n -= take;
+        if (s->fill == 64) sha_block(s, s->buf), s->fill = 0;
+    }
+    for (; n >= 64; p += 64, n -= 64) sha_block(s, p);
+    if (n) memcpy(s->buf, p, n), s->fill = n;
+}
+static void sha_final(sha256_t *s, char hex[65]) {
+    const uint64_t bits = s->len * 8;
+    uint8_t pad[72] = {0x80};
+    const size_t padn = (s->fill < 56 ? 56 : 120) - s->fill;
+    for (int i = 0; i < 8; i++) pad[padn + i] = (uint8_t)(bits >> (56 - 8 * i));
+    sha_update(s, pad, padn + 8);
+    for (int i = 0; i < 8; i++) sprintf(hex + 8 * i, "%08x", s->h[i]);
+}
+
+static double now_s(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define DIE(...) (fprintf(stderr, __VA_ARGS__), fprintf(stderr, " [%s]\n", gc_last_error()), exit(1))
+static void rd(FILE *f, void *p, size_t n) {
+    if (fread(p, 1, n, f) != n) DIE("stream_driver: short program file");
+}
+static uint32_t rd32(FILE *f) {
+    uint32_t v;
+    rd(f, &v, 4);
+    return v;
+}
+
+typedef struct {
+    uint32_t ngates, nwires, nin, nout, handle;
+    gc_gate *gates;
+} circ_t;
+typedef struct {
+    uint32_t circ;
+    uint32_t *in, *out;
+} step_t;
+
+int main(int argc, char **argv) {
+    if (argc < 2) DIE("usage: stream_driver program.bin");
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) DIE("stream_driver: cannot open %s", argv[1]);
+    char magic[4];
+    rd(f, magic, 4);
+    if (memcmp(magic, "GCSP", 4) || rd32(f) != 1) DIE("stream_driver: not a program file");
+    const uint32_t keylen = rd32(f);
+    uint8_t key[32];
+    if (keylen > 32) DIE("stream_driver: key length");
+    rd(f, key, keylen);
+    uint64_t rndlen;
+    rd(f, &rndlen, 8);
+    uint8_t *rnd = malloc(rndlen);
+    rd(f, rnd, rndlen);
+    const uint32_t nprim = rd32(f);
+    uint32_t *prim = malloc(4 * (size_t)nprim + 4);
+    rd(f, prim, 4 * (size_t)nprim);
+    const uint32_t ncirc = rd32(f);
+    circ_t *circ = calloc(ncirc, sizeof *circ);
+    for (uint32_t c = 0; c < ncirc; c++) {
+        circ[c].ngates = rd32(f), circ[c].nwires = rd32(f), circ[c].nin = rd32(f), circ[c].nout = rd32(f);
+        circ[c].gates = malloc(sizeof(gc_gate) * (size_t)circ[c].ngates);
+        rd(f, circ[c].gates, sizeof(gc_gate) * (size_t)circ[c].ngates);
+    }
+    const uint32_t nsteps = rd32(f);
+    step_t *step = calloc(nsteps, sizeof *step);
+    size_t cap = 64;
+    uint32_t max_wire = 0;
+    for (uint32_t k = 0; k < nsteps; k++) {
+        const uint32_t c = step[k].circ = rd32(f);
+        if (c >= ncirc) DIE("stream_driver: bad circuit index");
+        step[k].in = malloc(4 * (size_t)circ[c].nin + 4), step[k].out = malloc(4 * (size_t)circ[c].nout + 4);
+        rd(f, step[k].in, 4 * (size_t)circ[c].nin);
+        rd(f, step[k].out, 4 * (size_t)circ[c].nout);
+        cap += (size_t)circ[c].ngates * 61;
+        for (uint32_t i = 0; i < circ[c].nin; i++) max_wire = step[k].in[i] > max_wire ? step[k].in[i] : max_wire;
+        for (uint32_t i = 0; i < circ[c].nout; i++) max_wire = step[k].out[i] > max_wire ? step[k].out[i] : max_wire;
+    }
+    const uint32_t window = rd32(f);
+    fclose(f);
+
+    int st = 0;
+    gc_ctx *ctx = gc_ctx_create(0, &st);
+    if (!ctx) DIE("gc_ctx_create: %d", st);
+    uint8_t *bytes = malloc(cap);
+    size_t *sizes = malloc(sizeof(size_t) * (size_t)nsteps);
+    double garble_s = 0, eval_s = 0;
+    char hex[65] = "";
+    gc_label *in0 = malloc(sizeof(gc_label) * ((size_t)nprim + 1));
+    size_t total = 0;
+    for (int pass = 0; pass < 2; pass++) { /* the first pass loads the circuits and sizes the engine's buffers */
+        gc_stream *g = gc_stream_create(ctx, key, keylen, rnd, rndlen, prim, nprim, &st);
+        if (!g) DIE("gc_stream_create: %d", st);
+        for (uint32_t i = 0; i < nprim; i++) {
+            gc_wire w;
+            if (gc_stream_get_wire(g, prim[i], &w)) DIE("gc_stream_get_wire");
+            in0[i] = w.l0;
+        }
+        for (uint32_t c = 0; c < ncirc; c++)
+            if ((st = gc_stream_intern(g, circ[c].gates, circ[c].ngates, circ[c].nwires, circ[c].nin, circ[c].nout, &circ[c].handle)))
+                DIE("gc_stream_intern: %d", st);
+        size_t off = 0;
+        uint32_t issued = 0;
+        const double t0 = now_s();
+        for (uint32_t k = 0; k < nsteps; k++) {
+            const uint32_t lim = k + window < nsteps ? k + window : nsteps;
+            for (; issued < lim; issued++)
+                if ((st = gc_stream_garble_begin_h(g, circ[step[issued].circ].handle, step[issued].in, step[issued].out)))
+                    DIE("gc_stream_garble_begin_h(step %u): %d", issued, st);
+            size_t n = 0;
+            if ((st = gc_stream_garble_finish(g, bytes + off, cap - off, &n))) DIE("gc_stream_garble_finish(step %u): %d", k, st);
+            sizes[k] = n;
+            off += n;
+        }
+        garble_s = now_s() - t0;
+        total = off;
+        gc_stream_free(g);
+    }
+    sha256_t sh;
+    sha_init(&sh);
+    sha_update(&sh, bytes, total);
+    sha_final(&sh, hex);
+    uint64_t parsed = 0, matched = 0;
+    gc_label probe = {0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        gc_stream_eval *e = gc_stream_eval_create(ctx, key, keylen, &st);
+        if (!e) DIE("gc_stream_eval_create: %d", st);
+        for (uint32_t i = 0; i < nprim; i++)
+            if (gc_stream_eval_set_wire(e, prim[i], &in0[i])) DIE("gc_stream_eval_set_wire");
+        size_t off = 0;
+        const double t0 = now_s();
+        for (uint32_t k = 0; k < nsteps; k++) {
+            const circ_t *c = &circ[step[k].circ];
+            size_t used = 0;
+            if ((st = gc_stream_eval_circuit(e, c->ngates, c->nwires, max_wire + 1, bytes + off, sizes[k], &used)) || used != sizes[k])
+                DIE("gc_stream_eval_circuit(step %u): %d, used %zu of %zu", k, st, used, sizes[k]);
+            off += used;
+        }
+        if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe)) DIE("gc_stream_eval_get_wire"); /* waits for everything */
+        eval_s = now_s() - t0;
+        gc_stream_eval_stats(e, &parsed, &matched);
+        gc_stream_eval_free(e);
+    }
+    printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"bytes\": %zu, \"sha256\": \"%s\", "
+           "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\"}\n",
+           nsteps, window, garble_s, eval_s, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
+           (unsigned long long)probe.d0);
+    gc_ctx_destroy(ctx);
+    return 0;
+}
