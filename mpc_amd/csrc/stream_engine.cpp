@@ -1377,21 +1377,31 @@ struct SkelPool {
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    const EvalSkel *sk = nullptr;
-    const uint8_t *buf = nullptr;
-    gc_label *slab = nullptr;
-    uint64_t job = 0;
+    // the job on offer (written under mu; a worker copies it under mu when it wakes up)
+    struct Job {
+        const EvalSkel *sk = nullptr;
+        const uint8_t *buf = nullptr;
+        gc_label *slab = nullptr;
+        uint32_t id = 0;
+    } job;
     bool stop = false;
-    std::atomic<uint32_t> next{0}, done{0};
+    // next segment to hand out, tagged with the job it belongs to (id << 32 | index): a worker that was descheduled between
+    // its last segment of job k and its next look at the counter must not take — or skip — a segment of job k + 1
+    std::atomic<uint64_t> next{0};
+    std::atomic<uint32_t> done{0};
     std::atomic<bool> same{true};
     int helpers = -1;
 
-    void work() {
-        const uint32_t n = (uint32_t)sk->segs.size();
+    void work(const Job j) {
+        const uint32_t n = (uint32_t)j.sk->segs.size();
         for (;;) {
-            const uint32_t i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n) break;
-            if (same.load(std::memory_order_relaxed) && !sk->match_seg(sk->segs[i], buf, slab)) same.store(false, std::memory_order_relaxed);
+            uint64_t cur = next.load(std::memory_order_acquire);
+            if ((uint32_t)(cur >> 32) != j.id || (uint32_t)cur >= n) return;
+            if (!next.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) continue;
+            const uint32_t i = (uint32_t)cur;
+            if (same.load(std::memory_order_relaxed) && !j.sk->match_seg(j.sk->segs[i], j.buf, j.slab))
+                same.store(false, std::memory_order_relaxed);
+            // (the job cannot end before this increment: the caller waits for done == n)
             if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
                 std::lock_guard<std::mutex> lk(mu);
                 cv_done.notify_all();
@@ -1399,15 +1409,17 @@ struct SkelPool {
         }
     }
     void loop() {
-        uint64_t seen = 0;
+        uint32_t seen = 0;
         for (;;) {
+            Job j;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || job != seen; });
+                cv_work.wait(lk, [&] { return stop || job.id != seen; });
                 if (stop) return;
-                seen = job;
+                j = job;
+                seen = j.id;
             }
-            work();
+            work(j);
         }
     }
     bool match(const EvalSkel &s, const uint8_t *b, gc_label *rows) {
@@ -1423,14 +1435,18 @@ struct SkelPool {
         }
         if (th.empty())
             for (int i = 0; i < helpers; i++) th.emplace_back([this] { loop(); });
+        Job j;
         {
             std::lock_guard<std::mutex> lk(mu);
-            sk = &s, buf = b, slab = rows;
-            next.store(0), done.store(0), same.store(true);
-            job++;
+            job.sk = &s, job.buf = b, job.slab = rows;
+            job.id++;
+            j = job;
+            done.store(0, std::memory_order_relaxed);
+            same.store(true, std::memory_order_relaxed);
+            next.store((uint64_t)j.id << 32, std::memory_order_release);
         }
         cv_work.notify_all();
-        work();
+        work(j);
         const uint32_t n = (uint32_t)s.segs.size();
         if (done.load(std::memory_order_acquire) != n) {
             std::unique_lock<std::mutex> lk(mu);
