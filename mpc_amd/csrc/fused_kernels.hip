@@ -610,28 +610,19 @@ __device__ __forceinline__ void free_role(const Step &st, uint32_t n_free_lanes,
 }
 
 // hash waves H of a level with e_hash hash lanes and n_free free lanes (the other F = 16 - H waves stream the free lanes):
-// as few free waves as finish under the hash role, from a cost model fitted to the synthetic sweep (W = 1 024 / 16 384,
-// f = 0.17 / 0.5, both sides, H = 6 .. 15; ns):
-//   hash role  T = 2 500 (descriptor + operand round trip at the head of the level) + 700 per pass (of ~768 lanes)
-//              + 290 per 64 hash lanes (the AES: bound by the LDS array whatever H >= 6 is)
-//   free role  48 B per lane at 19 GB/s x F / (F + 1.7) (the memory pipe fills with the waves that feed it)
-//              = 2.53 n_free (1 + 1.7 / F)  <=  T   <=>   F >= 1.7 / (T / (2.53 n_free) - 1)
-// (closed form on purpose: a search over H with its two integer divisions per candidate cost 2.4 us of scalar code per level.)
-// tune != 0: H fixed, for measurements.
+// the waves are shared out in proportion to the work, a hash lane counting 3.4 free lanes — the ratio at which both sides
+// of the synthetic sweep have their optimum in steady state (W = 1 024 / 16 384, f = 0.17, H = 7 .. 14 measured after ten
+// warm-up passes: garbler, 2 784 hash lanes against 3 400 free ones, best with F = 4; evaluator, 1 392 against 3 400, with
+// F = 7; f = 0.5: F = 1 - 2; profiles/r03_exp_hbm_wire_overlap.txt).  No free gates -> 16, no hashed gates -> 0, never more
+// hash waves than the level has lanes for.  tune != 0: H fixed, for measurements.
 __device__ __forceinline__ uint32_t role_hash_waves(uint32_t e_hash, uint32_t n_free, uint32_t tune) {
     if (n_free == 0) return 16;
     if (e_hash == 0) return 0;
     const uint32_t need = (e_hash + 63) >> 6;
     if (tune) return need < tune ? need : tune;
-    // integers, thousandths of a ns: F = ceil(4.301 n_free / (T - 2.53 n_free)), at most 8 free waves
-    const uint32_t t_hash = 2500u + 58u * (need + 11u) + 290u * need;
-    const uint32_t num = 4301u * n_free, sub = 2530u * n_free, tt = 1000u * t_hash;
-    uint32_t F = 8;
-    if (tt > sub) {
-        const uint32_t den = tt - sub;
-        F = (num + den - 1) / den;
-        F = F < 1 ? 1 : F > 8 ? 8 : F;
-    }
+    const uint32_t den = 10u * n_free + 34u * e_hash;
+    uint32_t F = (160u * n_free + (den >> 1)) / den;
+    F = F < 1 ? 1 : F > 8 ? 8 : F;
     const uint32_t H = 16 - F;
     return need < H ? need : H;
 }
