@@ -392,7 +392,7 @@ def main():
         if not args.no_host_api and aes:
             # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
             from scripts.bench_host_api import run as host_api_run
-            res["host_api"] = host_api_run(batch, 3, key)
+            res["host_api"] = host_api_run(batch, 8, key)
         if not args.no_stream and aes:
             # config 5 shape: ONE instance through gc_stream_* (garbler pipelined, evaluator over the produced bytes);
             # bounded samples of scripts/bench_stream.py, SHA-256 of the byte streams checked against the oracle-made
