@@ -3,6 +3,7 @@
 OT/s per side and algorithmic GB/s (32 B per OT per side).  Prints one JSON line."""
 import json
 import os
+import time
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,13 +35,19 @@ def run(n=1 << 22, reps=10, device=0, ctx=None):
     d_lr = ctx.zeros((n, 16))
     d_ls = ctx.zeros((n, 16))
     rms, sms = [], []
-    for it in range(reps + 2):
+    # steady state: the GPU's clocks need ~30 ms of load after the host-side set-up above (profiles/r03_exp_hbm_wire_overlap.txt)
+    t_warm, it = time.perf_counter(), 0
+    while it < 2 or time.perf_counter() - t_warm < 0.04:
         rx.receive_dev(d_choice, n, d_u, d_lr)
         tx.send_dev(d_u, n, d_ls)
         ctx.sync()
-        if it >= 2:
-            rms.append(rx.last_ms)
-            sms.append(tx.last_ms)
+        it += 1
+    for it in range(max(reps, 10)):
+        rx.receive_dev(d_choice, n, d_u, d_lr)
+        tx.send_dev(d_u, n, d_ls)
+        ctx.sync()
+        rms.append(rx.last_ms)
+        sms.append(tx.last_ms)
     # correlation check on the last round (iknp_test.go:98-113): rcvd = sent ^ b*delta
     lr = d_lr.numpy().view(np.uint64).reshape(n, 2)
     ls = d_ls.numpy().view(np.uint64).reshape(n, 2)

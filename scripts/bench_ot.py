@@ -14,8 +14,13 @@ from mpc_amd.circuit import LABEL, WIRE
 
 
 def timed(ctx, fn, reps):
-    fn()
-    ctx.sync()
+    # steady state: warm up for >= 2 calls and 40 ms (clocks ramp after host-side set-up), then time >= 10 calls
+    t_warm, it = time.perf_counter(), 0
+    while it < 2 or time.perf_counter() - t_warm < 0.04:
+        fn()
+        ctx.sync()
+        it += 1
+    reps = max(reps, 10)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
