@@ -739,6 +739,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
         a.te0 = b->circ->ctx->d_te0;
         a.rounds = b->rounds;
         a.prof = b->d_prof;
+        a.narrow_col = !std::getenv("GC_NO_COL") && fused_col_form_fits(p.levels.data(), (uint32_t)p.levels.size(), b->g.ti_log2);
         // ONE instance of a wide circuit (a streamed SSA-step circuit): a single workgroup on one CU would walk it alone.
         // When the levels average >= 2.5 passes of 1024 lanes, spread every level's passes over workgroups, one launch
         // per level, recorded once in a hipGraph per (pass, key size, table pointer) and replayed.

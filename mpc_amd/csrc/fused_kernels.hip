@@ -296,6 +296,205 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
 }
 
 
+// ---- narrow levels, column-sliced: four lanes per AES block -------------------------------------------------------------
+// A level of ONE pass is bound by one wave's instruction issue (a lone wave issues one VALU per 2.5 ns whatever the opcode,
+// DESIGN §4): ~520 instructions for the pass around the hash plus 14 x 48 for a wide-form AES = 3.0 us per level on the
+// synthetic W = 64 rows (profiles/r03_exp_hbm_wire_overlap.txt).  When the level has no OR gate and its lanes still fit one
+// pass with FOUR lanes per block, it runs column-sliced like the narrow units of the flat kernels (aes_device.h:
+// hash_col_whitened; fused_flat_kernels.hip: garble_hash_narrow): one 32-bit state column per lane, ~15 instructions per
+// round, the hash lanes spread over four times the waves — SIMDs that were idle.  Same arithmetic as the wide form: label
+// word W_c (big-endian column c) sits at dword c ^ 1; the q ^ 1 / q ^ 2 partners of a gate are 4 / 8 lanes away inside the
+// row of 16.  Lane space of such a level: [4 x wide hash lanes | free lanes], J = threadIdx.x.
+constexpr uint32_t kColKeyTab = kTeDualBytes;  // LDS byte address of the column-addressable round keys (behind the table)
+
+template <int NR>
+__device__ __forceinline__ void load_col_keys(uint32_t *te, const uint32_t *__restrict__ rk) {
+    if (threadIdx.x < 4 * (NR + 1)) {  // the last round key folded with the first (the hashes run on whitened blocks)
+        uint32_t kv = rk[threadIdx.x];
+        if (threadIdx.x >= 4 * NR) kv ^= rk[threadIdx.x - 4 * NR];
+        te[kColKeyTab / 4 + threadIdx.x] = kv;
+    }
+}
+__device__ __forceinline__ uint32_t col_pair4(uint32_t v) {  // value of the lane 4 further on (q even) / 4 back (q odd)
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, 0x114, 0xf, 0xa, false);
+}
+__device__ __forceinline__ uint32_t col_whiten(uint32_t xc, uint32_t xc1, uint32_t c, uint32_t tweak, uint32_t k0) {
+    const uint32_t kcol = __builtin_amdgcn_alignbit(xc, c == 3 ? 0u : xc1, 31);
+    return xor3(kcol, c == 3 ? tweak : 0u, k0);
+}
+__device__ __forceinline__ uint32_t label_word(const uint4 *label, uint32_t byte_off) {
+    return *(const uint32_t *)((const char *)label + byte_off);
+}
+// lanes of a level in column form (LQA / LQI: log2 of the wide lanes per AND / INV gate-instance); 0xffffffff: has OR gates
+template <int LQA, int LQI>
+__device__ __forceinline__ uint32_t col_lanes(const Step &st, uint32_t ti_log2) {
+    if (st.n_or) return 0xffffffffu;
+    return ((((st.n_and << ti_log2) << LQA) + ((st.n_inv << ti_log2) << LQI)) << 2) + ((st.count - st.nonfree) << ti_log2);
+}
+// this lane's place in the column form and its gate's descriptor (fetched before the previous level's barrier)
+struct ColPos {
+    uint32_t kind, g, inst, q, c;  // kind: K_AND / K_INV / K_FREE / K_NONE
+};
+template <int LQA, int LQI>
+__device__ __forceinline__ ColPos col_classify(const Step &st, uint32_t J, uint32_t ti_log2, uint32_t tim) {
+    ColPos p{K_NONE, 0, 0, 0, 0};
+    const uint32_t e_and = ((st.n_and << ti_log2) << LQA) << 2, ncol = e_and + (((st.n_inv << ti_log2) << LQI) << 2);
+    if (J < e_and) {
+        const uint32_t w = J >> 2;
+        p.kind = K_AND, p.c = J & 3u, p.q = w & ((1u << LQA) - 1), p.inst = (w >> LQA) & tim, p.g = w >> (ti_log2 + LQA);
+    } else if (J < ncol) {
+        const uint32_t w = (J - e_and) >> 2;
+        p.kind = K_INV, p.c = J & 3u, p.q = w & ((1u << LQI) - 1), p.inst = (w >> LQI) & tim, p.g = st.n_and + (w >> (ti_log2 + LQI));
+    } else if (J - ncol < ((st.count - st.nonfree) << ti_log2)) {
+        const uint32_t u = J - ncol;
+        p.kind = K_FREE, p.inst = u & tim, p.g = st.nonfree + (u >> ti_log2);
+    }
+    return p;
+}
+
+template <int NR>
+__device__ __forceinline__ void garble_col_pass(const Step &st, const ColPos &p, const GateDesc &d, uint32_t ninputs,
+                                                uint32_t ti_log2, uint32_t TI, uint4 *Wt, uint4 *Tt, const uint4 *Rt, uint32_t lo) {
+    if (p.kind == K_NONE) return;
+    const uint32_t inst = p.inst;
+    uint4 *outl = Wt + ((size_t)(ninputs + st.first + p.g) << ti_log2) + inst;
+    const uint4 *la = Wt + ((size_t)d.in0 << ti_log2) + inst;
+    if (p.kind == K_FREE) {
+        uint4 v = lxor(*la, Wt[((size_t)d.in1 << ti_log2) + inst]);
+        if ((d.row_op >> kOpShift) == GC_XNOR) v = lxor(v, Rt[inst]);  // garble.go:342-351
+        *outl = v;
+        return;
+    }
+    const uint32_t c = p.c, q = p.q, wo = (c ^ 1u) << 2, wo1 = (((c + 1u) ^ 1u) << 2) & 12u;
+    const uint4 *lb = p.kind == K_AND ? Wt + ((size_t)d.in1 << ti_log2) + inst : la;
+    const uint4 *lown = (q & 2u) ? lb : la;  // INV lanes have q < 2
+    const uint32_t keyaddr = kColKeyTab + (c << 2);
+    const uint32_t bc = label_word(lown, wo), bc1 = label_word(lown, wo1);
+    const uint32_t a0c = label_word(la, wo), a0y = label_word(la, 4), b0y = label_word(lb, 4);
+    const uint32_t rc = label_word(Rt + inst, wo), rc1 = label_word(Rt + inst, wo1);
+    const uint32_t k0 = *(lds_u32 *)(uintptr_t)keyaddr;
+    const uint32_t modd = (q & 1u) ? ~0u : 0u;
+    const uint32_t xc = __builtin_amdgcn_bitop3_b32(bc, rc, modd, 0x78), xc1 = __builtin_amdgcn_bitop3_b32(bc1, rc1, modd, 0x78);
+    const uint32_t h = hash_col_whitened<NR>(col_whiten(xc, xc1, c, d.tweak + (q >> 1), k0), keyaddr, lo);
+    char *row0 = (char *)(Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst) + wo;
+    const uint32_t pp = h ^ col_pair4(h);
+    if (p.kind == K_AND) {  // garble.go:353-395, one column
+        const uint32_t m2 = (q & 2u) ? ~0u : 0u;
+        const uint32_t pa = (uint32_t)((int32_t)a0y >> 31), pb = (uint32_t)((int32_t)b0y >> 31);
+        const uint32_t mk = m2 ? pb : pa, rm = pb & ~m2;
+        const uint32_t w = __builtin_amdgcn_bitop3_b32(pp, rc, rm, 0x78);
+        const uint32_t tab = __builtin_amdgcn_bitop3_b32(w, a0c, m2, 0x78);
+        const uint32_t v = __builtin_amdgcn_bitop3_b32(h, w, mk, 0x78);
+        if (!(q & 1u)) *(uint32_t *)(row0 + (((q & 2u) ? (size_t)TI : 0) << 4)) = tab;
+        uint32_t o = v ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // the q ^ 2 partner: row_ror:8
+        asm volatile("" : "+v"(o));
+        if (q == 0) *(uint32_t *)((char *)outl + wo) = o;
+    } else if (q == 0) {  // INV, garble.go:446-474
+        *(uint32_t *)row0 = pp ^ rc;
+        *(uint32_t *)((char *)outl + wo) = h ^ (((int32_t)a0y < 0) ? pp : rc);
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void eval_col_pass(const Step &st, const ColPos &p, const GateDesc &d, uint32_t ninputs,
+                                              uint32_t ti_log2, uint32_t TI, uint4 *Wt, const uint4 *Tt, uint32_t lo) {
+    if (p.kind == K_NONE) return;
+    const uint32_t inst = p.inst;
+    uint4 *outl = Wt + ((size_t)(ninputs + st.first + p.g) << ti_log2) + inst;
+    const uint4 *la = Wt + ((size_t)d.in0 << ti_log2) + inst;
+    if (p.kind == K_FREE) {  // eval.go:49-51
+        *outl = lxor(*la, Wt[((size_t)d.in1 << ti_log2) + inst]);
+        return;
+    }
+    const uint32_t c = p.c, q = p.q, wo = (c ^ 1u) << 2, wo1 = (((c + 1u) ^ 1u) << 2) & 12u;
+    const uint4 *lb = p.kind == K_AND ? Wt + ((size_t)d.in1 << ti_log2) + inst : la;
+    const uint4 *lown = q ? lb : la;  // AND lane 1 hashes operand b (INV: q = 0)
+    const uint32_t keyaddr = kColKeyTab + (c << 2);
+    const uint32_t tab = label_word(Tt + ((size_t)(d.row_op & kRowMask) << ti_log2) + inst + (q ? TI : 0u), wo);
+    const uint32_t xc = label_word(lown, wo), xc1 = label_word(lown, wo1), xy = label_word(lown, 4);
+    const uint32_t ac = label_word(la, wo), k0 = *(lds_u32 *)(uintptr_t)keyaddr;
+    const uint32_t h = hash_col_whitened<NR>(col_whiten(xc, xc1, c, d.tweak + q, k0), keyaddr, lo);
+    const uint32_t sm = (uint32_t)((int32_t)xy >> 31);
+    if (p.kind == K_AND) {  // eval.go:53-78: lane 0 WG = H(a) ^ (sa ? TG : 0), lane 1 WE = H(b) ^ (sb ? TE ^ a : 0)
+        const uint32_t v = __builtin_amdgcn_bitop3_b32(h, __builtin_amdgcn_bitop3_b32(tab, ac, q ? ~0u : 0u, 0x78), sm, 0x78);
+        uint32_t o = v ^ (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x104, 0xf, 0xf, true);  // + the lane 4 further on (q = 1)
+        asm volatile("" : "+v"(o));
+        if (q == 0) *(uint32_t *)((char *)outl + wo) = o;
+    } else {  // eval.go:96-109
+        *(uint32_t *)((char *)outl + wo) = __builtin_amdgcn_bitop3_b32(h, tab, sm, 0x78);
+    }
+}
+
+// circuits whose EVERY level runs column-sliced in one pass — two for the odd wider level — (no OR gate anywhere, 4 x hash
+// lanes + free lanes <= 2 048 at this tile size; the host decides: FusedArgs::narrow_col): a loop of [this lane's gate, fetched before the barrier | pass | barrier]
+template <int NR>
+__global__ __launch_bounds__(kFusedThreads) void k_garble_col(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
+                                                              uint32_t nsteps, uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
+                                                              size_t t_tile, uint4 *__restrict__ W, const uint4 *__restrict__ Rv,
+                                                              uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
+                                                              const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeDualBytes / 4 + 64];  // + the column-addressable round keys (kColKeyTab)
+    __shared__ uint4 Rt[64];
+    load_te_dual(te, g_te0);
+    load_col_keys<NR>(te, rk);
+    const uint32_t TI = 1u << ti_log2, tim = TI - 1;
+    if (threadIdx.x < TI) Rt[threadIdx.x] = Rv[(size_t)blockIdx.x * TI + threadIdx.x];
+    __syncthreads();
+    const uint32_t lo = te_lane_off();
+    uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
+    uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
+    Step st_next = steps[0];
+    ColPos cp_next = col_classify<2, 1>(st_next, threadIdx.x, ti_log2, tim);
+    GateDesc d_next = descs[st_next.first + cp_next.g];
+    for (uint32_t lv = 0; lv < nsteps; lv++) {
+        const Step st = st_next;
+        garble_col_pass<NR>(st, cp_next, d_next, ninputs, ti_log2, TI, Wt, Tt, Rt, lo);
+        for (uint32_t J = kFusedThreads; J < col_lanes<2, 1>(st, ti_log2); J += kFusedThreads) {  // a level of a second pass
+            const ColPos cp = col_classify<2, 1>(st, J + threadIdx.x, ti_log2, tim);
+            garble_col_pass<NR>(st, cp, descs[st.first + cp.g], ninputs, ti_log2, TI, Wt, Tt, Rt, lo);
+        }
+        if (lv + 1 < nsteps) {
+            st_next = steps[lv + 1];
+            cp_next = col_classify<2, 1>(st_next, threadIdx.x, ti_log2, tim);
+            d_next = descs[st_next.first + cp_next.g];
+        }
+        __syncthreads();
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(kFusedThreads) void k_eval_col(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
+                                                            uint32_t nsteps, uint32_t ninputs, uint32_t ti_log2, size_t w_tile,
+                                                            size_t t_tile, uint4 *__restrict__ W, const uint4 *__restrict__ T,
+                                                            const uint32_t *__restrict__ rk, const uint32_t *__restrict__ g_te0) {
+    __shared__ uint32_t te[kTeDualBytes / 4 + 64];
+    load_te_dual(te, g_te0);
+    load_col_keys<NR>(te, rk);
+    __syncthreads();
+    const uint32_t TI = 1u << ti_log2, tim = TI - 1;
+    const uint32_t lo = te_lane_off();
+    uint4 *Wt = W + (size_t)blockIdx.x * w_tile;
+    const uint4 *Tt = T + (size_t)blockIdx.x * t_tile;
+    Step st_next = steps[0];
+    ColPos cp_next = col_classify<1, 0>(st_next, threadIdx.x, ti_log2, tim);
+    GateDesc d_next = descs[st_next.first + cp_next.g];
+    for (uint32_t lv = 0; lv < nsteps; lv++) {
+        const Step st = st_next;
+        eval_col_pass<NR>(st, cp_next, d_next, ninputs, ti_log2, TI, Wt, Tt, lo);
+        for (uint32_t J = kFusedThreads; J < col_lanes<1, 0>(st, ti_log2); J += kFusedThreads) {
+            const ColPos cp = col_classify<1, 0>(st, J + threadIdx.x, ti_log2, tim);
+            eval_col_pass<NR>(st, cp, descs[st.first + cp.g], ninputs, ti_log2, TI, Wt, Tt, lo);
+        }
+        if (lv + 1 < nsteps) {
+            st_next = steps[lv + 1];
+            cp_next = col_classify<1, 0>(st_next, threadIdx.x, ti_log2, tim);
+            d_next = descs[st_next.first + cp_next.g];
+        }
+        __syncthreads();
+    }
+}
+
 // ---- wide levels: hash waves and free waves ----------------------------------------------------------------------------
 // A level of several passes used to run as load -> wait -> hash -> store per group of four passes with all sixteen waves in
 // step, and the label traffic and the AES time of a level ADDED UP (profiles/r03_exp_hbm_wire_overlap.txt: the cost of the
@@ -1043,9 +1242,34 @@ static uint32_t tune_env() {
     return e ? (uint32_t)atoi(e) : 0u;
 }
 
+// every level of the circuit fits one or two column-sliced passes at this tile size (garbler lanes; the evaluator's are fewer)
+bool fused_col_form_fits(const Step *levels, uint32_t nsteps, uint32_t ti_log2) {
+    uint32_t hashed = 0;
+    for (uint32_t i = 0; i < nsteps; i++) {
+        const Step &st = levels[i];
+        if (st.n_or) return false;
+        const uint64_t lanes = ((((uint64_t)st.n_and << 2) + ((uint64_t)st.n_inv << 1)) << 2) + (st.count - st.nonfree);
+        if ((lanes << ti_log2) > 2u * (uint64_t)kFusedThreads) return false;  // (the kernels loop over a second pass)
+        hashed += st.nonfree;
+    }
+    return hashed != 0;  // (a circuit without hashed gates gains nothing from the form)
+}
+
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
+    if (a.narrow_col && !a.prof) {
+#define GC_GN(NR)                                                                                                          \
+    hipLaunchKernelGGL((k_garble_col<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, g.ti_log2,            \
+                       g.lw.tile_stride, g.lt.tile_stride, a.W, a.R, a.T, a.rk, a.te0)
+        switch (a.rounds) {
+        case 10: GC_GN(10); break;
+        case 12: GC_GN(12); break;
+        default: GC_GN(14); break;
+        }
+#undef GC_GN
+        return;
+    }
 #define GC_GF(NR)                                                                                               \
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_garble_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,    \
@@ -1064,6 +1288,18 @@ void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) 
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.nsteps == 0) return;
     dim3 grid(g.ntiles), block(kFusedThreads);
+    if (a.narrow_col && !a.prof) {
+#define GC_EN(NR)                                                                                                          \
+    hipLaunchKernelGGL((k_eval_col<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, g.ti_log2,              \
+                       g.lw.tile_stride, g.lt.tile_stride, a.W, (const uint4 *)a.T, a.rk, a.te0)
+        switch (a.rounds) {
+        case 10: GC_EN(10); break;
+        case 12: GC_EN(12); break;
+        default: GC_EN(14); break;
+        }
+#undef GC_EN
+        return;
+    }
 #define GC_EF(NR)                                                                                               \
     if (a.prof)                                                                                                 \
         hipLaunchKernelGGL((k_eval_fused<NR, true>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs,      \

@@ -73,7 +73,9 @@ struct FusedArgs {
     const uint32_t *te0;
     int rounds;
     uint64_t *prof;  // optional [ntiles][8] cycle breakdown (debug), nullptr in production
+    bool narrow_col; // every level fits one column-sliced pass (fused_col_form_fits): k_garble_col / k_eval_col
 };
+bool fused_col_form_fits(const Step *levels, uint32_t nsteps, uint32_t ti_log2);
 void launch_garble_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 // ONE instance with wires in HBM: one launch per level, pass k of the level = workgroup k (lanes along the gates);

@@ -478,6 +478,29 @@ def test_global_wire_kernels_hash_and_free_waves(ctx):
     check_garble_eval(ctx, c, KEY128, 1027, "roles1027", check_all_wires=False, schedule=1, sample=[0, 3, 512, 1023, 1026])
 
 
+@pytest.mark.parametrize("batch", [3, 520, 1030])
+def test_global_wire_kernels_column_sliced_narrow_levels(ctx, batch):
+    """a deep circuit of narrow levels WITHOUT OR gates, live labels beyond the LDS plans: every level runs column-sliced
+    (four lanes per AES block, k_garble_col / k_eval_col) — ANDs, INVs, XORs and XNORs; at the largest tile size some levels
+    need a second pass; every wire against the oracle for the small batch, sampled instances for the others; and the same
+    circuit with GC_NO_COL (the wide form) for the small batch"""
+    c = synthetic_levelised(700, 64, 0.2, seed=79, ninputs=64, inv_frac=0.08, xnor_frac=0.1)
+    assert c.stats()["OR"] == 0
+    dc = engine.DeviceCircuit(ctx, c)
+    b = engine.Batch(dc, batch)
+    assert not b.lds_wires, "expected the HBM-wire kernels (live labels %d)" % dc.info.n_flat_slots
+    b.close(); dc.close()
+    sample = None if batch < 10 else [0, 1, 255, 256, batch - 2, batch - 1]
+    check_garble_eval(ctx, c, KEY256, batch, "col%d" % batch, check_all_wires=(batch < 10), schedule=1, sample=sample)
+    if batch < 10:
+        check_garble_eval(ctx, c, KEY128, batch, "colk128", check_all_wires=True, schedule=1)
+        os.environ["GC_NO_COL"] = "1"
+        try:
+            check_garble_eval(ctx, c, KEY256, batch, "colwide", check_all_wires=True, schedule=1)
+        finally:
+            del os.environ["GC_NO_COL"]
+
+
 @pytest.mark.parametrize("batch", [2, 520])
 def test_global_wire_kernels_narrow_deep_circuit(ctx, batch):
     """the same kernels on levels of a single pass (their single-pass instantiation with the descriptor prefetched
