@@ -224,14 +224,14 @@ __device__ __forceinline__ void garble_group(const Step &st, const uint32_t t0, 
     GC_PROF_MARK(2)
 }
 
-template <int NR, bool PROF, int G, bool PRE = true, bool COH = false>
+template <int NR, bool PROF, int G, bool PRE = true, bool COH = false, bool PRE_TAB = false>
 __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, const int n_kind, const uint32_t n_g,
                                            const uint32_t n_inst, const uint32_t n_q, const uint32_t n_in0,
                                            const uint32_t n_in1, const uint32_t n_tweak, const uint32_t n_row_op, const GateDesc *__restrict__ descs,
                                            uint32_t ninputs, uint32_t ti_log2, uint32_t tim, uint32_t TI, uint4 *Wt,
                                            const uint4 *Tt, const uint32_t (&rkr)[4 * (NR + 1)], const uint32_t *te,
                                            uint32_t lo, uint64_t (&pacc)[4], uint64_t &plast,
-                                           const uint32_t lane_limit = kFusedThreads) {
+                                           const uint32_t lane_limit = kFusedThreads, const uint4 n_tab = uint4{0, 0, 0, 0}) {
     LanePos lp[G];
     GateDesc d[G];
     uint4 va[G], vb[G], tab[G];
@@ -256,7 +256,8 @@ __device__ __forceinline__ void eval_group(const Step &st, const uint32_t t0, co
         va[p] = load_label<COH>(Wt + ((size_t)((kind == K_AND && q) ? d[p].in1 : d[p].in0) << ti_log2) + inst);
         if (kind == K_FREE || kind == K_OR) vb[p] = load_label<COH>(Wt + ((size_t)d[p].in1 << ti_log2) + inst);
         const uint4 *row = Tt + ((size_t)(d[p].row_op & kRowMask) << ti_log2) + inst;
-        if (kind == K_AND) tab[p] = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
+        if (PRE_TAB && PRE && t0 == 0 && p == 0) tab[p] = n_tab;  // fetched with the descriptor, before the level's barrier
+        else if (kind == K_AND) tab[p] = row[q ? TI : 0];  // lane 0: TG, lane 1: TE
         else if (kind == K_INV) tab[p] = row[0];
     }
     GC_PROF_MARK(1)
@@ -1113,6 +1114,12 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
     }
 }
 
+// the table row an evaluator lane of ONE instance needs (TG for AND lane 0, TE for lane 1, the INV row)
+__device__ __forceinline__ uint4 eval_tab_row(const LanePos &lp, const GateDesc &d, const uint4 *T) {
+    if (lp.kind != K_AND && lp.kind != K_INV) return make_uint4(0, 0, 0, 0);
+    return T[(size_t)(d.row_op & kRowMask) + ((lp.kind == K_AND && lp.q) ? 1u : 0u)];
+}
+
 template <int NR>
 __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
                                                             uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
@@ -1133,13 +1140,14 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
     Step st_next = steps[0];
     LanePos lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    uint4 tab_next = eval_tab_row(lp_next, d_next, T);
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t chunks = (level_lanes<1, 0, 0>(st, 0u) + 63u) >> 6;
         if (c0 < chunks)
-            eval_group<NR, false, 1, true, true>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1,
-                                                 d_next.tweak, d_next.row_op, descs, ninputs, 0u, 0u, 1u, W, T, rkr, te, lo, pacc,
-                                                 plast, kCoopThreads);
+            eval_group<NR, false, 1, true, true, true>(st, 0u, lp_next.kind, lp_next.g, lp_next.inst, lp_next.q, d_next.in0, d_next.in1,
+                                                       d_next.tweak, d_next.row_op, descs, ninputs, 0u, 0u, 1u, W, T, rkr, te, lo,
+                                                       pacc, plast, kCoopThreads, tab_next);
         for (uint32_t c = c0 + stride; c < chunks; c += stride)
             eval_group<NR, false, 1, false, true>(st, (c - wave) << 6, 0, 0u, 0u, 0u, 0u, 0u, 0u, 0u, descs, ninputs, 0u, 0u, 1u, W, T,
                                                   rkr, te, lo, pacc, plast, kCoopThreads);
@@ -1148,6 +1156,9 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
             st_next = steps[lv + 1];
             lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
+            // the table row too: it is constant during the pass and comes from HBM (the rows were copied in, not written
+            // by this pass), the longest round trip of a level — under the barrier wait instead of behind it
+            tab_next = eval_tab_row(lp_next, d_next, T);
             coop_wait(ctl, lv + 1);
         }
     }
