@@ -87,6 +87,10 @@ static bool coop_ready(gc_ctx *c) {
         std::fprintf(stderr, "[gc trace] coop self-test: %s, error %u bad %u, 128 barriers in %u ticks\n", ok ? "passed" : "FAILED",
                      h->error, h->bad, h->ticks);
     *c->h_coop_err = 0;
+    // the passes find the counters at zero and leave them so
+    CoopCtl zero{};
+    if (hipHostGetDevicePointer((void **)&zero.host_err, c->h_coop_err, 0) != hipSuccess || !zero.host_err) return false;
+    if (hipMemcpy(c->d_coop, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) return false;
     if (ok) c->coop_state = 1;
     return ok;
 }
@@ -539,6 +543,7 @@ static hipError_t alloc_buffers(gc_batch *b) {
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_R, (size_t)b->g.bstride * sizeof(uint4));
     if (e == hipSuccess)
         e = hipMemsetAsync(b->d_R, 0, (size_t)b->g.bstride * sizeof(uint4), b->circ->ctx->stream);
+    b->r_known = false;
     return e;
 }
 
@@ -671,6 +676,16 @@ static bool uses_flat(const gc_batch *b) {
     return b->schedule == 1 && b->g.lds_wires && want_flat(b) && !b->circ->plan.p.fl_units.empty();
 }
 
+// ONE instance of a wide circuit with its wires in HBM (a streamed SSA-step circuit): levels averaging >= 2.5 passes of
+// 1024 lanes are spread over workgroups (run_levels)
+static bool wide_one_instance(const gc_batch *b, bool eval) {
+    const Plan &p = b->circ->plan.p;
+    if (b->schedule != 1 || b->g.lds_wires || b->g.batch != 1 || b->d_prof || p.levels.size() < 2) return false;
+    uint64_t passes = 0;
+    for (const Step &st : p.levels) passes += level1_passes(st, eval);
+    return passes * 2 >= (uint64_t)p.levels.size() * 5;
+}
+
 static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd = nullptr) {
     hipStream_t s = b->circ->ctx->stream;
     const Plan &p = b->circ->plan.p;
@@ -743,17 +758,14 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
         // ONE instance of a wide circuit (a streamed SSA-step circuit): a single workgroup on one CU would walk it alone.
         // When the levels average >= 2.5 passes of 1024 lanes, spread every level's passes over workgroups, one launch
         // per level, recorded once in a hipGraph per (pass, key size, table pointer) and replayed.
-        if (b->g.batch == 1 && !b->d_prof && a.nsteps >= 2) {
-            uint64_t passes = 0;
-            for (const Step &st : p.levels) passes += level1_passes(st, eval);
-            if (passes * 2 >= (uint64_t)a.nsteps * 5) {
+        if (wide_one_instance(b, eval)) {
+            {
                 if (coop_ready(b->circ->ctx)) {  // ONE launch: 32 workgroups of one XCD behind a barrier in its L2
                     gc_ctx *cx = b->circ->ctx;
-                    launch_coop(eval, a, cx->d_coop, s);
+                    // a workgroup that gives up raises the pinned word *h_coop_err itself (no copy per pass); it stays up
+                    // until gc_ctx_coop_check (gc_ctx_sync, gc_pass_dev, the streaming calls that hand results out) reports it
+                    launch_coop(eval, a, cx->d_coop, b->xchg, s);
                     GC_HIP(hipGetLastError());
-                    // the flag stays up on the device once raised, so every later copy repeats it until gc_ctx_coop_check
-                    // (gc_ctx_sync, gc_pass_dev, the streaming calls that hand results out) has reported it
-                    GC_HIP(hipMemcpyAsync(cx->h_coop_err, &cx->d_coop->error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     b->last_launches = 1;
                     return GC_OK;
                 }
@@ -837,6 +849,7 @@ int gc_batch_garble(gc_batch *b, const uint8_t *key, size_t keylen, const void *
     GC_HIP(hipSetDevice(ctx->device));
     int rc = set_key(b, key, keylen);
     if (rc != GC_OK) return rc;
+    b->r_known = false;  // (drawn on the device)
     const Plan &p = b->circ->plan.p;
     // the flattened fused kernel draws R and the input labels itself; the other schedules get them from a small
     // initialisation kernel (outside the timed bracket)
@@ -1225,6 +1238,19 @@ uint32_t gc_batch_last_launches(gc_batch *b) { return b ? b->last_launches : 0; 
 
 // ---- host-buffer API -------------------------------------------------------------------------
 
+// R of a one-instance pass from the host: a stream garbles every circuit under the same R, and the pooled batch it gets
+// back usually holds it already (a copy per pass is a blit kernel plus its gaps on the stream)
+static hipError_t upload_r(gc_batch *b, const gc_label *r) {
+    if (b->r_known && std::memcmp(&b->r_host, r, sizeof(gc_label)) == 0) return hipSuccess;
+    b->r_known = false;
+    hipError_t e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, b->circ->ctx->stream);
+    if (e == hipSuccess) {
+        b->r_host = *r;
+        b->r_known = true;
+    }
+    return e;
+}
+
 static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
     int schedule;
     bool single_phase;
@@ -1363,7 +1389,7 @@ int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const g
         hipError_t e = hipSetDevice(ctx->device);
         b->store_all = false;
         if (e == hipSuccess && (rc = relayout(b)) != GC_OK) break;  // before anything is written into the arrays
-        if (e == hipSuccess) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = upload_r(b, r);
         if (e != hipSuccess) {
             set_error("gc_garble_labels", e);
             rc = GC_E_HIP;
@@ -1416,13 +1442,20 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b) {
 
 int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
                 const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
-                gc_batch **bout) {
+                gc_batch **bout, const gc::StoreXchg *d_xchg) {
     if (!c || !bout || !d_store || (!eval && !r)) return GC_E_ARG;
+    // *bout set (gc_pass_batch): the caller took the batch beforehand and, as evaluator, has put (or is putting, on
+    // another stream the ctx stream waits for) the tables into b->d_T itself — slab_host is null then
+    gc_batch *b = *bout;
     *bout = nullptr;
     const Plan &p = c->plan.p;
-    if (eval && (slab_rows != p.info.slab_rows || (!slab_host && slab_rows))) return GC_E_ROWS;
+    if (b && (b->circ != c || b->g.batch != 1)) return GC_E_ARG;
+    if (eval && (slab_rows != p.info.slab_rows || (!slab_host && slab_rows && !b))) {
+        if (b) pool_put(c, b);
+        return GC_E_ROWS;
+    }
     int rc = GC_OK;
-    gc_batch *b = pool_get(c, 1, &rc);
+    if (!b) b = pool_get(c, 1, &rc);
     if (!b) return rc;
     gc_ctx *ctx = c->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1431,19 +1464,27 @@ int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const 
         b->store_all = false;
         if ((rc = gc_ctx_coop_check(ctx)) != GC_OK) break;
         if (e == hipSuccess && (rc = relayout(b)) != GC_OK) break;
-        if (e == hipSuccess && !eval) e = hipMemcpyAsync(b->d_R, r, sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !eval) e = upload_r(b, r);
         // one instance: a tile of one, the table array is the dense slab [row] and wire slot w is element w
-        if (e == hipSuccess && eval && slab_rows)
+        if (e == hipSuccess && eval && slab_rows && slab_host)
             e = hipMemcpyAsync(b->d_T, slab_host, slab_rows * sizeof(gc_label), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
             set_error("gc_pass_dev", e);
             rc = GC_E_HIP;
             break;
         }
-        launch_store_gather(b->d_W, (const uint4 *)d_store, d_in_idx, p.info.ninputs, ctx->stream);
+        // a cooperative pass exchanges the labels with the store itself (a kernel before and one behind it were 10 us
+        // plus their gaps of a 230 us step)
+        // (the caller has put the same pointers into *d_xchg, in device memory, with its other uploads)
+        const bool in_pass = d_xchg && wide_one_instance(b, eval) && coop_ready(ctx);
+        if (!in_pass) launch_store_gather(b->d_W, (const uint4 *)d_store, d_in_idx, p.info.ninputs, ctx->stream);
         if ((rc = set_key(b, key, keylen)) != GC_OK) break;
-        if ((rc = run_levels(b, eval, b->d_T)) != GC_OK) break;
-        launch_store_scatter((uint4 *)const_cast<void *>(d_store), b->d_W, c->d_out_slots, d_out_idx, p.info.noutputs, ctx->stream);
+        b->xchg = in_pass ? d_xchg : nullptr;
+        rc = run_levels(b, eval, b->d_T);
+        b->xchg = nullptr;
+        if (rc != GC_OK) break;
+        if (!in_pass)
+            launch_store_scatter((uint4 *)const_cast<void *>(d_store), b->d_W, c->d_out_slots, d_out_idx, p.info.noutputs, ctx->stream);
         e = hipGetLastError();
         if (e != hipSuccess) {
             set_error("gc_pass_dev", e);
@@ -1455,6 +1496,20 @@ int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const 
         return rc;
     }
     *bout = b;
+    return GC_OK;
+}
+
+int gc_pass_batch(gc_circ *c, gc_batch **bout) {
+    if (!c || !bout) return GC_E_ARG;
+    int rc = GC_OK;
+    *bout = pool_get(c, 1, &rc);
+    if (!*bout) return rc;
+    std::lock_guard<std::mutex> lk(c->ctx->mu);
+    if (hipSetDevice(c->ctx->device) != hipSuccess || (rc = relayout(*bout)) != GC_OK) {
+        pool_put(c, *bout);
+        *bout = nullptr;
+        return rc != GC_OK ? rc : GC_E_HIP;
+    }
     return GC_OK;
 }
 

@@ -40,8 +40,8 @@ struct gc_ctx {
     void *stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;
     // ONE instance of a wide circuit as one cooperative launch (fused_kernels.hip: k_garble_coop): barrier state in device
-    // memory, the verdict of the self-test (0 not run, 1 passed, -1 off), and a pinned word the error flag of every such
-    // pass is copied to (checked when the next pass is enqueued and by gc_ctx_sync)
+    // memory, the verdict of the self-test (0 not run, 1 passed, -1 off), and a pinned word a pass raises when a workgroup
+    // gives up at a barrier (checked when the next pass is enqueued and by gc_ctx_sync)
     gc::CoopCtl *d_coop = nullptr;
     int coop_state = 0;
     uint32_t *h_coop_err = nullptr;
@@ -98,6 +98,9 @@ struct gc_batch {
     uint32_t *d_rk = nullptr;
     uint64_t *d_prof = nullptr;  // debug cycle breakdown of the fused kernels (gc_batch_debug_profile)
     uint32_t rk_host[60] = {0};
+    const gc::StoreXchg *xchg = nullptr;  // gc_pass_dev: (device address) the cooperative pass exchanges labels with the wire store itself
+    gc_label r_host{};     // one-instance passes with R from the host: what d_R[0] holds, when r_known
+    bool r_known = false;
     int rounds = 0;
     int schedule = 1;
     bool use_graph = true;
@@ -126,4 +129,13 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b);
 bool gc_circ_flat_job(gc_circ *c, gc::FlatJob *job, size_t *lds_bytes, bool *has_or);
 int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
                 const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
-                gc_batch **bout);
+                gc_batch **bout, const gc::StoreXchg *d_xchg = nullptr);
+// d_xchg: optional DEVICE copy of gc_pass_xchg(...) — a wide circuit's cooperative pass then exchanges the labels with the
+// store itself instead of a kernel before and one behind it
+inline gc::StoreXchg gc_pass_xchg(const gc_circ *c, const void *d_store, const uint32_t *d_in_idx, const uint32_t *d_out_idx) {
+    return gc::StoreXchg{(uint4 *)const_cast<void *>(d_store), d_in_idx, c->d_out_slots, d_out_idx, c->plan.p.info.noutputs};
+}
+// internal: a pooled one-instance batch taken BEFORE the pass, so that the caller can upload the tables into b->d_T on a
+// stream of its own (under the kernels of the previous pass) and hand the batch to gc_pass_dev in *bout with a null
+// slab_host.  A batch held by the caller is not handed out again: two passes in flight get two table buffers.
+int gc_pass_batch(gc_circ *c, gc_batch **bout);

@@ -1056,6 +1056,7 @@ __device__ __forceinline__ void coop_wait(CoopCtl *ctl, uint32_t gen) {
                 if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 if (__builtin_amdgcn_s_memtime() - t0 > kCoopTimeout) {
                     __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (uint32_t *host_err = ctl->host_err) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -1066,9 +1067,40 @@ __device__ __forceinline__ void coop_wait(CoopCtl *ctl, uint32_t gen) {
     // (load_label<true>), everything else the pass reads is constant
 }
 
+// end of a pass: the last workgroup to get here puts the counters back to zero for the next pass on the stream (every
+// group is past its last wait: thread 0 is the one that waits)
+__device__ __forceinline__ void coop_leave(CoopCtl *ctl) {
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(&ctl->left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kCoopGroups - 1) {
+        __hip_atomic_store(&ctl->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ void coop_barrier(CoopCtl *ctl, uint32_t gen) {
     coop_arrive(ctl);
     coop_wait(ctl, gen);
+}
+
+// the input labels of the pass from the wire store, then a barrier (generation 1)
+__device__ __forceinline__ void coop_gather(const StoreXchg *xp, uint4 *W, uint32_t ninputs, uint32_t rank, CoopCtl *ctl) {
+    if (!xp) return;
+    const uint4 *store = xp->store;
+    const uint32_t *in_idx = xp->in_idx;
+    for (uint32_t i = rank * kCoopThreads + threadIdx.x; i < ninputs; i += kCoopGroups * kCoopThreads) W[i] = store[in_idx[i]];
+    coop_arrive(ctl);
+    coop_wait(ctl, 1);
+}
+// behind the last level: a barrier (generation gen), then the output labels into the wire store
+__device__ __forceinline__ void coop_scatter(const StoreXchg *xp, const uint4 *W, uint32_t rank, CoopCtl *ctl, uint32_t gen) {
+    if (!xp) return;
+    const StoreXchg x = *xp;
+    if (x.nout == 0) return;
+    coop_arrive(ctl);
+    coop_wait(ctl, gen);
+    for (uint32_t j = rank * kCoopThreads + threadIdx.x; j < x.nout; j += kCoopGroups * kCoopThreads) {
+        const uint32_t idx = x.out_idx[j];
+        if (idx != 0xffffffffu) x.store[idx] = load_label<true>(W + x.out_slots[j]);
+    }
 }
 
 template <int NR>
@@ -1076,7 +1108,8 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
                                                               uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
                                                               const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
                                                               const uint32_t *__restrict__ rk,
-                                                              const uint32_t *__restrict__ g_te0, CoopCtl *ctl) {
+                                                              const uint32_t *__restrict__ g_te0, CoopCtl *ctl,
+                                                              const StoreXchg *xp) {
     if (blockIdx.x & 7) return;
     const uint32_t rank = blockIdx.x >> 3;
     __shared__ uint32_t te[kTeDualBytes / 4];
@@ -1094,6 +1127,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
     Step st_next = steps[0];
     LanePos lp_next = classify<2, 2, 1>(st_next, t_first, 0u, 0u);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
+    coop_gather(xp, W, ninputs, rank, ctl);
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t chunks = (level_lanes<2, 2, 1>(st, 0u) + 63u) >> 6;
@@ -1109,9 +1143,11 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
             st_next = steps[lv + 1];
             lp_next = classify<2, 2, 1>(st_next, t_first, 0u, 0u);
             if (lp_next.kind) d_next = descs[st_next.first + lp_next.g];
-            coop_wait(ctl, lv + 1);
+            coop_wait(ctl, lv + 1 + (xp ? 1u : 0u));
         }
     }
+    coop_scatter(xp, W, rank, ctl, nsteps + 1);
+    coop_leave(ctl);
 }
 
 // the table row an evaluator lane of ONE instance needs (TG for AND lane 0, TE for lane 1, the INV row)
@@ -1124,7 +1160,8 @@ template <int NR>
 __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
                                                             uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
                                                             const uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
-                                                            const uint32_t *__restrict__ g_te0, CoopCtl *ctl) {
+                                                            const uint32_t *__restrict__ g_te0, CoopCtl *ctl,
+                                                            const StoreXchg *xp) {
     if (blockIdx.x & 7) return;
     const uint32_t rank = blockIdx.x >> 3;
     __shared__ uint32_t te[kTeDualBytes / 4];
@@ -1141,6 +1178,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
     LanePos lp_next = classify<1, 0, 0>(st_next, t_first, 0u, 0u);
     GateDesc d_next = lp_next.kind ? descs[st_next.first + lp_next.g] : GateDesc{0, 0, 0, 0};
     uint4 tab_next = eval_tab_row(lp_next, d_next, T);
+    coop_gather(xp, W, ninputs, rank, ctl);
     for (uint32_t lv = 0; lv < nsteps; lv++) {
         const Step st = st_next;
         const uint32_t chunks = (level_lanes<1, 0, 0>(st, 0u) + 63u) >> 6;
@@ -1159,9 +1197,11 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
             // the table row too: it is constant during the pass and comes from HBM (the rows were copied in, not written
             // by this pass), the longest round trip of a level — under the barrier wait instead of behind it
             tab_next = eval_tab_row(lp_next, d_next, T);
-            coop_wait(ctl, lv + 1);
+            coop_wait(ctl, lv + 1 + (xp ? 1u : 0u));
         }
     }
+    coop_scatter(xp, W, rank, ctl, nsteps + 1);
+    coop_leave(ctl);
 }
 
 // Are the kCoopGroups workgroups on one XCD, and does a value stored before the barrier arrive behind it?  64 rounds of:
@@ -1194,17 +1234,17 @@ void launch_coop_selftest(CoopCtl *ctl, hipStream_t s) {
     hipLaunchKernelGGL(k_coop_selftest, dim3(8 * kCoopGroups), dim3(kCoopThreads), 0, s, ctl);
 }
 
-void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, hipStream_t s) {
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, hipStream_t s) {
     if (a.nsteps == 0) return;
-    (void)hipMemsetAsync(ctl, 0, 4, s);  // count; error stays up once raised (gc_ctx_coop_check lowers it)
+    // ctl->count is zero here: the self-test's host code and every pass leave it so (coop_leave); error stays up once raised
     const dim3 grid(8 * kCoopGroups), block(kCoopThreads);
 #define GC_CO(NR)                                                                                                          \
     if (eval)                                                                                                              \
         hipLaunchKernelGGL((k_eval_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W,               \
-                           (const uint4 *)a.T, a.rk, a.te0, ctl);                                                         \
+                           (const uint4 *)a.T, a.rk, a.te0, ctl, x);                                                      \
     else                                                                                                                   \
         hipLaunchKernelGGL((k_garble_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W, a.R, a.T,   \
-                           a.rk, a.te0, ctl)
+                           a.rk, a.te0, ctl, x)
     switch (a.rounds) {
     case 10: GC_CO(10); break;
     case 12: GC_CO(12); break;

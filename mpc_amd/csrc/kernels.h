@@ -83,16 +83,33 @@ void launch_eval_fused(const FusedArgs &a, const BatchGeom &g, hipStream_t s);
 uint32_t level1_passes(const Step &st, bool eval);
 void launch_levels1(bool eval, const FusedArgs &a, const Step *levels, hipStream_t s);
 // the same walk as ONE launch: kCoopGroups workgroups of one XCD (one L2) walk the levels together, a counter in that L2
-// is the barrier between levels (fused_kernels.hip: k_garble_coop).  ctl lives in device memory and is zeroed by the launch.
+// is the barrier between levels (fused_kernels.hip: k_garble_coop).  ctl lives in device memory; a pass leaves the counters
+// at zero for the next one (no memset between passes: a fill kernel plus its gaps was 10 us of a 250 us step).
 struct CoopCtl {
-    uint32_t count;        // arrivals, monotonic over the barriers of one launch (zeroed by every launch)
+    uint32_t count;        // arrivals, monotonic over the barriers of one launch; zero between launches
     uint32_t error;        // a workgroup gave up waiting (never seen after a passed self-test; stays up until reported)
     uint32_t bad;          // self-test: values that did not arrive, workgroups on another XCD
     uint32_t ticks;        // self-test: s_memtime ticks of its 128 barriers
+    uint32_t left;         // workgroups that finished the pass (the last one zeroes count and left)
+    uint32_t pad;
+    uint32_t *host_err;    // a word of pinned host memory (device-visible) that a workgroup giving up raises as well: the
+                           // host reads it without a copy per pass
     uint32_t scratch[64];  // self-test
 };
 constexpr uint32_t kCoopGroups = 32;
-void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, hipStream_t s);
+// Label exchange with a device-resident wire store (the streaming passes), done by the cooperative kernel itself instead of
+// a kernel before and one behind it: W[i] = store[in_idx[i]] for the ninputs input slots, a barrier, the levels, a barrier,
+// store[out_idx[j]] = W[out_slots[j]] (out_idx 0xffffffff: not stored).
+struct StoreXchg {
+    uint4 *store;
+    const uint32_t *in_idx;
+    const uint32_t *out_slots;
+    const uint32_t *out_idx;
+    uint32_t nout;
+};
+// x: device address of the pass's StoreXchg, or nullptr (kernel arguments stay in SGPRs for the whole pass and the round
+// keys already fill them: the exchange by value cost 17 more spilled SGPRs and 30 us of a 200 us pass)
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, hipStream_t s);
 void launch_coop_selftest(CoopCtl *ctl, hipStream_t s);
 
 // Fused schedule with LDS-resident wires (fused_lds_kernels.hip)

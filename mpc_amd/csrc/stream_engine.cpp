@@ -335,6 +335,18 @@ struct gc_stream {
     GroupWindow win;              // the groups still accepting steps
     std::vector<CircEntry *> handles;  // gc_stream_intern
     hipStream_t copy_stream = nullptr;
+    // Big steps: the serialiser (byte sizes, their scan, the total down, the bytes) runs on ser_stream behind the pass
+    // (ev_pass) and under the pass of the NEXT step — which therefore gets another table buffer: the batch of the last big
+    // step is held out of the pool until the next one has taken its own, and a pass into a table buffer waits for the
+    // serialiser that last read it (ser_ev / ser_batch, two in flight).  Not on copy_stream: the copy of step k's bytes
+    // to the host (gc_stream_garble_finish) would queue behind the serialiser of step k + 1, that is behind pass k + 1.
+    hipStream_t ser_stream = nullptr;
+    hipEvent_t ev_pass = nullptr;
+    hipEvent_t ser_ev[2] = {nullptr, nullptr};
+    gc_batch *ser_batch[2] = {nullptr, nullptr};
+    uint32_t ser_turn = 0;
+    gc_circ *held_circ = nullptr;
+    gc_batch *held = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
 };
 
@@ -808,6 +820,10 @@ int stream_find_or_load(gc_stream *s, const gc_gate *gates, uint32_t ngates, uin
                 if (rcq != GC_OK) return rcq;
                 GC_HIP(hipStreamSynchronize(st));
                 GC_HIP(hipStreamSynchronize(s->copy_stream));
+                if (s->ser_stream) GC_HIP(hipStreamSynchronize(s->ser_stream));
+                if (s->held) gc_circ_release_batch(s->held_circ, s->held);  // (back into its circuit's pool before that may go)
+                s->held = nullptr;
+                s->ser_batch[0] = s->ser_batch[1] = nullptr;
                 cache_make_room(s->cache, &s->cache_gates, s->cache_budget, (size_t)ngates + 1, [](gc_circ *) {});
             }
             int stc = GC_OK;
@@ -892,6 +908,13 @@ void gc_stream_free(gc_stream *s) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
     }
+    if (s->ser_stream) {
+        (void)hipStreamSynchronize(s->ser_stream);
+        (void)hipStreamDestroy(s->ser_stream);
+    }
+    for (hipEvent_t ev : {s->ev_pass, s->ser_ev[0], s->ser_ev[1]})
+        if (ev) (void)hipEventDestroy(ev);
+    if (s->held) gc_circ_release_batch(s->held_circ, s->held);
     for (auto &kv : s->cache) gc_circ_free(kv.second.circ);
     for (auto &sl : s->slots) sl->release();
     if (s->d_rk) (void)hipFree(s->d_rk);
@@ -1140,38 +1163,48 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     }
     gc_circ *circ = ent->circ;
     const uint32_t nblocks = (ngates + kSerGates - 1) / kSerGates;
+    // the table buffer of this step: not the one of the step before, whose serialiser may still be reading it
+    gc_batch *bt = nullptr;
+    {
+        int rcb = gc_pass_batch(circ, &bt);
+        if (rcb != GC_OK) return rcb;
+    }
     // (1) this call's wire maps on the device: in[], out[], and out[] with "no store" marks for the scatter; host-set
     //     labels of the store are uploaded.  The maps go up from the slot's own PINNED staging: a true asynchronous copy
     //     that no later call can overwrite (every step in flight has its own slot).
     const size_t io_words = (size_t)nin + 2 * (size_t)nout + 1;
+    // ... and behind them the pass's label exchange record (gc_pass_xchg: a cooperative pass gathers and scatters itself)
+    static_assert(sizeof(gc::StoreXchg) % 4 == 0, "exchange record in the word staging");
+    const size_t x_off = (io_words + 1) & ~(size_t)1, io_alloc = x_off + sizeof(gc::StoreXchg) / 4;
+    const uint32_t turn = s->ser_turn++ & 1u;
     SerArgs a{};
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         int rcs = s->store.flush(ctx);
-        if (rcs != GC_OK) return rcs;
         hipError_t e = hipSuccess;
-        if (b.h_io_cap < io_words) {
+        if (rcs == GC_OK && b.h_io_cap < io_alloc) {
             if (b.h_io) (void)hipHostFree(b.h_io);
             b.h_io = nullptr;
             b.h_io_cap = 0;
-            e = hipHostMalloc((void **)&b.h_io, (io_words + io_words / 2) * sizeof(uint32_t), hipHostMallocDefault);
-            if (e == hipSuccess) b.h_io_cap = io_words + io_words / 2;
+            e = hipHostMalloc((void **)&b.h_io, (io_alloc + io_alloc / 2) * sizeof(uint32_t), hipHostMallocDefault);
+            if (e == hipSuccess) b.h_io_cap = io_alloc + io_alloc / 2;
         }
-        if (e == hipSuccess) e = grow(&b.d_io, &b.io_cap, io_words);
+        if (e == hipSuccess) e = grow(&b.d_io, &b.io_cap, io_alloc);
         if (e == hipSuccess) e = grow(&b.d_boff, &b.boff_cap, (size_t)nblocks + 1);
         // the bytes of this step: 13 header bytes + 3 rows per gate at most
         if (e == hipSuccess) e = grow(&b.d_bytes, &b.bytes_cap, (size_t)ngates * 61 + 16);
-        if (e == hipSuccess) {
-            for (uint32_t i = 0; i < nin; i++) b.h_io[i] = in[i];
-            for (uint32_t j = 0; j < nout; j++) {
-                b.h_io[nin + j] = out[j];
-                b.h_io[nin + nout + j] = s->skip_scratch[j];
-            }
-            e = hipMemcpyAsync(b.d_io, b.h_io, (io_words - 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && !s->ser_stream) e = hipStreamCreateWithFlags(&s->ser_stream, hipStreamNonBlocking);
+        for (hipEvent_t *ev : {&s->ev_pass, &s->ser_ev[0], &s->ser_ev[1]})
+            if (e == hipSuccess && !*ev) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (rcs != GC_OK || e != hipSuccess) {
+            gc_circ_release_batch(circ, bt);
+            if (e != hipSuccess) set_error("gc_stream_garble", e);
+            return rcs != GC_OK ? rcs : e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
         }
-        if (e != hipSuccess) {
-            set_error("gc_stream_garble", e);
-            return e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        for (uint32_t i = 0; i < nin; i++) b.h_io[i] = in[i];
+        for (uint32_t j = 0; j < nout; j++) {
+            b.h_io[nin + j] = out[j];
+            b.h_io[nin + nout + j] = s->skip_scratch[j];
         }
         a.gw = circ->d_gwires;
         a.ops = circ->d_ops;
@@ -1181,30 +1214,61 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         a.ngates = ngates;
         a.first_tmp = first_tmp;
         a.first_out = first_out;
-        // (2) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form)
-        hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, st, a, b.d_boff);
-        hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, st, b.d_boff, nblocks);
-        GC_HIP(hipMemcpyAsync(b.need, b.d_boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        {
+            const gc::StoreXchg x = gc_pass_xchg(circ, s->store.d, b.d_io, b.d_io + nin + nout);
+            std::memcpy(b.h_io + x_off, &x, sizeof x);
+        }
+        e = hipMemcpyAsync(b.d_io, b.h_io, io_alloc * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        // the pass writes bt's tables: behind the serialiser that last read them
+        for (int i = 0; i < 2 && e == hipSuccess; i++)
+            if (s->ser_batch[i] == bt) e = hipStreamWaitEvent(st, s->ser_ev[i], 0);
+        if (e != hipSuccess) {
+            gc_circ_release_batch(circ, bt);
+            set_error("gc_stream_garble", e);
+            return GC_E_HIP;
+        }
     }
-    tr.lap("uploads + sizes");
-    // (3) input labels through in[] (Get, :131-141), garble, outputs into the store (Set, :143-157) — all on the device
-    gc_batch *bt = nullptr;
-    int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, b.d_io, b.d_io + nin + nout, nullptr, 0, &bt);
+    tr.lap("uploads");
+    // (2) input labels through in[] (Get, :131-141), garble, outputs into the store (Set, :143-157) — all on the device
+    int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, b.d_io, b.d_io + nin + nout, nullptr, 0, &bt,
+                         (const gc::StoreXchg *)(b.d_io + x_off));
     if (rc != GC_OK) return rc;
     for (uint32_t j = 0; j < nout; j++)
         if (first_out + j >= first_tmp) s->store.on_dev[out[j]] = 1;
-    // (4) wire format (:391-446) written by the device at the scanned offsets
+    // (3) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form), then the
+    //     wire format (:391-446) written by the device at the scanned offsets — on the serialiser's stream, behind the pass
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, st, a, b.d_boff, bt->d_T, bt->g.lt, b.d_bytes);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(b.done, st);
+        hipStream_t ss = s->ser_stream;
+        hipError_t e = hipEventRecord(s->ev_pass, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ss, s->ev_pass, 0);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, ss, a, b.d_boff);
+            hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, ss, b.d_boff, nblocks);
+            e = hipMemcpyAsync(b.need, b.d_boff + nblocks, sizeof(uint64_t), hipMemcpyDeviceToHost, ss);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, ss, a, b.d_boff, bt->d_T, bt->g.lt, b.d_bytes);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(b.done, ss);
+        if (e == hipSuccess) e = hipEventRecord(s->ser_ev[turn], ss);
         if (e != hipSuccess) {
             set_error("gc_stream_garble", e);
             rc = GC_E_HIP;
+            (void)hipStreamSynchronize(ss);
+            (void)hipStreamSynchronize(st);
         }
     }
-    gc_circ_release_batch(circ, bt);  // later passes on the same stream may reuse it: stream order protects the tables
+    if (rc == GC_OK) {
+        s->ser_batch[turn ^ 1u] = s->ser_batch[turn ^ 1u] == bt ? nullptr : s->ser_batch[turn ^ 1u];
+        s->ser_batch[turn] = bt;
+        if (s->held) gc_circ_release_batch(s->held_circ, s->held);
+        s->held = bt;
+        s->held_circ = circ;
+    } else {
+        gc_circ_release_batch(circ, bt);
+    }
     if (rc == GC_OK) {
         b.kind = Slot::kBig;
         b.launched = true;
@@ -1497,10 +1561,28 @@ struct gc_stream_eval {
     size_t skel_bytes = 0;                  // reference bytes held by skels (capped: the blocks are the peer's data)
     // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
     // may still be in flight while block k + 1 is parsed
-    gc_label *slab_pin[2] = {nullptr, nullptr};
-    size_t slab_cap[2] = {0, 0};
-    hipEvent_t slab_ev[2] = {nullptr, nullptr};
+    // (kEvalRing buffers: a block's set is re-used once the pass of the block kEvalRing calls ago has run)
+    static constexpr uint32_t kEvalRing = 4;
+    gc_label *slab_pin[kEvalRing] = {};
+    size_t slab_cap[kEvalRing] = {};
+    hipEvent_t slab_ev[kEvalRing] = {};
+    // ... and its wire maps (inputs, then global outputs): pinned staging + a device copy per ring entry — from pageable
+    // memory the upload is synchronous with the stream (the host would wait for the previous block's kernels at every
+    // block: the evaluator ran at host time PLUS GPU time per big block), and one device copy would be overwritten under
+    // the pass still reading it
+    uint32_t *io_pin[kEvalRing] = {};
+    uint32_t *io_dev[kEvalRing] = {};
+    size_t io_pin_cap[kEvalRing] = {}, io_dev_cap[kEvalRing] = {};
     uint32_t slab_turn = 0;
+    // The uploads of a big block (rows, wire maps) run on a stream of their own, under the kernels of the block before:
+    // up_ev[i] = this entry's uploads done (the ctx stream waits for it); ring_batch[i] = the pooled batch whose table
+    // buffer they went into (an upload into it waits for slab_ev[i]: the pass that last read it); held = the batch of the
+    // last block, kept out of the pool until the next block has taken its own (two passes in flight, two table buffers)
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_ev[kEvalRing] = {};
+    gc_batch *ring_batch[kEvalRing] = {};
+    gc_circ *held_circ = nullptr;
+    gc_batch *held = nullptr;
 };
 
 namespace {
@@ -1585,13 +1667,21 @@ void gc_stream_eval_free(gc_stream_eval *e) {
         (void)hipSetDevice(e->ctx->device);
         (void)hipStreamSynchronize(e->ctx->stream);
     }
+    if (e->held) gc_circ_release_batch(e->held_circ, e->held);
     for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
     for (auto &sl : e->slots) sl->release();
     if (e->d_rk) (void)hipFree(e->d_rk);
     if (e->d_io) (void)hipFree(e->d_io);
-    for (int i = 0; i < 2; i++) {
+    if (e->up_stream) {
+        (void)hipStreamSynchronize(e->up_stream);
+        (void)hipStreamDestroy(e->up_stream);
+    }
+    for (int i = 0; i < (int)gc_stream_eval::kEvalRing; i++) {
+        if (e->up_ev[i]) (void)hipEventDestroy(e->up_ev[i]);
         if (e->slab_pin[i]) (void)hipHostFree(e->slab_pin[i]);
         if (e->slab_ev[i]) (void)hipEventDestroy(e->slab_ev[i]);
+        if (e->io_pin[i]) (void)hipHostFree(e->io_pin[i]);
+        if (e->io_dev[i]) (void)hipFree(e->io_dev[i]);
     }
     e->store.release();
     delete e;
@@ -1650,7 +1740,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     // a small block (candidate for a step group) parses its rows into plain host scratch: they are copied into the
     // group's pinned upload region when the block is queued; a big block uses the double-buffered pinned slab
     const bool small_block = ngates <= kSmallGates;
-    const uint32_t sb = e->slab_turn & 1u;
+    const uint32_t sb = e->slab_turn % gc_stream_eval::kEvalRing;
     if (small_block) {
         if (e->rows_scratch.size() < (size_t)ngates * 3 + 1) e->rows_scratch.resize((size_t)ngates * 3 + 1);
         GC_HIP(hipSetDevice(e->ctx->device));
@@ -1658,7 +1748,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         e->slab_turn++;
         GC_HIP(hipSetDevice(e->ctx->device));
         if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
-        else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the H2D of the block two calls ago (long done)
+        else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the pass of the block kEvalRing calls ago (long done)
         const size_t want = (size_t)ngates * 3 + 1;
         if (e->slab_cap[sb] < want) {
             if (e->slab_pin[sb]) (void)hipHostFree(e->slab_pin[sb]);
@@ -1857,6 +1947,9 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             GC_HIP(hipStreamSynchronize(e->ctx->stream));
             for (auto &sl : e->slots)
                 if (sl->kind == Slot::kGroup && sl->launched) sl->reset();
+            if (e->held) gc_circ_release_batch(e->held_circ, e->held);  // (back into its circuit's pool before that may go)
+            e->held = nullptr;
+            for (auto &rb : e->ring_batch) rb = nullptr;
             cache_make_room(e->cache, &e->cache_gates, e->cache_budget, (size_t)ngates + 1, [&](gc_circ *gone) {
                 for (auto &kv : e->skels) {
                     std::vector<EvalSkel> &v = kv.second;
@@ -1989,27 +2082,89 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (rcq != GC_OK) return rcq;
     }
     gc_circ *circ = ent->circ;
+    uint32_t *d_io = nullptr;
+    const gc::StoreXchg *d_xchg = nullptr;
+    gc_batch *b = nullptr;
+    const gc_label *slab_arg = slab;
+    if (!small_block) {
+        // the batch (its table buffer) first: not the one of the block before (held), so its pass may still be running
+        // while this block's rows are copied in
+        int rcb = gc_pass_batch(circ, &b);
+        if (rcb != GC_OK) return rcb;
+        slab_arg = nullptr;
+    }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        GC_HIP(hipSetDevice(ctx->device));
-        int rcs = e->store.flush(ctx);
-        if (rcs != GC_OK) return rcs;
-        hipError_t er = grow(&e->d_io, &e->io_cap, e->io_host.size());
-        if (er == hipSuccess)
-            er = hipMemcpyAsync(e->d_io, e->io_host.data(), e->io_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (er != hipSuccess) {
-            set_error("gc_stream_eval_circuit", er);
-            return er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        hipError_t er = hipSetDevice(ctx->device);
+        int rcs = er == hipSuccess ? e->store.flush(ctx) : GC_E_HIP;
+        const size_t nio = e->io_host.size();
+        const size_t x_off = (nio + 1) & ~(size_t)1, nio_alloc = x_off + sizeof(gc::StoreXchg) / 4;
+        if (rcs != GC_OK) {
+        } else if (small_block) {  // (without an LDS plan: rare; the pass is waited for below)
+            er = grow(&e->d_io, &e->io_cap, nio);
+            if (er == hipSuccess) er = hipMemcpyAsync(e->d_io, e->io_host.data(), nio * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            d_io = e->d_io;
+        } else {
+            // this ring entry's pinned staging and device copy (free: slab_ev[sb] was waited for above); rows and wire maps
+            // go up on the upload stream, behind the last pass that read this table buffer, and the ctx stream waits for them
+            if (e->io_pin_cap[sb] < nio_alloc) {
+                if (e->io_pin[sb]) (void)hipHostFree(e->io_pin[sb]);
+                e->io_pin[sb] = nullptr;
+                e->io_pin_cap[sb] = 0;
+                er = hipHostMalloc((void **)&e->io_pin[sb], (nio_alloc + nio_alloc / 2) * sizeof(uint32_t), hipHostMallocDefault);
+                if (er == hipSuccess) e->io_pin_cap[sb] = nio_alloc + nio_alloc / 2;
+            }
+            if (er == hipSuccess) er = grow(&e->io_dev[sb], &e->io_dev_cap[sb], nio_alloc);
+            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
+            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
+            for (uint32_t i = 0; i < gc_stream_eval::kEvalRing && er == hipSuccess; i++)
+                if (e->ring_batch[i] == b && i != sb && e->slab_ev[i]) er = hipStreamWaitEvent(e->up_stream, e->slab_ev[i], 0);
+            if (er == hipSuccess && nrows)
+                er = hipMemcpyAsync(b->d_T, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
+            if (er == hipSuccess) {
+                std::memcpy(e->io_pin[sb], e->io_host.data(), nio * sizeof(uint32_t));
+                // ... and the pass's label exchange record behind them (a cooperative pass gathers and scatters itself)
+                const gc::StoreXchg x = gc_pass_xchg(circ, e->store.d, e->io_dev[sb], e->io_dev[sb] + nin);
+                std::memcpy(e->io_pin[sb] + x_off, &x, sizeof x);
+                d_xchg = (const gc::StoreXchg *)(e->io_dev[sb] + x_off);
+                er = hipMemcpyAsync(e->io_dev[sb], e->io_pin[sb], nio_alloc * sizeof(uint32_t), hipMemcpyHostToDevice, e->up_stream);
+            }
+            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
+            if (er == hipSuccess) er = hipStreamWaitEvent(ctx->stream, e->up_ev[sb], 0);
+            d_io = e->io_dev[sb];
+        }
+        if (rcs != GC_OK || er != hipSuccess) {
+            if (er != hipSuccess) set_error("gc_stream_eval_circuit", er);
+            if (b) {
+                // a copy into the batch's buffers may be in flight: nothing else may use it before that has run
+                (void)hipStreamSynchronize(e->up_stream);
+                gc_circ_release_batch(circ, b);
+            }
+            return rcs != GC_OK ? rcs : er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
         }
     }
-    gc_batch *b = nullptr;
-    int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, e->d_io, e->d_io + nin, slab, nrows, &b);
-    // the pinned slab may be overwritten once what was enqueued from it has run: also when the pass failed half-way
-    // (an H2D copy from the slab may already be in flight)
-    if (!small_block) (void)hipEventRecord(e->slab_ev[sb], ctx->stream);
-    else (void)hipStreamSynchronize(ctx->stream);  // rows in plain host scratch (a small block without an LDS plan: rare)
-    if (rc != GC_OK) return rc;
-    gc_circ_release_batch(circ, b);
+    int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, d_io, d_io + nin, slab_arg, nrows, &b, d_xchg);
+    // the pinned slab (and this entry's buffers) may be overwritten once what was enqueued from it has run: also when the
+    // pass failed half-way (the uploads are in flight)
+    if (!small_block) {
+        (void)hipEventRecord(e->slab_ev[sb], ctx->stream);
+        for (auto &rb : e->ring_batch)
+            if (rb == b) rb = nullptr;
+        e->ring_batch[sb] = b;  // (null when the pass failed: gc_pass_dev has put the batch back)
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);  // rows in plain host scratch (a small block without an LDS plan: rare)
+    }
+    if (rc != GC_OK) {
+        if (!small_block) (void)hipStreamSynchronize(e->up_stream);
+        return rc;
+    }
+    if (small_block) {
+        gc_circ_release_batch(circ, b);
+    } else {
+        if (e->held) gc_circ_release_batch(e->held_circ, e->held);
+        e->held = b;
+        e->held_circ = circ;
+    }
     for (uint32_t k = 0; k < nout; k++) e->store.on_dev[e->wr_ids[k]] = 1;
     tr.lap("eval: enqueue");
     *consumed = pos;

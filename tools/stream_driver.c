@@ -147,7 +147,8 @@ int main(int argc, char **argv) {
     if (!ctx) DIE("gc_ctx_create: %d", st);
     uint8_t *bytes = malloc(cap);
     size_t *sizes = malloc(sizeof(size_t) * (size_t)nsteps);
-    double garble_s = 0, eval_s = 0;
+    double garble_s = 0, eval_s = 0, eval_steady_s = 0;
+    uint32_t eval_steady_steps = 0;
     char hex[65] = "";
     gc_label *in0 = malloc(sizeof(gc_label) * ((size_t)nprim + 1));
     size_t total = 0;
@@ -192,21 +193,34 @@ int main(int argc, char **argv) {
             if (gc_stream_eval_set_wire(e, prim[i], &in0[i])) DIE("gc_stream_eval_set_wire");
         size_t off = 0;
         const double t0 = now_s();
+        /* the blocks the evaluator sees for the first time are parsed gate by gate and their circuits loaded (the peer's
+         * data: nothing can be interned ahead, as the garbler does); "steady" is what follows the last such block */
+        double t_known = t0;
+        uint64_t parsed_before = 0;
+        eval_steady_steps = nsteps;
         for (uint32_t k = 0; k < nsteps; k++) {
             const circ_t *c = &circ[step[k].circ];
             size_t used = 0;
             if ((st = gc_stream_eval_circuit(e, c->ngates, c->nwires, max_wire + 1, bytes + off, sizes[k], &used)) || used != sizes[k])
                 DIE("gc_stream_eval_circuit(step %u): %d, used %zu of %zu", k, st, used, sizes[k]);
             off += used;
+            gc_stream_eval_stats(e, &parsed, &matched);
+            if (parsed != parsed_before) {
+                parsed_before = parsed;
+                t_known = now_s();
+                eval_steady_steps = nsteps - 1 - k;
+            }
         }
         if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe)) DIE("gc_stream_eval_get_wire"); /* waits for everything */
         eval_s = now_s() - t0;
+        eval_steady_s = now_s() - t_known;
         gc_stream_eval_stats(e, &parsed, &matched);
         gc_stream_eval_free(e);
     }
-    printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"bytes\": %zu, \"sha256\": \"%s\", "
+    printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
+           "\"eval_steady_steps\": %u, \"bytes\": %zu, \"sha256\": \"%s\", "
            "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\"}\n",
-           nsteps, window, garble_s, eval_s, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
+           nsteps, window, garble_s, eval_s, eval_steady_s, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
            (unsigned long long)probe.d0);
     gc_ctx_destroy(ctx);
     return 0;
