@@ -353,8 +353,8 @@ def run_for_line(key=bytes(range(32)), ctx=None):
     """the `stream` object of bench.py's line: the big-step program (bounded sample: 152 steps), the two uniform
     small-step programs and the mixed program; every SHA-256 checked against the oracle's"""
     out = {}
-    b = run_program("big", key, ctx, window=2)
-    out.update({"steps": b["steps"], "gates": b["gates"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
+    b = run_program("big", key, ctx, window=4)  # (an interpreter's jitter between the calls: 2 in flight are enough for a C host)
+    out.update({"steps": b["steps"], "gates": b["gates"], "window": b["window"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
                 "steady_gates_per_s": b["garble_gates_per_s"],
                 # the evaluator cannot intern: the first block of each circuit is parsed and loaded inside the timed run
                 "eval_ms_per_step_all": b["eval_us_per_step"] / 1e3, "eval_gates_per_s_all": b["eval_gates_per_s"],
@@ -368,14 +368,15 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                                        "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
-    for name, win in (("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
+    for name, win in (("big", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
         try:
             r = run_native(name, key, win)
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
             r = {"error": str(e)[:200]}
         if r is not None:
             native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
-                                                      "eval_us_per_step", "sha256_ok", "error")}
+                                                      "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
+                                                      "window", "sha256_ok", "error")}
     if native:
         out["native_host"] = native
     out["published_reference"] = "1.4e7 gates/s, Go, i5-8257U (benchmarks.md:677-704: Ed25519 sign.mpcl streamed)"
