@@ -126,6 +126,7 @@ PROGRAMS = {
     "uniform4096": lambda: program_uniform(4096, 1500, 8),
     "uniform512x64": lambda: program_uniform(512, 8000, 64),
     "mixed": lambda: program_mixed(3000),
+    "mixed100": lambda: program_mixed(10000),  # config 5's size: adders / multipliers / wide steps, >= 1e8 gates in all
 }
 
 
