@@ -639,6 +639,46 @@ def test_stream_circuit_cache_is_bounded(monkeypatch):
     gg.close(); ge.close(); ctx.close()
 
 
+def test_stream_big_steps_in_flight_while_their_circuits_are_evicted(monkeypatch):
+    """big steps keep two table buffers in flight (the batch of the last step is held while the next one's pass runs; the
+    serialiser and the evaluator's uploads run on their own streams) — with a cache that holds ONE of the four circuits,
+    every step evicts the circuit whose batch is held: three steps queued ahead on the garbler, the evaluator fed the
+    blocks back to back; bytes, and the labels of the last step, equal the oracle's"""
+    from scripts.bench_stream import make_steps
+    monkeypatch.setenv("GC_STREAM_CACHE_GATES", "60000")  # one 49 152-gate circuit
+    nin = 256
+    steps = make_steps(11, 24, 2048, 0.3, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("evict-big", 32)
+    rnd = drbg("evict-big-rnd", 16 * (len(prim) + 1))
+    og, oe = oracle.Stream(key, rnd, prim), oracle.StreamEval(key)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    ctx = engine.Context(0)
+    gg, ge = engine.Stream(ctx, key, rnd, prim), engine.StreamEval(ctx, key)
+    for w in prim:
+        lab = og.get(w)["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    got, issued = [], 0
+    for k in range(len(steps)):
+        while issued < min(len(steps), k + 3):
+            c, in_, out_ = steps[issued]
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        got.append(gg.garble_finish())
+    assert got == want
+    for (c, in_, out_), wbytes in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, wbytes) == len(wbytes)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, wbytes) == len(wbytes)
+    assert [ge.get(o) for o in steps[-1][2]] == [oe.get(o) for o in steps[-1][2]]
+    assert ge.stats()[0] == len(steps)  # every block was a first-time block again: nothing was kept
+    ctx.sync()
+    gg.close(); ge.close(); ctx.close()
+
+
 def test_stream_mixed_program_matches_oracle():
     """the mixed program of scripts/bench_stream.py (64-bit adders, 64 x 64 multipliers — 13 740 gates, still one
     workgroup each — and 131 072-gate steps, operands mostly from the last few steps, variables overwritten) at a size
