@@ -351,11 +351,12 @@ def run_native(name, key=bytes(range(32)), window=64):
 
 
 def run_for_line(key=bytes(range(32)), ctx=None):
-    """the `stream` object of bench.py's line: the big-step program (bounded sample: 152 steps), the two uniform
-    small-step programs and the mixed program; every SHA-256 checked against the oracle's"""
+    """the `stream` object of bench.py's line: the big-step program at config 5's size (991 steps of 131 072 gates =
+    1.3e8 gates, 2.4 GB of stream: about 2 s for both sides and both hosts), the two uniform small-step programs and the
+    mixed program; every SHA-256 checked against the oracle's"""
     out = {}
-    b = run_program("big", key, ctx, window=4)  # (an interpreter's jitter between the calls: 2 in flight are enough for a C host)
-    out.update({"steps": b["steps"], "gates": b["gates"], "window": b["window"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
+    b = run_program("big130", key, ctx, window=4)  # (an interpreter's jitter between the calls: 2 in flight are enough for a C host)
+    out.update({"program": "big130", "steps": b["steps"], "gates": b["gates"], "window": b["window"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
                 "steady_gates_per_s": b["garble_gates_per_s"],
                 # the evaluator cannot intern: the first block of each circuit is parsed and loaded inside the timed run
                 "eval_ms_per_step_all": b["eval_us_per_step"] / 1e3, "eval_gates_per_s_all": b["eval_gates_per_s"],
@@ -369,7 +370,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                                        "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
-    for name, win in (("big", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
+    for name, win in (("big130", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
         try:
             r = run_native(name, key, win)
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
