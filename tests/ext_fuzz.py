@@ -162,3 +162,61 @@ for seed in range(max(2, N // 12)):
         bad5 += 1
         print("FAIL(hbm wires) seed", seed, "levels", levels, "width", width, "batch", batch, str(e)[:160])
 print("hbm-wire circuits done, failures:", bad5)
+
+# ---- sixth pass: streams of BIG steps (one cooperative launch per step that also gathers / scatters the store labels;
+# uploads and serialiser on their own streams, two table buffers in flight): random level shapes and gate mixes, few to
+# many thousand input wires (the in-kernel gather then spans workgroups), 16- and 32-bit ids, queued 1 to 4 ahead, repeated
+# circuits under new bindings, against the oracle on both sides
+bad6 = 0
+for seed in range(max(2, N // 10)):
+    rng = np.random.default_rng(66000 + seed)
+    key = drbg("bk%d" % seed, int(rng.choice([16, 24, 32])))
+    shapes = []
+    for v in range(int(rng.integers(1, 4))):
+        width = int(rng.choice([1100, 2048, 3000, 6000]))
+        levels = int(max(3, rng.integers(34000, 70000) // width))
+        shapes.append(synthetic_levelised(levels, width, float(rng.choice([0.1, 0.25, 0.5])), seed=int(rng.integers(1, 1 << 30)),
+                                          ninputs=int(rng.choice([2, 64, 256, 1000, 9000])), or_frac=float(rng.choice([0.0, 0.03])),
+                                          inv_frac=float(rng.choice([0.0, 0.05])), xnor_frac=float(rng.choice([0.0, 0.1]))))
+    nextid = int(rng.choice([0, 0xfe00, 0x10000]))
+    steps, prim, avail = [], [], []
+    for k in range(int(rng.integers(2, 8))):
+        c = shapes[int(rng.integers(0, len(shapes)))]
+        in_ = []
+        for i in range(c.num_inputs):
+            if avail and rng.random() < 0.5:
+                in_.append(int(avail[int(rng.integers(0, len(avail)))]))
+            else:
+                in_.append(nextid); prim.append(nextid); nextid += 1
+        out_ = list(range(nextid, nextid + c.num_outputs)); nextid += c.num_outputs
+        avail += out_
+        steps.append((c, in_, out_))
+    window = int(rng.integers(1, 5))
+    try:
+        rnd = drbg("br%d" % seed, 16 * (len(prim) + 1))
+        og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+        oe, ge = oracle.StreamEval(key), engine.StreamEval(ctx, key)
+        for w in prim:
+            l = gg.get(w)["l0"]
+            ge.set(w, l); oe.set(w, l)
+        want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+        got, issued = [], 0
+        for k in range(len(steps)):
+            while issued < min(len(steps), k + window):
+                c, in_, out_ = steps[issued]
+                gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+                issued += 1
+            got.append(gg.garble_finish())
+        assert got == want, "stream bytes"
+        for (c, in_, out_), b in zip(steps, got):
+            nw = max(max(in_), max(out_)) + 1
+            assert ge.circuit(c.NumGates, c.NumWires, nw, b) == len(b)
+            assert oe.circuit(c.NumGates, c.NumWires, nw, b) == len(b)
+        for o in steps[-1][2][:16] + steps[0][2][:4]:
+            assert ge.get(o) == oe.get(o), "evaluated label of wire %d" % o
+        ctx.sync()
+        gg.close(); ge.close()
+    except (AssertionError, engine.EngineError) as e:
+        bad6 += 1
+        print("FAIL(big steps) seed", seed, "steps", len(steps), "window", window, str(e)[:160])
+print("big-step streams done, failures:", bad6)
