@@ -179,6 +179,7 @@ struct JobRec {
 struct Slot {
     enum Kind { kFree, kGroup, kBig } kind = kFree;
     bool launched = false, synced = false;
+    uint64_t launch_no = 0;  // order of the launches (the evaluator waits for its OLDEST group when it runs out of slots)
     int error = GC_OK;          // close failed: the group's steps report it
     uint32_t handed = 0;        // steps whose bytes have been handed out
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
@@ -707,6 +708,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     hipStream_t st = ctx->stream;
     std::lock_guard<std::mutex> lk(ctx->mu);
     g.launched = true;
+    static std::atomic<uint64_t> launches{0};
+    g.launch_no = ++launches;
     auto fail = [&](const char *what, hipError_t e) {
         set_error(what, e);
         g.error = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
@@ -1615,12 +1618,16 @@ Slot *eval_slot(gc_stream_eval *e, uint32_t *index) {
         bool any_free = false;
         for (auto &sl : e->slots) any_free = any_free || sl->kind == Slot::kFree;
         if (!any_free) {
+            // the OLDEST launched group (the first one in slot order may be the newest: waiting for that one drains
+            // everything queued, and the GPU then idles until the next group is ready — 136 us between the groups of the mixed
+            // program)
+            Slot *oldest = nullptr;
             for (auto &sl : e->slots)
-                if (sl->kind == Slot::kGroup && sl->launched) {
-                    (void)hipEventSynchronize(sl->done);
-                    sl->reset();
-                    break;
-                }
+                if (sl->kind == Slot::kGroup && sl->launched && (!oldest || sl->launch_no < oldest->launch_no)) oldest = sl.get();
+            if (oldest) {
+                (void)hipEventSynchronize(oldest->done);
+                oldest->reset();
+            }
         }
     }
     return slot_new(e->slots, index);
@@ -1804,7 +1811,8 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     {
         auto it = e->skels.find(((uint64_t)ngates << 32) | ntmp);
         if (e->use_skels && it != e->skels.end())
-            for (const EvalSkel &sk : it->second) {
+            for (size_t si = 0; si < it->second.size(); si++) {
+                const EvalSkel &sk = it->second[si];
                 if (sk.nbytes > len) continue;
                 const bool same = e->pool.match(sk, buf, slab);
                 const size_t nr = sk.nrows;
@@ -1820,6 +1828,9 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                     wr_ids[k] = gf_ids[sk.out_gf[k]];
                     e->io_host[nin + k] = sk.out_live[k] ? wr_ids[k] : 0xffffffffu;
                 }
+                // most recently matched first: the variants of a circuit (which operands have 16-bit ids, which repeat) are
+                // tried in that order and the least recently matched one goes when there are too many
+                if (si) std::rotate(it->second.begin(), it->second.begin() + (long)si, it->second.begin() + (long)si + 1);
                 break;
             }
     }
@@ -1997,12 +2008,15 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }
     // keep the skeleton: the next block of this circuit is matched byte-wise instead of parsed
     e->n_parsed++;
+    constexpr size_t kSkelVariants = 32;
     constexpr size_t kSkelCap = (size_t)1 << 30;  // beyond 1 GiB of reference blocks every new circuit is parsed each time
     if (e->use_skels && rec_ok && e->skel_bytes + pos <= kSkelCap) {
         std::vector<EvalSkel> &v = e->skels[((uint64_t)ngates << 32) | ntmp];
-        if (v.size() >= 8) {
-            e->skel_bytes -= v.front().bytes.size();
-            v.erase(v.begin());
+        // one circuit serialises differently with the widths of the ids it is bound to (per gate: 16-bit ids if all of the
+        // gate's are <= 0xffff) and with operands that repeat: an adder of a mixed program shows up in a dozen forms
+        if (v.size() >= kSkelVariants) {
+            e->skel_bytes -= v.back().bytes.size();
+            v.pop_back();
         }
         EvalSkel sk;
         sk.nbytes = pos;
@@ -2015,7 +2029,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
         if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) {
             e->skel_bytes += sk.bytes.size();
-            v.push_back(std::move(sk));
+            v.insert(v.begin(), std::move(sk));
         }
     }
     }  // parsed
@@ -2038,6 +2052,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             }
             uint32_t idx = 0;
             Slot *ng = eval_slot(e, &idx);
+            tr.lap("eval: launch + free slot");
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
