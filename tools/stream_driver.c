@@ -148,6 +148,7 @@ int main(int argc, char **argv) {
     uint8_t *bytes = malloc(cap);
     size_t *sizes = malloc(sizeof(size_t) * (size_t)nsteps);
     double garble_s = 0, eval_s = 0, eval_steady_s = 0;
+    double g_t0 = 0, g_t1 = 0, e_t0 = 0, e_t1 = 0; /* CLOCK_MONOTONIC: the same clock in every process of the box */
     uint32_t eval_steady_steps = 0;
     char hex[65] = "";
     gc_label *in0 = malloc(sizeof(gc_label) * ((size_t)nprim + 1));
@@ -177,6 +178,7 @@ int main(int argc, char **argv) {
             off += n;
         }
         garble_s = now_s() - t0;
+        g_t0 = t0, g_t1 = t0 + garble_s;
         total = off;
         gc_stream_free(g);
     }
@@ -213,15 +215,17 @@ int main(int argc, char **argv) {
         }
         if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe)) DIE("gc_stream_eval_get_wire"); /* waits for everything */
         eval_s = now_s() - t0;
+        e_t0 = t0, e_t1 = t0 + eval_s;
         eval_steady_s = now_s() - t_known;
         gc_stream_eval_stats(e, &parsed, &matched);
         gc_stream_eval_free(e);
     }
     printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
            "\"eval_steady_steps\": %u, \"bytes\": %zu, \"sha256\": \"%s\", "
-           "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\"}\n",
+           "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\", "
+           "\"garble_t0\": %.6f, \"garble_t1\": %.6f, \"eval_t0\": %.6f, \"eval_t1\": %.6f}\n",
            nsteps, window, garble_s, eval_s, eval_steady_s, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
-           (unsigned long long)probe.d0);
+           (unsigned long long)probe.d0, g_t0, g_t1, e_t0, e_t1);
     gc_ctx_destroy(ctx);
     return 0;
 }
