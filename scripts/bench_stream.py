@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 from mpc_amd import engine
-from mpc_amd.circuit import GATE, adder, multiplier, synthetic_levelised
+from mpc_amd.circuit import GATE, adder, comparator64, multiplier, synthetic_levelised
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "stream_bench_golden.json")
 
@@ -119,7 +119,83 @@ def program_mixed(nsteps=3000, seed=5, big_every=20):
     return steps, prim
 
 
+def ssa_circuits():
+    """23 distinct circuits, as many as the streamed Ed25519 program of the reference caches (benchmarks.md:698): the
+    instruction mix of a compiled MPCL program — adders and multipliers from 8 to 512 / 256 bits, a comparator, bitwise
+    operations (all-AND, all-OR, all-XOR, NOT: the last two garble without a table), mux- and shift-like blocks and one
+    wide hash-like block.  (name, circuit, weight in the instruction mix)"""
+    syn = synthetic_levelised
+    out = []
+    for bits, wgt in ((8, 3), (16, 4), (32, 10), (64, 14), (128, 2), (256, 2), (512, 1)):
+        out.append(("add%d" % bits, adder(bits), wgt))
+    for bits, wgt in ((8, 2), (16, 3), (32, 6), (64, 6), (128, 2), (256, 1)):
+        out.append(("mul%d" % bits, multiplier(bits), wgt))
+    out.append(("cmp64", comparator64(), 5))
+    out.append(("and64", syn(1, 64, 1.0, seed=41, ninputs=128), 5))
+    out.append(("or64", syn(1, 64, 0.0, seed=42, ninputs=128, or_frac=1.0), 3))
+    out.append(("xor64", syn(1, 64, 0.0, seed=43, ninputs=128), 7))
+    out.append(("and256", syn(1, 256, 1.0, seed=44, ninputs=512), 3))
+    out.append(("xor256", syn(1, 256, 0.0, seed=45, ninputs=512), 4))
+    out.append(("not256", syn(1, 256, 0.0, seed=46, ninputs=512, inv_frac=1.0), 3))
+    out.append(("mux64", syn(3, 64, 0.34, seed=47, ninputs=128), 6))
+    out.append(("shift64", syn(6, 64, 0.0, seed=48, ninputs=128), 4))
+    out.append(("hash512", syn(16, 512, 0.25, seed=49, ninputs=512, inv_frac=0.05), 2))
+    assert len(out) == 23
+    return out
+
+
+def program_ssa(nsteps=6000, seed=11):
+    """a stream of `nsteps` instructions drawn from ssa_circuits(): operands are live values of the instruction's width — 60 %
+    the result of one of the last eight instructions of that width (dependency chains), else a variable of the pool — and
+    30 % of the results overwrite a variable (the allocator recycles wires)"""
+    rng = np.random.default_rng(seed)
+    circs = ssa_circuits()
+    wsum = float(sum(w for _, _, w in circs))
+    probs = [w / wsum for _, _, w in circs]
+    widths = sorted({c.num_inputs // 2 for _, c, _ in circs})
+    nxt = 0
+    prim, pool, recent = [], {}, {}
+    for w in widths:  # eight variables per width: the program's primary inputs
+        pool[w] = []
+        for _ in range(8):
+            pool[w].append(list(range(nxt, nxt + w)))
+            prim += pool[w][-1]
+            nxt += w
+        recent[w] = []
+    nxt = max(nxt, 0x18000)  # results get ids beyond 16 bits, as in a program of this length
+    steps = []
+    for _ in range(nsteps):
+        _, c, _ = circs[int(rng.choice(len(circs), p=probs))]
+        w = c.num_inputs // 2
+
+        def operand():
+            r = recent[w]
+            if r and rng.random() < 0.6:
+                return r[int(rng.integers(max(0, len(r) - 8), len(r)))]
+            return pool[w][int(rng.integers(0, len(pool[w])))]
+
+        in_ = operand() + operand()
+        nout = c.num_outputs
+        out_ = None
+        if nout == w and rng.random() < 0.3:  # overwrite a variable that is not an operand of this instruction
+            t = int(rng.integers(0, len(pool[w])))
+            if not set(pool[w][t]) & set(in_):
+                out_ = pool[w][t]
+        if out_ is None:
+            out_ = list(range(nxt, nxt + nout))
+            nxt += nout
+            if nout == w:
+                pool[w][int(rng.integers(0, len(pool[w])))] = out_
+        if nout == w:
+            recent[w].append(out_)
+        elif nout in recent:  # (a 128-bit result of a wider block is a 128-bit value)
+            recent[nout].append(out_)
+        steps.append((c, in_, out_))
+    return steps, prim
+
+
 PROGRAMS = {
+    "ssa23": lambda: program_ssa(6000),
     "big": lambda: program_big(20_000_000),
     "big130": lambda: program_big(130_000_000),
     "uniform512": lambda: program_uniform(512, 4000, 8),
@@ -353,7 +429,7 @@ def run_native(name, key=bytes(range(32)), window=64):
 def run_for_line(key=bytes(range(32)), ctx=None):
     """the `stream` object of bench.py's line: the big-step program at config 5's size (991 steps of 131 072 gates =
     1.3e8 gates, 2.4 GB of stream: about 2 s for both sides and both hosts), the two uniform small-step programs and the
-    mixed program; every SHA-256 checked against the oracle's"""
+    mixed program and the 23-circuit instruction mix (ssa23); every SHA-256 checked against the oracle's"""
     out = {}
     b = run_program("big130", key, ctx, window=4)  # (an interpreter's jitter between the calls: 2 in flight are enough for a C host)
     out.update({"program": "big130", "steps": b["steps"], "gates": b["gates"], "window": b["window"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
@@ -364,13 +440,13 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                 "eval_steady_gates_per_s": b.get("eval_steady_gates_per_s", b["eval_gates_per_s"]),
                 "eval_first_blocks_s": b.get("eval_first_blocks_s"), "eval_blocks_parsed": b["eval_blocks_parsed"],
                 "first_pass_s": b["first_pass_s"], "sha256": b["sha256"], "sha256_ok": b["sha256_ok"]})
-    for name in ("uniform512", "uniform4096", "mixed"):
+    for name in ("uniform512", "uniform4096", "mixed", "ssa23"):
         r = run_program(name, key, ctx)
         out[name] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
                                        "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
-    for name, win in (("big130", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64)):
+    for name, win in (("big130", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64), ("ssa23", 64)):
         try:
             r = run_native(name, key, win)
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
