@@ -94,6 +94,7 @@ constexpr uint32_t kTailMax = 192;
 constexpr uint32_t kTailMaxGarble = 128;
 constexpr uint32_t kKeyTab = kTeDualBytes;            // byte address of the round-key table of the column-sliced hashes
 constexpr uint32_t kStageOff = kTeDualBytes / 16 + 16;  // 256 bytes: 15 round keys x 4 columns
+static_assert(kStageOff == kFlatStageOff16, "plan.h: the planner's copy of the LDS geometry");
 
 #define GC_FPROF(slot)                                               \
     if constexpr (PROF) {                                            \

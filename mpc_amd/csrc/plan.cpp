@@ -42,12 +42,41 @@ struct OpView {  // build_flat only reads gates[g].op: it runs from the gate lis
 };
 }  // namespace
 
+// late == false: every table-producing gate runs in the first hash phase its operands allow (as the serial loop would reach
+// it).  late == true: in the LAST phase its consumers allow.  The order of execution is free — tweaks and table rows follow the
+// gate list, not the schedule — and what it changes is how long labels live: a compiled n-bit multiplier forms its n^2
+// partial products from the inputs alone, so "as early as possible" keeps all of them alive (8 500 labels for 128 bits: no
+// LDS plan, 630 levels walked through HBM), "as late as possible" forms each row when the adder below it needs it (a few
+// hundred).  finish_flat tries the late form when the early one does not fit a workgroup's LDS.
 static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
                        const std::vector<uint32_t> &src0, const std::vector<uint32_t> &src1,
-                       const std::vector<uint32_t> &cur, Plan *out) {
+                       const std::vector<uint32_t> &cur, Plan *out, bool late = false) {
     Plan &p = *out;
     const uint32_t NONE = 0xffffffffu;
     const uint32_t nprod = ninputs + ngates;
+    std::vector<uint32_t> phase_of;  // late: the hash phase of every table-producing gate
+    if (late) {
+        std::vector<uint32_t> early(nprod, 0);
+        uint32_t last = 0;
+        for (uint32_t g = 0; g < ngates; g++) {
+            const uint32_t a = std::max(early[src0[g]], early[src1[g]]);
+            early[ninputs + g] = op_class(gates[g].op) != 3 ? a + 1 : a;
+            last = std::max(last, early[ninputs + g]);
+        }
+        // latest chunk in which a value may come into being: consumers come later in the gate list, so one backward pass
+        std::vector<uint32_t> need_by(nprod, last);
+        phase_of.assign(ngates, 0);
+        for (uint32_t g = ngates; g-- > 0;) {
+            const uint32_t pid = ninputs + g;
+            uint32_t by = need_by[pid];
+            if (op_class(gates[g].op) != 3) {
+                phase_of[g] = std::max(by, early[pid]);  // (by >= early: every consumer sits at least one phase later)
+                by = phase_of[g] - 1;
+            }
+            need_by[src0[g]] = std::min(need_by[src0[g]], by);
+            need_by[src1[g]] = std::min(need_by[src1[g]], by);
+        }
+    }
     // chunk a (= hash phases before the value exists) and XOR round r (0: input / hashed gate) of every producer
     std::vector<uint32_t> A(nprod, 0), Rr(nprod, 0);
     std::vector<uint8_t> is_free(nprod, 0), rpar(ngates, 0);
@@ -57,7 +86,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         const uint32_t pid = ninputs + g, s0 = src0[g], s1 = src1[g];
         const uint32_t a = std::max(A[s0], A[s1]);
         if (op_class(gates[g].op) != 3) {
-            A[pid] = a + 1;
+            A[pid] = late ? phase_of[g] : a + 1;
             continue;
         }
         is_free[pid] = 1;
@@ -527,8 +556,29 @@ void finish_flat(Plan *pp) {
     if (p.flat_built) return;
     build_fused(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
                 p.lazy_src1, p.lazy_cur, &p);
-    build_flat(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
-               p.lazy_src1, p.lazy_cur, &p);
+    auto flat = [&](bool late) {
+        p.fl_prog.clear(), p.fl_units.clear(), p.fl_hgslot.clear(), p.fl_ogslot.clear(), p.fl_in_lds.clear();
+        p.n_flat_slots = 0xffffffffu;
+        p.n_flat_outs = p.n_flat_terms = p.n_flat_steps = p.fl_unit_stride = 0;
+        build_flat(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
+                   p.lazy_src1, p.lazy_cur, &p, late);
+    };
+    // does ONE instance fit a workgroup's LDS beside the AES table (fused_flat_bytes, fused_flat_kernels.hip)?
+    auto fits = [&]() {
+        return p.n_flat_slots != 0xffffffffu &&
+               ((size_t)kFlatStageOff16 + 2 * (size_t)p.fl_unit_stride + p.n_flat_slots + 1) * 16 <= kFlatLdsBytes;
+    };
+    if (std::getenv("GC_PLAN_LATE")) {  // developer aid: the late schedule for every circuit
+        flat(true);
+        p.flat_late = true;
+    } else {
+        flat(false);
+    }
+    if (!p.flat_late && !fits() && !std::getenv("GC_PLAN_NO_LATE")) {
+        flat(true);
+        p.flat_late = fits();
+        if (!p.flat_late) flat(false);  // no LDS plan either way: keep the schedule every other circuit has
+    }
     p.flat_built = true;
     p.info.n_flat_slots = p.n_flat_slots;
     p.info.n_flat_outs = p.n_flat_outs;

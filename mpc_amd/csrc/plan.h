@@ -132,6 +132,7 @@ struct Plan {
     std::vector<uint16_t> fl_in_lds;    // LDS slot of every input wire (0xffff: never read)
     uint32_t n_flat_slots = 0xffffffffu;  // live labels incl. the zero slot (= slot n_flat_slots - 1)
     uint32_t n_flat_outs = 0, n_flat_terms = 0, n_flat_steps = 0;
+    bool flat_late = false;             // the flattened schedule runs every hashed gate as late as its consumers allow (plan.cpp: build_flat)
     uint32_t fl_unit_stride = 0;        // uint4 per LDS stage buffer = the largest unit (<= kUnit16)
     uint32_t fl_max_parts = 1;          // largest XOut part count: a tile may hold at most 16 / fl_max_parts instances
     std::vector<uint16_t> in_lds;       // LDS slot of every input wire (0xffff: never read)
@@ -157,6 +158,10 @@ bool wide_for_one_instance(const Plan &p, bool eval);
 
 // plaintext walk of the flattened unit program (host-side self-check, see plan.cpp)
 int simulate_flat(const Plan &p, const uint8_t *in_bits, uint8_t *out_bits);
+
+// LDS geometry of the flattened kernels that the planner needs to know (fused_flat_kernels.hip asserts the same values)
+constexpr uint32_t kFlatStageOff16 = 65536 / 16 + 16;  // uint4 in front of the stage buffers: the AES table + column keys
+constexpr size_t kFlatLdsBytes = 160 * 1024;
 
 }  // namespace gc
 

@@ -162,6 +162,39 @@ def test_flat_schedule_simulates_to_plaintext(aes_circ, sha_circ, add64_circ):
             assert (pl.simulate(b) == want).all(), repr(c)
 
 
+def test_late_schedule_when_the_early_one_does_not_fit_lds(monkeypatch):
+    """a circuit whose labels all exist early and die late (an array multiplier forms its n^2 partial products from the
+    inputs alone) has no LDS plan when every hashed gate runs as early as its operands allow; the planner then runs every
+    hashed gate as late as its consumers allow (plan.cpp: build_flat late) — same unit program format, far fewer live
+    labels — and that schedule too must walk to the plaintext result.  GC_PLAN_NO_LATE keeps the early one."""
+    import numpy as np
+    from mpc_amd.circuit import multiplier, synthetic_levelised
+    rng = np.random.default_rng(5)
+    lds_labels = (160 * 1024 - 65536 - 256) // 16  # what fits beside the AES table, stage buffers not counted
+    for c in (multiplier(128), multiplier(112)):
+        pl = engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs)
+        assert pl.info.n_lds_slots > lds_labels          # the early (level-walking) schedule does not fit
+        assert pl.info.n_flat_slots < lds_labels // 4     # the late flattened one does, with room for several instances
+        for _ in range(3):
+            b = rng.integers(0, 2, c.num_inputs).astype(np.uint8)
+            assert (pl.simulate(b) == c.compute_bits(b)[c.NumWires - c.num_outputs:]).all()
+        a, bb = int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 62))
+        w = c.num_inputs // 2
+        bits = np.array([(a >> i) & 1 for i in range(w)] + [(bb >> i) & 1 for i in range(w)], np.uint8)
+        got = pl.simulate(bits)
+        assert sum(int(v) << i for i, v in enumerate(got)) == (a * bb) % (1 << w)
+    # a circuit that fits keeps the early schedule (nothing changes for the circuits every other test pins)
+    c = multiplier(64)
+    monkeypatch.setenv("GC_PLAN_NO_LATE", "1")
+    early = engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).info.n_flat_slots
+    monkeypatch.delenv("GC_PLAN_NO_LATE")
+    assert engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).info.n_flat_slots == early
+    # ... and with the switch the big multiplier keeps its early schedule (no LDS plan)
+    monkeypatch.setenv("GC_PLAN_NO_LATE", "1")
+    c = multiplier(128)
+    assert engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).info.n_flat_slots > lds_labels
+
+
 def test_header_is_plain_c(tmp_path):
     """include/gcengine.h is what cgo compiles: it must be valid, warning-free plain C (C99, pedantic), not just C++;
     every declared function can be referenced from C and the Go-layout structs have the documented sizes"""

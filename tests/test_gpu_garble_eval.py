@@ -512,3 +512,18 @@ def test_global_wire_kernels_narrow_deep_circuit(ctx, batch):
     b.close(); dc.close()
     sample = None if batch < 10 else [0, 1, 255, 256, 519]
     check_garble_eval(ctx, c, KEY128, batch, "globn%d" % batch, check_all_wires=(batch < 10), schedule=1, sample=sample)
+
+
+@pytest.mark.gpu
+def test_late_schedule_circuits_match_oracle(ctx):
+    """circuits that only get an LDS plan with the late schedule (plan.cpp: build_flat late; a 112-bit array multiplier keeps
+    6 500 labels alive when every gate runs as early as it can): the flattened kernels on that schedule, one instance and
+    tiles of several, all three key sizes — tables, wire labels of inputs and outputs and the evaluated labels equal the
+    oracle's serial loop (tweaks and table rows follow the gate list, not the schedule)"""
+    from mpc_amd.circuit import multiplier
+    c = multiplier(112)
+    dc = engine.DeviceCircuit(ctx, c)
+    assert dc.info.n_flat_slots < 2000 < dc.info.n_lds_slots
+    for batch, keylen in ((1, 32), (5, 16), (300, 24), (1030, 32)):
+        sample = None if batch <= 5 else [0, 1, batch // 2, batch - 1]
+        check_garble_eval(ctx, c, drbg("late%d" % batch, keylen), batch, "late/%d" % batch, check_all_wires=False, sample=sample)
