@@ -714,3 +714,55 @@ def test_stream_mixed_program_matches_oracle():
         for o in out_[::7]:
             assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
     gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_instruction_mix_matches_oracle():
+    """the 23-circuit instruction mix of scripts/bench_stream.py (ssa23: adders to 512 bits, array multipliers to 256 bits —
+    those of 128 and 256 bits run on the planner's late schedule —, a comparator with OR gates, table-free blocks, mux /
+    shift / hash-like blocks) at a size the oracle restates in seconds, every one of the 23 circuits at least once: every
+    step's bytes and the evaluated labels equal the oracle's, evaluated on random input bits"""
+    from scripts.bench_stream import program_ssa, ssa_circuits
+    ctx = engine.Context(0)
+    steps, prim = program_ssa(220, seed=3)
+    seen = {id(c) for c, _, _ in steps}
+    pools = {}
+    for c, in_, _ in steps:
+        pools.setdefault(c.num_inputs // 2, in_[:c.num_inputs // 2])
+    nxt = max(max(max(i), max(o)) for _, i, o in steps) + 1
+    for _, c, _ in ssa_circuits():  # (the cached circuit objects differ: compare by shape)
+        if not any(s[0].name == c.name and s[0].NumGates == c.NumGates for s in steps):
+            w = c.num_inputs // 2
+            base = pools.get(w)
+            if base is None:
+                base = list(range(nxt, nxt + w)); prim = prim + base; nxt += w
+                pools[w] = base
+            steps.append((c, base + base, list(range(nxt, nxt + c.num_outputs))))
+            nxt += c.num_outputs
+    assert len({(c.name, c.NumGates) for c, _, _ in steps}) == 23 and seen
+    key = drbg("ssakey", 32)
+    rnd = drbg("ssarnd", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    issued = 0
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + 32:
+            c, in_, out_ = steps[issued]
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        assert gg.garble_finish() == want[k], "step %d (%s)" % (k, steps[k][0].name)
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("ssabits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = og.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    for (c, in_, out_), data in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    for k, (c, in_, out_) in enumerate(steps):
+        for o in out_[::5]:
+            assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
+    ctx.sync()
+    gg.close(); ge.close(); ctx.close()
