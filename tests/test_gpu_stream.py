@@ -766,3 +766,38 @@ def test_stream_instruction_mix_matches_oracle():
             assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
     ctx.sync()
     gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_closed_with_big_steps_in_flight():
+    """a garbler closed with big steps begun and not finished, an evaluator closed right behind its last big block (uploads on
+    their own stream, a batch held for the next step, the serialiser still running): nothing is waited for by the caller,
+    nothing may be freed under a kernel — and the context is as good as new afterwards (a second stream on it matches the
+    oracle)"""
+    from scripts.bench_stream import make_steps
+    nin = 256
+    steps = make_steps(5, 24, 2048, 0.3, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("close-big", 32)
+    rnd = drbg("close-big-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    ctx = engine.Context(0)
+    for rounds in range(3):
+        gg = engine.Stream(ctx, key, rnd, prim)
+        for c, in_, out_ in steps[:3]:
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+        assert gg.garble_finish() == want[0]
+        gg.close()  # two steps still in flight
+        ge = engine.StreamEval(ctx, key)
+        for w in prim:
+            ge.set(w, og.get(w)["l0"])
+        for (c, in_, out_), data in zip(steps[:3], want):
+            nw = max(max(in_), max(out_)) + 1
+            assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        ge.close()  # the last passes may still be running
+    gg = engine.Stream(ctx, key, rnd, prim)
+    assert [gg.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps] == want
+    ctx.sync()
+    gg.close(); ctx.close()
