@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <numeric>
 
 namespace gc {
@@ -80,7 +81,9 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     // chunk a (= hash phases before the value exists) and XOR round r (0: input / hashed gate) of every producer
     std::vector<uint32_t> A(nprod, 0), Rr(nprod, 0);
     std::vector<uint8_t> is_free(nprod, 0), rpar(ngates, 0);
-    std::vector<std::vector<uint32_t>> ex(ngates);  // sorted term list of every XOR gate
+    std::vector<std::vector<uint32_t>> ex(ngates);  // sorted term list of every XOR gate (and of the block sums behind them)
+    std::map<std::vector<uint32_t>, uint32_t> sums;  // block of terms -> the producer that stands for its sum
+    const bool two_level = std::getenv("GC_PLAN_NO_TWO_LEVEL") == nullptr;  // (developer switch: the chain of rounds)
     std::vector<uint32_t> t0, t1, tmp;
     for (uint32_t g = 0; g < ngates; g++) {
         const uint32_t pid = ninputs + g, s0 = src0[g], s1 = src1[g];
@@ -105,6 +108,62 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         terms_of(s0, &t0);
         terms_of(s1, &t1);
         symdiff(t0, t1, &tmp);
+        if (tmp.size() > kFlatMaxTerms && two_level) {
+            // Two levels instead of a chain of rounds.  The list is expanded all the way down to what exists when the chunk
+            // begins (this chunk's own XOR values are replaced by THEIR lists, whatever their round); those terms are summed
+            // in blocks of kFlatMaxTerms by XOuts of ROUND 1 that stand for no wire of the circuit — shared by content: the
+            // next value of an accumulator chain has the same leading terms — and the value itself is the XOR of the block
+            // sums in ROUND 2.  A chain of n values with 2 n terms (the anti-diagonal of an array multiplier: 64 .. 256 values
+            // in ONE chunk) then takes 2 rounds, not n / 16.
+            const uint32_t nreal = ninputs + ngates;
+            auto own = [&](uint32_t t) { return t < nreal && is_free[t] && A[t] == a; };  // an XOR value of this chunk
+            std::vector<uint32_t> full = tmp, acc, nxt;
+            uint8_t fpar = par;
+            for (bool again = true; again;) {
+                again = false;
+                acc.clear();
+                for (uint32_t t : full) {
+                    if (own(t)) {
+                        symdiff(acc, ex[t - ninputs], &nxt);
+                        fpar ^= rpar[t - ninputs];
+                        again = true;
+                    } else {
+                        t0.assign(1, t);
+                        symdiff(acc, t0, &nxt);
+                    }
+                    acc.swap(nxt);
+                }
+                full.swap(acc);
+            }
+            std::vector<uint32_t> raw, rest;
+            for (uint32_t t : full) ((t >= nreal && A[t] == a) ? rest : raw).push_back(t);  // rest: this chunk's block sums
+            const size_t nblocks = (raw.size() + kFlatMaxTerms - 1) / kFlatMaxTerms;
+            if (rest.size() + nblocks <= kFlatMaxTerms) {
+                for (size_t b0 = 0; b0 < raw.size(); b0 += kFlatMaxTerms) {
+                    std::vector<uint32_t> blk(raw.begin() + (long)b0, raw.begin() + (long)std::min(raw.size(), b0 + kFlatMaxTerms));
+                    if (blk.size() == 1) {
+                        rest.push_back(blk[0]);
+                        continue;
+                    }
+                    auto it = sums.find(blk);
+                    if (it == sums.end() || A[it->second] > a) {
+                        const uint32_t sp = (uint32_t)A.size();
+                        A.push_back(a);  // round 1 of THIS chunk: every term exists by then (an earlier chunk's sum is reused as is)
+                        Rr.push_back(1);
+                        is_free.push_back(1);
+                        ex.push_back(blk);
+                        rpar.push_back(0);
+                        sums[blk] = sp;
+                        it = sums.find(blk);
+                    }
+                    rest.push_back(it->second);
+                }
+                std::sort(rest.begin(), rest.end());
+                tmp.swap(rest);
+                par = fpar;
+                r = 2;
+            }
+        }
         if (tmp.size() > kFlatMaxTerms) {  // materialise the operands, continue in the next round
             r += 1;
             par = gates[g].op == GC_XNOR;
@@ -117,7 +176,8 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         ex[g] = tmp;
     }
     // what has to exist as a label: operands of hashed gates, circuit outputs, and the terms of those
-    std::vector<uint8_t> need(nprod, 0), is_output(nprod, 0);
+    const uint32_t nprod2 = (uint32_t)A.size(), ngates2 = (uint32_t)ex.size();  // with the block sums
+    std::vector<uint8_t> need(nprod2, 0), is_output(nprod2, 0);
     std::vector<uint32_t> stack;
     for (uint32_t j = 0; j < noutputs; j++) {
         const uint32_t w = nwires - noutputs + j;
@@ -143,7 +203,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     }
     // steps: (a, r) in order; r = 0 is the hash phase of chunk a
     std::vector<uint32_t> gl;  // needed gates
-    for (uint32_t g = 0; g < ngates; g++)
+    for (uint32_t g = 0; g < ngates2; g++)
         if (need[ninputs + g]) gl.push_back(g);
     auto key_of = [&](uint32_t g) { return ((uint64_t)A[ninputs + g] << 32) | ((uint64_t)Rr[ninputs + g] << 8); };
     auto sub_of = [&](uint32_t g) -> uint64_t {  // order inside a step
@@ -155,7 +215,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         return kx < ky;
     });
     std::vector<uint32_t> step_first;  // index into gl
-    std::vector<uint32_t> step_of(ngates, 0);
+    std::vector<uint32_t> step_of(ngates2, 0);
     for (uint32_t k = 0; k < gl.size(); k++) {
         if (k == 0 || key_of(gl[k]) != key_of(gl[k - 1])) step_first.push_back(k);
         step_of[gl[k]] = (uint32_t)step_first.size() - 1;
@@ -164,7 +224,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     step_first.push_back((uint32_t)gl.size());
     p.n_flat_steps = nsteps;
     // last reader (step + 1; 0 = never read)
-    std::vector<uint32_t> last_use(nprod, 0);
+    std::vector<uint32_t> last_use(nprod2, 0);
     for (uint32_t g : gl) {
         const uint32_t st = step_of[g] + 1;
         if (is_free[ninputs + g]) {
@@ -175,7 +235,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         }
     }
     // linear scan over the steps; slots freed after step s are reusable from step s + 1
-    std::vector<uint32_t> lds_of(nprod, 0xffffu), free_list;
+    std::vector<uint32_t> lds_of(nprod2, 0xffffu), free_list;
     std::vector<std::vector<uint32_t>> expire((size_t)nsteps + 2);
     uint32_t high = 0;
     auto take = [&]() {
@@ -338,7 +398,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
                                              (P == 2 ? kXoJoin2 : P == 4 ? kXoJoin4 : 0));
                     }
                     uo.push_back(x);
-                    uog.push_back(part == 0 ? p.slot_of_gate[g] : 0);
+                    uog.push_back(part == 0 && g < ngates ? p.slot_of_gate[g] : 0);  // (a block sum is no wire of the circuit)
                 }
                 u.xparts = std::max(u.xparts, P);
                 p.fl_max_parts = std::max(p.fl_max_parts, P);

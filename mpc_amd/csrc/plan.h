@@ -69,8 +69,11 @@ struct Chunk {
 // chunks).  Instead of walking the XOR gates level by level — a serial, latency-bound chain of ~8 dependent
 // LDS round trips per hash phase — the plan expands each XOR output that somebody actually needs (a hashed
 // gate, a later chunk, a circuit output) into its term list and the kernels compute all of them in ONE
-// parallel step per hash phase; intermediate XOR wires are never materialised.  Term lists longer than
-// kFlatMaxTerms are cut by materialising the operands and opening a second XOR round in that chunk.
+// parallel step per hash phase; intermediate XOR wires are never materialised.  A term list longer than
+// kFlatMaxTerms becomes two levels: blocks of kFlatMaxTerms chunk-entry terms are summed by XOuts of round 1 that stand
+// for no wire (shared by content between the values of an accumulator chain), the value is the XOR of the block sums in
+// round 2 (plan.cpp: build_flat); only a list of more than kFlatMaxTerms block sums falls back to materialising the
+// operands and opening another round.
 // (garble.go:331-351 / eval.go:49-51 compute the same labels gate by gate.)
 constexpr uint32_t kFlatMaxTerms = 32;
 // One XOR work item (24 bytes, self-contained: a lane needs ONE LDS round trip for it and one for its labels).

@@ -195,6 +195,26 @@ def test_late_schedule_when_the_early_one_does_not_fit_lds(monkeypatch):
     assert engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).info.n_flat_slots > lds_labels
 
 
+def test_long_xor_lists_take_two_rounds(monkeypatch):
+    """an accumulator chain (the anti-diagonal of an array multiplier: up to n XOR values with 2 n terms each in ONE chunk)
+    used to cost a round per 16 values; block sums shared by content make it two rounds — fewer barrier-separated steps,
+    the same plaintext result"""
+    import numpy as np
+    from mpc_amd.circuit import multiplier
+    rng = np.random.default_rng(8)
+    for bits, most in ((64, 190), (128, 400)):
+        c = multiplier(bits)
+        pl = engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs)
+        assert pl.info.n_flat_steps <= most, (bits, pl.info.n_flat_steps)
+        assert pl.info.n_flat_steps <= 3 * pl.info.n_hash_phases
+        for _ in range(3):
+            b = rng.integers(0, 2, c.num_inputs).astype(np.uint8)
+            assert (pl.simulate(b) == c.compute_bits(b)[c.NumWires - c.num_outputs:]).all()
+    monkeypatch.setenv("GC_PLAN_NO_TWO_LEVEL", "1")
+    c = multiplier(64)
+    assert engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).info.n_flat_steps > 230
+
+
 def test_header_is_plain_c(tmp_path):
     """include/gcengine.h is what cgo compiles: it must be valid, warning-free plain C (C99, pedantic), not just C++;
     every declared function can be referenced from C and the Go-layout structs have the documented sizes"""
