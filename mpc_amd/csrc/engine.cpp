@@ -615,6 +615,9 @@ static int relayout(gc_batch *b) {
         b->g = g;  // same arrays; lds_wires may differ
         return GC_OK;
     }
+    if (std::getenv("GC_TRACE"))
+        std::fprintf(stderr, "[gc trace] relayout: batch %u re-sized (ti %u -> %u, stride %u -> %u, tiles %u -> %u, had arrays %d)\n", b->g.batch,
+                     b->g.ti_log2, g.ti_log2, b->g.bstride, g.bstride, b->g.ntiles, g.ntiles, b->d_W != nullptr);
     GC_HIP(hipSetDevice(b->circ->ctx->device));
     GC_HIP(hipStreamSynchronize(b->circ->ctx->stream));
     drop_graphs(b);
@@ -1274,6 +1277,9 @@ static gc_batch *pool_get(gc_circ *c, uint32_t batch, int *rc) {
             }
         }
     }
+    if (std::getenv("GC_TRACE"))
+        std::fprintf(stderr, "[gc trace] pool_get: NEW batch of %u for a circuit of %u gates (pool holds %zu, schedule %d)\n", batch,
+                     c->plan.p.info.ngates, c->pool.size(), schedule);
     gc_batch *b = gc_batch_create(c, batch, rc);
     if (b && (b->schedule != schedule || b->single_phase != single_phase)) {
         int r2 = gc_batch_set_schedule(b, schedule == 0 ? 0 : single_phase ? 2 : 1);

@@ -628,16 +628,24 @@ void finish_flat(Plan *pp) {
         return p.n_flat_slots != 0xffffffffu &&
                ((size_t)kFlatStageOff16 + 2 * (size_t)p.fl_unit_stride + p.n_flat_slots + 1) * 16 <= kFlatLdsBytes;
     };
+    // (the level-walking schedule just built keeps the same labels alive as the early flattened one, give or take the zero
+    // slot: when those cannot fit, the early flattened build is not worth its time — 50 ms for a 256-bit multiplier)
+    const bool early_cannot_fit = p.n_lds_slots == 0xffffffffu || ((size_t)kFlatStageOff16 + p.n_lds_slots) * 16 > kFlatLdsBytes;
+    const bool may_late = !std::getenv("GC_PLAN_NO_LATE");
     if (std::getenv("GC_PLAN_LATE")) {  // developer aid: the late schedule for every circuit
         flat(true);
         p.flat_late = true;
-    } else {
-        flat(false);
-    }
-    if (!p.flat_late && !fits() && !std::getenv("GC_PLAN_NO_LATE")) {
+    } else if (early_cannot_fit && may_late) {
         flat(true);
         p.flat_late = fits();
         if (!p.flat_late) flat(false);  // no LDS plan either way: keep the schedule every other circuit has
+    } else {
+        flat(false);
+        if (!fits() && may_late) {
+            flat(true);
+            p.flat_late = fits();
+            if (!p.flat_late) flat(false);
+        }
     }
     p.flat_built = true;
     p.info.n_flat_slots = p.n_flat_slots;

@@ -936,6 +936,16 @@ int gc_stream_intern(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     int rc = stream_find_or_load(s, gates, ngates, nwires, nin, nout, &ent);
     if (rc != GC_OK) return rc;
     ent->pinned = true;
+    // interning is where a circuit's one-time work belongs: the flattened plan (built on first demand: 0.1 s for a 256-bit
+    // multiplier, early and late schedule) and, for a step that runs as a pass of its own, the two batches it alternates
+    // between — not inside the caller's first steps
+    if (!entry_is_small(ent)) {
+        gc_batch *b0 = nullptr, *b1 = nullptr;
+        if (gc_pass_batch(ent->circ, &b0) == GC_OK && gc_pass_batch(ent->circ, &b1) == GC_OK) {
+        }
+        if (b0) gc_circ_release_batch(ent->circ, b0);
+        if (b1) gc_circ_release_batch(ent->circ, b1);
+    }
     for (uint32_t i = 0; i < s->handles.size(); i++)
         if (s->handles[i] == ent) {
             *handle = i;
@@ -2159,6 +2169,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         }
     }
     int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, d_io, d_io + nin, slab_arg, nrows, &b, d_xchg);
+
     // the pinned slab (and this entry's buffers) may be overwritten once what was enqueued from it has run: also when the
     // pass failed half-way (the uploads are in flight)
     if (!small_block) {
