@@ -3,6 +3,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -66,6 +67,15 @@ struct Trace {
     }
 };
 }  // namespace
+
+// Contexts alive in the process.  The engine records a pass as a hipGraph on its own only while there is ONE: a kernel launch
+// on another thread's stream invalidates a capture under way here (hipErrorStreamCaptureInvalidated from the launches inside
+// it, measured with three streams on three threads and GC_NO_COOP) — with several contexts the same kernels are launched
+// directly.  (gc_ctx_capture_begin / _end, the caller's own recording, is the caller's to keep single-threaded.)
+static std::atomic<int> &live_contexts() {
+    static std::atomic<int> n{0};
+    return n;
+}
 
 // ---- cooperative one-launch passes of ONE instance (kernels.h: launch_coop) ------------------------------------------------
 // First use: allocate the barrier state and run the self-test (are the kCoopGroups workgroups on one XCD, do values stored
@@ -137,6 +147,7 @@ gc_ctx *gc_ctx_create(int device, int *status) try {
     int rc = GC_OK;
     gc_ctx *c = new (std::nothrow) gc_ctx;
     if (!c) rc = GC_E_NOMEM;
+    else live_contexts()++;
     if (rc == GC_OK) {
         c->device = device;
         hipError_t e = hipSetDevice(device);
@@ -163,6 +174,7 @@ gc_ctx *gc_ctx_create(int device, int *status) try {
 
 void gc_ctx_destroy(gc_ctx *c) {
     if (!c) return;
+    live_contexts()--;
     (void)hipSetDevice(c->device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
@@ -643,6 +655,14 @@ int gc_batch_set_graph(gc_batch *b, int on) {
     return GC_OK;
 }
 
+// The engine's own stream captures (a pass recorded once as a hipGraph and replayed) run one at a time in the process: two
+// contexts capturing at once on two threads invalidated each other's capture (hipErrorStreamCaptureInvalidated in one, a
+// sticky error in the other: three streams with GC_NO_COOP, tests/test_gpu_stream.py).
+static std::mutex &capture_mu() {
+    static std::mutex m;
+    return m;
+}
+
 static int set_key(gc_batch *b, const uint8_t *key, size_t keylen) {
     AesKey k;
     if (!key || !aes_expand_key(key, keylen, &k)) return GC_E_KEYSIZE;
@@ -774,7 +794,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
                 }
                 b->last_launches = a.nsteps;
                 const int kGraphKey = 3;  // distinct from the schedule-0 graphs of this batch
-                if (!b->use_graph || b->circ->ctx->capturing) {
+                if (!b->use_graph || b->circ->ctx->capturing || live_contexts() > 1) {
                     launch_levels1(eval, a, p.levels.data(), s);
                     GC_HIP(hipGetLastError());
                     return GC_OK;
@@ -786,12 +806,23 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
                     }
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
-                hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
-                if (e == hipSuccess) {
-                    launch_levels1(eval, a, p.levels.data(), s);
-                    e = hipStreamEndCapture(s, &graph);
+                hipError_t e;
+                {
+                    std::lock_guard<std::mutex> cap(capture_mu());  // (one capture at a time in the process, see capture_mu)
+                    e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+                    const hipError_t e_begin = e;
+                    hipError_t e_launch = hipSuccess, e_end = hipSuccess;
+                    if (e == hipSuccess) {
+                        launch_levels1(eval, a, p.levels.data(), s);
+                        e_launch = hipGetLastError();
+                        e = e_end = hipStreamEndCapture(s, &graph);
+                        if (e == hipSuccess) e = e_launch;
+                    }
+                    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                    if (e != hipSuccess && std::getenv("GC_TRACE"))
+                        std::fprintf(stderr, "[gc trace] level-launch capture failed: begin %d launch %d end %d instantiate %d\n", (int)e_begin,
+                                     (int)e_launch, (int)e_end, (int)e);
                 }
-                if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
                 if (graph) (void)hipGraphDestroy(graph);
                 if (e != hipSuccess) {  // capture unavailable: direct launches of the same kernels
                     (void)hipGetLastError();
@@ -812,7 +843,7 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
         return GC_OK;
     }
     b->last_launches = (uint32_t)p.levels.size();
-    if (!b->use_graph || p.levels.size() < 2) {
+    if (!b->use_graph || p.levels.size() < 2 || live_contexts() > 1) {
         enqueue_levels(b, eval, T, s);
         GC_HIP(hipGetLastError());
         return GC_OK;
@@ -826,12 +857,16 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
     }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
-    if (e == hipSuccess) {
-        enqueue_levels(b, eval, T, s);
-        e = hipStreamEndCapture(s, &graph);
+    hipError_t e;
+    {
+        std::lock_guard<std::mutex> cap(capture_mu());
+        e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+        if (e == hipSuccess) {
+            enqueue_levels(b, eval, T, s);
+            e = hipStreamEndCapture(s, &graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     }
-    if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
     if (e != hipSuccess) {
         // capture unsupported in this environment: fall back to direct launches (same kernels)

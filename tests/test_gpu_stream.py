@@ -187,9 +187,14 @@ def test_stream_big_steps_cooperative_and_level_launches_agree(monkeypatch):
     assert outs[0] == outs[1]
 
 
-def test_stream_concurrent_cooperative_passes():
+@pytest.mark.parametrize("no_coop", [False, True])
+def test_stream_concurrent_cooperative_passes(no_coop, monkeypatch):
     """three garbler streams (three contexts, three threads) send big steps to the same GPU at once: their cooperative
-    passes share the XCD's resident slots; every stream's bytes are the oracle's and no pass reports a lost workgroup"""
+    passes share the XCD's resident slots; every stream's bytes are the oracle's and no pass reports a lost workgroup.
+    GC_NO_COOP: the level launches instead — launched directly, not recorded, while several contexts are alive (a launch on
+    another thread's stream invalidates a stream capture under way: engine.cpp, live_contexts)"""
+    if no_coop:
+        monkeypatch.setenv("GC_NO_COOP", "1")
     import hashlib
     import threading
     from scripts.bench_stream import make_steps
