@@ -42,6 +42,17 @@ int on_exception() noexcept {
 
 }  // namespace gc
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (4 by default), and two
+// streams that share a queue run one after the other.  A garbler / evaluator stream of this engine uses up to seven HIP
+// streams that are meant to run side by side (ctx stream, copy / serialiser / upload streams, the deep lanes of
+// stream_engine.cpp), so the default becomes 8 — when the library is loaded before the runtime has read its settings (it
+// reads them on the first HIP call of the process), and only if the environment does not say otherwise (GC_KEEP_HW_QUEUES
+// leaves the runtime's default).  Without it the engine still works: lanes that share the ctx stream's queue are detected and
+// not used (DeepLanes::setup).
+__attribute__((constructor(101))) static void gc_default_hw_queues() {
+    if (!std::getenv("GC_KEEP_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 using namespace gc;
 
 namespace {
@@ -104,6 +115,47 @@ static bool coop_ready(gc_ctx *c) {
     if (ok) c->coop_state = 1;
     return ok;
 }
+
+namespace gc {
+constexpr size_t kBufMin = (size_t)64 << 10;
+constexpr size_t kDevCacheMax = (size_t)6 << 30, kPinCacheMax = (size_t)2 << 30;
+hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *cap) {
+    size_t want = kBufMin;
+    while (want < need) want *= 2;
+    {
+        std::lock_guard<std::mutex> lk(c->cache_mu);
+        auto &list = pinned ? c->pin_cache : c->dev_cache;
+        for (size_t i = list.size(); i-- > 0;)
+            if (list[i].cap == want) {
+                *p = list[i].p;
+                *cap = want;
+                (pinned ? c->pin_cached : c->dev_cached) -= want;
+                list.erase(list.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    void *q = nullptr;
+    hipError_t e = pinned ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want);
+    if (e != hipSuccess) return e;
+    *p = q;
+    *cap = want;
+    return hipSuccess;
+}
+void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(c->cache_mu);
+        size_t &held = pinned ? c->pin_cached : c->dev_cached;
+        if (held + cap <= (pinned ? kPinCacheMax : kDevCacheMax)) {
+            (pinned ? c->pin_cache : c->dev_cache).push_back(gc_ctx::CachedBuf{p, cap});
+            held += cap;
+            return;
+        }
+    }
+    if (pinned) (void)hipHostFree(p);
+    else (void)hipFree(p);
+}
+}  // namespace gc
 
 int gc_ctx_coop_check(gc_ctx *c) {
     if (!c || !c->h_coop_err || *c->h_coop_err == 0) return GC_OK;
@@ -189,6 +241,10 @@ void gc_ctx_destroy(gc_ctx *c) {
         if (c->ev_c[b]) (void)hipEventDestroy(c->ev_c[b]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipStream_t l : c->lanes) (void)hipStreamDestroy(l);
+    for (hipStream_t l : c->lanes_aside) (void)hipStreamDestroy(l);
+    for (auto &b : c->dev_cache) (void)hipFree(b.p);
+    for (auto &b : c->pin_cache) (void)hipHostFree(b.p);
     delete c;
 }
 

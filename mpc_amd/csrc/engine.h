@@ -45,7 +45,28 @@ struct gc_ctx {
     gc::CoopCtl *d_coop = nullptr;
     int coop_state = 0;
     uint32_t *h_coop_err = nullptr;
+    // Streaming engine (stream_engine.cpp), kept per ctx so that a stream created per connection does not pay for them again:
+    //  * the deep lanes — extra HIP streams that were probed to run beside `stream` (DeepLanes::setup; lanes_state 0: not set
+    //    up, 1: ready, -1: none) and the candidates that were set aside;
+    //  * the buffers of the launch slots (upload / arena / download regions, device and pinned): taken from and returned to
+    //    these lists in power-of-two sizes instead of hipMalloc / hipFree — hipFree waits for the whole device, and a slot
+    //    that grows in the middle of a stream would stall every queue.
+    int lanes_state = 0;
+    std::vector<hipStream_t> lanes, lanes_aside;
+    struct CachedBuf {
+        void *p;
+        size_t cap;
+    };
+    std::mutex cache_mu;
+    std::vector<CachedBuf> dev_cache, pin_cache;
+    size_t dev_cached = 0, pin_cached = 0;
 };
+namespace gc {
+// a buffer of at least `need` bytes (device, or pinned host memory) from the ctx's lists or the runtime; *cap = its real size
+hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *cap);
+// back to the lists (nothing on the GPU may still use it); freed when the lists hold more than a few GiB
+void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap);
+}  // namespace gc
 // internal: GC_E_HIP (and the cooperative passes switched off) if a cooperative pass of this ctx reported a lost workgroup
 int gc_ctx_coop_check(gc_ctx *c);
 

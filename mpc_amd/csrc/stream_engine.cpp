@@ -69,6 +69,7 @@ struct CircEntry {
     // step groups: can ONE workgroup run this circuit from LDS (-1: not asked yet), and if so the circuit-constant part
     // of its job record
     int small = -1;
+    int deep = -1;          // ... and is its pass long enough for a lane of its own (DeepLanes; -1: not asked yet)
     gc::FlatJob job{};
     size_t lds = 0;
     bool has_or = false;
@@ -90,6 +91,8 @@ struct DevStore {
     std::vector<uint32_t> dirty;  // host-set wires not uploaded yet
     uint4 *d = nullptr;
     size_t cap = 0;
+    hipEvent_t up_ev = nullptr;  // behind the latest upload of host-set labels (on the ctx stream): a deep step on a lane of
+                                 // its own waits for it (DeepLanes); null until the first upload
 
     void ensure(size_t n) {
         if (host.size() < n) {
@@ -110,6 +113,8 @@ struct DevStore {
             const size_t ncap = std::max(host.size(), cap * 2);
             uint4 *nd = nullptr;
             GC_HIP(hipMalloc((void **)&nd, ncap * sizeof(uint4)));
+            // the store moves: nothing may still be writing the old array (deep steps run on lanes of their own, DeepLanes)
+            if (d) GC_HIP(hipDeviceSynchronize());
             GC_HIP(hipMemsetAsync(nd, 0, ncap * sizeof(uint4), st));  // a never-set wire reads as the zero label
             if (d) GC_HIP(hipMemcpyAsync(nd, d, cap * sizeof(uint4), hipMemcpyDeviceToDevice, st));
             GC_HIP(hipStreamSynchronize(st));
@@ -131,6 +136,10 @@ struct DevStore {
                         GC_HIP(hipMemcpyAsync(d + dirty[k], &host[dirty[k]], sizeof(gc_label), hipMemcpyHostToDevice, st));
             i = j;
         }
+        if (!dirty.empty()) {
+            if (!up_ev) GC_HIP(hipEventCreateWithFlags(&up_ev, hipEventDisableTiming));
+            GC_HIP(hipEventRecord(up_ev, st));
+        }
         dirty.clear();
         return GC_OK;
     }
@@ -149,6 +158,8 @@ struct DevStore {
     }
     void release() {
         if (d) (void)hipFree(d);
+        if (up_ev) (void)hipEventDestroy(up_ev);
+        up_ev = nullptr;
         d = nullptr;
         cap = 0;
     }
@@ -174,20 +185,52 @@ struct JobRec {
     size_t off_rows = 0;          // evaluator: the block's table rows in the upload region
     size_t off_w = 0, off_t = 0;  // arena: wire array [nslots], table array [rows]
     size_t off_bytes = 0;         // download region: where the serialised gates go (garbler)
+    // evaluator, a deep block of many gates: its rows stay where the parser put them (pinned) and go up from there, behind
+    // the slot's upload region (no pass through h_up)
+    const gc_label *rows_src = nullptr;
+    size_t rows_ext = 0;
+};
+
+// the deep steps in flight (DeepLanes) that a step — or a group of steps — has to follow
+struct DeepDeps {
+    uint32_t ids[6] = {};  // exactly these: the latest deep writers of wires it reads or writes
+    uint32_t n = 0;
+    uint32_t upto = 0;     // ... and every deep step up to this id: the deep READERS of a wire it writes (the per-wire record
+                           // names only the latest of them), or writers beyond what ids[] holds
+    bool any() const { return n != 0 || upto != 0; }
+    void add(uint32_t id) {
+        for (uint32_t i = 0; i < n; i++)
+            if (ids[i] == id) return;
+        if (n < 6) ids[n++] = id;
+        else upto = std::max(upto, id);
+    }
+    void merge(const DeepDeps &o) {
+        for (uint32_t i = 0; i < o.n; i++) add(o.ids[i]);
+        upto = std::max(upto, o.upto);
+    }
 };
 
 struct Slot {
     enum Kind { kFree, kGroup, kBig } kind = kFree;
+    gc_ctx *ctx = nullptr;   // the upload / arena / download regions come from (and go back to) the ctx's buffer lists
     bool launched = false, synced = false;
     uint64_t launch_no = 0;  // order of the launches (the evaluator waits for its OLDEST group when it runs out of slots)
+    // deep lanes: deep_id != 0: the slot's one job runs on lane `lane` (DeepLanes); deps: the deep steps in flight that the
+    // slot's steps have a dependency on (its kernel waits for them)
+    uint32_t deep_id = 0;
+    DeepDeps deps;
+    int lane = -1;
+    hipEvent_t dep = nullptr;   // deep: "everything launched on the ctx stream before this step" (the lane waits for it) ...
+    bool after_tail = false;    // ... when the step must follow a pass of the ctx stream that has no event of its own;
+    hipEvent_t after_ev = nullptr;  // else the kernel of the latest group it conflicts with (null: none, or done already)
     int error = GC_OK;          // close failed: the group's steps report it
     uint32_t handed = 0;        // steps whose bytes have been handed out
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
     std::vector<JobRec> jobs;
     size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
     bool has_or = false;
-    uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr;
-    size_t h_up_cap = 0, d_up_cap = 0, arena_cap = 0, d_down_cap = 0, h_down_cap = 0;
+    uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr, *d_lane_boff = nullptr;
+    size_t h_up_cap = 0, d_up_cap = 0, arena_cap = 0, d_down_cap = 0, h_down_cap = 0, lane_boff_cap = 0;
     // a big step (more than kSmallGates gates): its own wire maps, block offsets, byte buffer and size word
     uint32_t *h_io = nullptr, *d_io = nullptr;  // h_io pinned: the upload is a true asynchronous copy
     size_t h_io_cap = 0, io_cap = 0;
@@ -202,16 +245,24 @@ struct Slot {
         launched = synced = false;
         error = GC_OK;
         handed = 0;
+        deep_id = 0;
+        deps = DeepDeps{};
+        after_tail = false;
+        after_ev = nullptr;
+        lane = -1;
         jobs.clear();
         up_used = arena_used = down_used = lds = 0;
         has_or = false;
     }
     void release() {
-        if (h_up) (void)hipHostFree(h_up);
-        if (d_up) (void)hipFree(d_up);
-        if (d_arena) (void)hipFree(d_arena);
-        if (d_down) (void)hipFree(d_down);
-        if (h_down) (void)hipHostFree(h_down);
+        if (ctx) {
+            gc::ctx_buf_put(ctx, true, h_up, h_up_cap);
+            gc::ctx_buf_put(ctx, false, d_up, d_up_cap);
+            gc::ctx_buf_put(ctx, false, d_arena, arena_cap);
+            gc::ctx_buf_put(ctx, false, d_down, d_down_cap);
+            gc::ctx_buf_put(ctx, true, h_down, h_down_cap);
+            gc::ctx_buf_put(ctx, false, d_lane_boff, lane_boff_cap);
+        }
         if (h_io) (void)hipHostFree(h_io);
         if (d_io) (void)hipFree(d_io);
         if (d_boff) (void)hipFree(d_boff);
@@ -219,6 +270,7 @@ struct Slot {
         if (need) (void)hipHostFree(need);
         if (kdone) (void)hipEventDestroy(kdone);
         if (done) (void)hipEventDestroy(done);
+        if (dep) (void)hipEventDestroy(dep);
     }
     // pinned upload region with room for `more` further bytes (contents preserved)
     hipError_t reserve_up(size_t more) {
@@ -226,37 +278,35 @@ struct Slot {
         if (need_cap <= h_up_cap) return hipSuccess;
         size_t ncap = std::max<size_t>((size_t)1 << 20, h_up_cap * 2);
         while (ncap < need_cap) ncap *= 2;
-        uint8_t *n = nullptr;
-        hipError_t e = hipHostMalloc((void **)&n, ncap, hipHostMallocDefault);
+        void *n = nullptr;
+        hipError_t e = gc::ctx_buf_get(ctx, true, ncap, &n, &ncap);
         if (e != hipSuccess) return e;
         if (up_used) std::memcpy(n, h_up, up_used);
-        if (h_up) (void)hipHostFree(h_up);
-        h_up = n;
+        gc::ctx_buf_put(ctx, true, h_up, h_up_cap);
+        h_up = (uint8_t *)n;
         h_up_cap = ncap;
         return hipSuccess;
     }
 };
 
-static hipError_t grow_dev(uint8_t **p, size_t *cap, size_t need) {
+// a slot's region of at least `need` bytes (contents not kept); from the ctx's buffer lists: no hipFree (it would wait for
+// every queue of the device) and, after the first stream of a ctx, no hipMalloc either
+static hipError_t grow_buf(gc_ctx *ctx, bool pinned, uint8_t **p, size_t *cap, size_t need) {
     if (need <= *cap) return hipSuccess;
-    if (*p) (void)hipFree(*p);
+    gc::ctx_buf_put(ctx, pinned, *p, *cap);
     *p = nullptr;
     *cap = 0;
-    const size_t n = need + need / 2 + 4096;
-    hipError_t e = hipMalloc((void **)p, n);
-    if (e == hipSuccess) *cap = n;
+    void *n = nullptr;
+    size_t ncap = 0;
+    hipError_t e = gc::ctx_buf_get(ctx, pinned, need + need / 4, &n, &ncap);
+    if (e == hipSuccess) {
+        *p = (uint8_t *)n;
+        *cap = ncap;
+    }
     return e;
 }
-static hipError_t grow_pin(uint8_t **p, size_t *cap, size_t need) {
-    if (need <= *cap) return hipSuccess;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const size_t n = need + need / 2 + 4096;
-    hipError_t e = hipHostMalloc((void **)p, n, hipHostMallocDefault);
-    if (e == hipSuccess) *cap = n;
-    return e;
-}
+static hipError_t grow_dev(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) { return grow_buf(ctx, false, p, cap, need); }
+static hipError_t grow_pin(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) { return grow_buf(ctx, true, p, cap, need); }
 
 // The open groups of a stream, oldest first: a small window of launch sequences that have not been launched yet, filled
 // by list scheduling.  Group i of the window carries sequence number first_seq + i; per global wire the window remembers
@@ -298,6 +348,31 @@ struct GroupWindow {
         for (uint32_t j = 0; j < nw; j++)
             if (writes[j] != 0xffffffffu) wr[writes[j]] = seq;
     }
+    // Launched groups, by sequence number (the last 64): a deep step that conflicts with a step of one of them waits for THAT
+    // group's kernel on its lane, not for everything the ctx stream holds.  slot 0xffffffff: a pass of the ctx stream that is
+    // no group (a big step): the deep step waits for the stream's tail instead.
+    struct Launched {
+        uint32_t seq = 0, slot = 0;
+        uint64_t launch_no = 0;
+    };
+    Launched ring[64];
+    void note(uint32_t seq, uint32_t slot, uint64_t launch_no) { ring[seq & 63u] = Launched{seq, slot, launch_no}; }
+    // sequence number of the latest group — open, launched or long gone — with a step that the step with these reads / writes
+    // must follow (0: none)
+    uint32_t last_conflict(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < nr; i++) q = std::max(q, wr[reads[i]]);
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) q = std::max(q, std::max(wr[writes[j]], rd[writes[j]]));
+        return q;
+    }
+    // a pass of the ctx stream that is no group (the window is empty: everything queued was launched in front of it) takes a
+    // sequence number of its own, so that later deep steps see what it reads and writes
+    void mark_pass(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        mark(0, reads, nr, writes, nw);
+        note(first_seq, 0xffffffffu, 0);
+        first_seq++;
+    }
     // the oldest group leaves the window (it is being launched)
     uint32_t pop() {
         const uint32_t slot = open.front();
@@ -313,6 +388,207 @@ struct GroupWindow {
 
 struct StepRef {
     uint32_t slot, job;
+};
+
+// ---- deep lanes ---------------------------------------------------------------------------------------------------------
+// A step whose one-workgroup plan is LONG (hundreds of dependent hash phases: a 128- / 256-bit multiplier, a 256- / 512-bit
+// adder — 0.5 to 2 ms on one CU) would hold up a whole group of short steps if it joined one, and the whole ctx stream if it
+// ran there as a pass of its own.  It runs on a LANE instead: one of a few extra HIP streams, as a group of one job (the same
+// kernels, launch sequence and serialiser as a group), beside the groups of the ctx stream and the deep steps of the other
+// lanes.  Program order is kept by events, and only where two steps share a wire:
+//   * a deep step conflicts with EARLIER small steps -> the open groups that hold them are launched first, and the lane waits
+//     for an event recorded on the ctx stream at that point (everything launched there so far: groups, big steps, uploads);
+//   * a deep step conflicts with earlier DEEP steps  -> per wire the id of the latest deep reader / writer (ids ascend in
+//     program order); the lane waits, per other lane, for that lane's latest step with an id up to the conflicting one (a lane
+//     runs in order, so that covers every earlier step of the lane — readers that the per-wire record no longer names too);
+//   * a LATER small step conflicts with a deep step   -> its group remembers which (Slot::deps) and the ctx stream
+//     waits for the lanes' steps up to it before the group's kernel; a later big step waits for every deep step in flight.
+// Every wait names work that was enqueued before the waiter, so the streams cannot deadlock.  Whether a lane really runs
+// beside the ctx stream is up to the runtime: it multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+// environment says otherwise; engine.cpp raises the default to 8 when the library is loaded before the runtime starts), and
+// two streams on one queue run one after the other.  Lanes are therefore PROBED when they are created (k_lane_probe): a
+// candidate whose kernel cannot see a flag raised by a kernel enqueued afterwards on the ctx stream (or on a lane already
+// accepted) shares a queue with it and is set aside; without a usable lane deep steps keep the path of the big steps.
+namespace {
+__global__ void k_lane_probe(uint32_t *flag, uint32_t *seen, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    uint32_t v = 0;
+    while (!(v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    *seen = v;
+}
+__global__ void k_lane_flag(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+
+constexpr uint32_t kDeepStepsDefault = 300;  // barriers per pass (hash phases + XOR rounds) from which a step is deep: ~0.4 ms
+constexpr uint32_t kDeepLanesDefault = 3;
+constexpr uint32_t kDeepMaxGates = 1u << 20;
+constexpr uint32_t kDeepInFlight = 24;       // deep steps launched and not known to be done, at most (then the oldest is waited for)
+
+struct DeepLanes {
+    struct InFlight {
+        uint32_t id;
+        hipEvent_t ev;  // the step's kernel has run (its slot's kdone; the slot is not re-used before retire())
+    };
+    int state = 0;  // 0: not set up, 1: lanes ready, -1: off
+    uint32_t min_steps = kDeepStepsDefault;
+    std::vector<hipStream_t> lanes;         // the ctx's lanes (owned by the ctx: set up once, shared by its streams)
+    std::vector<std::deque<InFlight>> inflight;  // per lane, ids ascending
+    std::vector<uint32_t> rd, wr;           // per global wire: id of the latest deep step that reads / writes it
+    uint32_t next_id = 1, n_inflight = 0;
+    uint64_t n_steps = 0;
+    uint8_t lane_of[256] = {};              // lane of the deep step with id & 255 (at most kDeepInFlight are in flight)
+
+    // the ctx's lanes, created and probed on first use (under ctx->mu)
+    static void setup_ctx(gc_ctx *ctx) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->lanes_state != 0) return;
+        ctx->lanes_state = -1;
+        const char *v = std::getenv("GC_STREAM_DEEP_LANES");
+        int want = v && *v ? std::atoi(v) : (int)kDeepLanesDefault;
+        if (want <= 0) return;
+        want = std::min(want, 8);
+        if (hipSetDevice(ctx->device) != hipSuccess) return;
+        uint32_t *h = nullptr, *d_probe = nullptr;
+        if (hipMalloc((void **)&d_probe, 2 * sizeof(uint32_t)) != hipSuccess ||
+            hipHostMalloc((void **)&h, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (d_probe) (void)hipFree(d_probe);
+            return;
+        }
+        // does a kernel on `a` run while one on `b`, enqueued EARLIER, is still spinning?  (b's kernel waits up to 0.4 ms
+        // for the flag a's kernel raises)
+        auto beside = [&](hipStream_t b, hipStream_t a) -> bool {
+            h[0] = h[1] = 0;
+            if (hipMemcpyAsync(d_probe, h, 8, hipMemcpyHostToDevice, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+            hipLaunchKernelGGL(k_lane_probe, dim3(1), dim3(1), 0, b, d_probe, d_probe + 1, 40000ull);
+            hipLaunchKernelGGL(k_lane_flag, dim3(1), dim3(1), 0, a, d_probe);
+            if (hipStreamSynchronize(b) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+            if (hipMemcpy(h, d_probe, 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            return h[1] == 1;
+        };
+        const bool trace = std::getenv("GC_TRACE") != nullptr;
+        for (int tries = 0; (int)ctx->lanes.size() < want && tries < want + 8; tries++) {
+            hipStream_t c = nullptr;
+            if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+            bool ok = beside(c, ctx->stream);
+            for (size_t i = 0; ok && i < ctx->lanes.size(); i++) ok = beside(c, ctx->lanes[i]);
+            if (trace) std::fprintf(stderr, "[gc trace] deep lane candidate %d: %s\n", tries, ok ? "runs beside the ctx stream" : "shares a hardware queue: set aside");
+            (ok ? ctx->lanes : ctx->lanes_aside).push_back(c);
+        }
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        (void)hipFree(d_probe);
+        if (!ctx->lanes.empty()) ctx->lanes_state = 1;
+    }
+    bool setup(gc_ctx *ctx) {
+        if (state != 0) return state > 0;
+        state = -1;
+        const char *v = std::getenv("GC_STREAM_DEEP_STEPS");
+        if (v && *v) min_steps = (uint32_t)std::max(1, std::atoi(v));
+        setup_ctx(ctx);
+        if (ctx->lanes_state <= 0) return false;
+        lanes = ctx->lanes;
+        inflight.resize(lanes.size());
+        state = 1;
+        return true;
+    }
+    void ensure(size_t n) {
+        if (rd.size() < n) {
+            rd.resize(n, 0);
+            wr.resize(n, 0);
+        }
+    }
+    // every id up to this one is known to be done
+    uint32_t floor() const {
+        uint32_t f = next_id - 1;
+        for (const auto &q : inflight)
+            if (!q.empty()) f = std::min(f, q.front().id - 1);
+        return f;
+    }
+    // the deep steps in flight that a step with these reads / writes depends on
+    DeepDeps conflicts(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        DeepDeps d;
+        if (n_inflight == 0 || rd.empty()) return d;
+        const uint32_t fl = floor();
+        for (uint32_t i = 0; i < nr; i++)
+            if (wr[reads[i]] > fl) d.add(wr[reads[i]]);  // read after write
+        for (uint32_t j = 0; j < nw; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            if (wr[writes[j]] > fl) d.add(wr[writes[j]]);                                      // write after write
+            if (rd[writes[j]] > fl && rd[writes[j]] > wr[writes[j]]) d.upto = std::max(d.upto, rd[writes[j]]);  // write after read
+        }
+        return d;
+    }
+    void mark(uint32_t id, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        for (uint32_t i = 0; i < nr; i++) rd[reads[i]] = id;
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) wr[writes[j]] = id;
+    }
+    // steps whose kernels have run leave the lists (cheap: one query per lane head)
+    void poll() {
+        for (auto &q : inflight)
+            while (!q.empty() && hipEventQuery(q.front().ev) == hipSuccess) {
+                q.pop_front();
+                n_inflight--;
+            }
+        (void)hipGetLastError();  // hipErrorNotReady of the queries
+    }
+    // `st` waits for every deep step with an id up to x (per lane: the latest such step); skip: the lane `st` itself is
+    hipError_t wait_upto(hipStream_t st, uint32_t x, int skip) {
+        for (size_t l = 0; l < inflight.size(); l++) {
+            if ((int)l == skip) continue;
+            const auto &q = inflight[l];
+            hipEvent_t ev = nullptr;
+            for (const InFlight &f : q) {
+                if (f.id > x) break;
+                ev = f.ev;
+            }
+            if (ev) {
+                hipError_t e = hipStreamWaitEvent(st, ev, 0);
+                if (e != hipSuccess) return e;
+            }
+        }
+        return hipSuccess;
+    }
+    hipError_t wait_all(hipStream_t st) { return n_inflight ? wait_upto(st, next_id, -1) : hipSuccess; }
+    // `st` waits for the deep steps of d that are still in flight; skip: the lane `st` itself is (-1: none)
+    hipError_t wait_deps(hipStream_t st, const DeepDeps &d, int skip) {
+        for (uint32_t i = 0; i < d.n; i++) {
+            const int l = lane_of[d.ids[i] & 255u];
+            if (l == skip || (size_t)l >= inflight.size()) continue;
+            for (const InFlight &f : inflight[(size_t)l])
+                if (f.id == d.ids[i]) {
+                    hipError_t e = hipStreamWaitEvent(st, f.ev, 0);
+                    if (e != hipSuccess) return e;
+                    break;
+                }
+        }
+        return d.upto ? wait_upto(st, d.upto, skip) : hipSuccess;
+    }
+    // the step is known to be done (its slot is about to be re-used): it and everything older on its lane leave the list
+    void retire(int lane, uint32_t id) {
+        if (lane < 0 || (size_t)lane >= inflight.size()) return;
+        auto &q = inflight[(size_t)lane];
+        while (!q.empty() && q.front().id <= id) {
+            q.pop_front();
+            n_inflight--;
+        }
+    }
+    // the least busy lane (fewest steps in flight; ties: the one whose last step is the oldest)
+    int pick() const {
+        int best = 0;
+        for (size_t l = 1; l < inflight.size(); l++) {
+            const auto &a = inflight[l], &b = inflight[(size_t)best];
+            if (a.size() < b.size() || (a.size() == b.size() && !a.empty() && a.back().id < b.back().id)) best = (int)l;
+        }
+        return best;
+    }
+    void drain() {
+        for (hipStream_t l : lanes) (void)hipStreamSynchronize(l);
+        for (auto &q : inflight) q.clear();
+        n_inflight = 0;
+    }
+    void release() { drain(); }
 };
 
 struct gc_stream {
@@ -334,6 +610,7 @@ struct gc_stream {
     std::vector<std::unique_ptr<Slot>> slots;
     std::deque<StepRef> queue;
     GroupWindow win;              // the groups still accepting steps
+    DeepLanes deep;               // long one-workgroup steps run beside the groups, on streams of their own
     std::vector<CircEntry *> handles;  // gc_stream_intern
     hipStream_t copy_stream = nullptr;
     // Big steps: the serialiser (byte sizes, their scan, the total down, the bytes) runs on ser_stream behind the pass
@@ -433,7 +710,7 @@ __global__ __launch_bounds__(kSerThreads) void k_ser_sizes(SerArgs a, uint64_t *
 }
 // exclusive scan of the block sizes in place (one workgroup; a step has a few hundred to a few thousand blocks);
 // boff[nblocks] = total
-__global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblocks) {
+__global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblocks, uint32_t *total_out = nullptr) {
     __shared__ uint64_t part[1024];
     const uint32_t per = (nblocks + 1023) / 1024;
     const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nblocks);
@@ -449,6 +726,7 @@ __global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblo
             run += v;
         }
         boff[nblocks] = run;
+        if (total_out) *total_out = (uint32_t)run;
     }
     __syncthreads();
     uint64_t run = part[threadIdx.x];
@@ -683,13 +961,41 @@ bool entry_is_small(CircEntry *e) {
     return e->small == 1;
 }
 
-Slot *slot_new(std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index) {
+// does ONE workgroup run this circuit from LDS, and LONG enough for a lane of its own (DeepLanes)?  Either a step that is too
+// big for a group but has a one-workgroup plan (a 128- / 256-bit multiplier on the late schedule), or a small one whose pass
+// has at least min_steps barriers (a 256- / 512-bit adder).  A wide circuit is asked nothing: its level launches never need
+// the flattened plan (building it for a 131 072-gate step costs more than the step).
+bool entry_is_deep(CircEntry *e, uint32_t min_steps) {
+    if (e->deep < 0) {
+        e->deep = 0;
+        const size_t n = e->gates.size();
+        if (n <= kDeepMaxGates && (n <= kSmallWideGates || !wide_for_one_instance(e->circ->plan.p, false))) {
+            const bool ok = e->small == 1 || gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or);
+            if (ok && (n > kSmallGates || e->circ->plan.p.n_flat_steps >= min_steps)) e->deep = 1;
+        }
+    }
+    return e->deep == 1;
+}
+
+// a free slot; big: for a deep step (megabytes of wire / table arrays) — a free slot that has grown that far already is
+// preferred for those and avoided for groups of small steps, so that not every slot of a stream ends up with big regions
+Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big = false) {
+    constexpr size_t kBigArena = (size_t)2 << 20;
+    int other = -1;
     for (uint32_t i = 0; i < slots.size(); i++)
         if (slots[i]->kind == Slot::kFree) {
-            *index = i;
-            return slots[i].get();
+            if ((slots[i]->arena_cap >= kBigArena) == big) {
+                *index = i;
+                return slots[i].get();
+            }
+            if (other < 0) other = (int)i;
         }
+    if (other >= 0 && (!big || slots.size() >= 64)) {
+        *index = (uint32_t)other;
+        return slots[(size_t)other].get();
+    }
     std::unique_ptr<Slot> sl(new Slot);
+    sl->ctx = ctx;
     if (hipEventCreateWithFlags(&sl->kdone, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
@@ -701,11 +1007,29 @@ Slot *slot_new(std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index) {
     return slots.back().get();
 }
 
+// Which launch of the ctx stream does a deep step have to follow on its lane?  cs: sequence number of the latest group with a
+// step it conflicts with (GroupWindow::last_conflict; the open ones among them have just been launched).
+void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng) {
+    if (cs == 0) return;
+    const GroupWindow::Launched &l = win.ring[cs & 63u];
+    if (l.seq != cs || l.slot == 0xffffffffu) {  // launched too long ago to know, or a pass without an event of its own
+        ng->after_tail = true;
+        return;
+    }
+    const Slot &g = *slots[l.slot];
+    // (a slot that has been given back or re-used meanwhile: that group was done long ago)
+    if (g.kind == Slot::kGroup && g.launched && g.launch_no == l.launch_no && g.error == GC_OK) ng->after_ev = g.kdone;
+}
+
 // Launch sequence of a group (see the head of this file).  eval: the jobs' table rows are part of the upload region and
 // nothing comes back.  On return the slot is `launched`; a failure is kept in slot.error for the group's steps.
+// A deep step (g.deep_id != 0, one job) takes the same sequence on its lane, behind an event recorded on the ctx stream here
+// and behind the deep steps of the other lanes named by g.deps; a group of small steps on the ctx stream waits for the deep
+// steps of g.deps (DeepLanes).
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream) {
-    hipStream_t st = ctx->stream;
+                 hipStream_t copy_stream, DeepLanes &deep) {
+    const bool on_lane = g.deep_id != 0;
+    hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : ctx->stream;
     std::lock_guard<std::mutex> lk(ctx->mu);
     g.launched = true;
     static std::atomic<uint64_t> launches{0};
@@ -719,16 +1043,38 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (e != hipSuccess) return fail("launch_group", e);
     int rcs = store.flush(ctx);  // host-set labels go up first; the store may move (its pointer is taken below)
     if (rcs != GC_OK) return g.error = rcs;
+    if (on_lane) {
+        if (store.up_ev) e = hipStreamWaitEvent(st, store.up_ev, 0);  // host-set labels it may read (long done, as a rule)
+        if (e == hipSuccess && g.after_tail) {
+            if (!g.dep) e = hipEventCreateWithFlags(&g.dep, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(g.dep, ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, g.dep, 0);
+        } else if (e == hipSuccess && g.after_ev) {
+            e = hipStreamWaitEvent(st, g.after_ev, 0);
+        }
+        if (e == hipSuccess && g.deps.any()) e = deep.wait_deps(st, g.deps, g.lane);
+    } else if (g.deps.any()) {
+        deep.poll();
+        e = deep.wait_deps(st, g.deps, -1);
+    }
+    if (e != hipSuccess) return fail("launch_group (order)", e);
     const uint32_t n = (uint32_t)g.jobs.size();
     const size_t off_fj = up16(g.up_used), off_fin = off_fj + (size_t)n * sizeof(FlatJob);
     const size_t total_up = off_fin + (size_t)n * sizeof(FinJob);
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
+    // rows that go up from where the parser left them (a deep block of the evaluator): behind the upload region
+    size_t ext_total = 0;
+    for (JobRec &j : g.jobs)
+        if (j.rows_src) {
+            j.off_rows = up256(total_up) + ext_total;
+            ext_total += up256(j.rows_ext * sizeof(gc_label));
+        }
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
-    if ((e = grow_dev(&g.d_up, &g.d_up_cap, total_up)) != hipSuccess) return fail("launch_group (upload)", e);
-    if ((e = grow_dev(&g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
+    if ((e = grow_dev(ctx, &g.d_up, &g.d_up_cap, up256(total_up) + ext_total)) != hipSuccess) return fail("launch_group (upload)", e);
+    if ((e = grow_dev(ctx, &g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
     if (!eval) {
-        if ((e = grow_dev(&g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
-        if ((e = grow_pin(&g.h_down, &g.h_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (pinned bytes)", e);
+        if ((e = grow_dev(ctx, &g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
+        if ((e = grow_pin(ctx, &g.h_down, &g.h_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (pinned bytes)", e);
     }
     FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
     FinJob *fin = (FinJob *)(g.h_up + off_fin);
@@ -764,12 +1110,36 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         fin[k] = q;
     }
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
+    for (uint32_t k = 0; k < n && e == hipSuccess; k++)
+        if (g.jobs[k].rows_src && g.jobs[k].rows_ext)
+            e = hipMemcpyAsync(g.d_up + g.jobs[k].off_rows, g.jobs[k].rows_src, g.jobs[k].rows_ext * sizeof(gc_label), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
+    if (e == hipSuccess) e = hipEventRecord(g.kdone, st);
+    if (e == hipSuccess && on_lane) {
+        deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kdone});
+        deep.lane_of[g.deep_id & 255u] = (uint8_t)g.lane;
+        deep.n_inflight++;
+        deep.n_steps++;
+    }
     if (e == hipSuccess && !eval) {
         // serialiser and bytes on the copy stream: the next group's garbling need not wait for either
-        e = hipEventRecord(g.kdone, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
-        if (e == hipSuccess) {
+        e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (e == hipSuccess && on_lane && n == 1 && g.jobs[0].ngates > 4 * kSerGates) {
+            // a deep step of many gates: the serialiser of the big steps, spread over the chip (one workgroup would write
+            // megabytes byte by byte: 1 - 2 ms on the copy stream, more than the step's pass)
+            const FinJob &q = fin[0];
+            const uint32_t nblocks = (q.a.ngates + kSerGates - 1) / kSerGates;
+            if (g.lane_boff_cap < ((size_t)nblocks + 1) * sizeof(uint64_t))
+                e = grow_dev(ctx, &g.d_lane_boff, &g.lane_boff_cap, ((size_t)nblocks + 1) * sizeof(uint64_t));
+            uint64_t *boff = (uint64_t *)g.d_lane_boff;
+            if (e == hipSuccess) {
+                const Layout dense{0, 0, 1, 0};
+                hipLaunchKernelGGL(k_ser_sizes, dim3(nblocks), dim3(kSerThreads), 0, copy_stream, q.a, boff);
+                hipLaunchKernelGGL(k_ser_scan, dim3(1), dim3(1024), 0, copy_stream, boff, nblocks, q.size_out);
+                hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, copy_stream, q.a, boff, q.T, dense, q.bytes);
+                e = hipGetLastError();
+            }
+        } else if (e == hipSuccess) {
             hipLaunchKernelGGL(k_stream_serialise, dim3(n), dim3(kFinThreads), 0, copy_stream, (const FinJob *)(g.d_up + off_fin));
             e = hipGetLastError();
         }
@@ -786,10 +1156,13 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
 // the oldest open group leaves the window and is launched
 int launch_oldest(gc_stream *s) {
     if (s->win.open.empty()) return GC_OK;
-    Slot &g = *s->slots[s->win.pop()];
+    const uint32_t seq = s->win.first_seq, slot = s->win.pop();
+    Slot &g = *s->slots[slot];
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
-    return launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream);
+    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
+    s->win.note(seq, slot, g.launch_no);
+    return rc;
 }
 // everything queued is launched, in order (a read-back, a big step or the caller's flush follows)
 int close_group(gc_stream *s) {
@@ -824,6 +1197,8 @@ int stream_find_or_load(gc_stream *s, const gc_gate *gates, uint32_t ngates, uin
                 GC_HIP(hipStreamSynchronize(st));
                 GC_HIP(hipStreamSynchronize(s->copy_stream));
                 if (s->ser_stream) GC_HIP(hipStreamSynchronize(s->ser_stream));
+                s->deep.drain();
+                GC_HIP(hipStreamSynchronize(s->copy_stream));  // (the serialisers of the deep steps)
                 if (s->held) gc_circ_release_batch(s->held_circ, s->held);  // (back into its circuit's pool before that may go)
                 s->held = nullptr;
                 s->ser_batch[0] = s->ser_batch[1] = nullptr;
@@ -907,6 +1282,7 @@ void gc_stream_free(gc_stream *s) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
     }
+    s->deep.release();
     if (s->copy_stream) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
@@ -939,7 +1315,9 @@ int gc_stream_intern(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     // interning is where a circuit's one-time work belongs: the flattened plan (built on first demand: 0.1 s for a 256-bit
     // multiplier, early and late schedule) and, for a step that runs as a pass of its own, the two batches it alternates
     // between — not inside the caller's first steps
-    if (!entry_is_small(ent)) {
+    if (entry_is_deep(ent, s->deep.min_steps) && s->deep.setup(s->ctx)) {
+        // (a long one-workgroup pass: it will run on a lane, as a group of one job — the lanes are set up here as well)
+    } else if (!entry_is_small(ent)) {
         gc_batch *b0 = nullptr, *b1 = nullptr;
         if (gc_pass_batch(ent->circ, &b0) == GC_OK && gc_pass_batch(ent->circ, &b1) == GC_OK) {
         }
@@ -985,6 +1363,7 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streami
     if (!s || !out) return GC_E_ARG;
     int rc = close_group(s);  // a queued step may be the one that sets the wire
     if (rc != GC_OK) return rc;
+    if (s->deep.n_inflight) s->deep.drain();  // ... or a deep step on its lane
     gc_label l0;
     rc = s->store.get(s->ctx, w, &l0);
     if (rc != GC_OK) return rc;
@@ -1089,34 +1468,62 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     s->skip_scratch.resize(nout);
     for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
 
-    // ---- a small step joins the earliest open group it has no dependency on (or behind) --------------------------
-    if (ngates && entry_is_small(ent)) {
+    // ---- a small step joins the earliest open group it has no dependency on (or behind); a deep one takes a lane ---------
+    const bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps) && s->deep.setup(ctx);
+    if (is_deep || (ngates && entry_is_small(ent))) {
         s->win.ensure(s->store.host.size());
+        if (is_deep || s->deep.n_inflight) s->deep.ensure(s->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
         uint32_t gi = s->win.place(in, nin, s->skip_scratch.data(), nout);
-        auto full = [&](const Slot &g) {
-            return g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
-        };
-        while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
-        if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
-            if (s->win.open.size() >= kOpenGroups) {
+        uint32_t slot_idx = 0;
+        if (is_deep) {
+            // the open groups this step depends on go to the GPU first (place(): every conflict sits in a group before gi)
+            for (; gi > 0; gi--) {
                 int rcq = launch_oldest(s);
                 if (rcq != GC_OK) return rcq;
-                gi--;
             }
-            uint32_t idx = 0;
-            Slot *ng = slot_new(s->slots, &idx);
+            s->deep.poll();
+            if (s->deep.n_inflight >= kDeepInFlight) {  // bounded: wait for the oldest deep step of the fullest lane
+                size_t l = 0;
+                for (size_t k = 1; k < s->deep.inflight.size(); k++)
+                    if (s->deep.inflight[k].size() > s->deep.inflight[l].size()) l = k;
+                (void)hipEventSynchronize(s->deep.inflight[l].front().ev);
+                s->deep.poll();
+            }
+            Slot *ng = slot_new(ctx, s->slots, &slot_idx, true);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            s->win.open.push_back(idx);
+            ng->deep_id = s->deep.next_id++;
+            ng->lane = s->deep.pick();
+            ng->deps = s->deep.conflicts(in, nin, s->skip_scratch.data(), nout);
+            deep_after(s->win, s->slots, s->win.last_conflict(in, nin, s->skip_scratch.data(), nout), ng);
+        } else {
+            auto full = [&](const Slot &g) {
+                return g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
+            };
+            while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
+            if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
+                if (s->win.open.size() >= kOpenGroups) {
+                    int rcq = launch_oldest(s);
+                    if (rcq != GC_OK) return rcq;
+                    gi--;
+                }
+                uint32_t idx = 0;
+                Slot *ng = slot_new(ctx, s->slots, &idx);
+                if (!ng) return GC_E_NOMEM;
+                ng->reset();
+                ng->kind = Slot::kGroup;
+                s->win.open.push_back(idx);
+            }
+            slot_idx = s->win.open[gi];
         }
-        const uint32_t slot_idx = s->win.open[gi];
         Slot &g = *s->slots[slot_idx];
         const size_t io_bytes = up16(((size_t)nin + 2 * (size_t)nout) * sizeof(uint32_t));
         hipError_t e = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes);
         if (e != hipSuccess) {
             set_error("gc_stream_garble (pinned)", e);
+            if (is_deep) g.reset();
             return GC_E_NOMEM;
         }
         JobRec j;
@@ -1140,18 +1547,37 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
         g.jobs.push_back(j);
-        s->win.mark(gi, in, nin, s->skip_scratch.data(), nout);
+        if (!is_deep) {
+            s->win.mark(gi, in, nin, s->skip_scratch.data(), nout);
+            // a deep step in flight that this one must follow: the group waits for it (and for the older ones of its lane)
+            if (s->deep.n_inflight) g.deps.merge(s->deep.conflicts(in, nin, s->skip_scratch.data(), nout));
+        }
         // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
         // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it)
         if (!s->store.dirty.empty()) {
             std::lock_guard<std::mutex> lk(ctx->mu);
             int rcs = s->store.flush(ctx);
-            if (rcs != GC_OK) return rcs;
+            if (rcs != GC_OK) {
+                if (is_deep) g.reset();
+                return rcs;
+            }
+        }
+        if (is_deep) {  // launched at once, on its lane
+            int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
+            if (rcl != GC_OK) {
+                (void)hipStreamSynchronize(s->deep.lanes[(size_t)g.lane]);
+                s->deep.retire(g.lane, g.deep_id);
+                g.reset();
+                return rcl;
+            }
+            s->deep.mark(g.deep_id, in, nin, s->skip_scratch.data(), nout);
+            s->n_groups++;
+            s->n_group_steps++;
         }
         for (uint32_t k = 0; k < nout; k++)
             if (s->skip_scratch[k] != 0xffffffffu) s->store.on_dev[out[k]] = 1;
         s->queue.push_back(StepRef{slot_idx, (uint32_t)g.jobs.size() - 1});
-        tr.lap("queued in group");
+        tr.lap(is_deep ? "launched on a lane" : "queued in group");
         return GC_OK;
     }
 
@@ -1159,9 +1585,18 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     {
         int rcq = close_group(s);
         if (rcq != GC_OK) return rcq;
+        if (s->deep.n_inflight) {  // a pass on the ctx stream: behind every deep step in flight (DeepLanes)
+            s->deep.poll();
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            GC_HIP(s->deep.wait_all(st));
+        }
+        if (ngates) {  // ... and later deep steps must see what it reads and writes
+            s->win.ensure(s->store.host.size());
+            s->win.mark_pass(in, nin, s->skip_scratch.data(), nout);
+        }
     }
     uint32_t idx = 0;
-    Slot *bg = slot_new(s->slots, &idx);
+    Slot *bg = slot_new(ctx, s->slots, &idx);
     if (!bg) return GC_E_NOMEM;
     bg->reset();
     Slot &b = *bg;
@@ -1327,7 +1762,10 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
             if (need > cap) rc = GC_E_ARG;
             else if (need) std::memcpy(buf, g.h_down + sizes_bytes + j.off_bytes, need);
         }
-        if (++g.handed == g.jobs.size()) g.reset();
+        if (++g.handed == g.jobs.size()) {
+            if (g.deep_id) s->deep.retire(g.lane, g.deep_id);  // (its kernel has run: `done` sits behind it)
+            g.reset();
+        }
         tr.lap("wait + copy out");
         return rc;
     }
@@ -1553,6 +1991,7 @@ struct gc_stream_eval {
     // step groups (see the head of this file): small blocks that share no global wire are evaluated by ONE launch sequence
     std::vector<std::unique_ptr<Slot>> slots;
     GroupWindow win;
+    DeepLanes deep;
     std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
     uint64_t n_groups = 0, n_group_blocks = 0;
     std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
@@ -1602,10 +2041,13 @@ namespace {
 
 int eval_launch_oldest(gc_stream_eval *e) {
     if (e->win.open.empty()) return GC_OK;
-    Slot &g = *e->slots[e->win.pop()];
+    const uint32_t seq = e->win.first_seq, slot = e->win.pop();
+    Slot &g = *e->slots[slot];
     e->n_groups++;
     e->n_group_blocks += g.jobs.size();
-    return launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr);
+    const int rc = launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
+    e->win.note(seq, slot, g.launch_no);
+    return rc;
 }
 int eval_close_group(gc_stream_eval *e) {
     int rc = GC_OK;
@@ -1617,30 +2059,38 @@ int eval_close_group(gc_stream_eval *e) {
 }
 
 // a slot for a new group of blocks: nothing comes back from an evaluator group, so a launched group's slot is free as
-// soon as its kernels have run; at most eight groups in flight, then the oldest is waited for
-Slot *eval_slot(gc_stream_eval *e, uint32_t *index) {
+// soon as its kernels have run; at most eight groups of the ctx stream in flight, then the oldest is waited for (deep
+// blocks on their lanes are bounded by kDeepInFlight and not counted: waiting for a 2 ms multiplier would idle the ctx stream)
+Slot *eval_slot(gc_stream_eval *e, uint32_t *index, bool big = false) {
+    auto done_with = [&](Slot &sl) {
+        if (sl.deep_id) {
+            if (sl.error != GC_OK) (void)hipStreamSynchronize(e->deep.lanes[(size_t)sl.lane]);
+            e->deep.retire(sl.lane, sl.deep_id);
+        }
+        sl.reset();
+    };
+    uint32_t on_ctx = 0;
+    bool any_free = false;
     for (uint32_t i = 0; i < e->slots.size(); i++) {
         Slot &sl = *e->slots[i];
-        if (sl.kind == Slot::kGroup && sl.launched && (sl.error != GC_OK || hipEventQuery(sl.done) == hipSuccess)) sl.reset();
+        if (sl.kind == Slot::kGroup && sl.launched && (sl.error != GC_OK || hipEventQuery(sl.done) == hipSuccess)) done_with(sl);
+        if (sl.kind == Slot::kGroup && !sl.deep_id) on_ctx++;
+        any_free = any_free || sl.kind == Slot::kFree;
     }
     (void)hipGetLastError();  // hipErrorNotReady of the queries
-    if (e->slots.size() >= 8) {
-        bool any_free = false;
-        for (auto &sl : e->slots) any_free = any_free || sl->kind == Slot::kFree;
-        if (!any_free) {
-            // the OLDEST launched group (the first one in slot order may be the newest: waiting for that one drains
-            // everything queued, and the GPU then idles until the next group is ready — 136 us between the groups of the mixed
-            // program)
-            Slot *oldest = nullptr;
-            for (auto &sl : e->slots)
-                if (sl->kind == Slot::kGroup && sl->launched && (!oldest || sl->launch_no < oldest->launch_no)) oldest = sl.get();
-            if (oldest) {
-                (void)hipEventSynchronize(oldest->done);
-                oldest->reset();
-            }
+    if (on_ctx >= 8 && !any_free) {
+        // the OLDEST launched group (the first one in slot order may be the newest: waiting for that one drains
+        // everything queued, and the GPU then idles until the next group is ready — 136 us between the groups of the mixed
+        // program)
+        Slot *oldest = nullptr;
+        for (auto &sl : e->slots)
+            if (sl->kind == Slot::kGroup && sl->launched && !sl->deep_id && (!oldest || sl->launch_no < oldest->launch_no)) oldest = sl.get();
+        if (oldest) {
+            (void)hipEventSynchronize(oldest->done);
+            done_with(*oldest);
         }
     }
-    return slot_new(e->slots, index);
+    return slot_new(e->ctx, e->slots, index, big);
 }
 
 }  // namespace
@@ -1684,6 +2134,7 @@ void gc_stream_eval_free(gc_stream_eval *e) {
         (void)hipSetDevice(e->ctx->device);
         (void)hipStreamSynchronize(e->ctx->stream);
     }
+    e->deep.release();
     if (e->held) gc_circ_release_batch(e->held_circ, e->held);
     for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
     for (auto &sl : e->slots) sl->release();
@@ -1708,6 +2159,7 @@ int gc_stream_eval_set_wire(gc_stream_eval *e, uint32_t w, const gc_label *l) tr
     if (!e || !l) return GC_E_ARG;
     int rc = eval_close_group(e);  // a queued block reads the wire's OLD label (the reference runs in program order)
     if (rc != GC_OK) return rc;
+    if (e->deep.n_inflight) e->deep.drain();  // ... also a deep block on its lane
     e->store.set(w, *l);
     return GC_OK;
 } catch (...) {
@@ -1725,6 +2177,7 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
     if (!e || !l) return GC_E_ARG;
     int rc = eval_close_group(e);  // a queued block may be the one that writes the wire
     if (rc != GC_OK) return rc;
+    if (e->deep.n_inflight) e->deep.drain();  // ... or a deep block on its lane
     return e->store.get(e->ctx, w, l);
 } catch (...) {
     return gc::on_exception();
@@ -1966,6 +2419,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             int rcq = eval_close_group(e);
             if (rcq != GC_OK) return rcq;
             GC_HIP(hipStreamSynchronize(e->ctx->stream));
+            e->deep.drain();
             for (auto &sl : e->slots)
                 if (sl->kind == Slot::kGroup && sl->launched) sl->reset();
             if (e->held) gc_circ_release_batch(e->held_circ, e->held);  // (back into its circuit's pool before that may go)
@@ -2045,34 +2499,65 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     }  // parsed
     ent->last_use = ++e->tick;
     gc_ctx *ctx = e->ctx;
-    // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence -------
-    if (small_block && entry_is_small(ent)) {
+    // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence; a deep
+    //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
+    const bool is_deep = entry_is_deep(ent, e->deep.min_steps) && e->deep.setup(ctx);
+    if (is_deep || (small_block && entry_is_small(ent))) {
         e->win.ensure(e->store.host.size());
+        if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
         uint32_t gi = e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
-        auto full = [&](const Slot &g) {
-            return g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes;
-        };
-        while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
-        if (gi == e->win.open.size()) {
-            if (e->win.open.size() >= kOpenGroups) {
+        uint32_t slot_idx = 0;
+        if (is_deep) {
+            for (; gi > 0; gi--) {  // the open groups this block depends on go first
                 int rcq = eval_launch_oldest(e);
                 if (rcq != GC_OK) return rcq;
-                gi--;
             }
-            uint32_t idx = 0;
-            Slot *ng = eval_slot(e, &idx);
-            tr.lap("eval: launch + free slot");
+            e->deep.poll();
+            if (e->deep.n_inflight >= kDeepInFlight) {
+                size_t l = 0;
+                for (size_t k = 1; k < e->deep.inflight.size(); k++)
+                    if (e->deep.inflight[k].size() > e->deep.inflight[l].size()) l = k;
+                (void)hipEventSynchronize(e->deep.inflight[l].front().ev);
+                e->deep.poll();
+            }
+            Slot *ng = eval_slot(e, &slot_idx, true);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            e->win.open.push_back(idx);
+            ng->deep_id = e->deep.next_id++;
+            ng->lane = e->deep.pick();
+            ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
+            deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
+        } else {
+            auto full = [&](const Slot &g) {
+                return g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes;
+            };
+            while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
+            if (gi == e->win.open.size()) {
+                if (e->win.open.size() >= kOpenGroups) {
+                    int rcq = eval_launch_oldest(e);
+                    if (rcq != GC_OK) return rcq;
+                    gi--;
+                }
+                uint32_t idx = 0;
+                Slot *ng = eval_slot(e, &idx);
+                tr.lap("eval: launch + free slot");
+                if (!ng) return GC_E_NOMEM;
+                ng->reset();
+                ng->kind = Slot::kGroup;
+                e->win.open.push_back(idx);
+            }
+            slot_idx = e->win.open[gi];
         }
-        Slot &g = *e->slots[e->win.open[gi]];
-        const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = up16(nrows * sizeof(gc_label));
+        Slot &g = *e->slots[slot_idx];
+        // the rows of a block of many gates were parsed into the pinned ring: they go up from there (launch_group)
+        const bool ext_rows = is_deep && !small_block;
+        const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = ext_rows ? 0 : up16(nrows * sizeof(gc_label));
         hipError_t er = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes + row_bytes + 16);
         if (er != hipSuccess) {
             set_error("gc_stream_eval_circuit (pinned)", er);
+            if (is_deep) g.reset();
             return GC_E_NOMEM;
         }
         JobRec j;
@@ -2083,21 +2568,49 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (nin + nout) std::memcpy(g.h_up + g.up_used, e->io_host.data(), ((size_t)nin + nout) * sizeof(uint32_t));
         g.up_used += io_bytes;
         j.off_rows = g.up_used;
-        if (nrows) std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
+        if (ext_rows) {
+            j.rows_src = slab;
+            j.rows_ext = nrows;
+        } else if (nrows) {
+            std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
+        }
         g.up_used += row_bytes;
         j.off_w = g.arena_used;
         g.arena_used += wbytes;
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
         g.jobs.push_back(j);
-        e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout);
+        if (!is_deep) {
+            e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout);
+            if (e->deep.n_inflight) g.deps.merge(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
+        }
         if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned
             std::lock_guard<std::mutex> lk(ctx->mu);
             int rcs = e->store.flush(ctx);
-            if (rcs != GC_OK) return rcs;
+            if (rcs != GC_OK) {
+                if (is_deep) g.reset();
+                return rcs;
+            }
+        }
+        if (is_deep) {  // launched at once, on its lane
+            int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
+            hipStream_t lane = e->deep.lanes[(size_t)g.lane];
+            if (ext_rows) {  // the ring entry is free again once its rows have gone up
+                (void)hipEventRecord(e->slab_ev[sb], lane);
+                e->ring_batch[sb] = nullptr;
+            }
+            if (rcl != GC_OK) {
+                (void)hipStreamSynchronize(lane);
+                e->deep.retire(g.lane, g.deep_id);
+                g.reset();
+                return rcl;
+            }
+            e->deep.mark(g.deep_id, e->io_host.data(), nin, wr_ids.data(), nout);
+            e->n_groups++;
+            e->n_group_blocks++;
         }
         for (uint32_t k = 0; k < nout; k++) e->store.on_dev[wr_ids[k]] = 1;
-        tr.lap("eval: queued in group");
+        tr.lap(is_deep ? "eval: launched on a lane" : "eval: queued in group");
         *consumed = pos;
         return GC_OK;
     }
@@ -2105,6 +2618,15 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     {
         int rcq = eval_close_group(e);
         if (rcq != GC_OK) return rcq;
+        if (e->deep.n_inflight) {  // a pass on the ctx stream: behind every deep block in flight (DeepLanes)
+            e->deep.poll();
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            GC_HIP(e->deep.wait_all(ctx->stream));
+        }
+        {  // ... and later deep blocks must see what it reads and writes
+            e->win.ensure(e->store.host.size());
+            e->win.mark_pass(e->io_host.data(), nin, wr_ids.data(), nout);
+        }
     }
     gc_circ *circ = ent->circ;
     uint32_t *d_io = nullptr;
