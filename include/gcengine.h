@@ -274,6 +274,16 @@ int gc_stream_garble_begin_h(gc_stream *, uint32_t handle, const uint32_t *in, c
 /* launch sequences so far: groups of small circuits, circuits that ran in them, circuits with a sequence of their own
  * (any pointer may be NULL) */
 int gc_stream_stats(const gc_stream *, uint64_t *groups, uint64_t *grouped_steps, uint64_t *big_steps);
+/* Deep lanes (additive).  A step whose one-workgroup pass is long — hundreds of dependent hash phases: a 128- / 256-bit
+ * multiplier, a 256- / 512-bit adder, 0.5 - 2 ms on one CU — runs on one of a few extra HIP streams of the ctx, beside the
+ * groups of small steps, and is ordered against them by events only where two steps share a wire; the bytes still leave in
+ * program order (circuit/stream_garble.go:161-192 is one serial loop: nothing on the wire or in the wire store may differ
+ * from it).  deep_steps: steps that ran that way so far (they are also counted as groups of one by gc_stream_stats);
+ * lanes: streams in use (0: none — GC_STREAM_DEEP_LANES=0, or no stream of the runtime runs beside the ctx stream: such
+ * steps then keep the launch sequence of the big steps).  GC_STREAM_DEEP_LANES (default 3) and GC_STREAM_DEEP_STEPS
+ * (barriers per pass from which a step counts as deep, default 300) are read when a ctx / a stream first needs them.
+ * Either pointer may be NULL. */
+int gc_stream_deep_stats(const gc_stream *, uint64_t *deep_steps, uint32_t *lanes);
 
 /* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
  * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
@@ -300,6 +310,8 @@ int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uin
  * repeating in the same pattern): those are not decoded again.  Either pointer may be NULL.  (GC_STREAM_NO_SKELETON in the
  * environment at gc_stream_eval_create time switches the recognition off: every block is decoded.) */
 int gc_stream_eval_stats(const gc_stream_eval *, uint64_t *parsed, uint64_t *matched);
+/* the evaluator's counterpart of gc_stream_deep_stats */
+int gc_stream_eval_deep_stats(const gc_stream_eval *, uint64_t *deep_blocks, uint32_t *lanes);
 
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,

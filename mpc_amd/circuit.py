@@ -342,6 +342,43 @@ def adder(bits=64):
     return _finish(gates, nw, [bits, bits], [bits], "adder%d" % bits)
 
 
+def subtractor(bits=64):
+    """a - b mod 2^bits as a + ~b + 1, ripple borrow with ONE AND per bit and the XNORs of the reference's full subtractor
+    (compiler/circuits/circ_subtractor.go:17-31: w1 = XNOR(y, cin), d = XNOR(x, w1), cout = cin ^ (w1 & (x ^ cin)) — here with
+    the carry of the two's-complement sum, so that bit 0 needs no constant wire: d0 = a0 ^ b0, c1 = a0 | ~b0 = ~(~a0 & b0)).
+    Inputs a = wires [0, bits), b = [bits, 2 bits), LSB first; the difference is the LAST `bits` wires."""
+    gates, nw = [], 2 * bits
+    diffs, carry = [], None  # carry of a + ~b + 1 into bit i (None: the constant 1 into bit 0)
+    for i in range(bits):
+        a, b = i, bits + i
+        if carry is None:
+            d = nw; gates.append((a, b, d, XOR)); nw += 1          # a ^ ~b ^ 1
+            if bits > 1:
+                na = nw; gates.append((a, 0, na, INV)); nw += 1
+                t = nw; gates.append((na, b, t, AND)); nw += 1     # borrow out of bit 0
+                c = nw; gates.append((t, 0, c, INV)); nw += 1      # carry = ~borrow
+        else:
+            w1 = nw; gates.append((b, carry, w1, XNOR)); nw += 1    # ~b ^ c
+            d = nw; gates.append((a, w1, d, XOR)); nw += 1          # a ^ ~b ^ c
+            if i < bits - 1:
+                w2 = nw; gates.append((a, carry, w2, XOR)); nw += 1
+                w3 = nw; gates.append((w1, w2, w3, AND)); nw += 1
+                c = nw; gates.append((w3, carry, c, XOR)); nw += 1
+        diffs.append(d)
+        if i < bits - 1:
+            carry = c
+    zero = nw; gates.append((0, 0, zero, XOR)); nw += 1
+    for d in diffs:  # the difference bits last, in order
+        o = nw; gates.append((d, zero, o, XOR)); nw += 1
+    return _finish(gates, nw, [bits, bits], [bits], "subtractor%d" % bits)
+
+
+def bitwise(bits, op):
+    """bits independent two-input gates (op = AND / XOR / OR): r[i] = a[i] op b[i] (compiler/circuits/circ_binary.go:14-66)"""
+    gates = [(i, bits + i, 2 * bits + i, op) for i in range(bits)]
+    return _finish(gates, 3 * bits, [bits, bits], [bits], "bitwise%d_%d" % (bits, op))
+
+
 def multiplier(bits=64):
     """a * b mod 2^bits: array multiplier (row j adds (a & b_j) << j into the running sum; only bits < `bits` are formed).
     64 bits: 2 080 partial-product ANDs + 2 016 one-AND full adders = 12.2 k gates, AND depth ~2 x bits."""

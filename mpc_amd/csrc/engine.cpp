@@ -461,6 +461,7 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
 
 void gc_circ_free(gc_circ *c) {
     if (!c) return;
+    if (c->flat_thread.joinable()) c->flat_thread.join();
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
     for (gc_batch *b : c->pool) gc_batch_free(b);
     c->pool.clear();
@@ -488,13 +489,13 @@ void gc_circ_free(gc_circ *c) {
 // plan: the level-walking / HBM-wire kernels serve it)
 static void circ_ensure_flat(gc_circ *c) {
     std::lock_guard<std::mutex> lk(c->flat_mu);
-    if (c->flat_ready) return;
+    if (c->flat_ready.load(std::memory_order_acquire)) return;
     Plan &p = c->plan.p;
     // flat_ready flips only when the plan is in its final state — complete, or marked "no LDS / flattened plan" —
     // so a later call never launches the LDS kernels on a half-built plan
     struct Done {
         gc_circ *c;
-        ~Done() { c->flat_ready = true; }
+        ~Done() { c->flat_ready.store(true, std::memory_order_release); }
     } done{c};
     auto no_plans = [&] {
         p.n_lds_slots = 0xffffffffu;
@@ -546,6 +547,11 @@ static void circ_ensure_flat(gc_circ *c) {
     }
 }
 
+// the flattened plan is being built by the circuit's thread: a pass that starts now keeps its wires in HBM
+static bool flat_pending(const gc_circ *c) {
+    return c->flat_async.load(std::memory_order_acquire) == 1 && !c->flat_ready.load(std::memory_order_acquire);
+}
+
 // introspection wants the whole plan
 const gc_plan *gc_circ_plan(const gc_circ *c) {
     if (!c) return nullptr;
@@ -586,7 +592,7 @@ static bool one_wide(const gc_batch *b) {
 }
 
 static bool want_flat(const gc_batch *b) {
-    if (one_wide(b)) return false;
+    if (one_wide(b) || flat_pending(b->circ)) return false;
     circ_ensure_flat(b->circ);
     const Plan &p = b->circ->plan.p;
     return !b->store_all && !b->single_phase && p.n_flat_slots != 0xffffffffu && p.info.slab_rows < (1u << 22);
@@ -594,8 +600,9 @@ static bool want_flat(const gc_batch *b) {
 
 static BatchGeom geom_for(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    const bool flat = want_flat(b);
-    const uint32_t nls = one_wide(b) ? 0xffffffffu : flat ? p.n_flat_slots : p.n_lds_slots;
+    const bool pend = flat_pending(b->circ);  // (no plan with the wires in LDS yet: the HBM-wire kernels)
+    const bool flat = !pend && want_flat(b);
+    const uint32_t nls = one_wide(b) || pend ? 0xffffffffu : flat ? p.n_flat_slots : p.n_lds_slots;
     // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
     const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
     return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat, p.fl_unit_stride);
@@ -1506,6 +1513,21 @@ int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const g
     return GC_OK;
 }
 
+bool gc_circ_flat_poll(gc_circ *c, bool start) {
+    if (c->flat_ready.load(std::memory_order_acquire)) return true;
+    int idle = 0;
+    if (start && c->flat_async.compare_exchange_strong(idle, 1)) {
+        try {
+            c->flat_thread = std::thread([c] {
+                (void)hipSetDevice(c->ctx->device);
+                circ_ensure_flat(c);
+            });
+        } catch (...) {  // no thread: the next caller that needs the plan builds it itself
+            c->flat_async.store(0);
+        }
+    }
+    return false;
+}
 bool gc_circ_flat_job(gc_circ *c, gc::FlatJob *j, size_t *lds_bytes, bool *has_or) {
     if (!c || !j) return false;
     circ_ensure_flat(c);

@@ -3,8 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/gcengine.h"
@@ -95,7 +97,11 @@ struct gc_circ {
     uint32_t *d_fl_hgslot = nullptr, *d_fl_ogslot = nullptr;
     uint16_t *d_fl_in_lds = nullptr;
     std::mutex flat_mu;       // the flattened plan and its device arrays are built on first demand (circ_ensure_flat)
-    bool flat_ready = false;
+    std::atomic<bool> flat_ready{false};
+    // ... or, for a streamed circuit seen for the first time, by a thread of the circuit's own while its first passes take the
+    // kernels that need no LDS plan (gc_circ_flat_poll): 0 never asked, 1 that thread was started
+    std::atomic<int> flat_async{0};
+    std::thread flat_thread;
     int schedule = 1;  // default schedule of pooled batches
     bool single_phase = false;
     std::mutex pool_mu;
@@ -148,6 +154,11 @@ void gc_circ_release_batch(gc_circ *c, gc_batch *b);
 // plan arrays, geometry, Te0 — and the dynamic LDS the job needs; false when the circuit has no flattened plan or its
 // live labels do not fit next to the AES table.  Builds the flattened plan on first demand (thread-safe).
 bool gc_circ_flat_job(gc_circ *c, gc::FlatJob *job, size_t *lds_bytes, bool *has_or);
+// internal: is the flattened plan of the circuit built (and on the device)?  If not and `start`, a thread of the circuit's own
+// builds it (once); until it is there the circuit's passes run on the kernels that keep the wires in HBM and need no LDS plan
+// (a 256-bit multiplier plans for 0.13 s: the streaming evaluator, which meets its circuits in the middle of a stream, does not
+// wait for that)
+bool gc_circ_flat_poll(gc_circ *c, bool start);
 int gc_pass_dev(gc_circ *c, bool eval, const uint8_t *key, size_t keylen, const gc_label *r, const void *d_store,
                 const uint32_t *d_in_idx, const uint32_t *d_out_idx, const gc_label *slab_host, size_t slab_rows,
                 gc_batch **bout, const gc::StoreXchg *d_xchg = nullptr);

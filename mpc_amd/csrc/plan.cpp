@@ -10,6 +10,20 @@
 
 namespace gc {
 
+namespace {
+// developer aid: GC_TRACE=1 prints the planner's laps to stderr
+struct PlanLaps {
+    bool on = std::getenv("GC_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gc trace] plan: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
 static inline int op_class(uint8_t op) {
     // execution order inside a level: table-producing gates first so that the blocks that need
     // the AES tables are contiguous; XOR/XNOR (free) last
@@ -53,6 +67,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
                        const std::vector<uint32_t> &src0, const std::vector<uint32_t> &src1,
                        const std::vector<uint32_t> &cur, Plan *out, bool late = false) {
     Plan &p = *out;
+    PlanLaps laps;
     const uint32_t NONE = 0xffffffffu;
     const uint32_t nprod = ninputs + ngates;
     std::vector<uint32_t> phase_of;  // late: the hash phase of every table-producing gate
@@ -175,6 +190,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         rpar[g] = par;
         ex[g] = tmp;
     }
+    laps.lap("flat: term lists");
     // what has to exist as a label: operands of hashed gates, circuit outputs, and the terms of those
     const uint32_t nprod2 = (uint32_t)A.size(), ngates2 = (uint32_t)ex.size();  // with the block sums
     std::vector<uint8_t> need(nprod2, 0), is_output(nprod2, 0);
@@ -210,10 +226,15 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         if (!is_free[ninputs + g]) return (uint64_t)op_class(gates[g].op);
         return 0xffu - std::min<uint64_t>(0xfeu, ex[g].size());  // longest term lists first
     };
-    std::stable_sort(gl.begin(), gl.end(), [&](uint32_t x, uint32_t y) {
-        const uint64_t kx = key_of(x) | sub_of(x), ky = key_of(y) | sub_of(y);
-        return kx < ky;
-    });
+    {
+        // stable order by (key, order inside the step): gl is ascending, so sorting (key, gate) pairs gives what a stable sort
+        // by key would — with the keys computed once (the comparator's indirect look-ups were half of the planner's time on
+        // a 256-bit multiplier)
+        std::vector<std::pair<uint64_t, uint32_t>> keyed(gl.size());
+        for (size_t k = 0; k < gl.size(); k++) keyed[k] = {key_of(gl[k]) | sub_of(gl[k]), gl[k]};
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t k = 0; k < gl.size(); k++) gl[k] = keyed[k].second;
+    }
     std::vector<uint32_t> step_first;  // index into gl
     std::vector<uint32_t> step_of(ngates2, 0);
     for (uint32_t k = 0; k < gl.size(); k++) {
@@ -223,6 +244,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     const uint32_t nsteps = (uint32_t)step_first.size();
     step_first.push_back((uint32_t)gl.size());
     p.n_flat_steps = nsteps;
+    laps.lap("flat: needed + step order");
     // last reader (step + 1; 0 = never read)
     std::vector<uint32_t> last_use(nprod2, 0);
     for (uint32_t g : gl) {
@@ -290,6 +312,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     for (uint32_t w = 0; w < ninputs; w++)
         if (lds_of[w] != 0xffffu) p.fl_in_lds[w] = (uint16_t)lds_of[w];
 
+    laps.lap("flat: slots");
     // units
     std::vector<FDesc> uh;
     std::vector<XOut> uo;
@@ -408,6 +431,7 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
         }
     }
     emit();
+    laps.lap("flat: units");
 }
 
 // ---- hash-phase schedule + LDS slot allocation of the level-walking fused kernels (fused_lds_kernels.hip) ------------
@@ -442,8 +466,12 @@ static void build_fused(const OpView gates, uint32_t ngates, uint32_t nwires, ui
             gkey[g] = ((uint64_t)a << 40) | ((uint64_t)x << 8) | (uint64_t)op_class(gates[g].op);
         }
         std::vector<uint32_t> ford(ngates);
-        std::iota(ford.begin(), ford.end(), 0u);
-        std::stable_sort(ford.begin(), ford.end(), [&](uint32_t a, uint32_t b) { return gkey[a] < gkey[b]; });
+        {  // stable by key = sorted (key, gate) pairs
+            std::vector<std::pair<uint64_t, uint32_t>> keyed(ngates);
+            for (uint32_t g = 0; g < ngates; g++) keyed[g] = {gkey[g], g};
+            std::sort(keyed.begin(), keyed.end());
+            for (uint32_t g = 0; g < ngates; g++) ford[g] = keyed[g].second;
+        }
         std::vector<uint32_t> step_of_gate(ngates);
         for (uint32_t k = 0; k < ngates;) {
             const uint64_t key = gkey[ford[k]] >> 8;
@@ -614,8 +642,10 @@ bool wide_for_one_instance(const Plan &p, bool eval) {
 void finish_flat(Plan *pp) {
     Plan &p = *pp;
     if (p.flat_built) return;
+    PlanLaps laps;
     build_fused(OpView{p.lazy_ops.data()}, p.info.ngates, p.info.nwires, p.info.ninputs, p.info.noutputs, p.lazy_src0,
                 p.lazy_src1, p.lazy_cur, &p);
+    laps.lap("level-walking schedule");
     auto flat = [&](bool late) {
         p.fl_prog.clear(), p.fl_units.clear(), p.fl_hgslot.clear(), p.fl_ogslot.clear(), p.fl_in_lds.clear();
         p.n_flat_slots = 0xffffffffu;

@@ -185,10 +185,9 @@ struct JobRec {
     size_t off_rows = 0;          // evaluator: the block's table rows in the upload region
     size_t off_w = 0, off_t = 0;  // arena: wire array [nslots], table array [rows]
     size_t off_bytes = 0;         // download region: where the serialised gates go (garbler)
-    // evaluator, a deep block of many gates: its rows stay where the parser put them (pinned) and go up from there, behind
-    // the slot's upload region (no pass through h_up)
-    const gc_label *rows_src = nullptr;
-    size_t rows_ext = 0;
+    // evaluator, a deep block of many gates: its rows went up from where the parser put them (pinned ring), on the upload
+    // stream, into the slot's arena at off_t (no pass through h_up; the slot's rows_ev says when they are there)
+    bool rows_in_arena = false;
 };
 
 // the deep steps in flight (DeepLanes) that a step — or a group of steps — has to follow
@@ -221,11 +220,13 @@ struct Slot {
     DeepDeps deps;
     int lane = -1;
     hipEvent_t dep = nullptr;   // deep: "everything launched on the ctx stream before this step" (the lane waits for it) ...
+    hipEvent_t rows_ev = nullptr;   // evaluator, deep: the block's rows are in the arena (JobRec::rows_in_arena; not owned)
     bool after_tail = false;    // ... when the step must follow a pass of the ctx stream that has no event of its own;
     hipEvent_t after_ev = nullptr;  // else the kernel of the latest group it conflicts with (null: none, or done already)
     int error = GC_OK;          // close failed: the group's steps report it
     uint32_t handed = 0;        // steps whose bytes have been handed out
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
+    hipEvent_t kernel_ev = nullptr;              // whichever of the two says "the group's kernel has run" (set at launch)
     std::vector<JobRec> jobs;
     size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
     bool has_or = false;
@@ -249,6 +250,7 @@ struct Slot {
         deps = DeepDeps{};
         after_tail = false;
         after_ev = nullptr;
+        rows_ev = nullptr;
         lane = -1;
         jobs.clear();
         up_used = arena_used = down_used = lds = 0;
@@ -315,7 +317,29 @@ static hipError_t grow_pin(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) {
 // groups behind i, beside the steps of group i): the earliest such group is one past the latest group it has a
 // read-after-write, write-after-write or write-after-read relation with.  Groups are launched in sequence order on one
 // HIP stream, so "later group" = "later in time".
-constexpr uint32_t kOpenGroups = 4;
+// How many groups may be open at once.  A chain of dependent steps interleaved with independent ones — an expression like
+// f0*g0 + f1*g9 + ... compiles to mul, mul, add, mul, add, ...: every add follows the add before it — needs one open group per
+// link of the chain while the independent steps keep joining the first: with 4 open groups the hundred products of an Ed25519
+// field multiplication left in groups of 5 (round 4: 16; GC_STREAM_OPEN_GROUPS for experiments).
+// The garbler ties the number to how far ahead its caller queues: a group that stays open keeps gathering steps, but the GPU
+// only sees it when the window is full or the caller asks for its bytes — with 64 steps in flight and steps that chain in
+// fours, sixteen open groups would hold everything the caller allows and the ctx stream would run dry between two calls of
+// gc_stream_garble_finish (ssa23, 64 in flight: 1.1e8 gates/s with 4 open groups, 0.7e8 with 16; the Ed25519 program, 1 024 in
+// flight: 0.9e8 with 4, 4.4e8 with 16).  in_flight / 16, between 4 and 16.  The evaluator has no caller waiting for
+// results: 16.
+constexpr uint32_t kOpenGroupsMin = 4, kOpenGroupsMax = 16;
+static uint32_t open_groups_env() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("GC_STREAM_OPEN_GROUPS");
+        const int n = e && *e ? std::atoi(e) : 0;
+        return (uint32_t)std::min(std::max(n, 0), 48);
+    }();
+    return v;
+}
+static uint32_t open_groups_limit(size_t in_flight) {
+    if (open_groups_env()) return open_groups_env();
+    return (uint32_t)std::min<size_t>(std::max<size_t>(in_flight / 16, kOpenGroupsMin), kOpenGroupsMax);
+}
 struct GroupWindow {
     std::deque<uint32_t> open;      // slots of the open groups, oldest first
     uint32_t first_seq = 1;         // sequence number of open.front()
@@ -388,6 +412,36 @@ struct GroupWindow {
 
 struct StepRef {
     uint32_t slot, job;
+};
+
+// Groups launched on the ctx stream whose kernels may still be running, oldest first.  The stream is HUNGRY while fewer than
+// kKeepQueued of them are.  The garbler looks at it when its caller is about to wait for bytes (gc_stream_garble_finish): the
+// open groups behind the one it waits for then go to the GPU too, so that the GPU has a group to run and one behind it while
+// the host is busy with the bytes; everything younger stays open and keeps gathering steps.
+constexpr size_t kKeepQueued = 2;
+struct CtxQueue {
+    struct E {
+        uint32_t slot;
+        uint64_t launch_no;
+    };
+    std::deque<E> q;
+    std::chrono::steady_clock::time_point last{};
+    void pushed(uint32_t slot, uint64_t launch_no) { q.push_back(E{slot, launch_no}); }
+    template <typename Slots>
+    bool hungry(const Slots &slots) {
+        if (q.size() < kKeepQueued) return true;
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last < std::chrono::microseconds(8)) return false;  // (an event query costs a microsecond or two)
+        last = now;
+        while (!q.empty()) {
+            const auto &g = *slots[q.front().slot];
+            const bool gone = !g.launched || g.launch_no != q.front().launch_no || g.error != GC_OK;  // its slot was given back
+            if (!gone && hipEventQuery(g.kernel_ev) != hipSuccess) break;
+            q.pop_front();
+        }
+        (void)hipGetLastError();  // hipErrorNotReady
+        return q.size() < kKeepQueued;
+    }
 };
 
 // ---- deep lanes ---------------------------------------------------------------------------------------------------------
@@ -480,11 +534,13 @@ struct DeepLanes {
         (void)hipFree(d_probe);
         if (!ctx->lanes.empty()) ctx->lanes_state = 1;
     }
+    void read_env() {  // (at stream creation: the threshold is asked before the lanes are)
+        const char *v = std::getenv("GC_STREAM_DEEP_STEPS");
+        if (v && *v) min_steps = (uint32_t)std::max(1, std::atoi(v));
+    }
     bool setup(gc_ctx *ctx) {
         if (state != 0) return state > 0;
         state = -1;
-        const char *v = std::getenv("GC_STREAM_DEEP_STEPS");
-        if (v && *v) min_steps = (uint32_t)std::max(1, std::atoi(v));
         setup_ctx(ctx);
         if (ctx->lanes_state <= 0) return false;
         lanes = ctx->lanes;
@@ -610,6 +666,7 @@ struct gc_stream {
     std::vector<std::unique_ptr<Slot>> slots;
     std::deque<StepRef> queue;
     GroupWindow win;              // the groups still accepting steps
+    CtxQueue ctxq;                // ... and the launched ones the ctx stream has not run yet
     DeepLanes deep;               // long one-workgroup steps run beside the groups, on streams of their own
     std::vector<CircEntry *> handles;  // gc_stream_intern
     hipStream_t copy_stream = nullptr;
@@ -965,14 +1022,20 @@ bool entry_is_small(CircEntry *e) {
 // big for a group but has a one-workgroup plan (a 128- / 256-bit multiplier on the late schedule), or a small one whose pass
 // has at least min_steps barriers (a 256- / 512-bit adder).  A wide circuit is asked nothing: its level launches never need
 // the flattened plan (building it for a 131 072-gate step costs more than the step).
-bool entry_is_deep(CircEntry *e, uint32_t min_steps) {
+// in_stream: the circuit is met in the middle of a stream (the evaluator's blocks; a garbler step that was not interned) —
+// the plan of a big one (0.13 s of planning for a 256-bit multiplier) is then built by a thread of the circuit's own, and
+// until it is there the answer is "not yet": the step takes the path of the big steps, on kernels that need no LDS plan.
+bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream) {
     if (e->deep < 0) {
-        e->deep = 0;
         const size_t n = e->gates.size();
-        if (n <= kDeepMaxGates && (n <= kSmallWideGates || !wide_for_one_instance(e->circ->plan.p, false))) {
-            const bool ok = e->small == 1 || gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or);
-            if (ok && (n > kSmallGates || e->circ->plan.p.n_flat_steps >= min_steps)) e->deep = 1;
+        if (n > kDeepMaxGates || (n > kSmallWideGates && wide_for_one_instance(e->circ->plan.p, false))) {
+            e->deep = 0;
+            return false;
         }
+        if (in_stream && n > kSmallGates && !gc_circ_flat_poll(e->circ, true)) return false;
+        e->deep = 0;
+        const bool ok = e->small == 1 || gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or);
+        if (ok && (n > kSmallGates || e->circ->plan.p.n_flat_steps >= min_steps)) e->deep = 1;
     }
     return e->deep == 1;
 }
@@ -1018,7 +1081,7 @@ void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>>
     }
     const Slot &g = *slots[l.slot];
     // (a slot that has been given back or re-used meanwhile: that group was done long ago)
-    if (g.kind == Slot::kGroup && g.launched && g.launch_no == l.launch_no && g.error == GC_OK) ng->after_ev = g.kdone;
+    if (g.kind == Slot::kGroup && g.launched && g.launch_no == l.launch_no && g.error == GC_OK) ng->after_ev = g.kernel_ev;
 }
 
 // Launch sequence of a group (see the head of this file).  eval: the jobs' table rows are part of the upload region and
@@ -1062,15 +1125,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     const size_t off_fj = up16(g.up_used), off_fin = off_fj + (size_t)n * sizeof(FlatJob);
     const size_t total_up = off_fin + (size_t)n * sizeof(FinJob);
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
-    // rows that go up from where the parser left them (a deep block of the evaluator): behind the upload region
-    size_t ext_total = 0;
-    for (JobRec &j : g.jobs)
-        if (j.rows_src) {
-            j.off_rows = up256(total_up) + ext_total;
-            ext_total += up256(j.rows_ext * sizeof(gc_label));
-        }
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
-    if ((e = grow_dev(ctx, &g.d_up, &g.d_up_cap, up256(total_up) + ext_total)) != hipSuccess) return fail("launch_group (upload)", e);
+    if ((e = grow_dev(ctx, &g.d_up, &g.d_up_cap, total_up)) != hipSuccess) return fail("launch_group (upload)", e);
     if ((e = grow_dev(ctx, &g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
     if (!eval) {
         if ((e = grow_dev(ctx, &g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
@@ -1083,7 +1139,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
         FlatJob f = j.ent->job;
         f.W = (uint4 *)(g.d_arena + j.off_w);
-        f.T = eval ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
+        f.T = eval && !j.rows_in_arena ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
         f.R = d_R;
         f.Rout = nullptr;
         f.rk = d_rk;
@@ -1110,13 +1166,14 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         fin[k] = q;
     }
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
-    for (uint32_t k = 0; k < n && e == hipSuccess; k++)
-        if (g.jobs[k].rows_src && g.jobs[k].rows_ext)
-            e = hipMemcpyAsync(g.d_up + g.jobs[k].off_rows, g.jobs[k].rows_src, g.jobs[k].rows_ext * sizeof(gc_label), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
     if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
-    if (e == hipSuccess) e = hipEventRecord(g.kdone, st);
+    // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
+    // done itself for the evaluator (nothing follows)
+    g.kernel_ev = eval ? g.done : g.kdone;
+    if (e == hipSuccess) e = hipEventRecord(g.kernel_ev, st);
     if (e == hipSuccess && on_lane) {
-        deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kdone});
+        deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
         deep.lane_of[g.deep_id & 255u] = (uint8_t)g.lane;
         deep.n_inflight++;
         deep.n_steps++;
@@ -1146,8 +1203,6 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         if (e == hipSuccess)
             e = hipMemcpyAsync(g.h_down, g.d_down, sizes_bytes + g.down_used, hipMemcpyDeviceToHost, copy_stream);
         if (e == hipSuccess) e = hipEventRecord(g.done, copy_stream);
-    } else if (e == hipSuccess) {
-        e = hipEventRecord(g.done, st);
     }
     if (e != hipSuccess) return fail("launch_group", e);
     return GC_OK;
@@ -1162,6 +1217,7 @@ int launch_oldest(gc_stream *s) {
     s->n_group_steps += g.jobs.size();
     const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
     s->win.note(seq, slot, g.launch_no);
+    if (rc == GC_OK) s->ctxq.pushed(slot, g.launch_no);
     return rc;
 }
 // everything queued is launched, in order (a read-back, a big step or the caller's flush follows)
@@ -1249,6 +1305,7 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
         s->key.assign(key, key + keylen);
         s->rounds = k.rounds;
         s->cache_budget = cache_budget_from_env();
+        s->deep.read_env();
         s->r = gc_label{be64(rnd) | 0x8000000000000000ull, be64(rnd + 8)};  // R.SetS(true)
         uint32_t mx = 0;
         for (uint32_t i = 0; i < ninputs; i++) mx = std::max(mx, inputs[i]);
@@ -1315,7 +1372,7 @@ int gc_stream_intern(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
     // interning is where a circuit's one-time work belongs: the flattened plan (built on first demand: 0.1 s for a 256-bit
     // multiplier, early and late schedule) and, for a step that runs as a pass of its own, the two batches it alternates
     // between — not inside the caller's first steps
-    if (entry_is_deep(ent, s->deep.min_steps) && s->deep.setup(s->ctx)) {
+    if (entry_is_deep(ent, s->deep.min_steps, false) && s->deep.setup(s->ctx)) {
         // (a long one-workgroup pass: it will run on a lane, as a group of one job — the lanes are set up here as well)
     } else if (!entry_is_small(ent)) {
         gc_batch *b0 = nullptr, *b1 = nullptr;
@@ -1356,6 +1413,13 @@ int gc_stream_stats(const gc_stream *s, uint64_t *groups, uint64_t *grouped_step
     if (groups) *groups = s->n_groups;
     if (grouped_steps) *grouped_steps = s->n_group_steps;
     if (big_steps) *big_steps = s->n_big_steps;
+    return GC_OK;
+}
+
+int gc_stream_deep_stats(const gc_stream *s, uint64_t *deep_steps, uint32_t *lanes) {
+    if (!s) return GC_E_ARG;
+    if (deep_steps) *deep_steps = s->deep.n_steps;
+    if (lanes) *lanes = s->deep.state > 0 ? (uint32_t)s->deep.lanes.size() : 0;
     return GC_OK;
 }
 
@@ -1469,7 +1533,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
 
     // ---- a small step joins the earliest open group it has no dependency on (or behind); a deep one takes a lane ---------
-    const bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps) && s->deep.setup(ctx);
+    const bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps, known == nullptr) && s->deep.setup(ctx);
     if (is_deep || (ngates && entry_is_small(ent))) {
         s->win.ensure(s->store.host.size());
         if (is_deep || s->deep.n_inflight) s->deep.ensure(s->store.host.size());
@@ -1504,7 +1568,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             };
             while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
             if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
-                if (s->win.open.size() >= kOpenGroups) {
+                if (s->win.open.size() >= open_groups_limit(s->queue.size())) {
                     int rcq = launch_oldest(s);
                     if (rcq != GC_OK) return rcq;
                     gi--;
@@ -1745,6 +1809,15 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
     GC_HIP(hipSetDevice(ctx->device));
     int rc = g.error;
     if (rc == GC_OK && !g.synced) {
+        // The caller is about to wait for the GPU: nothing new can join an open group meanwhile, so the ctx stream gets the
+        // groups behind this one now (up to kKeepQueued in flight) and runs them while the caller digests these bytes.
+        // (Launching them any earlier — whenever the stream runs dry — was measured: the groups shrink to 3 - 4 steps and the
+        // host's launch sequences become the bound: 1.5e8 against 4.7e8 gates/s on the Ed25519 program.)
+        while (!s->win.open.empty() && hipEventQuery(g.done) != hipSuccess && s->ctxq.hungry(s->slots)) {
+            int rcq = launch_oldest(s);
+            if (rcq != GC_OK) break;
+        }
+        (void)hipGetLastError();
         hipError_t e = hipEventSynchronize(g.done);
         if (e != hipSuccess) {
             set_error("gc_stream_garble_finish", e);
@@ -1878,10 +1951,21 @@ struct EvalSkel {
             if (acc) return false;
             p += c.cmp + c.skip;
             q += c.cmp + c.skip;
-            for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
+            if (slab)
+                for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
+            else
+                p += 16u * c.nrows;
             q += 16u * c.nrows;
         }
         return true;
+    }
+    // the table rows of a block that matched this skeleton with slab == nullptr, into dst (host order)
+    void copy_rows(const uint8_t *buf, gc_label *dst) const {
+        const uint8_t *p = buf;
+        for (const Chunk &c : chunks) {
+            p += c.cmp + c.skip;
+            for (uint32_t r = 0; r < c.nrows; r++, p += 16) *dst++ = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
+        }
     }
 };
 
@@ -1991,6 +2075,7 @@ struct gc_stream_eval {
     // step groups (see the head of this file): small blocks that share no global wire are evaluated by ONE launch sequence
     std::vector<std::unique_ptr<Slot>> slots;
     GroupWindow win;
+    CtxQueue ctxq;
     DeepLanes deep;
     std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
     uint64_t n_groups = 0, n_group_blocks = 0;
@@ -2047,6 +2132,7 @@ int eval_launch_oldest(gc_stream_eval *e) {
     e->n_group_blocks += g.jobs.size();
     const int rc = launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
     e->win.note(seq, slot, g.launch_no);
+    if (rc == GC_OK) e->ctxq.pushed(slot, g.launch_no);
     return rc;
 }
 int eval_close_group(gc_stream_eval *e) {
@@ -2071,13 +2157,17 @@ Slot *eval_slot(gc_stream_eval *e, uint32_t *index, bool big = false) {
     };
     uint32_t on_ctx = 0;
     bool any_free = false;
-    for (uint32_t i = 0; i < e->slots.size(); i++) {
-        Slot &sl = *e->slots[i];
-        if (sl.kind == Slot::kGroup && sl.launched && (sl.error != GC_OK || hipEventQuery(sl.done) == hipSuccess)) done_with(sl);
-        if (sl.kind == Slot::kGroup && !sl.deep_id) on_ctx++;
-        any_free = any_free || sl.kind == Slot::kFree;
+    for (auto &sl : e->slots) any_free = any_free || (sl->kind == Slot::kFree && (sl->arena_cap >= ((size_t)2 << 20)) == big);
+    if (!any_free) {  // (an event query is a microsecond or two: only when a slot is wanted)
+        for (uint32_t i = 0; i < e->slots.size(); i++) {
+            Slot &sl = *e->slots[i];
+            if (sl.kind == Slot::kGroup && sl.launched && (sl.error != GC_OK || hipEventQuery(sl.done) == hipSuccess)) done_with(sl);
+            any_free = any_free || sl.kind == Slot::kFree;
+        }
+        (void)hipGetLastError();  // hipErrorNotReady of the queries
     }
-    (void)hipGetLastError();  // hipErrorNotReady of the queries
+    for (auto &sl : e->slots)
+        if (sl->kind == Slot::kGroup && sl->launched && !sl->deep_id) on_ctx++;
     if (on_ctx >= 8 && !any_free) {
         // the OLDEST launched group (the first one in slot order may be the newest: waiting for that one drains
         // everything queued, and the GPU then idles until the next group is ready — 136 us between the groups of the mixed
@@ -2109,6 +2199,7 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
         e->key.assign(key, key + keylen);
         e->rounds = k.rounds;
         e->cache_budget = cache_budget_from_env();
+        e->deep.read_env();
         e->use_skels = std::getenv("GC_STREAM_NO_SKELETON") == nullptr;
         hipError_t er = hipSetDevice(ctx->device);
         if (er == hipSuccess) er = hipMalloc((void **)&e->d_rk, sizeof k.w);
@@ -2170,6 +2261,13 @@ int gc_stream_eval_stats(const gc_stream_eval *e, uint64_t *parsed, uint64_t *ma
     if (!e) return GC_E_ARG;
     if (parsed) *parsed = e->n_parsed;
     if (matched) *matched = e->n_matched;
+    return GC_OK;
+}
+
+int gc_stream_eval_deep_stats(const gc_stream_eval *e, uint64_t *deep_blocks, uint32_t *lanes) {
+    if (!e) return GC_E_ARG;
+    if (deep_blocks) *deep_blocks = e->deep.n_steps;
+    if (lanes) *lanes = e->deep.state > 0 ? (uint32_t)e->deep.lanes.size() : 0;
     return GC_OK;
 }
 
@@ -2267,6 +2365,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         return true;
     };
     CircEntry *ent = nullptr;
+    const EvalSkel *rows_from = nullptr;  // a matched small block whose rows are still in buf
     uint32_t nin = 0, nout = 0;
     size_t pos = 0;
     std::vector<uint32_t> &gf_ids = e->gf_ids, &wr_ids = e->wr_ids;
@@ -2277,7 +2376,8 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             for (size_t si = 0; si < it->second.size(); si++) {
                 const EvalSkel &sk = it->second[si];
                 if (sk.nbytes > len) continue;
-                const bool same = e->pool.match(sk, buf, slab);
+                // (a small block's rows are copied ONCE, into the upload region of the group it joins — below)
+                const bool same = e->pool.match(sk, buf, small_block ? nullptr : slab);
                 const size_t nr = sk.nrows;
                 if (!same || !canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) continue;
                 ent = sk.ent;
@@ -2294,6 +2394,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                 // most recently matched first: the variants of a circuit (which operands have 16-bit ids, which repeat) are
                 // tried in that order and the least recently matched one goes when there are too many
                 if (si) std::rotate(it->second.begin(), it->second.begin() + (long)si, it->second.begin() + (long)si + 1);
+                if (small_block) rows_from = &it->second[0];
                 break;
             }
     }
@@ -2501,7 +2602,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     gc_ctx *ctx = e->ctx;
     // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence; a deep
     //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
-    const bool is_deep = entry_is_deep(ent, e->deep.min_steps) && e->deep.setup(ctx);
+    const bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
     if (is_deep || (small_block && entry_is_small(ent))) {
         e->win.ensure(e->store.host.size());
         if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
@@ -2535,7 +2636,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             };
             while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
             if (gi == e->win.open.size()) {
-                if (e->win.open.size() >= kOpenGroups) {
+                if (e->win.open.size() >= open_groups_limit((size_t)kOpenGroupsMax * 16)) {
                     int rcq = eval_launch_oldest(e);
                     if (rcq != GC_OK) return rcq;
                     gi--;
@@ -2568,15 +2669,37 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (nin + nout) std::memcpy(g.h_up + g.up_used, e->io_host.data(), ((size_t)nin + nout) * sizeof(uint32_t));
         g.up_used += io_bytes;
         j.off_rows = g.up_used;
-        if (ext_rows) {
-            j.rows_src = slab;
-            j.rows_ext = nrows;
-        } else if (nrows) {
-            std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
+        if (!ext_rows && nrows) {
+            if (rows_from) rows_from->copy_rows(buf, (gc_label *)(g.h_up + g.up_used));
+            else std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
         }
         g.up_used += row_bytes;
         j.off_w = g.arena_used;
         g.arena_used += wbytes;
+        if (ext_rows) {
+            // the rows go up NOW, on the upload stream, from the pinned ring entry into the slot's arena: the entry is free
+            // again as soon as that copy has run (on the lane it would wait for the deep blocks queued there, and the parser
+            // for the entry)
+            j.rows_in_arena = true;
+            j.off_t = g.arena_used;
+            g.arena_used += up256(nrows * sizeof(gc_label));
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            er = grow_dev(ctx, &g.d_arena, &g.arena_cap, g.arena_used);
+            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
+            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
+            if (er == hipSuccess && nrows)
+                er = hipMemcpyAsync(g.d_arena + j.off_t, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
+            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
+            (void)hipEventRecord(e->slab_ev[sb], e->up_stream);
+            e->ring_batch[sb] = nullptr;
+            if (er != hipSuccess) {
+                set_error("gc_stream_eval_circuit (rows)", er);
+                (void)hipStreamSynchronize(e->up_stream);
+                g.reset();
+                return er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            }
+            g.rows_ev = e->up_ev[sb];
+        }
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
         g.jobs.push_back(j);
@@ -2595,10 +2718,6 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (is_deep) {  // launched at once, on its lane
             int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
             hipStream_t lane = e->deep.lanes[(size_t)g.lane];
-            if (ext_rows) {  // the ring entry is free again once its rows have gone up
-                (void)hipEventRecord(e->slab_ev[sb], lane);
-                e->ring_batch[sb] = nullptr;
-            }
             if (rcl != GC_OK) {
                 (void)hipStreamSynchronize(lane);
                 e->deep.retire(g.lane, g.deep_id);
@@ -2632,6 +2751,10 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     uint32_t *d_io = nullptr;
     const gc::StoreXchg *d_xchg = nullptr;
     gc_batch *b = nullptr;
+    if (rows_from) {  // (a matched small block without a one-workgroup plan: rare — its rows into the scratch after all)
+        rows_from->copy_rows(buf, slab);
+        rows_from = nullptr;
+    }
     const gc_label *slab_arg = slab;
     if (!small_block) {
         // the batch (its table buffer) first: not the one of the block before (held), so its pass may still be running

@@ -92,6 +92,8 @@ def lib():
         "gc_stream_intern": (i32, [vp, vp, u32, u32, u32, u32, C.POINTER(C.c_uint32)]),
         "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+        "gc_stream_eval_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
         "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
@@ -679,6 +681,12 @@ class Stream:
         _check(lib().gc_stream_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "gc_stream_stats")
         return a.value, b.value, c.value
 
+    def deep_stats(self):
+        """(steps that ran on a deep lane — long one-workgroup passes beside the step groups —, lanes in use)"""
+        a, b = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().gc_stream_deep_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_deep_stats")
+        return a.value, b.value
+
     def garble_begin(self, gates, nwires, in_, out_):
         """gc_stream_garble_begin: queue one circuit, do not wait (up to 4 096 in flight; small independent circuits
         share a launch sequence)"""
@@ -733,6 +741,12 @@ class StreamEval:
         """(blocks parsed gate by gate, blocks recognised by their byte skeleton)"""
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(lib().gc_stream_eval_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_stats")
+        return a.value, b.value
+
+    def deep_stats(self):
+        """(blocks that ran on a deep lane, lanes in use)"""
+        a, b = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().gc_stream_eval_deep_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_deep_stats")
         return a.value, b.value
 
     def close(self):

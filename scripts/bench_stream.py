@@ -194,7 +194,155 @@ def program_ssa(nsteps=6000, seed=11):
     return steps, prim
 
 
+class _Ssa:
+    """values of a compiled program as lists of global wire ids (LSB first), one circuit per arithmetic instruction
+    (compiler/ssa/streamer.go:412-524); casts, shifts by constants and truncations re-name wires and garble nothing
+    (streamer.go:330-391: the Lshift / Rshift / Slice cases fill `out` with ids).  Results take their ids from a ring of
+    `ring` wires behind the primary inputs: the allocator of the reference recycles wires the same way
+    (compiler/ssa/wire_allocator.go), so a long program writes wires that earlier instructions read and wrote."""
+
+    def __init__(self, ring=1 << 21):
+        self.zero, self.one = 0, 1          # prog.zeroWire and a wire holding 1: constants are lists of these two
+        self.prim = [0, 1]
+        self.base = None
+        self.ring = ring
+        self.pos = 0
+        self.steps = []
+
+    def inputs(self, n):
+        assert self.base is None, "primary inputs come first"
+        ids = list(range(len(self.prim), len(self.prim) + n))
+        self.prim += ids
+        return ids
+
+    def _new(self, n):
+        if self.base is None:
+            self.base = max(len(self.prim), 0x10000)  # a program of this length names its wires with 32 bits
+        if self.pos + n > self.ring:
+            self.pos = 0
+        ids = list(range(self.base + self.pos, self.base + self.pos + n))
+        self.pos += n
+        return ids
+
+    def op(self, circ, a, b):
+        out = self._new(circ.num_outputs)
+        self.steps.append((circ, a + b, out))
+        return out
+
+    def const(self, v, bits):
+        return [self.one if (v >> i) & 1 else self.zero for i in range(bits)]
+
+    def sext(self, x, bits=64):   # int64(x)
+        return x + [x[-1]] * (bits - len(x))
+
+    def shl(self, x, k):
+        return [self.zero] * k + x[:len(x) - k]
+
+    def sar(self, x, k):
+        return x[k:] + [x[-1]] * k
+
+
+def program_ed25519(iterations=10):
+    """The inner loop of Ed25519 signing as the reference streams it (benchmarks.md:677-704: `sign.mpcl`, 8.45e8 gates, 32 %
+    AND, 23 cached circuits; 96 % of the time in Garble).  pkg/crypto/ed25519/internal/edwards25519/ed25519.mpcl is the ref10
+    code: a field element is [10]int32, FeMul (:388-439) forms 100 int64 products from sign-extended limbs and constant
+    multiples (2 f_i, 19 g_i: int32 multiplications), adds ten of them per output limb and runs the carry chain of FeCombine
+    (:270-385: c = (h + 2^25) >> 26; h' += c; h -= c << 26 — twelve times, two of them in parallel, one carry times 19);
+    GeScalarMultBase (:991-1045) repeats per scalar digit: selectPoint (:966-989: eight constant-time conditional moves of a
+    table point — FeCMove :69-81 is XOR / AND / XOR per limb — behind equal() :949-954, then the conditional negation),
+    geMixedAdd (:832-845: three FeMul, seven FeAdd / FeSub) and ToExtended (:787-792: four FeMul).  This program is
+    `iterations` digits of that loop, instruction by instruction, in the reference's dependency order: per digit 2 624
+    instructions, 1.04e7 gates, 29 % AND, from eight circuits (64-bit multiplier, adder, subtractor; 32-bit multiplier, adder,
+    subtractor, AND, XOR).  The multiplier is the array form of compiler/circuits/circ_multiplier.go:38 (the reference picks
+    Karatsuba above ~21 bits, :18-36), adder and subtractor are its one-AND-per-bit full adder / subtractor
+    (circ_adder.go:30-55, circ_subtractor.go:17-31).  Small constants (1 << 25, 19, 2, 0, 1) are lists of the zero / one wire."""
+    from mpc_amd.circuit import AND as OP_AND, XOR as OP_XOR, bitwise, subtractor
+    mul64, add64, sub64 = multiplier(64), adder(64), subtractor(64)
+    mul32, add32, sub32 = multiplier(32), adder(32), subtractor(32)
+    and32, xor32 = bitwise(32, OP_AND), bitwise(32, OP_XOR)
+    P = _Ssa()
+    digits = [P.inputs(32) for _ in range(iterations)]   # e[i], sign-extended to int32 (the scalar's signed digits)
+    # base[pos][i] (const.mpcl): 8 points x 3 field elements x 10 limbs per digit.  The reference's compiler folds such constants
+    # into the instruction's circuit (streamer.go:468-476: ConstPropagate + Prune before the circuit is cached); here a table
+    # limb is a 32-bit word of wires of its own, so that the program keeps to its eight circuits (bound to wires of constant
+    # value the same XOR block would reach the evaluator in a different repeat pattern for every table entry)
+    tables = [[[[P.inputs(32) for _ in range(10)] for _ in range(3)] for _ in range(8)] for _ in range(iterations)]
+
+    def fe_add(a, b):
+        return [P.op(add32, x, y) for x, y in zip(a, b)]
+
+    def fe_sub(a, b):
+        return [P.op(sub32, x, y) for x, y in zip(a, b)]
+
+    def fe_combine(h):  # :270-385
+        h = list(h)
+
+        def carry(i, shift, nxt, times19=False):
+            c = P.sar(P.op(add64, h[i], P.const(1 << (shift - 1), 64)), shift)
+            h[nxt] = P.op(add64, h[nxt], P.op(mul64, c, P.const(19, 64)) if times19 else c)
+            h[i] = P.op(sub64, h[i], P.shl(c, shift))
+
+        for i, j in ((0, 4), (1, 5), (2, 6), (3, 7), (4, 8)):  # the two chains run side by side
+            carry(i, 26 if i % 2 == 0 else 25, i + 1)
+            carry(j, 26 if j % 2 == 0 else 25, j + 1)
+        carry(9, 25, 0, times19=True)
+        carry(0, 26, 1)
+        return [x[:32] for x in h]  # int32(h_i)
+
+    def fe_mul(f, g):  # :388-439
+        f2 = {i: P.sext(P.op(mul32, f[i], P.const(2, 32))) for i in (1, 3, 5, 7, 9)}
+        g19 = {i: P.sext(P.op(mul32, g[i], P.const(19, 32))) for i in range(1, 10)}
+        F = [P.sext(x) for x in f]
+        G = [P.sext(x) for x in g]
+        h = []
+        for k in range(10):
+            acc = None
+            for i in range(10):
+                j = (k - i) % 10
+                a = f2[i] if (i % 2 == 1 and k % 2 == 0) else F[i]
+                b = g19[j] if i + j >= 10 else G[j]
+                pr = P.op(mul64, a, b)
+                acc = pr if acc is None else P.op(add64, acc, pr)
+            h.append(acc)
+        return fe_combine(h)
+
+    def fe_cmove(f, g, mask):  # :69-81, b already negated into a mask
+        return [P.op(xor32, x, P.op(and32, P.op(xor32, x, y), mask)) for x, y in zip(f, g)]
+
+    def select_point(b, tab):  # :966-989
+        bneg = P.op(and32, P.sar(b, 31), P.const(1, 32))
+        nmask = P.op(sub32, P.const(0, 32), bneg)
+        babs = P.op(sub32, b, P.shl(P.op(and32, nmask, b), 1))
+        t = [[P.const(1, 32)] + [P.const(0, 32)] * 9, [P.const(1, 32)] + [P.const(0, 32)] * 9, [P.const(0, 32)] * 10]
+        for i in range(8):
+            x = P.op(sub32, P.op(xor32, babs, P.const(i + 1, 32)), P.const(1, 32))  # equal(): (b ^ c) - 1 >> 31
+            mask = P.op(sub32, P.const(0, 32), P.sar(x, 31)[:1] + [P.zero] * 31)
+            t = [fe_cmove(t[k], tab[i][k], mask) for k in range(3)]
+        minus = [t[1], t[0], [P.op(sub32, P.const(0, 32), x) for x in t[2]]]  # FeCopy, FeCopy, FeNeg
+        return [fe_cmove(t[k], minus[k], nmask) for k in range(3)]
+
+    hX, hY, hZ, hT = ([P.const(v, 32)] + [P.const(0, 32)] * 9 for v in (0, 1, 1, 0))  # h.Zero()
+    for it in range(iterations):
+        ypx, ymx, xy2d = select_point(digits[it], tables[it])
+        # geMixedAdd (:832-845)
+        rX = fe_add(hY, hX)
+        rY = fe_sub(hY, hX)
+        rZ = fe_mul(rX, ypx)
+        rY = fe_mul(rY, ymx)
+        rT = fe_mul(xy2d, hT)
+        t0 = fe_add(hZ, hZ)
+        rX = fe_sub(rZ, rY)
+        rY = fe_add(rZ, rY)
+        rZ = fe_add(t0, rT)
+        rT = fe_sub(t0, rT)
+        # ToExtended (:787-792)
+        hX, hY, hZ, hT = fe_mul(rX, rT), fe_mul(rY, rZ), fe_mul(rZ, rT), fe_mul(rX, rY)
+    return P.steps, P.prim
+
+
 PROGRAMS = {
+    "ed25519like": lambda: program_ed25519(10),
+    "ed25519like1": lambda: program_ed25519(1),   # one digit: the parity tests' size
     "ssa23": lambda: program_ssa(6000),
     "big": lambda: program_big(20_000_000),
     "big130": lambda: program_big(130_000_000),

@@ -40,4 +40,4 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["big", "big130", "uniform512", "uniform4096", "uniform512x64", "mixed", "mixed100", "ssa23"])
+    main(sys.argv[1:] or ["big", "big130", "uniform512", "uniform4096", "uniform512x64", "mixed", "mixed100", "ssa23", "ed25519like", "ed25519like1"])

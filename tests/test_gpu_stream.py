@@ -806,3 +806,227 @@ def test_stream_closed_with_big_steps_in_flight():
     assert [gg.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps] == want
     ctx.sync()
     gg.close(); ctx.close()
+
+
+# ---- deep lanes: long one-workgroup steps on streams of their own, beside the step groups (round 4) ------------------------
+
+def _deep_dependency_program(base):
+    """Every kind of dependency ACROSS the two scheduling classes.  With GC_STREAM_DEEP_STEPS = 100 the 128- and 256-bit
+    adders / subtractors (255 / 511 barriers) are DEEP steps (a lane each), the 64-bit ones and the bitwise blocks are small
+    (step groups on the ctx stream); so is a 64-bit array multiplier (179 barriers); a 40 000-gate wide circuit is a BIG step (a
+    pass of the ctx stream)."""
+    from mpc_amd.circuit import AND, XOR, adder, bitwise, multiplier, subtractor, synthetic_levelised
+    add64, add128, add256 = adder(64), adder(128), adder(256)
+    sub128 = subtractor(128)
+    xor128, and128, xor64 = bitwise(128, XOR), bitwise(128, AND), bitwise(64, XOR)
+    mul64 = multiplier(64)
+    big = synthetic_levelised(20, 2000, 0.2, seed=55, ninputs=256, inv_frac=0.05)
+    prim = [base + i for i in range(1024)]
+    v = lambda k, n: prim[(k * 64) % 768:(k * 64) % 768 + n]  # an input value of n bits
+    nxt = [base + 2000]
+    steps = []
+
+    def add(c, a, b, out_=None):
+        if out_ is None:
+            out_ = list(range(nxt[0], nxt[0] + c.num_outputs))
+            nxt[0] += c.num_outputs
+        steps.append((c, a + b, out_))
+        return out_
+
+    # 1. independent deep steps (they spread over the lanes) between independent small ones
+    d = [add(add128, v(k, 128), v(k + 2, 128)) for k in range(4)]
+    s = [add(xor64, v(k, 64), v(k + 1, 64)) for k in range(6)]
+    # 2. read after write: small <- deep, deep <- small, deep <- deep (other lane), small <- small <- deep
+    x = add(xor128, d[0], d[1])                       # a group waits for two deep steps
+    y = add(sub128, x, d[2])                          # a deep step waits for a group and for a deep step
+    z = add(add128, y, d[3])                          # deep <- deep
+    w = add(and128, z, x)
+    w = add(xor128, w, y)
+    # 3. write after write: two deep steps, then a small and a deep step, write the SAME wires; the reader sees the last
+    tgt = list(range(nxt[0], nxt[0] + 128)); nxt[0] += 128
+    add(add128, v(1, 128), v(3, 128), tgt)
+    add(sub128, v(5, 128), v(2, 128), tgt)
+    r1 = add(xor128, tgt, v(4, 128))
+    add(xor128, v(6, 128), v(7, 128), tgt)            # small over deep
+    add(add128, v(8, 128), v(9, 128), tgt)            # deep over small
+    r2 = add(and128, tgt, r1)
+    # 4. write after read: a deep step reads wires that a small step overwrites right after, and the other way round
+    a = add(xor128, v(2, 128), v(6, 128))
+    r3 = add(add128, a, v(1, 128))                    # deep reads a
+    add(and128, v(3, 128), v(5, 128), a)              # small overwrites a: the deep step must have read the old labels
+    r4 = add(xor128, a, r3)
+    b = add(xor128, v(7, 128), v(0, 128))
+    r5 = add(and128, b, v(2, 128))                    # small reads b
+    add(sub128, v(4, 128), v(8, 128), b)              # deep overwrites b
+    r6 = add(xor128, b, r5)
+    # 5. several deep readers of one value on different lanes, then a writer of that value (it must wait for all of them)
+    c0 = add(xor128, v(1, 128), v(9, 128))
+    rs = [add(add128, c0, v(k, 128)) for k in range(4)]
+    add(xor128, v(3, 128), v(4, 128), c0)
+    r7 = add(add128, c0, rs[3])
+    # 6. in-place updates: out[] names wires of in[] — a deep step, then a small one on the same value
+    acc = add(xor128, v(0, 128), v(5, 128))
+    add(add128, acc, v(2, 128), acc)
+    add(xor128, acc, v(3, 128), acc)
+    add(sub128, acc, v(7, 128), acc)
+    # 7. a big step (a pass of the ctx stream) between deep ones, consuming and feeding them; a long small step beside
+    p256 = add(add256, v(0, 256), v(4, 256))
+    bo = add(big, p256[:128], r7)
+    q = add(add128, bo[:128], bo[:128])
+    m = add(mul64, q[:64], s[0])
+    add(xor64, m, s[1])
+    # 8. a chain of deep steps (one lane's worth of order) while small steps stream by
+    ch = d[0]
+    for k in range(6):
+        ch = add(add128 if k % 2 else sub128, ch, v(k, 128))
+        for j in range(5):
+            add(xor64, v(k + j, 64), s[j])
+    add(xor128, ch, r6)
+    add(xor128, r2, r4)
+    return steps, prim
+
+
+@pytest.mark.parametrize("base,keylen,lanes,by_handle", [(0, 32, None, True), (0x20000, 16, "1", False), (0xfe00, 24, "2", True),
+                                                         (0, 32, "0", True)])
+def test_stream_deep_lanes_match_oracle(base, keylen, lanes, by_handle, monkeypatch):
+    """deep steps (lanes) beside step groups and a big step: every byte in program order, every wire afterwards and the
+    evaluator's labels equal the oracle's serial loop, with 3 / 1 / 2 lanes and with the lanes switched off"""
+    monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    if lanes is not None:
+        monkeypatch.setenv("GC_STREAM_DEEP_LANES", lanes)
+    ctx = engine.Context(0)
+    steps, prim = _deep_dependency_program(base)
+    key = drbg("deepkey", keylen)
+    rnd = drbg("deep%d" % base, 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    got, issued, handles = [], 0, {}
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + 48:
+            c, in_, out_ = steps[issued]
+            if by_handle:
+                if id(c) not in handles:
+                    handles[id(c)] = gg.intern(c.Gates, c.NumWires, len(in_), len(out_))
+                gg.garble_begin_h(handles[id(c)], in_, out_)
+            else:
+                gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        got.append(gg.garble_finish())
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert g == w, "step %d of %d (%s)" % (k, len(steps), steps[k][0].name)
+    deep_steps, nlanes = gg.deep_stats()
+    # (with the threshold at 100 barriers the 64-bit multiplier — 179 — is a deep step as well)
+    ndeep = sum(1 for c, _, _ in steps if c.name in ("adder128", "subtractor128", "adder256", "multiplier64"))
+    if lanes == "0":
+        assert (deep_steps, nlanes) == (0, 0)
+    else:
+        assert nlanes >= 1 and deep_steps == ndeep, (deep_steps, ndeep, nlanes)
+    for c, in_, out_ in steps:
+        for o in out_[::7]:
+            assert gg.get(o) == og.get(o)
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("deepbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = og.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    for (c, in_, out_), data in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    if lanes != "0":
+        assert ge.deep_stats()[0] == ndeep
+    for k, (c, in_, out_) in enumerate(steps):
+        for o in out_[::7]:
+            assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
+    ctx.sync()
+    gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_deep_steps_in_flight_while_circuits_are_evicted(monkeypatch):
+    """a circuit cache too small for the program's circuits, deep steps in flight on their lanes when room is made: the lanes
+    are drained before a circuit goes, the bytes stay the oracle's (both sides)"""
+    from mpc_amd.circuit import AND, XOR, adder, bitwise, subtractor
+    monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    monkeypatch.setenv("GC_STREAM_CACHE_GATES", "2500")
+    shapes = [adder(128), subtractor(128), bitwise(128, XOR), adder(256), bitwise(128, AND), adder(192), subtractor(160)]
+    prim = list(range(512))
+    steps, nxt = [], 600
+    prev = prim[:128]
+    for k in range(40):
+        c = shapes[k % len(shapes)]
+        w = c.num_inputs // 2
+        a = (prev + prim)[:w]
+        b = prim[(k * 32) % 256:(k * 32) % 256 + w]
+        out_ = list(range(nxt, nxt + c.num_outputs))
+        nxt += c.num_outputs
+        steps.append((c, a + b, out_))
+        if k % 3 == 0:
+            prev = out_
+    key = drbg("deep-evict", 32)
+    rnd = drbg("deep-evict-rnd", 16 * (len(prim) + 1))
+    ctx = engine.Context(0)
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    issued = 0
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + 12:
+            c, in_, out_ = steps[issued]
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        assert gg.garble_finish() == want[k], "step %d (%s)" % (k, steps[k][0].name)
+    assert gg.deep_stats()[0] > 10
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    for w in prim:
+        ge.set(w, og.get(w)["l0"])
+        oe.set(w, og.get(w)["l0"])
+    for (c, in_, out_), data in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    for c, in_, out_ in steps:
+        for o in out_[::9]:
+            assert ge.get(o) == oe.get(o)
+    ctx.sync()
+    gg.close(); ge.close(); ctx.close()
+
+
+def test_stream_ed25519like_matches_oracle():
+    """one scalar digit of the Ed25519-shaped program of scripts/bench_stream.py (program_ed25519: selectPoint, geMixedAdd,
+    ToExtended of the reference's ed25519.mpcl, instruction by instruction — 2 605 steps, 1.04e7 gates, constants as wires,
+    operands with repeated sign wires): every step's bytes and the evaluator's labels equal the oracle's"""
+    from scripts.bench_stream import PROGRAMS
+    steps, prim = PROGRAMS["ed25519like1"]()
+    key = drbg("edkey", 32)
+    rnd = drbg("edrnd", 16 * (len(prim) + 1))
+    ctx = engine.Context(0)
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    handles, issued = {}, 0
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + 64:
+            c, in_, out_ = steps[issued]
+            if id(c) not in handles:
+                handles[id(c)] = gg.intern(c.Gates, c.NumWires, len(in_), len(out_))
+            gg.garble_begin_h(handles[id(c)], in_, out_)
+            issued += 1
+        assert gg.garble_finish() == want[k], "step %d (%s)" % (k, steps[k][0].name)
+    groups, grouped, bigs = gg.stats()
+    assert bigs == 0 and groups < len(steps) // 4, (groups, grouped, bigs)  # the hundred products of a FeMul share launches
+    ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("edbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = og.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        ge.set(w, lab)
+        oe.set(w, lab)
+    for (c, in_, out_), data in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    for k, (c, in_, out_) in enumerate(steps[-300:]):
+        for o in out_[::11]:
+            assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
+    ctx.sync()
+    gg.close(); ge.close(); ctx.close()
