@@ -8,8 +8,11 @@ libgcengine.so = ncclAllGather over xGMI called from the C ABI).  No torch in th
 gc_dev_alloc / gc_dev_upload of the same C ABI a Go host binds, `python -m torch.distributed.run` is only the process
 launcher, and the 128-byte communicator id travels through a file (mpc_amd/dist.py).
 Workload at N=1: BASELINE.json configs[1] — aes_128 (36 663 gates, 6 400 AND) x 1 024 instances,
-32-byte garbling key (AES-256, as circuit.Garbler uses).  N > 1: the same per-GPU batch on every
-rank (weak scaling, independent instances, no data-path collective except the output gather).
+32-byte garbling key (AES-256, as circuit.Garbler uses).  N > 1: BASELINE.json configs[3]'s shape — 8 192 instances per
+GPU on every rank (65 536 at N = 8; weak scaling, independent instances, circuit/garble.go:253-278 draws fresh R and labels
+per instance), no data-path collective except the gather of the decoded outputs; `--batch` overrides either.
+Every wait of the N > 1 path is bounded (communicator id hand-over, ncclCommInitRank, the run itself: mpc_amd/dist.py
+Watchdog); on any failure rank 0 prints ONE JSON line with "error" and the process exits non-zero instead of hanging.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -107,23 +110,73 @@ def kernel_build_hash():
     return h.hexdigest()[:16]
 
 
+SWEEP_KEEP = ("circuit", "gates", "and", "levels", "gates_materialised", "wires_in_lds", "garble_ms", "eval_ms", "and_gates_per_s",
+              "gates_per_s", "hbm_alg_GBs", "hbm_roofline_frac", "hbm_read_roofline_frac", "lds_array_frac", "model_note",
+              "outputs_ok")
+REF_BENCH_KEY = b"0123456789abcdef"  # benchKey of circuit/garble_bench_test.go:35
+
+
 def sweep_rows_for_line(batch, key, ctx):
-    """SURVEY §8d's synthetic levelised circuits, three rows for the default line (W = 1 024, f in {0, 0.17, 1};
-    `python bench.py --sweep` runs the whole grid)"""
+    """SURVEY §8d's synthetic levelised circuits for the default line: W = 1 024 at f in {0, 0.17, 1} and one row each of the
+    narrow (W = 64) and the wide (W = 16 384) end at the AES-like f = 0.17 (`python bench.py --sweep` runs the whole grid)"""
     from scripts.sweep_synthetic import run as sweep_run
-    rows = sweep_run(batch, 131072, key, ctx=ctx, cases=[(1024, 0.0), (1024, 0.17), (1024, 1.0)], chain=0)
-    keep = ("circuit", "gates", "and", "gates_materialised", "wires_in_lds", "garble_ms", "eval_ms", "and_gates_per_s",
-            "gates_per_s", "hbm_alg_GBs", "hbm_roofline_frac", "hbm_read_roofline_frac", "lds_array_frac", "model_note",
-            "outputs_ok")
-    return [{k: r[k] for k in keep if k in r} for r in rows]
+    rows = sweep_run(batch, 131072, key, ctx=ctx, cases=[(1024, 0.0), (1024, 0.17), (1024, 1.0), (64, 0.17), (16384, 0.17)],
+                     chain=0)
+    return [{k: r[k] for k in SWEEP_KEEP if k in r} for r in rows]
+
+
+def reference_bench_rows(batch, circ, ctx):
+    """SURVEY §8d's remaining rows, under the reference's own benchmark key (circuit/garble_bench_test.go:35, 16 bytes =
+    AES-128): config 2 again (`key16`) and buildANDChain(10000) (:19-33, :39 — depth 10 000, width 1: the worst case)"""
+    from mpc_amd.circuit import and_chain
+    from scripts.sweep_synthetic import run as sweep_run
+    rows = sweep_run(batch, 131072, REF_BENCH_KEY, ctx=ctx, cases=[], chain=0, circuits=[circ, and_chain(10000)])
+    keep = SWEEP_KEEP + ("hash_phases", "live_labels")
+    k16, chain = ({k: r[k] for k in keep if k in r} for r in rows)
+    t = (k16["garble_ms"] + k16["eval_ms"]) * 1e-3
+    k16.update({"key_bytes": 16, "value": k16["and_gates_per_s"], "ms_per_step_device": t * 1e3,
+                "note": "device time of garble + eval per pass (HIP events), without the label hand-over and decode kernels "
+                        "of the headline's step"})
+    chain.update({"key_bytes": 16, "ns_per_and_per_instance_garble": chain["garble_ms"] * 1e6 / 10000,
+                  "published_reference": "BenchmarkGarble on this circuit: 155.1 ns per AND, one instance, i5-8257U "
+                                         "(benchmarks.md:726)"})
+    return {"key16": k16, "and_chain_10000": chain}
+
+
+METRIC = "AND-gates/sec (garble+eval), AES-128 circuit batch"
+
+
+def error_line(msg, stage, world):
+    """the ONE line of a failed run: same metric, no value, what went wrong and where"""
+    return json.dumps({"metric": METRIC, "value": None, "unit": "AND-gates/s", "n_gpus": world, "error": str(msg)[:600],
+                       "stage": stage, "higher_is_better": True})
 
 
 def main():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    stage = ["start"]
+    try:
+        run(stage)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 — a failed rank must say so and leave; the launcher ends the others
+        sys.stderr.write("bench.py rank %d failed at stage '%s': %r\n" % (rank, stage[0], e))
+        if rank == 0:
+            print(error_line("%s: %s" % (type(e).__name__, e), stage[0], world), flush=True)
+        sys.stdout.flush()
+        os._exit(1)  # (not sys.exit: a wedged collective must not be waited for by destructors)
+
+
+def run(stage):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default: 1 024 at N = 1 = BASELINE config 2, "
+                    "8 192 at N > 1 = config 4's per-GPU share)")
+    ap.add_argument("--init-timeout", type=float, default=240.0, help="N > 1: seconds the communicator may take to form")
+    ap.add_argument("--run-timeout", type=float, default=1500.0, help="N > 1: seconds the whole run may take")
     ap.add_argument("--circuit", default=os.path.join(ROOT, "tests", "golden", "aes_128.gcf"))
     ap.add_argument("--key-bytes", type=int, default=32, choices=[16, 24, 32])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,7 +184,9 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 5 shape) side measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the sha256xor x 256 + 65 536 OTs pipeline (config 3) side measurement")
-    ap.add_argument("--no-synthetic", action="store_true", help="skip the three synthetic levelised rows (SURVEY §8d)")
+    ap.add_argument("--no-synthetic", action="store_true", help="skip the five synthetic levelised rows (SURVEY §8d)")
+    ap.add_argument("--no-extra-rows", action="store_true", help="skip config 2 under the reference's 16-byte benchmark key "
+                    "and the AND-chain row (circuit/garble_bench_test.go:19-39)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="run the output gather even with one rank (testing)")
     ap.add_argument("--schedule", type=int, default=1)
@@ -150,16 +205,36 @@ def main():
         args.gpus = world
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes); before the runtime starts
+    import importlib
+
     import numpy as np
 
-    from mpc_amd import dist as gdist, engine, parse_file
+    from mpc_amd import dist as gdist, parse_file
+    # (GC_BENCH_ENGINE: the CPU suite runs this very rank entry at world 2 on a stand-in engine module, tests/stub_engine.py)
+    engine = importlib.import_module(os.environ.get("GC_BENCH_ENGINE", "mpc_amd.engine"))
 
+    if args.batch is None:
+        args.batch = 1024 if world == 1 else 8192
     circ = parse_file(args.circuit)
     circ.name = os.path.splitext(os.path.basename(args.circuit))[0]
     key = bytes(range(args.key_bytes))
+    # N > 1: nothing may hang the lease — a watchdog thread ends the process with the error line when a stage overruns
+    # (the main thread may be inside ncclCommInitRank or a collective, i.e. inside a C call that never returns)
+    dog = gdist.Watchdog(lambda what: (print(error_line(what, stage[0], world), flush=True) if rank == 0 else None)) if world > 1 else None
+    stage[0] = "context"
     ctx = engine.Context(local_rank)  # one process per GPU: this rank's device, its own HIP stream
     collective = world > 1 or args.force_collective
-    comm = gdist.open_comm(ctx, rank, world) if collective else None  # gc_comm_init_rank: RCCL, one rank per GPU
+    comm = None
+    if collective:  # gc_comm_init_rank: RCCL, one rank per GPU
+        stage[0] = "communicator (id hand-over + ncclCommInitRank)"
+        if dog:
+            dog.arm(args.init_timeout, "no communicator of %d ranks within %.0f s" % (world, args.init_timeout))
+        comm = gdist.open_comm(ctx, rank, world, timeout=args.init_timeout * 0.75, engine=engine)
+        if comm.nranks != world:
+            raise RuntimeError("communicator has %d ranks, launched %d" % (comm.nranks, world))
+        if dog:
+            dog.arm(args.run_timeout, "the run did not finish within %.0f s" % args.run_timeout)
+    stage[0] = "set-up"
     if args.sweep:  # every rank sweeps its own GPU (independent instances); rank 0 reports the job
         from scripts.sweep_synthetic import run as sweep_run
         t0 = time.perf_counter()
@@ -233,10 +308,20 @@ def main():
             print("bench: hipGraph capture unavailable (%s); launching directly" % e, file=sys.stderr)
             graphs = None
             ctx.sync()
+    stage[0] = "timed steps"
     loop = gdist.StepLoop(K, launch, gather if collective else None)
     elapsed = gdist.run_timed(loop, fence, args.steps, args.warmup,
                               allreduce_max=comm.allreduce_max if comm is not None else None)
     assert loop.steps_gathered == loop.steps_done == args.steps + args.warmup
+    stage[0] = "after the timed steps"
+    gather_us = None
+    if collective:  # the gather alone: a few calls between device syncs (config 4's "RCCL gather over xGMI")
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gather(K)
+        ctx.sync()
+        gather_us = (time.perf_counter() - t0) / 5 * 1e6
 
     # per-pass device times (events on the engine stream) from a few extra, untimed-by-wall steps
     g_ms, e_ms = [], []
@@ -300,7 +385,7 @@ def main():
     lds_e = blocks_e * batch * lookups_per_block / (e_avg * 1e-3) / LDS_B32_PEAK_LOOKUPS
     frac_read = value / world * (read_b / max(n_and, 1)) / 1e9 / HBM_PEAK_GBS
     res = {
-        "metric": "AND-gates/sec (garble+eval), AES-128 circuit batch",
+        "metric": METRIC,
         "value": value,
         "unit": "AND-gates/s",
         "n_gpus": world,
@@ -326,6 +411,9 @@ def main():
             "device_memory": "gc_dev_alloc / gc_dev_upload (C ABI); no torch in the process",
             "gathers": loop.gathers,
         },
+        # what the communicator itself says (gc_comm_nranks / gc_comm_version), not what the launcher promised
+        "n_ranks_seen": comm.nranks if comm is not None else 1,
+        "rccl_version": engine.comm_version() if comm is not None else None,
         "garble_ms": g_avg,
         "eval_ms": e_avg,
         "and_gates_per_s_garble_only": n_and * batch / (g_avg * 1e-3),
@@ -371,6 +459,19 @@ def main():
             "lds_array_peak_lookups_per_s": LDS_B32_PEAK_LOOKUPS,
         },
     }
+    if collective:
+        res["config4"] = {
+            "workload": "aes_128 x %d instances = %d per GPU x %d GPUs (BASELINE config 4 is 8 192 x 8), outputs of %d steps per "
+                        "gather" % (batch * world, batch, world, K),
+            "instances_total": batch * world,
+            "gathered_bytes_per_gpu": int(d_acc.nbytes),
+            "gathered_bytes_total": int(d_acc.nbytes) * world,
+            "gather_us": gather_us,
+            "gather_GBs_per_gpu_received": (int(d_acc.nbytes) * (world - 1) / (gather_us * 1e-6) / 1e9) if gather_us and world > 1 else None,
+            "gathers_in_timed_region": loop.gathers,
+            "collective": "ncclAllGather (gc_comm_allgather, RCCL over xGMI), one per %d steps" % K,
+            "gathered_outputs_ok": ok,
+        }
     gb.close()
     ev.close()
     dc.close()
@@ -382,6 +483,8 @@ def main():
         if not args.no_synthetic and aes:
             # SURVEY §8d / north star: synthetic levelised circuits as absolute numbers and as fractions of the rooflines
             res["synthetic"] = sweep_rows_for_line(batch, key, ctx)
+        if not args.no_extra_rows and aes:
+            res.update(reference_bench_rows(batch, circ, ctx))
         if not args.no_iknp:
             # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):
             # device-resident API, 4 Mi OTs
@@ -406,10 +509,24 @@ def main():
             res["config3"] = config3_run(256, 10, key)
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
+        # "probe `go version` first" — with a Go toolchain on the box the baseline would be the reference itself
+        import shutil
+        go = shutil.which("go")
+        go_ver = None
+        if go:
+            try:
+                import subprocess
+                go_ver = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+            except Exception as e:  # noqa: BLE001
+                go_ver = "go found, `go version` failed: %s" % e
+        res.setdefault("cpu_baseline", {})["go_on_box"] = go_ver or False
+    stage[0] = "shutdown"
     if comm is not None:
         comm.barrier()
         comm.close()
     ctx.close()
+    if dog:
+        dog.disarm()
     if rank == 0:
         # the JSON line goes out LAST: flush whatever native libraries (RCCL banner) left in C stdio first
         import ctypes

@@ -114,6 +114,13 @@ int gc_device_count(void);
 gc_ctx *gc_ctx_create(int device, int *status);
 void gc_ctx_destroy(gc_ctx *);
 int gc_ctx_sync(gc_ctx *);
+/* ONE instance of a wide circuit (a big streamed step) runs as one launch of 32 workgroups that meet at a barrier between
+ * levels; their wait is bounded, and a pass that lost a workgroup is done again on the device, on the same stream, before
+ * anything that follows it (so no call fails and no result differs: (*Streaming).Garble of the reference never fails
+ * spuriously, circuit/stream_garble.go:161-192) — it costs time, and the ctx keeps to one launch per level from then on.
+ * state: 0 not used yet, 1 in use, -1 off (GC_NO_COOP, the self-test failed, or after a timeout); timeouts: passes that were
+ * done again.  Either pointer may be NULL.  (GC_COOP_FORCE_TIMEOUT=n makes the n-th pass of every ctx lose a workgroup.) */
+int gc_ctx_coop_stats(gc_ctx *, int *state, uint64_t *timeouts);
 /* the ctx's HIP stream as an opaque pointer (hipStream_t) for callers that enqueue their own work */
 void *gc_ctx_stream(gc_ctx *);
 

@@ -47,6 +47,8 @@ struct gc_ctx {
     gc::CoopCtl *d_coop = nullptr;
     int coop_state = 0;
     uint32_t *h_coop_err = nullptr;
+    uint64_t coop_timeouts = 0;  // passes that lost a workgroup (each was done again on the device: gc_ctx_coop_check)
+    uint32_t coop_launched = 0;  // cooperative passes launched on d_coop (= its `passes` counter once they have run)
     // Streaming engine (stream_engine.cpp), kept per ctx so that a stream created per connection does not pay for them again:
     //  * the deep lanes — extra HIP streams that were probed to run beside `stream` (DeepLanes::setup; lanes_state 0: not set
     //    up, 1: ready, -1: none) and the candidates that were set aside;
@@ -69,7 +71,8 @@ hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *ca
 // back to the lists (nothing on the GPU may still use it); freed when the lists hold more than a few GiB
 void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap);
 }  // namespace gc
-// internal: GC_E_HIP (and the cooperative passes switched off) if a cooperative pass of this ctx reported a lost workgroup
+// internal: notes a cooperative pass of this ctx that lost a workgroup (repeated on the device already) and switches the
+// cooperative passes off; GC_OK always
 int gc_ctx_coop_check(gc_ctx *c);
 
 struct gc_graph {

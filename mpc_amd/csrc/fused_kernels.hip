@@ -18,6 +18,7 @@
 // All hash lanes of all gate types share one AES code path, so mixed waves never run it twice.
 #include "aes_device.h"
 #include "kernels.h"
+#include "level_gate.h"
 #include <cstdlib>
 
 namespace gc {
@@ -1073,6 +1074,61 @@ __device__ __forceinline__ void coop_leave(CoopCtl *ctl) {
     if (threadIdx.x == 0 && __hip_atomic_fetch_add(&ctl->left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kCoopGroups - 1) {
         __hip_atomic_store(&ctl->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ctl->left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctl->passes, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// testing (GC_COOP_FORCE_TIMEOUT): in pass number ctl->drop_at one workgroup takes no part — to the others it looks exactly
+// like a workgroup that did not become resident in time
+__device__ __forceinline__ bool coop_dropped(CoopCtl *ctl, uint32_t rank) {
+    if (rank != 5) return false;
+    const uint32_t at = __hip_atomic_load(&ctl->drop_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (at == 0 || __hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != at) return false;
+    coop_leave(ctl);
+    return true;
+}
+
+// The stand-by of a pass (kernels.h: launch_coop): workgroup number kCoopGroups of the same XCD.  te: the kernel's LDS table
+// area (the classic tables take its first 4 KiB).
+template <int NR, bool EVAL>
+__device__ __noinline__ void coop_standby(CoopCtl *ctl, uint32_t seq, const GateDesc *__restrict__ descs, const Step *__restrict__ steps,
+                                          uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W, const uint4 *__restrict__ Rv,
+                                          uint4 *__restrict__ T, const uint32_t *__restrict__ rk, const uint32_t *__restrict__ g_te0,
+                                          const StoreXchg *xp, uint32_t *te) {
+    if (threadIdx.x == 0) {
+        // the last workgroup to leave counts the pass; every wait inside the pass is bounded, so this one ends (the bound here
+        // is a backstop: ~2 s)
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+            __builtin_amdgcn_s_sleep(100);
+            if (__builtin_amdgcn_s_memtime() - t0 > 50u * kCoopTimeout) break;
+        }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // the rule: a good pass
+    load_te_tables(te, g_te0);
+    if (xp)  // Get through in[] again: the failed pass left the wire store alone (it skips its scatter once the flag is up)
+        for (uint32_t i = threadIdx.x; i < ninputs; i += kCoopThreads) W[i] = xp->store[xp->in_idx[i]];
+    __syncthreads();
+    uint4 R = make_uint4(0, 0, 0, 0);
+    if (!EVAL) R = Rv[0];
+    for (uint32_t lv = 0; lv < nsteps; lv++) {
+        const Step st = steps[lv];
+        for (uint32_t g = threadIdx.x; g < st.count; g += kCoopThreads) {
+            const GateDesc d = descs[st.first + g];
+            uint4 *out = W + ninputs + st.first + g;  // desc k writes slot ninputs + k; one instance: column 0, stride 1
+            if (EVAL) eval_one<NR>(d, 0, 1, W, (const uint4 *)T, out, rk, te);
+            else garble_one<NR>(d, 0, 1, W, R, T, out, rk, te);
+        }
+        __syncthreads();  // (one workgroup, one CU: the level's labels are in its L1 / the XCD's L2 for the next level)
+    }
+    if (xp)
+        for (uint32_t j = threadIdx.x; j < xp->nout; j += kCoopThreads)
+            if (xp->out_idx[j] != 0xffffffffu) xp->store[xp->out_idx[j]] = W[xp->out_slots[j]];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ctl->repaired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1097,6 +1153,8 @@ __device__ __forceinline__ void coop_scatter(const StoreXchg *xp, const uint4 *W
     if (x.nout == 0) return;
     coop_arrive(ctl);
     coop_wait(ctl, gen);
+    // a pass that lost a workgroup leaves the wire store alone: k_coop_repair does the pass again behind it, from the same inputs
+    if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     for (uint32_t j = rank * kCoopThreads + threadIdx.x; j < x.nout; j += kCoopGroups * kCoopThreads) {
         const uint32_t idx = x.out_idx[j];
         if (idx != 0xffffffffu) x.store[idx] = load_label<true>(W + x.out_slots[j]);
@@ -1109,10 +1167,15 @@ __global__ __launch_bounds__(kCoopThreads) void k_garble_coop(const GateDesc *__
                                                               const uint4 *__restrict__ Rv, uint4 *__restrict__ T,
                                                               const uint32_t *__restrict__ rk,
                                                               const uint32_t *__restrict__ g_te0, CoopCtl *ctl,
-                                                              const StoreXchg *xp) {
+                                                              const StoreXchg *xp, uint32_t seq) {
     if (blockIdx.x & 7) return;
     const uint32_t rank = blockIdx.x >> 3;
     __shared__ uint32_t te[kTeDualBytes / 4];
+    if (rank == kCoopGroups) {
+        coop_standby<NR, false>(ctl, seq, descs, steps, nsteps, ninputs, W, Rv, T, rk, g_te0, xp, te);
+        return;
+    }
+    if (coop_dropped(ctl, rank)) return;
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, rk);
@@ -1161,10 +1224,15 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
                                                             uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W,
                                                             const uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
                                                             const uint32_t *__restrict__ g_te0, CoopCtl *ctl,
-                                                            const StoreXchg *xp) {
+                                                            const StoreXchg *xp, uint32_t seq) {
     if (blockIdx.x & 7) return;
     const uint32_t rank = blockIdx.x >> 3;
     __shared__ uint32_t te[kTeDualBytes / 4];
+    if (rank == kCoopGroups) {
+        coop_standby<NR, true>(ctl, seq, descs, steps, nsteps, ninputs, W, nullptr, const_cast<uint4 *>(T), rk, g_te0, xp, te);
+        return;
+    }
+    if (coop_dropped(ctl, rank)) return;
     load_te_dual(te, g_te0);
     uint32_t rkr[4 * (NR + 1)];
     load_round_keys<NR>(rkr, rk);
@@ -1209,6 +1277,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_eval_coop(const GateDesc *__re
 __global__ __launch_bounds__(kCoopThreads) void k_coop_selftest(CoopCtl *ctl) {
     if (blockIdx.x & 7) return;
     const uint32_t rank = blockIdx.x >> 3;
+    if (coop_dropped(ctl, rank)) return;
     uint32_t *scratch = ctl->scratch;  // written with plain stores and read past the L1, as the labels are
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID
     if (threadIdx.x == 0) scratch[32 + rank] = xcc;
@@ -1234,17 +1303,17 @@ void launch_coop_selftest(CoopCtl *ctl, hipStream_t s) {
     hipLaunchKernelGGL(k_coop_selftest, dim3(8 * kCoopGroups), dim3(kCoopThreads), 0, s, ctl);
 }
 
-void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, hipStream_t s) {
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, uint32_t seq, hipStream_t s) {
     if (a.nsteps == 0) return;
-    // ctl->count is zero here: the self-test's host code and every pass leave it so (coop_leave); error stays up once raised
-    const dim3 grid(8 * kCoopGroups), block(kCoopThreads);
+    // ctl->count is zero here: the self-test's host code and every pass leave it so (coop_leave)
+    const dim3 grid(8 * (kCoopGroups + 1)), block(kCoopThreads);  // + the stand-by, on the same XCD
 #define GC_CO(NR)                                                                                                          \
     if (eval)                                                                                                              \
         hipLaunchKernelGGL((k_eval_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W,               \
-                           (const uint4 *)a.T, a.rk, a.te0, ctl, x);                                                      \
+                           (const uint4 *)a.T, a.rk, a.te0, ctl, x, seq);                                                 \
     else                                                                                                                   \
         hipLaunchKernelGGL((k_garble_coop<NR>), grid, block, 0, s, a.descs, a.steps, a.nsteps, a.ninputs, a.W, a.R, a.T,   \
-                           a.rk, a.te0, ctl, x)
+                           a.rk, a.te0, ctl, x, seq)
     switch (a.rounds) {
     case 10: GC_CO(10); break;
     case 12: GC_CO(12); break;

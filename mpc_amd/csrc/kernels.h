@@ -91,9 +91,12 @@ struct CoopCtl {
     uint32_t bad;          // self-test: values that did not arrive, workgroups on another XCD
     uint32_t ticks;        // self-test: s_memtime ticks of its 128 barriers
     uint32_t left;         // workgroups that finished the pass (the last one zeroes count and left)
-    uint32_t pad;
+    uint32_t repaired;     // passes that lost a workgroup and were done again by k_coop_repair (gc_kernels.hip)
     uint32_t *host_err;    // a word of pinned host memory (device-visible) that a workgroup giving up raises as well: the
                            // host reads it without a copy per pass
+    uint32_t passes;       // passes launched so far (counted by the last workgroup to leave)
+    uint32_t drop_at;      // testing (GC_COOP_FORCE_TIMEOUT = n): in the n-th pass one workgroup takes no part: the others'
+                           // bounded wait runs out, exactly as if it had not become resident in time
     uint32_t scratch[64];  // self-test
 };
 constexpr uint32_t kCoopGroups = 32;
@@ -109,7 +112,13 @@ struct StoreXchg {
 };
 // x: device address of the pass's StoreXchg, or nullptr (kernel arguments stay in SGPRs for the whole pass and the round
 // keys already fill them: the exchange by value cost 17 more spilled SGPRs and 30 us of a 200 us pass)
-void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, hipStream_t s);
+// seq: cooperative passes launched on this ctl before this one (= ctl->passes when the pass starts).  The launch carries a
+// STAND-BY workgroup on the same XCD: it sleeps until the pass has ended (ctl->passes > seq) and returns — unless the pass
+// raised ctl->error (a workgroup's bounded wait ran out): then it does the whole pass again by itself, level by level behind a
+// barrier of its own (slow, correct: the per-gate code of the level launches, level_gate.h), including the exchange with the
+// wire store that the failed pass skipped, and clears the flag.  The kernel ends when the stand-by does, so a lost workgroup
+// costs time, never a result: what follows on the stream sees the labels and table rows of a good pass.
+void launch_coop(bool eval, const FusedArgs &a, CoopCtl *ctl, const StoreXchg *x, uint32_t seq, hipStream_t s);
 void launch_coop_selftest(CoopCtl *ctl, hipStream_t s);
 
 // Fused schedule with LDS-resident wires (fused_lds_kernels.hip)

@@ -1431,6 +1431,7 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streami
     gc_label l0;
     rc = s->store.get(s->ctx, w, &l0);
     if (rc != GC_OK) return rc;
+    (void)gc_ctx_coop_check(s->ctx);  // (the stream was waited for: a cooperative pass that lost a workgroup is noted here)
     out->l0 = l0;
     out->l1 = gc_label{l0.d0 ^ s->r.d0, l0.d1 ^ s->r.d1};
     return GC_OK;
@@ -2276,7 +2277,9 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
     int rc = eval_close_group(e);  // a queued block may be the one that writes the wire
     if (rc != GC_OK) return rc;
     if (e->deep.n_inflight) e->deep.drain();  // ... or a deep block on its lane
-    return e->store.get(e->ctx, w, l);
+    rc = e->store.get(e->ctx, w, l);
+    (void)gc_ctx_coop_check(e->ctx);  // (the stream was waited for: a cooperative pass that lost a workgroup is noted here)
+    return rc;
 } catch (...) {
     return gc::on_exception();
 }

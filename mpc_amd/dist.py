@@ -6,8 +6,9 @@ C ABI — what a Go host binds).  The ranks of bench.py import no torch at all: 
 the process launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment), the 128-byte ncclUniqueId travels from rank 0
 to the other ranks of the node through a file (exchange_unique_id_file — the job a Go host does over its own
 p2p.Conn), barrier and max-over-ranks timing are gc_comm_* calls.  In the CPU tests a gloo group stands in as the
-gather transport (GlooGather) so that the sharding / padding / reassembly logic and the bench's step loop (StepLoop,
-run_timed) are exercised with world_size 2 and 3 without a GPU."""
+gather transport (tests/gloo_transport.py: GlooGather) so that the sharding / padding / reassembly logic, the bench's step
+loop (StepLoop, run_timed) and bench.py's own rank entry (on tests/stub_engine.py) are exercised with world_size 2 and 3
+without a GPU."""
 import os
 import time
 
@@ -63,31 +64,59 @@ def exchange_unique_id(make_id, rank, world):
     return box[0]
 
 
+def _rendezvous_path(directory=None):
+    """The file of this launch: in GC_RENDEZVOUS_DIR (a directory the launcher made for the job) if set, else in a
+    directory of this user's own under TMPDIR (created 0700, refused if somebody else owns it); the name carries the
+    launcher's pid — the common parent of the ranks —, MASTER_PORT and the launcher's run id, so neither concurrent nor
+    earlier launches collide."""
+    directory = directory or os.environ.get("GC_RENDEZVOUS_DIR")
+    if not directory:
+        directory = os.path.join(os.environ.get("TMPDIR") or "/tmp", "gc_comm.%d" % os.getuid())
+        try:
+            os.mkdir(directory, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(directory)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError("rendezvous directory %s is not a private directory of this user" % directory)
+    nonce = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:32]
+    return os.path.join(directory, "gc_comm_id.%d.%s.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), nonce or "x"))
+
+
 def exchange_unique_id_file(make_id, rank, world, timeout=180.0, directory=None):
-    """The same hand-over without any torch: the ranks of ONE node share a file.  Rank 0 draws the id and publishes it
-    atomically (write + rename); the others poll for it.  The name carries the launcher's pid (the common parent of
-    all ranks of this launch) and MASTER_PORT, so neither concurrent nor earlier launches collide; rank 0 removes
-    leftovers of a crashed launch with a recycled pid before it publishes, the readers remove nothing."""
+    """The same hand-over without any torch: the ranks of ONE node share a file.  Rank 0 removes whatever an earlier launch
+    left under the name, draws the id and publishes it atomically (exclusive create of a temporary, no symlink followed,
+    then rename); the others poll for a regular file of this user that is not older than their own start, for at most
+    `timeout` seconds (TimeoutError).  The readers remove nothing."""
     if world == 1:
         return make_id()
-    directory = directory or os.environ.get("GC_RENDEZVOUS_DIR") or os.environ.get("TMPDIR") or "/tmp"
-    name = os.path.join(directory, "gc_comm_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    name = _rendezvous_path(directory)
     if rank == 0:
+        for stale in (name, name + ".tmp"):
+            try:
+                os.unlink(stale)
+            except OSError:
+                pass
         uid = make_id()
-        tmp = "%s.tmp.%d" % (name, os.getpid())
-        with open(tmp, "wb") as f:
+        fd = os.open(name + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
-        os.replace(tmp, name)
+        os.replace(name + ".tmp", name)
         return uid
     t0 = time.monotonic()
     start = time.time()
     while True:
         try:
-            st = os.stat(name)
-            # a file older than this process is a leftover of an earlier launch whose pid was recycled: wait for rank 0
-            if st.st_mtime >= start - 600 and st.st_size > 0:
-                with open(name, "rb") as f:
-                    return f.read()
+            fd = os.open(name, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+            try:
+                st = os.fstat(fd)
+                import stat as _stat
+                # rank 0 starts with this process (same launcher): a file much older than this rank is a leftover
+                if _stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_size > 0 and st.st_mtime >= start - 120:
+                    return os.read(fd, 4096)
+            finally:
+                os.close(fd)
         except OSError:
             pass
         if time.monotonic() - t0 > timeout:
@@ -99,19 +128,57 @@ def cleanup_unique_id_file(rank, directory=None):
     """rank 0, after the communicator exists on every rank (i.e. after a barrier)"""
     if rank != 0:
         return
-    directory = directory or os.environ.get("GC_RENDEZVOUS_DIR") or os.environ.get("TMPDIR") or "/tmp"
     try:
-        os.unlink(os.path.join(directory, "gc_comm_id.%d.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))))
+        os.unlink(_rendezvous_path(directory))
     except OSError:
         pass
 
 
-def open_comm(ctx, rank, world):
-    """the RCCL communicator of this rank's gc_ctx (gc_comm_init_rank); no torch involved"""
-    from . import engine
+class Watchdog:
+    """Bounds a stage of a multi-rank run from OUTSIDE the main thread: ncclCommInitRank and the collectives are C calls that
+    never return when a peer is missing, so a timer thread ends the process instead — on_timeout(message) first (rank 0
+    prints its one JSON error line there), then os._exit(3).  arm() re-arms for the next stage, disarm() when done."""
+
+    def __init__(self, on_timeout):
+        import threading
+        self._on_timeout = on_timeout
+        self._lock = threading.Lock()
+        self._deadline, self._what = None, ""
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def arm(self, seconds, what):
+        with self._lock:
+            self._deadline, self._what = time.monotonic() + float(seconds), what
+
+    def disarm(self):
+        with self._lock:
+            self._deadline = None
+
+    def _run(self):
+        import sys
+        while True:
+            time.sleep(0.05)
+            with self._lock:
+                late = self._deadline is not None and time.monotonic() > self._deadline
+                what = self._what
+            if late:
+                try:
+                    sys.stderr.write("bench watchdog: %s\n" % what)
+                    self._on_timeout(what)
+                    sys.stdout.flush()
+                finally:
+                    os._exit(3)
+
+
+def open_comm(ctx, rank, world, timeout=180.0, engine=None):
+    """the RCCL communicator of this rank's gc_ctx (gc_comm_init_rank); no torch involved.  The id hand-over waits at most
+    `timeout` seconds; ncclCommInitRank itself is bounded by the caller's Watchdog."""
+    if engine is None:
+        from . import engine
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
-    uid = exchange_unique_id_file(engine.comm_unique_id, rank, world)
+    uid = exchange_unique_id_file(engine.comm_unique_id, rank, world, timeout=timeout)
     comm = engine.Comm(ctx, uid, world, rank)
     if world > 1:
         comm.barrier()
@@ -173,40 +240,6 @@ def run_timed(loop, fence, steps, warmup, allreduce_max=None, clock=time.perf_co
     if allreduce_max is not None:
         elapsed = allreduce_max(elapsed)
     return elapsed
-
-
-class GlooGather:
-    """stand-in transport of the CPU tests: same call shape as engine.Comm for host arrays"""
-
-    def __init__(self, rank, world):
-        self.rank, self.nranks = rank, world
-
-    def allgather_host(self, local):
-        import torch
-        import torch.distributed as dist
-
-        t = torch.from_numpy(np.ascontiguousarray(local))
-        if self.nranks == 1:
-            return t.unsqueeze(0).numpy()
-        out = torch.empty((self.nranks,) + tuple(t.shape), dtype=t.dtype)
-        dist.all_gather_into_tensor(out.view(self.nranks * t.shape[0], *t.shape[1:]), t)
-        return out.numpy()
-
-    def allreduce_max(self, value):
-        import torch
-        import torch.distributed as dist
-
-        if self.nranks == 1:
-            return float(value)
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def barrier(self):
-        import torch.distributed as dist
-
-        if self.nranks > 1:
-            dist.barrier()
 
 
 def gather_sharded(transport, local_rows, total, world):

@@ -93,6 +93,7 @@ def lib():
         "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+        "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
         "gc_stream_eval_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
@@ -296,6 +297,13 @@ class Context:
         if not self.h:
             raise EngineError(st.value, "gc_ctx_create(%d)" % device)
         self.device = device
+
+    def coop_stats(self):
+        """(state of the cooperative one-instance passes: 0 unused / 1 in use / -1 off, passes that lost a workgroup and were
+        done again on the device)"""
+        a, b = C.c_int(0), C.c_uint64(0)
+        _check(lib().gc_ctx_coop_stats(self.h, C.byref(a), C.byref(b)), "gc_ctx_coop_stats")
+        return a.value, b.value
 
     def sync(self):
         _check(lib().gc_ctx_sync(self.h), "gc_ctx_sync")
@@ -762,6 +770,11 @@ COMM_ID_BYTES = 128
 
 def comm_available():
     return bool(lib().gc_comm_available())
+
+
+def comm_version():
+    """ncclGetVersion of the RCCL the library opened (0: no RCCL)"""
+    return int(lib().gc_comm_version())
 
 
 def comm_unique_id():

@@ -354,6 +354,15 @@ PROGRAMS = {
 }
 
 
+# what a program looks like (the driver line says which rows are friendly synthetic shapes and which are
+# instruction mixes) and how far ahead its driver queues (steps begun and not finished; the Ed25519 program needs the hundred
+# products of a field multiplication in flight together)
+SHAPES = {"big": "wide-synthetic", "big130": "wide-synthetic", "uniform512": "uniform-synthetic", "uniform4096": "uniform-synthetic",
+          "uniform512x64": "uniform-synthetic", "mixed": "instruction-mix", "mixed100": "instruction-mix", "ssa23": "instruction-mix",
+          "ed25519like": "instruction-mix (ref10 Ed25519 inner loop)", "ed25519like1": "instruction-mix (ref10 Ed25519 inner loop)"}
+WINDOWS = {"ed25519like": 1024}
+
+
 def stream_rnd(name, nprim):
     return hashlib.shake_256(b"stream-bench/" + name.encode()).digest(16 * (nprim + 1))
 
@@ -486,7 +495,7 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
         res = {"program": name, "steps": len(steps), "gates": gates, "and": ands, "window": window, "interned": intern,
                "garble_s": dt, "garble_gates_per_s": gates / dt, "garble_us_per_step": dt / len(steps) * 1e6,
                "stream_bytes": int(len(stream)), "launch_groups": stats[0], "grouped_steps": stats[1], "big_steps": stats[2],
-               "sha256": sha}
+               "deep_steps": g.deep_stats()[0], "lanes": g.deep_stats()[1], "sha256": sha}
         if rep == 0:
             res["first_pass_s"] = dt
             first = dt
@@ -588,13 +597,17 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                 "eval_steady_gates_per_s": b.get("eval_steady_gates_per_s", b["eval_gates_per_s"]),
                 "eval_first_blocks_s": b.get("eval_first_blocks_s"), "eval_blocks_parsed": b["eval_blocks_parsed"],
                 "first_pass_s": b["first_pass_s"], "sha256": b["sha256"], "sha256_ok": b["sha256_ok"]})
-    for name in ("uniform512", "uniform4096", "mixed", "ssa23"):
-        r = run_program(name, key, ctx)
-        out[name] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
-                                       "eval_us_per_step", "launch_groups", "grouped_steps", "big_steps", "sha256", "sha256_ok")}
+    out["shape"] = SHAPES["big130"]
+    for name in ("ed25519like", "ssa23", "mixed", "uniform512", "uniform4096"):
+        r = run_program(name, key, ctx, window=WINDOWS.get(name, 64))
+        out[name] = {k: r[k] for k in ("steps", "gates", "and", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
+                                       "eval_us_per_step", "eval_steady_gates_per_s", "launch_groups", "grouped_steps", "big_steps",
+                                       "deep_steps", "lanes", "sha256", "sha256_ok") if k in r}
+        out[name]["shape"] = SHAPES[name]
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
-    for name, win in (("big130", 2), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64), ("ssa23", 64)):
+    for name, win in (("big130", 2), ("ed25519like", WINDOWS["ed25519like"]), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64),
+                      ("ssa23", 64)):
         try:
             r = run_native(name, key, win)
         except Exception as e:  # a side measurement: reported, never fatal for the bench line

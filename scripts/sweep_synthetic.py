@@ -23,7 +23,9 @@ BLOCKS = {"and": (4, 2), "inv": (2, 1), "or": (4, 1)}
 HBM_PEAK, LDS_LOOKUPS = 8000e9, 75e12 / 4
 
 
-def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4096, cases=None):
+def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4096, cases=None, circuits=()):
+    """circuits: further circuits measured the same way (bench.py: aes_128 under the 16-byte key of
+    circuit/garble_bench_test.go:35)"""
     own = ctx is None
     if own:
         ctx = engine.Context(0)
@@ -34,6 +36,7 @@ def run(batch=1024, gates_target=131072, key=bytes(range(32)), ctx=None, chain=4
     circs = [synthetic_levelised(max(2, gates_target // w), w, f, seed=100 + grid.index((w, f)), ninputs=256) for w, f in cases]
     if chain:
         circs.append(and_chain(chain))
+    circs += list(circuits)
     rows = []
     for c in circs:
         dc = engine.DeviceCircuit(ctx, c)

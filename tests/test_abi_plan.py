@@ -264,3 +264,83 @@ def test_go_shim_names_only_declared_entry_points_and_covers_the_table():
             "gc_batch_garble", "gc_batch_select_inputs", "gc_batch_eval", "gc_batch_decode", "gc_batch_read_slab",
             "gc_batch_read_r", "gc_batch_read_outputs", "gc_ctx_capture_begin", "gc_ctx_capture_end", "gc_graph_launch"}
     assert must <= used, sorted(must - used)
+
+
+def _prototypes():
+    """name -> list of 'ptr' / 'scalar' per parameter, from include/gcengine.h"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "gcengine.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"\b(gc_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        name, params = m.group(1), m.group(2).strip()
+        if params in ("", "void"):
+            protos[name] = []
+            continue
+        kinds = []
+        for p in params.split(","):
+            kinds.append("ptr" if ("*" in p or "[" in p) else "scalar")
+        protos[name] = kinds
+    return protos
+
+
+def _go_calls(text):
+    """(name, [argument expressions]) for every C.gc_*(...) call, parentheses balanced, strings and comments skipped"""
+    import re
+    text = re.sub(r"//[^\n]*", "", text)
+    out = []
+    for m in re.finditer(r"\bC\.(gc_[a-z0-9_]+)\(", text):
+        i, depth, args, cur = m.end(), 1, [], ""
+        while depth:
+            ch = text[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur.strip())
+        out.append((m.group(1), args))
+    return out
+
+
+def test_go_shim_calls_match_the_prototypes():
+    """the shim has never met a compiler (no Go toolchain in the image): every C.gc_*(...) call in go/ is checked against the
+    prototype in include/gcengine.h — the NUMBER of arguments, and for every argument whose kind can be read off the Go
+    expression (a C.uint32_t(...) / C.size_t(...) / C.int(...) conversion or a literal is a scalar; &x, (*C.T)(...),
+    unsafe.Pointer(...), nil are pointers) that it meets a parameter of that kind.  Signatures the shim keeps:
+    circuit/garble.go:248, eval.go:17, stream_garble.go:41,161, ot/iknp.go:129,364."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    protos = _prototypes()
+    assert len(protos) > 100 and protos["gc_garble"].count("ptr") >= 6
+    scalar = re.compile(r"^(C\.(u?int(8|16|32|64)?_t|size_t|int|uint|double|float|long|ulong)\(|[0-9]|C\.GC_)")
+    pointer = re.compile(r"^(&|\(\*C\.|\(\*\*C\.|unsafe\.Pointer\(|nil$|\(C\.uintptr_t\)|\(unsafe\.Pointer\))")
+    bad, ncalls = [], 0
+    for path in sorted(glob.glob(os.path.join(root, "go", "*", "*.go"))):
+        for name, args in _go_calls(open(path).read()):
+            ncalls += 1
+            want = protos.get(name)
+            where = "%s: C.%s" % (os.path.relpath(path, root), name)
+            if want is None:
+                bad.append(where + " is not declared")
+                continue
+            if len(args) != len(want):
+                bad.append("%s takes %d arguments, the call passes %d: %s" % (where, len(want), len(args), args))
+                continue
+            for k, (a, w) in enumerate(zip(args, want)):
+                if scalar.match(a) and w != "scalar":
+                    bad.append("%s argument %d: scalar expression %r for a pointer parameter" % (where, k + 1, a))
+                if pointer.match(a) and w != "ptr":
+                    bad.append("%s argument %d: pointer expression %r for a scalar parameter" % (where, k + 1, a))
+    assert ncalls > 100 and not bad, "\n".join(bad)

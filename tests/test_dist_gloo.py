@@ -20,6 +20,7 @@ sys.path.insert(0, %r)
 import numpy as np, torch
 from mpc_amd import dist as gdist, engine, parse_file
 from tests.util import drbg
+from tests.gloo_transport import GlooGather
 rank, local_rank, world = gdist.init_control()
 c = parse_file(os.path.join(%r, "tests", "golden", "add64.gcf"))
 plan = engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs)
@@ -29,7 +30,7 @@ out = np.zeros((hi - lo, c.num_outputs), np.uint8)
 for k, i in enumerate(range(lo, hi)):
     bits = np.frombuffer(drbg("dist%%d" %% i, c.num_inputs), np.uint8) & 1
     out[k] = plan.simulate(bits)
-tr = gdist.GlooGather(rank, world)
+tr = GlooGather(rank, world)
 uid = gdist.exchange_unique_id(lambda: b"id-from-rank-%%d" %% rank, rank, world)
 assert uid == b"id-from-rank-0"
 allout = gdist.gather_sharded(tr, out, total, world)
@@ -53,12 +54,13 @@ import os, sys, json, time
 sys.path.insert(0, %r)
 import numpy as np
 from mpc_amd import dist as gdist
+from tests.gloo_transport import GlooGather
 rank, local_rank, world = gdist.init_control()   # gloo: only the stand-in transport needs it
 steps, warmup, K = int(sys.argv[2]), int(sys.argv[3]), 8
 uid = gdist.exchange_unique_id_file(lambda: b"file-id-from-rank-%%d" %% rank + bytes(100), rank, world,
                                     directory=os.path.dirname(sys.argv[1]))
 assert uid.startswith(b"file-id-from-rank-0")
-tr = gdist.GlooGather(rank, world)
+tr = GlooGather(rank, world)
 acc = np.zeros((K, 4), np.int64)
 seen = {}          # (rank, step) -> times gathered, as observed by THIS rank
 counter = [0]

@@ -1030,3 +1030,54 @@ def test_stream_ed25519like_matches_oracle():
             assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
     ctx.sync()
     gg.close(); ge.close(); ctx.close()
+
+
+@pytest.mark.parametrize("drop_at", ["1", "3", "4"])
+def test_stream_cooperative_pass_that_loses_a_workgroup_is_repeated(drop_at, monkeypatch):
+    """GC_COOP_FORCE_TIMEOUT=n: in the n-th cooperative pass of the context one workgroup takes no part, the others' bounded
+    wait runs out — as when a workgroup does not become resident in time.  The pass is done again on the device before
+    anything that follows it: no call fails, every byte and every evaluated label is the oracle's ((*Streaming).Garble never
+    fails spuriously, circuit/stream_garble.go:161-192), the context counts the timeout and keeps to level launches from
+    then on.  Passes 1 / 3 belong to the garbler (its 1st and 3rd big step), pass 4 to the evaluator's first block."""
+    from scripts.bench_stream import make_steps
+    monkeypatch.setenv("GC_COOP_FORCE_TIMEOUT", drop_at)
+    nin = 256
+    steps = make_steps(3, 24, 2048, 0.3, nin)
+    prim = list(range(nin))
+    for k in range(1, len(steps)):
+        prim += [k * nin + i for i in range(steps[k - 1][0].num_outputs, nin)]
+    key = drbg("coopdrop", 32)
+    rnd = drbg("coopdrop-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    ctx = engine.Context(0)
+    gg, ge, oe = engine.Stream(ctx, key, rnd, prim), engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    for w in prim:
+        ge.set(w, og.get(w)["l0"])
+        oe.set(w, og.get(w)["l0"])
+    # all three steps queued before the first bytes are asked for: the steps behind the failed pass are on the stream already
+    for c, in_, out_ in steps:
+        gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+    got = [gg.garble_finish() for _ in steps]
+    state, timeouts = ctx.coop_stats()
+    if state == 0 or (state < 0 and timeouts == 0):
+        pytest.skip("cooperative passes are not in use on this box (self-test / GC_NO_COOP)")
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "step %d" % k
+    for c, in_, out_ in steps:
+        for o in out_[::5]:
+            assert gg.get(o) == og.get(o)
+    for (c, in_, out_), data in zip(steps, want):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    for c, in_, out_ in steps:
+        for o in out_[::5]:
+            assert ge.get(o) == oe.get(o)
+    ctx.sync()
+    state, timeouts = ctx.coop_stats()
+    assert timeouts == 1 and state == -1, (state, timeouts)
+    # ... and the context is as good as new: another stream on it (level launches now) matches the oracle
+    g2 = engine.Stream(ctx, key, rnd, prim)
+    assert [g2.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps] == want
+    g2.close(); gg.close(); ge.close(); ctx.close()
