@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _launch(world, extra, env_extra, tmp_path, timeout=240):
-    port = 32500 + (os.getpid() * 11 + len(extra) * 17 + int(time.time())) % 2000
+    import socket
+    with socket.socket() as sk:  # a port nobody holds right now (the launcher's rendezvous)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, PYTHONPATH=ROOT, GC_BENCH_ENGINE="tests.stub_engine", GC_RENDEZVOUS_DIR=str(tmp_path), **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "19",
