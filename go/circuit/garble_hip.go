@@ -68,6 +68,28 @@ func (c *Circuit) hip() (*hipCircuit, error) {
 	return h, h.err
 }
 
+// ReleaseDevice frees the device twin of the circuit (plan, uploaded gate lists, pooled batches) and its context
+// (additive).  The reference's Circuit is plain garbage-collected memory; the device copy is not, and the table above keeps
+// it alive for as long as the process runs — a server that compiles circuits per request calls this when it drops one.
+// Safe to call more than once and for a circuit that never reached the device; a later Garble / Eval loads it again.  Not
+// to be called while another goroutine garbles or evaluates the same circuit.
+func (c *Circuit) ReleaseDevice() {
+	v, ok := hipCircuits.LoadAndDelete(c)
+	if !ok {
+		return
+	}
+	h := v.(*hipCircuit)
+	h.once.Do(func() {}) // (a concurrent first use has finished, or never starts on this record)
+	if h.circ != nil {
+		C.gc_circ_free(h.circ)
+		h.circ = nil
+	}
+	if h.ctx != nil {
+		C.gc_ctx_destroy(h.ctx)
+		h.ctx = nil
+	}
+}
+
 func statusError(st C.int) error {
 	switch st {
 	case C.GC_E_KEYSIZE:

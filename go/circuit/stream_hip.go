@@ -30,8 +30,15 @@ type Streaming struct {
 	ctx     *C.gc_ctx
 	h       *C.gc_stream
 	buf     []byte              // serialised gates of one circuit
-	handles map[*Circuit]uint32 // gc_stream_intern: a compiled circuit is recognised by content once, not per call
+	handles map[*Circuit]streamHandle // gc_stream_intern: a compiled circuit is recognised by content once, not per call
 	pending []int               // gate counts of the circuits queued by Begin and not yet written out by Finish
+}
+
+// streamHandle names an interned circuit together with the in / out lengths it was interned with (gc_stream_garble_begin_h
+// reads exactly that many wire ids from the caller's slices).
+type streamHandle struct {
+	id        uint32
+	nin, nout int
 }
 
 // NewStreaming creates a new streaming garbled circuit garbler (stream_garble.go:41-75).  The random stream is
@@ -114,7 +121,26 @@ func (stream *Streaming) Begin(c *Circuit, in, out []Wire) error {
 		stream.pending = append(stream.pending, 0)
 		return nil
 	}
+	var inPtr, outPtr *C.uint32_t
+	if len(in) > 0 {
+		inPtr = (*C.uint32_t)(unsafe.Pointer(&in[0]))
+	}
+	if len(out) > 0 {
+		outPtr = (*C.uint32_t)(unsafe.Pointer(&out[0]))
+	}
 	h, ok := stream.handles[c]
+	if ok && (h.nin != len(in) || h.nout != len(out)) {
+		// The handle was interned with the in / out lengths of the circuit's FIRST call and gc_stream_garble_begin_h reads
+		// that many ids: a call with other lengths goes by content (the engine then sees another input / output split of the
+		// same gate list — as the reference would, which takes the lengths from the slices every time).
+		st := C.gc_stream_garble_begin(stream.h, (*C.gc_gate)(unsafe.Pointer(&c.Gates[0])), C.uint32_t(len(c.Gates)),
+			C.uint32_t(c.NumWires), inPtr, C.uint32_t(len(in)), outPtr, C.uint32_t(len(out)))
+		if st != C.GC_OK {
+			return statusError(st)
+		}
+		stream.pending = append(stream.pending, len(c.Gates))
+		return nil
+	}
 	if !ok {
 		var ch C.uint32_t
 		st := C.gc_stream_intern(stream.h, (*C.gc_gate)(unsafe.Pointer(&c.Gates[0])), C.uint32_t(len(c.Gates)),
@@ -126,19 +152,12 @@ func (stream *Streaming) Begin(c *Circuit, in, out []Wire) error {
 			return statusError(st)
 		}
 		if stream.handles == nil {
-			stream.handles = make(map[*Circuit]uint32)
+			stream.handles = make(map[*Circuit]streamHandle)
 		}
-		h = uint32(ch)
+		h = streamHandle{id: uint32(ch), nin: len(in), nout: len(out)}
 		stream.handles[c] = h
 	}
-	var inPtr, outPtr *C.uint32_t
-	if len(in) > 0 {
-		inPtr = (*C.uint32_t)(unsafe.Pointer(&in[0]))
-	}
-	if len(out) > 0 {
-		outPtr = (*C.uint32_t)(unsafe.Pointer(&out[0]))
-	}
-	if st := C.gc_stream_garble_begin_h(stream.h, C.uint32_t(h), inPtr, outPtr); st != C.GC_OK {
+	if st := C.gc_stream_garble_begin_h(stream.h, C.uint32_t(h.id), inPtr, outPtr); st != C.GC_OK {
 		return statusError(st)
 	}
 	stream.pending = append(stream.pending, len(c.Gates))

@@ -278,7 +278,9 @@ struct Slot {
     hipError_t reserve_up(size_t more) {
         const size_t need_cap = up_used + more;
         if (need_cap <= h_up_cap) return hipSuccess;
-        size_t ncap = std::max<size_t>((size_t)1 << 20, h_up_cap * 2);
+        // (64 KiB to start with: a driver that queues a long chain of dependent small steps gets one slot per step — up to
+        // kMaxPending of them —, and a MiB of pinned memory each was gigabytes)
+        size_t ncap = std::max<size_t>((size_t)64 << 10, h_up_cap * 2);
         while (ncap < need_cap) ncap *= 2;
         void *n = nullptr;
         hipError_t e = gc::ctx_buf_get(ctx, true, ncap, &n, &ncap);
@@ -1536,6 +1538,14 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     // ---- a small step joins the earliest open group it has no dependency on (or behind); a deep one takes a lane ---------
     const bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps, known == nullptr) && s->deep.setup(ctx);
     if (is_deep || (ngates && entry_is_small(ent))) {
+        // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
+        // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it) —
+        // and before the step is put anywhere: a failure here leaves nothing half-queued
+        if (!s->store.dirty.empty()) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            int rcs = s->store.flush(ctx);
+            if (rcs != GC_OK) return rcs;
+        }
         s->win.ensure(s->store.host.size());
         if (is_deep || s->deep.n_inflight) s->deep.ensure(s->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
@@ -1616,16 +1626,6 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             s->win.mark(gi, in, nin, s->skip_scratch.data(), nout);
             // a deep step in flight that this one must follow: the group waits for it (and for the older ones of its lane)
             if (s->deep.n_inflight) g.deps.merge(s->deep.conflicts(in, nin, s->skip_scratch.data(), nout));
-        }
-        // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
-        // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it)
-        if (!s->store.dirty.empty()) {
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            int rcs = s->store.flush(ctx);
-            if (rcs != GC_OK) {
-                if (is_deep) g.reset();
-                return rcs;
-            }
         }
         if (is_deep) {  // launched at once, on its lane
             int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
@@ -2607,6 +2607,11 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
     const bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
     if (is_deep || (small_block && entry_is_small(ent))) {
+        if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned (and before
+            std::lock_guard<std::mutex> lk(ctx->mu);  // the block is put anywhere: a failure leaves nothing half-queued)
+            int rcs = e->store.flush(ctx);
+            if (rcs != GC_OK) return rcs;
+        }
         e->win.ensure(e->store.host.size());
         if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
@@ -2709,14 +2714,6 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (!is_deep) {
             e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout);
             if (e->deep.n_inflight) g.deps.merge(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
-        }
-        if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            int rcs = e->store.flush(ctx);
-            if (rcs != GC_OK) {
-                if (is_deep) g.reset();
-                return rcs;
-            }
         }
         if (is_deep) {  // launched at once, on its lane
             int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);

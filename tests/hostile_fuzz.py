@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Hostile bytes for the streaming evaluator: gc_stream_eval_circuit parses the PEER's data, and its fast
+path decides from untrusted bytes which bytes to skip (the byte-skeleton matcher + helper threads of stream_engine.cpp).
+Mutational fuzz over recorded valid OpCircuit blocks of scripts-style programs:
+
+  bit flips anywhere · truncation · the id-width flag 0x10 flipped · tmp flags 0x80 / 0x40 / 0x20 flipped · ids swapped inside a
+  gate · an id replaced by another id of the block (breaks the repeat pattern of the global ids) or by one out of range ·
+  table-row bytes changed only · the op nibble changed (valid and invalid) · the header's gate count off by a few
+
+Every mutant goes to an evaluator that has SEEN the valid block (so the skeleton path is tried first, the gate-by-gate parser
+when it does not match), with GC_STREAM_THREADS 0 and 3 for the big blocks, and to the oracle's restated StreamEval
+(oracle/stream_oracle.c, circuit/stream_evaluator.go:271-432) started from the same wire store.  Required:
+
+  * no crash, no hang;
+  * ACCEPTED by the engine  =>  the oracle accepts it too, consumes the same number of bytes and ends with the same labels on
+    every wire the block names (and on a sample of the others);
+  * REJECTED by the engine  =>  the oracle rejects it (same class: truncated / unknown operation), or the block is one of the
+    cases where the engine is stricter than the reference's loop by design — a global wire id beyond the block's numWires
+    (the reference indexes its slice with it: a panic there), a tmp id beyond numTmpWires, a tmp wire read before the block
+    wrote it (the reference would hand out a label of an EARLIER circuit), more gates announced than the bytes can hold —
+    and the engine's wire store is exactly what it was before the block; the stream stays usable.
+
+usage: tests/hostile_fuzz.py [mutants [seed]]   (one summary line per 500 mutants; profiles/r04_hostile_fuzz.log)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import numpy as np
+
+import oracle
+from mpc_amd import engine
+from tests.util import drbg
+
+ROWS = {0: 0, 1: 0, 2: 2, 3: 3, 4: 1}  # XOR XNOR AND OR INV
+
+
+def parse(block, ngates):
+    """the reference's reading of a block: [(pos of the op byte, op, flags, short, [ids], [pos of ids], pos of rows, nrows)],
+    or the error class ("rows" / "gate") where it stops"""
+    gates, pos = [], 0
+    for _ in range(ngates):
+        if pos + 1 > len(block):
+            return gates, "rows"
+        gop = block[pos]
+        flags, short, op = gop & 0xe0, bool(gop & 0x10), gop & 0x0f
+        p0 = pos
+        pos += 1
+        if op > 4:
+            return gates, "gate"
+        nw = 2 if op == 4 else 3
+        sz = 2 if short else 4
+        if pos + nw * sz + 16 * ROWS[op] > len(block):
+            return gates, "rows"
+        ids, idpos = [], []
+        for i in range(nw):
+            idpos.append(pos)
+            ids.append(int.from_bytes(block[pos:pos + sz], "big"))
+            pos += sz
+        gates.append((p0, op, flags, short, ids, idpos, pos, ROWS[op]))
+        pos += 16 * ROWS[op]
+    return gates, None
+
+
+def stricter(block, ngates, ntmp, nwires):
+    """is the block one the engine refuses by design although the reference's loop would walk it?"""
+    if ngates > len(block) // 5:
+        return "more gates than bytes"
+    gates, err = parse(block, ngates)
+    written = set()
+    for p0, op, flags, short, ids, idpos, rpos, nrows in gates:
+        ins = [(ids[0], flags & 0x80)] + ([(ids[1], flags & 0x40)] if op != 4 else [])
+        for v, t in ins:
+            if t:
+                if v >= ntmp:
+                    return "tmp id out of range"
+                if v not in written:
+                    return "tmp read before written"
+            elif v >= nwires:
+                return "global id out of range"
+        c = ids[-1]
+        if flags & 0x20:
+            if c >= ntmp:
+                return "tmp id out of range"
+            written.add(c)
+        elif c >= nwires:
+            return "global id out of range"
+    return None
+
+
+def mutate(rng, block, ngates):
+    """one mutant: (bytes, gate count for the header, what was done)"""
+    b = bytearray(block)
+    gates, _ = parse(block, ngates)
+    kind = int(rng.integers(0, 11))
+    g = gates[int(rng.integers(0, len(gates)))]
+    p0, op, flags, short, ids, idpos, rpos, nrows = g
+    sz = 2 if short else 4
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(0, len(b)))
+            b[i] ^= 1 << int(rng.integers(0, 8))
+        return bytes(b), ngates, "bit flips"
+    if kind == 1:
+        return bytes(b[:int(rng.integers(0, len(b)))]), ngates, "truncated"
+    if kind == 2:
+        b[p0] ^= 0x10
+        return bytes(b), ngates, "id width flipped"
+    if kind == 3:
+        b[p0] ^= int(rng.choice([0x80, 0x40, 0x20]))
+        return bytes(b), ngates, "tmp flag flipped"
+    if kind == 4 and len(ids) == 3:
+        i, j = rng.choice(3, 2, replace=False)
+        vi, vj = b[idpos[i]:idpos[i] + sz], b[idpos[j]:idpos[j] + sz]
+        b[idpos[i]:idpos[i] + sz], b[idpos[j]:idpos[j] + sz] = vj, vi
+        return bytes(b), ngates, "ids swapped"
+    if kind == 5:
+        other = gates[int(rng.integers(0, len(gates)))]
+        v = other[4][int(rng.integers(0, len(other[4])))]
+        i = int(rng.integers(0, len(ids)))
+        b[idpos[i]:idpos[i] + sz] = (v & ((1 << (8 * sz)) - 1)).to_bytes(sz, "big")
+        return bytes(b), ngates, "id replaced by another of the block"
+    if kind == 6:
+        i = int(rng.integers(0, len(ids)))
+        v = int(rng.choice([0xffff, 0xfffe, 0x7fff])) if short else int(rng.choice([0xffffffff, 0x80000000, 0x00ffffff, 0x10000]))
+        b[idpos[i]:idpos[i] + sz] = v.to_bytes(sz, "big")
+        return bytes(b), ngates, "id out of range"
+    if kind == 7:
+        rowed = [q for q in gates if q[7]]
+        if rowed:
+            q = rowed[int(rng.integers(0, len(rowed)))]
+            for _ in range(int(rng.integers(1, 5))):
+                b[q[6] + int(rng.integers(0, 16 * q[7]))] ^= int(rng.integers(1, 256))
+            return bytes(b), ngates, "row bytes only"
+    if kind == 8:
+        b[p0] = (b[p0] & 0xf0) | int(rng.integers(0, 16))
+        return bytes(b), ngates, "op nibble changed"
+    if kind == 9:
+        return bytes(b), max(1, ngates + int(rng.integers(-3, 4))), "gate count off"
+    i = int(rng.integers(0, len(b)))
+    b[i] = int(rng.integers(0, 256))
+    return bytes(b), ngates, "byte replaced"
+
+
+def programs(big=False):
+    """valid blocks to mutate: small SSA-step circuits of every gate type (tmp wires, 16- and 32-bit ids, repeated ids) and,
+    with big=True, two blocks of ~49 000 gates whose skeletons are matched in segments by the helper threads"""
+    from mpc_amd.circuit import adder, comparator64, synthetic_levelised
+    shapes = [synthetic_levelised(6, 40, 0.3, seed=51, ninputs=24, inv_frac=0.1, xnor_frac=0.1),
+              synthetic_levelised(3, 60, 0.4, seed=52, ninputs=24, or_frac=0.15, inv_frac=0.05),
+              adder(16), comparator64(), synthetic_levelised(10, 64, 0.25, seed=57, ninputs=64)]
+    if big:
+        shapes = [synthetic_levelised(24, 2048, 0.3, seed=58, ninputs=256, inv_frac=0.05)]
+    out = []
+    for k, c in enumerate(shapes):
+        for base in (0, 0x11000):  # short and long id forms
+            n = c.num_inputs
+            ins = [base + (7 * k + i) % 300 for i in range(n)]
+            if k % 2:
+                ins[1] = ins[0]  # a repeated global id
+            outs = [base + 400 + i for i in range(c.num_outputs)]
+            out.append((c, ins, outs))
+    return out
+
+
+def run(mutants=200, seed=1, big=False, log=None):
+    """returns (mutants run, accepted, rejected, by kind) — raises AssertionError on the first violation"""
+    rng = np.random.default_rng(seed)
+    key = drbg("hostile-key", 32)
+    ctx = engine.Context(0)
+    steps = programs(big)
+    prim = sorted({w for _, i, _ in steps for w in i})
+    rnd = drbg("hostile-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    blocks = []
+    for c, in_, out_ in steps:
+        data = og.garble(c.Gates, c.NumWires, in_, out_)
+        ntmp = c.NumWires
+        nw = max(max(in_), max(out_)) + 1
+        blocks.append((data, c.NumGates, ntmp, nw, sorted(set(in_) | set(out_))))
+    ge = engine.StreamEval(ctx, key)
+    model = {}  # wire -> label: what both stores hold
+    for w in prim:
+        model[w] = (int(og.get(w)["l0"]["d0"]), int(og.get(w)["l0"]["d1"]))
+        ge.set(w, model[w])
+
+    def oracle_on(block, ngates, ntmp, nw, wires):
+        oe = oracle.StreamEval(key)
+        for w, l in model.items():
+            oe.set(w, l)
+        try:
+            used = oe.circuit(ngates, ntmp, nw, block)
+        except oracle.OracleError as e:
+            return e.code, None, None
+        after = {}
+        for w in wires:
+            try:
+                after[w] = oe.get(w)
+            except oracle.OracleError:
+                after[w] = (0, 0)
+        return 0, used, after
+
+    # the evaluator sees every valid block first: its skeleton is recorded, the mutants meet the fast path
+    for data, ng, ntmp, nw, wires in blocks:
+        rc, used, after = oracle_on(data, ng, ntmp, nw, wires)
+        assert rc == 0 and ge.circuit(ng, ntmp, nw, data) == used == len(data)
+        model.update(after)
+    stats = {"accepted": 0, "rejected": 0, "rejected_stricter": 0}
+    kinds = {}
+    for m in range(mutants):
+        data, ng, ntmp, nw, wires = blocks[int(rng.integers(0, len(blocks)))]
+        mut, mng, what = mutate(rng, data, ng)
+        named = set(wires)
+        for q in parse(mut, mng)[0]:
+            named |= {v for v in q[4] if v < nw + 64}
+        named = sorted(w for w in named if w < (1 << 22))
+        orc, oused, oafter = oracle_on(mut, mng, ntmp, nw, named)
+        try:
+            used = ge.circuit(mng, ntmp, nw, mut)
+            erc = 0
+        except engine.EngineError as e:
+            erc, used = e.code, None
+        kinds[what] = kinds.get(what, 0) + 1
+        if erc == 0:
+            stats["accepted"] += 1
+            assert orc == 0, "mutant %d (%s): the engine accepted what the oracle rejects (%d)" % (m, what, orc)
+            assert used == oused, "mutant %d (%s): consumed %d, oracle %d" % (m, what, used, oused)
+            for w in named:
+                if w in oafter and w < nw:
+                    got = ge.get(w)
+                    assert got == oafter[w], "mutant %d (%s): wire %d differs from the oracle's" % (m, what, w)
+                    model[w] = oafter[w]
+        else:
+            why = stricter(mut, mng, ntmp, nw)
+            if orc != 0:
+                stats["rejected"] += 1
+            else:
+                assert why, "mutant %d (%s): the engine rejects (%d) what the reference's loop walks" % (m, what, erc)
+                stats["rejected_stricter"] += 1
+            # nothing of a rejected block may have reached the store
+            for w in list(rng.choice(named, min(len(named), 6), replace=False)) if named else []:
+                w = int(w)
+                if w in model and w < nw:
+                    assert ge.get(w) == model[w], "mutant %d (%s): a rejected block changed wire %d" % (m, what, w)
+        if m % 50 == 49:  # the stream is still usable: a valid block evaluates to the oracle's labels
+            data, ng, ntmp, nw, wires = blocks[int(rng.integers(0, len(blocks)))]
+            rc, oused, oafter = oracle_on(data, ng, ntmp, nw, wires)
+            assert rc == 0 and ge.circuit(ng, ntmp, nw, data) == oused
+            for w in wires[::3]:
+                assert ge.get(w) == oafter[w], "after mutant %d: a valid block no longer evaluates to the oracle's labels" % m
+            model.update(oafter)
+        if log and m % 500 == 499:
+            log("%6d mutants: %s  parsed / matched blocks %s" % (m + 1, stats, ge.stats()))
+    parsed, matched = ge.stats()
+    ge.close()
+    ctx.close()
+    return mutants, stats, kinds, (parsed, matched)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    for threads in ("0", "3"):
+        os.environ["GC_STREAM_THREADS"] = threads
+        say = lambda s: print("threads=%s %s" % (threads, s), flush=True)
+        r = run(n // 2, seed, big=False, log=say)
+        print("threads=%s small blocks: %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
+        r = run(max(50, n // 100), seed + 1, big=True, log=say)
+        print("threads=%s big blocks (helper-thread skeleton match): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)

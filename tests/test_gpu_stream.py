@@ -1081,3 +1081,17 @@ def test_stream_cooperative_pass_that_loses_a_workgroup_is_repeated(drop_at, mon
     g2 = engine.Stream(ctx, key, rnd, prim)
     assert [g2.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps] == want
     g2.close(); gg.close(); ge.close(); ctx.close()
+
+
+@pytest.mark.parametrize("threads,big", [("0", False), ("3", False), ("3", True), ("0", True)])
+def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
+    """a slice of tests/hostile_fuzz.py (10 000 mutants logged in profiles/r04_hostile_fuzz.log): mutated OpCircuit blocks — bit
+    flips, truncation, id-width / tmp-flag flips, swapped and replaced ids, row bytes only, gate counts off — through the
+    skeleton matcher and the gate-by-gate parser; an accepted mutant ends on the oracle's labels, a rejected one is one the
+    oracle rejects or the engine refuses by design, and leaves the wire store untouched"""
+    from tests import hostile_fuzz
+    monkeypatch.setenv("GC_STREAM_THREADS", threads)
+    n, stats, kinds, (parsed, matched) = hostile_fuzz.run(24 if big else 100, seed=7 + int(threads), big=big)
+    assert stats["accepted"] + stats["rejected"] + stats["rejected_stricter"] == n and len(kinds) >= (5 if big else 8)
+    assert stats["accepted"] > 0 and stats["rejected"] + stats["rejected_stricter"] > 0
+    assert matched > 0 and parsed > 0
