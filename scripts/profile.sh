@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-iknp --no-stream --no-config3 --no-host-api --no-synthetic $*"
+ARGS="--steps 100 --warmup 20 --no-cpu-baseline --no-iknp --no-stream --no-config3 --no-host-api --no-synthetic --no-extra-rows $*"
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/bench_kt.log 2>&1
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/kt -name "*kernel_trace.csv" -exec sh -c 'head -400 "$1" > '$OUT'/kernel_trace_head.csv' _ {} \;
