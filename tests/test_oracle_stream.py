@@ -86,3 +86,35 @@ def test_stream_tweak_restarts_per_circuit_and_r_first():
     # garbling the same circuit twice on the same inputs gives the same bytes: id restarts at 0 (:174)
     c, in_, out_ = steps[0]
     assert g.garble(c.Gates, c.NumWires, in_, out_) == g.garble(c.Gates, c.NumWires, in_, out_)
+
+
+def test_hostile_fuzz_helpers_read_blocks_like_the_reference():
+    """tests/hostile_fuzz.py's own reading of an OpCircuit block (the classifier behind the GPU fuzz): it walks the oracle's
+    bytes gate by gate, recognises the cases the engine refuses by design, and every mutation operator yields a block"""
+    import numpy as np
+    from mpc_amd.circuit import adder
+    from tests import hostile_fuzz as hf
+    from tests.util import drbg
+    c = adder(16)
+    prim = list(range(40))
+    og = oracle.Stream(drbg("hfk", 32), drbg("hfr", 16 * (len(prim) + 1)), prim)
+    in_, out_ = list(range(32)), list(range(100, 116))
+    data = og.garble(c.Gates, c.NumWires, in_, out_)
+    gates, err = hf.parse(data, c.NumGates)
+    assert err is None and len(gates) == c.NumGates and gates[-1][6] + 16 * gates[-1][7] == len(data)
+    assert sum(q[7] for q in gates) == c.slab_rows()
+    nw = 116
+    assert hf.stricter(data, c.NumGates, c.NumWires, nw) is None
+    assert hf.stricter(data, c.NumGates, c.NumWires, 50) == "global id out of range"
+    assert hf.stricter(data, c.NumGates, 3, nw) in ("tmp id out of range", "tmp read before written")
+    assert hf.stricter(data[:9], 1000, c.NumWires, nw) == "more gates than bytes"
+    assert hf.parse(data[:-1], c.NumGates)[1] == "rows"
+    bad = bytearray(data); bad[gates[3][0]] = (bad[gates[3][0]] & 0xf0) | 9
+    assert hf.parse(bytes(bad), c.NumGates)[1] == "gate"
+    rng = np.random.default_rng(3)
+    kinds = set()
+    for _ in range(300):
+        mut, ng, what = hf.mutate(rng, data, c.NumGates)
+        assert isinstance(mut, bytes) and ng >= 1
+        kinds.add(what)
+    assert len(kinds) >= 10
