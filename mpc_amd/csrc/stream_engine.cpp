@@ -478,7 +478,7 @@ __global__ void k_lane_flag(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATO
 constexpr uint32_t kDeepStepsDefault = 300;  // barriers per pass (hash phases + XOR rounds) from which a step is deep: ~0.4 ms
 constexpr uint32_t kDeepLanesDefault = 3;
 constexpr uint32_t kDeepMaxGates = 1u << 20;
-constexpr uint32_t kDeepInFlight = 24;       // deep steps launched and not known to be done, at most (then the oldest is waited for)
+constexpr uint32_t kDeepInFlight = 96;       // deep steps launched and not known to be done, at most (then the oldest is waited for)
 
 struct DeepLanes {
     struct InFlight {
@@ -487,12 +487,12 @@ struct DeepLanes {
     };
     int state = 0;  // 0: not set up, 1: lanes ready, -1: off
     uint32_t min_steps = kDeepStepsDefault;
+    bool follow = true;
     std::vector<hipStream_t> lanes;         // the ctx's lanes (owned by the ctx: set up once, shared by its streams)
     std::vector<std::deque<InFlight>> inflight;  // per lane, ids ascending
     std::vector<uint32_t> rd, wr;           // per global wire: id of the latest deep step that reads / writes it
     uint32_t next_id = 1, n_inflight = 0;
     uint64_t n_steps = 0;
-    uint8_t lane_of[256] = {};              // lane of the deep step with id & 255 (at most kDeepInFlight are in flight)
 
     // the ctx's lanes, created and probed on first use (under ctx->mu)
     static void setup_ctx(gc_ctx *ctx) {
@@ -539,6 +539,8 @@ struct DeepLanes {
     void read_env() {  // (at stream creation: the threshold is asked before the lanes are)
         const char *v = std::getenv("GC_STREAM_DEEP_STEPS");
         if (v && *v) min_steps = (uint32_t)std::max(1, std::atoi(v));
+        // GC_STREAM_NO_FOLLOW: short steps never follow a deep step onto its lane (they wait for it in a group)
+        follow = std::getenv("GC_STREAM_NO_FOLLOW") == nullptr;
     }
     bool setup(gc_ctx *ctx) {
         if (state != 0) return state > 0;
@@ -611,16 +613,18 @@ struct DeepLanes {
     hipError_t wait_all(hipStream_t st) { return n_inflight ? wait_upto(st, next_id, -1) : hipSuccess; }
     // `st` waits for the deep steps of d that are still in flight; skip: the lane `st` itself is (-1: none)
     hipError_t wait_deps(hipStream_t st, const DeepDeps &d, int skip) {
-        for (uint32_t i = 0; i < d.n; i++) {
-            const int l = lane_of[d.ids[i] & 255u];
-            if (l == skip || (size_t)l >= inflight.size()) continue;
-            for (const InFlight &f : inflight[(size_t)l])
-                if (f.id == d.ids[i]) {
-                    hipError_t e = hipStreamWaitEvent(st, f.ev, 0);
-                    if (e != hipSuccess) return e;
-                    break;
+        for (uint32_t i = 0; i < d.n; i++)
+            for (size_t l = 0; l < inflight.size(); l++) {  // (a few dozen entries in all; ids ascend inside a lane)
+                if ((int)l == skip) continue;
+                for (const InFlight &f : inflight[l]) {
+                    if (f.id > d.ids[i]) break;
+                    if (f.id == d.ids[i]) {
+                        hipError_t e = hipStreamWaitEvent(st, f.ev, 0);
+                        if (e != hipSuccess) return e;
+                        break;
+                    }
                 }
-        }
+            }
         return d.upto ? wait_upto(st, d.upto, skip) : hipSuccess;
     }
     // the step is known to be done (its slot is about to be re-used): it and everything older on its lane leave the list
@@ -631,6 +635,23 @@ struct DeepLanes {
             q.pop_front();
             n_inflight--;
         }
+    }
+    // the lane of the LATEST deep step in flight among d's (-1: d names none that is still in flight)
+    int lane_to_follow(const DeepDeps &d) const {
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < d.n; i++) best = std::max(best, d.ids[i]);
+        best = std::max(best, d.upto);
+        if (best == 0 || best <= floor()) return -1;
+        // (the lane that holds the latest step in flight with an id up to `best`)
+        int lane = -1;
+        uint32_t found = 0;
+        for (size_t l = 0; l < inflight.size(); l++)
+            for (const InFlight &f : inflight[l])
+                if (f.id <= best && f.id > found) {
+                    found = f.id;
+                    lane = (int)l;
+                }
+        return lane;
     }
     // the least busy lane (fewest steps in flight; ties: the one whose last step is the oldest)
     int pick() const {
@@ -1176,7 +1197,6 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (e == hipSuccess) e = hipEventRecord(g.kernel_ev, st);
     if (e == hipSuccess && on_lane) {
         deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
-        deep.lane_of[g.deep_id & 255u] = (uint8_t)g.lane;
         deep.n_inflight++;
         deep.n_steps++;
     }
@@ -1536,7 +1556,18 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
 
     // ---- a small step joins the earliest open group it has no dependency on (or behind); a deep one takes a lane ---------
-    const bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps, known == nullptr) && s->deep.setup(ctx);
+    bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps, known == nullptr) && s->deep.setup(ctx);
+    // A SHORT step that reads or overwrites what a deep step in flight writes or reads FOLLOWS that step onto its lane (as a
+    // deep step of its own: a group of one job, ordered by the lane).  In a group it would make the ctx stream wait for the
+    // deep step — with every group behind it, whether they have anything to do with it or not (an in-order stream); on the
+    // lane only the chain that really depends on the long step waits for it (ssa23: the 256- and 512-bit values chain among
+    // themselves; the ctx stream idled 74 of 286 ms behind multipliers before).
+    int follow_lane = -1;
+    if (!is_deep && ngates && s->deep.n_inflight && s->deep.follow && entry_is_small(ent)) {
+        s->deep.ensure(s->store.host.size());
+        follow_lane = s->deep.lane_to_follow(s->deep.conflicts(in, nin, s->skip_scratch.data(), nout));
+        is_deep = follow_lane >= 0;
+    }
     if (is_deep || (ngates && entry_is_small(ent))) {
         // labels the host has set and not uploaded yet go up BEFORE this step's outputs are marked device-owned (the
         // upload skips device-owned wires: an output that overwrites a host-set input of the same step would lose it) —
@@ -1565,12 +1596,12 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
                 (void)hipEventSynchronize(s->deep.inflight[l].front().ev);
                 s->deep.poll();
             }
-            Slot *ng = slot_new(ctx, s->slots, &slot_idx, true);
+            Slot *ng = slot_new(ctx, s->slots, &slot_idx, follow_lane < 0);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
             ng->deep_id = s->deep.next_id++;
-            ng->lane = s->deep.pick();
+            ng->lane = follow_lane >= 0 ? follow_lane : s->deep.pick();
             ng->deps = s->deep.conflicts(in, nin, s->skip_scratch.data(), nout);
             deep_after(s->win, s->slots, s->win.last_conflict(in, nin, s->skip_scratch.data(), nout), ng);
         } else {
@@ -2605,7 +2636,13 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     gc_ctx *ctx = e->ctx;
     // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence; a deep
     //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
-    const bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
+    bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
+    int follow_lane = -1;  // a short block that depends on a deep block in flight follows it onto its lane (see the garbler)
+    if (!is_deep && small_block && e->deep.n_inflight && e->deep.follow && entry_is_small(ent)) {
+        e->deep.ensure(e->store.host.size());
+        follow_lane = e->deep.lane_to_follow(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
+        is_deep = follow_lane >= 0;
+    }
     if (is_deep || (small_block && entry_is_small(ent))) {
         if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned (and before
             std::lock_guard<std::mutex> lk(ctx->mu);  // the block is put anywhere: a failure leaves nothing half-queued)
@@ -2630,12 +2667,12 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                 (void)hipEventSynchronize(e->deep.inflight[l].front().ev);
                 e->deep.poll();
             }
-            Slot *ng = eval_slot(e, &slot_idx, true);
+            Slot *ng = eval_slot(e, &slot_idx, follow_lane < 0);
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
             ng->deep_id = e->deep.next_id++;
-            ng->lane = e->deep.pick();
+            ng->lane = follow_lane >= 0 ? follow_lane : e->deep.pick();
             ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
             deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
         } else {

@@ -226,83 +226,12 @@ print("big-step streams done, failures:", bad6)
 # big step; results overwrite live wires (write-after-write, write-after-read against steps still in flight on another
 # stream), operands repeat, some steps update their inputs in place; 1 to 300 steps queued ahead, 0 to 3 lanes, by handle or
 # by content; every byte in program order, every wire afterwards and the evaluator's labels against the oracle
+from tests.queued_case import run_case
 bad7 = 0
 for seed in range(max(2, N // 6)):
-    rng = np.random.default_rng(123000 + seed)
-    os.environ["GC_STREAM_DEEP_STEPS"] = str(int(rng.choice([4, 12, 40])))
-    lanes = rng.choice(["", "0", "1", "2", "3"])
-    if lanes:
-        os.environ["GC_STREAM_DEEP_LANES"] = str(lanes)
-    else:
-        os.environ.pop("GC_STREAM_DEEP_LANES", None)
-    cx = engine.Context(0)  # (the lanes belong to the context: a fresh one per case)
-    key = drbg("qk%d" % seed, int(rng.choice([16, 24, 32])))
-    shapes = [random_circuit(rng, int(rng.integers(2, 40)), int(rng.integers(1, 2500)), p_xor=float(rng.choice([0.3, 0.7, 0.9])),
-                             reuse=0.0, nout=int(rng.integers(1, 24))) for _ in range(int(rng.integers(2, 7)))]
-    if rng.random() < 0.3:
-        shapes.append(synthetic_levelised(18, 2048, 0.25, seed=int(rng.integers(1, 1 << 30)), ninputs=64, inv_frac=0.05))
-    base = int(rng.choice([0, 0xff00, 0x10000]))
-    npool = int(rng.integers(40, 400))
-    prim = [base + i for i in range(npool)]
-    pool = list(prim)
-    nextid = base + npool
-    steps = []
-    for k in range(int(rng.integers(5, 120))):
-        c = shapes[int(rng.integers(0, len(shapes)))]
-        in_ = [int(pool[int(rng.integers(0, len(pool)))]) for _ in range(c.num_inputs)]
-        u = rng.random()
-        if u < 0.45:      # fresh wires
-            out_ = list(range(nextid, nextid + c.num_outputs)); nextid += c.num_outputs
-        elif u < 0.9:     # overwrite live wires (distinct ones)
-            out_ = [int(x) for x in rng.choice(pool, c.num_outputs, replace=False)] if len(pool) >= c.num_outputs else \
-                list(range(nextid, nextid + c.num_outputs))
-            nextid = max(nextid, max(out_) + 1)
-        else:             # in place: the first outputs are wires of in[]
-            uniq = list(dict.fromkeys(in_))[: c.num_outputs]
-            out_ = uniq + list(range(nextid, nextid + c.num_outputs - len(uniq))); nextid += c.num_outputs - len(uniq)
-        for o in out_:
-            if o not in pool:
-                pool.append(o)
-        steps.append((c, in_, out_))
-    window = int(rng.choice([1, 2, 7, 33, 300]))
-    by_handle = bool(rng.random() < 0.5)
     try:
-        rnd = drbg("qr%d" % seed, 16 * (len(prim) + 1))
-        og, gg = oracle.Stream(key, rnd, prim), engine.Stream(cx, key, rnd, prim)
-        oe, ge = oracle.StreamEval(key), engine.StreamEval(cx, key)
-        for w in prim:
-            l = gg.get(w)["l0"]
-            ge.set(w, l); oe.set(w, l)
-        want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
-        got, issued, handles = [], 0, {}
-        for k in range(len(steps)):
-            while issued < min(len(steps), k + window):
-                c, in_, out_ = steps[issued]
-                if by_handle:
-                    if id(c) not in handles:
-                        handles[id(c)] = gg.intern(c.Gates, c.NumWires, len(in_), len(out_))
-                    gg.garble_begin_h(handles[id(c)], in_, out_)
-                else:
-                    gg.garble_begin(c.Gates, c.NumWires, in_, out_)
-                issued += 1
-            got.append(gg.garble_finish())
-        for k, (g, w) in enumerate(zip(got, want)):
-            assert g == w, "stream bytes of step %d of %d" % (k, len(steps))
-        for o in pool[::3]:
-            assert gg.get(o) == og.get(o), "garbler's wire %d" % o
-        for (c, in_, out_), b in zip(steps, got):
-            nw = max(max(in_), max(out_)) + 1
-            assert ge.circuit(c.NumGates, c.NumWires, nw, b) == len(b)
-            assert oe.circuit(c.NumGates, c.NumWires, nw, b) == len(b)
-        for o in pool[::3]:
-            assert ge.get(o) == oe.get(o), "evaluated label of wire %d" % o
-        cx.sync()
-        gg.close(); ge.close()
+        run_case(seed)
     except (AssertionError, engine.EngineError) as e:
         bad7 += 1
-        print("FAIL(queued) seed", seed, "steps", len(steps), "window", window, "lanes", lanes or "default", "deep >=",
-              os.environ["GC_STREAM_DEEP_STEPS"], "handle" if by_handle else "content", str(e)[:160])
-    cx.close()
-os.environ.pop("GC_STREAM_DEEP_STEPS", None)
-os.environ.pop("GC_STREAM_DEEP_LANES", None)
+        print("FAIL(queued) seed", seed, str(e)[:300])
 print("queued programs across the scheduling classes done, failures:", bad7)

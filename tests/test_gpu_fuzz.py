@@ -179,3 +179,15 @@ def device_pipeline_case(ctx, seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_device_pipeline_random(ctx, seed):
     device_pipeline_case(ctx, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 14, 22, 41, 75, 96, 150])
+def test_queued_programs_across_the_scheduling_classes(seed):
+    """a slice of tests/ext_fuzz.py's seventh pass (tests/queued_case.py): random programs queued 1 to 300 steps ahead — step
+    groups, deep steps and the short steps that follow them on their lanes, big steps; results overwrite live wires, operands
+    repeat, in-place updates; 0 to 3 lanes, by handle or content — byte for byte and wire for wire against the oracle, both
+    sides.  (Seeds 14, 22 and 75 are the ones an early version of the GENERATOR got wrong: it let later steps read output
+    wires that no gate writes, which read (0, R) here and (0, 0) in the reference — INTEGRATION.md.)"""
+    from tests.queued_case import run_case
+    run_case(seed)

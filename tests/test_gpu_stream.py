@@ -887,11 +887,18 @@ def _deep_dependency_program(base):
 
 
 @pytest.mark.parametrize("base,keylen,lanes,by_handle", [(0, 32, None, True), (0x20000, 16, "1", False), (0xfe00, 24, "2", True),
-                                                         (0, 32, "0", True)])
+                                                         (0, 32, "0", True), (0x20000, 32, "nofollow", False)])
 def test_stream_deep_lanes_match_oracle(base, keylen, lanes, by_handle, monkeypatch):
     """deep steps (lanes) beside step groups and a big step: every byte in program order, every wire afterwards and the
-    evaluator's labels equal the oracle's serial loop, with 3 / 1 / 2 lanes and with the lanes switched off"""
+    evaluator's labels equal the oracle's serial loop, with 3 / 1 / 2 lanes, with the lanes switched off, and with short
+    steps kept off the lanes (GC_STREAM_NO_FOLLOW: they wait for the deep steps they depend on in a group instead)"""
     monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    if lanes == "nofollow":
+        monkeypatch.setenv("GC_STREAM_NO_FOLLOW", "1")
+        lanes = None
+        nofollow = True
+    else:
+        nofollow = False
     if lanes is not None:
         monkeypatch.setenv("GC_STREAM_DEEP_LANES", lanes)
     ctx = engine.Context(0)
@@ -919,8 +926,10 @@ def test_stream_deep_lanes_match_oracle(base, keylen, lanes, by_handle, monkeypa
     ndeep = sum(1 for c, _, _ in steps if c.name in ("adder128", "subtractor128", "adder256", "multiplier64"))
     if lanes == "0":
         assert (deep_steps, nlanes) == (0, 0)
-    else:
+    elif nofollow:
         assert nlanes >= 1 and deep_steps == ndeep, (deep_steps, ndeep, nlanes)
+    else:  # (short steps that depend on a deep step in flight follow it onto its lane: they count as well)
+        assert nlanes >= 1 and deep_steps >= ndeep, (deep_steps, ndeep, nlanes)
     for c, in_, out_ in steps:
         for o in out_[::7]:
             assert gg.get(o) == og.get(o)
@@ -936,7 +945,7 @@ def test_stream_deep_lanes_match_oracle(base, keylen, lanes, by_handle, monkeypa
         assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
         assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
     if lanes != "0":
-        assert ge.deep_stats()[0] == ndeep
+        assert ge.deep_stats()[0] >= ndeep
     for k, (c, in_, out_) in enumerate(steps):
         for o in out_[::7]:
             assert ge.get(o) == oe.get(o), "step %d (%s) wire %d" % (k, c.name, o)
