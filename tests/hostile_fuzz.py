@@ -143,15 +143,19 @@ def mutate(rng, block, ngates):
     return bytes(b), ngates, "byte replaced"
 
 
-def programs(big=False):
-    """valid blocks to mutate: small SSA-step circuits of every gate type (tmp wires, 16- and 32-bit ids, repeated ids) and,
-    with big=True, two blocks of ~49 000 gates whose skeletons are matched in segments by the helper threads"""
-    from mpc_amd.circuit import adder, comparator64, synthetic_levelised
+def programs(big=False, deep=False):
+    """valid blocks to mutate: small SSA-step circuits of every gate type (tmp wires, 16- and 32-bit ids, repeated ids); with
+    big=True two blocks of ~49 000 gates whose skeletons are matched in segments by the helper threads; with deep=True blocks
+    that run on the evaluator's deep lanes (GC_STREAM_DEEP_STEPS=100: a 128-bit adder and subtractor — rows through the group's
+    upload region — and a 128-bit multiplier of 56 140 gates, whose rows go up from the pinned ring into the slot's arena)"""
+    from mpc_amd.circuit import adder, comparator64, multiplier, subtractor, synthetic_levelised
     shapes = [synthetic_levelised(6, 40, 0.3, seed=51, ninputs=24, inv_frac=0.1, xnor_frac=0.1),
               synthetic_levelised(3, 60, 0.4, seed=52, ninputs=24, or_frac=0.15, inv_frac=0.05),
               adder(16), comparator64(), synthetic_levelised(10, 64, 0.25, seed=57, ninputs=64)]
     if big:
         shapes = [synthetic_levelised(24, 2048, 0.3, seed=58, ninputs=256, inv_frac=0.05)]
+    if deep:
+        shapes = [adder(128), subtractor(128), multiplier(128)]
     out = []
     for k, c in enumerate(shapes):
         for base in (0, 0x11000):  # short and long id forms
@@ -164,12 +168,14 @@ def programs(big=False):
     return out
 
 
-def run(mutants=200, seed=1, big=False, log=None):
+def run(mutants=200, seed=1, big=False, log=None, deep=False):
     """returns (mutants run, accepted, rejected, by kind) — raises AssertionError on the first violation"""
     rng = np.random.default_rng(seed)
     key = drbg("hostile-key", 32)
     ctx = engine.Context(0)
-    steps = programs(big)
+    if deep:
+        os.environ["GC_STREAM_DEEP_STEPS"] = "100"
+    steps = programs(big, deep)
     prim = sorted({w for _, i, _ in steps for w in i})
     rnd = drbg("hostile-rnd", 16 * (len(prim) + 1))
     og = oracle.Stream(key, rnd, prim)
@@ -253,6 +259,9 @@ def run(mutants=200, seed=1, big=False, log=None):
         if log and m % 500 == 499:
             log("%6d mutants: %s  parsed / matched blocks %s" % (m + 1, stats, ge.stats()))
     parsed, matched = ge.stats()
+    if deep:
+        assert ge.deep_stats()[0] > 0, "no block ran on a deep lane"
+        os.environ.pop("GC_STREAM_DEEP_STEPS", None)
     ge.close()
     ctx.close()
     return mutants, stats, kinds, (parsed, matched)
@@ -268,3 +277,5 @@ if __name__ == "__main__":
         print("threads=%s small blocks: %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
         r = run(max(50, n // 100), seed + 1, big=True, log=say)
         print("threads=%s big blocks (helper-thread skeleton match): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
+        r = run(max(50, n // 50), seed + 2, deep=True, log=say)
+        print("threads=%s deep blocks (lanes; rows through the upload region / from the pinned ring): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)

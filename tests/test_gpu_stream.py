@@ -1092,7 +1092,7 @@ def test_stream_cooperative_pass_that_loses_a_workgroup_is_repeated(drop_at, mon
     g2.close(); gg.close(); ge.close(); ctx.close()
 
 
-@pytest.mark.parametrize("threads,big", [("0", False), ("3", False), ("3", True), ("0", True)])
+@pytest.mark.parametrize("threads,big", [("0", False), ("3", False), ("3", True), ("0", True), ("3", "deep")])
 def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     """a slice of tests/hostile_fuzz.py (10 000 mutants logged in profiles/r04_hostile_fuzz.log): mutated OpCircuit blocks — bit
     flips, truncation, id-width / tmp-flag flips, swapped and replaced ids, row bytes only, gate counts off — through the
@@ -1100,7 +1100,10 @@ def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     oracle rejects or the engine refuses by design, and leaves the wire store untouched"""
     from tests import hostile_fuzz
     monkeypatch.setenv("GC_STREAM_THREADS", threads)
-    n, stats, kinds, (parsed, matched) = hostile_fuzz.run(24 if big else 100, seed=7 + int(threads), big=big)
+    if big == "deep":  # blocks that run on the deep lanes
+        n, stats, kinds, (parsed, matched) = hostile_fuzz.run(30, seed=11, deep=True)
+    else:
+        n, stats, kinds, (parsed, matched) = hostile_fuzz.run(24 if big else 100, seed=7 + int(threads), big=big)
     assert stats["accepted"] + stats["rejected"] + stats["rejected_stricter"] == n and len(kinds) >= (5 if big else 8)
     assert stats["accepted"] > 0 and stats["rejected"] + stats["rejected_stricter"] > 0
     assert matched > 0 and parsed > 0
