@@ -222,7 +222,9 @@ def run(stage):
     # (the main thread may be inside ncclCommInitRank or a collective, i.e. inside a C call that never returns)
     dog = gdist.Watchdog(lambda what: (print(error_line(what, stage[0], world), flush=True) if rank == 0 else None)) if world > 1 else None
     stage[0] = "context"
-    ctx = engine.Context(local_rank)  # one process per GPU: this rank's device, its own HIP stream
+    # one process per GPU: this rank's device, its own HIP stream (GC_BENCH_DEVICE: a probe that puts every rank on one
+    # device to see how far the N > 1 path gets on a one-GPU box — RCCL refuses such a communicator)
+    ctx = engine.Context(int(os.environ.get("GC_BENCH_DEVICE", local_rank)))
     collective = world > 1 or args.force_collective
     comm = None
     if collective:  # gc_comm_init_rank: RCCL, one rank per GPU

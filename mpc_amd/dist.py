@@ -137,13 +137,22 @@ def cleanup_unique_id_file(rank, directory=None):
 class Watchdog:
     """Bounds a stage of a multi-rank run from OUTSIDE the main thread: ncclCommInitRank and the collectives are C calls that
     never return when a peer is missing, so a timer thread ends the process instead — on_timeout(message) first (rank 0
-    prints its one JSON error line there), then os._exit(3).  arm() re-arms for the next stage, disarm() when done."""
+    prints its one JSON error line there), then os._exit(3).  arm() re-arms for the next stage, disarm() when done.  The same
+    thread catches the launcher's SIGTERM (sent to the surviving ranks when one rank fails): exit code 4 after the line."""
 
-    def __init__(self, on_timeout):
+    def __init__(self, on_timeout, catch_sigterm=True):
+        import signal
         import threading
         self._on_timeout = on_timeout
         self._lock = threading.Lock()
         self._deadline, self._what = None, ""
+        # The launcher ends the surviving ranks with SIGTERM when one rank fails.  A Python handler would only run once the
+        # main thread leaves the C call it may be stuck in, so the signal is BLOCKED here (the timer thread inherits the mask)
+        # and the timer thread waits for it synchronously: the rank says why it ends (rank 0: its one error line) and leaves.
+        self._sigs = None
+        if catch_sigterm and hasattr(signal, "pthread_sigmask") and hasattr(signal, "sigtimedwait"):
+            signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+            self._sigs = {signal.SIGTERM}
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
@@ -156,9 +165,19 @@ class Watchdog:
             self._deadline = None
 
     def _run(self):
+        import signal
         import sys
         while True:
-            time.sleep(0.05)
+            if self._sigs:
+                if signal.sigtimedwait(self._sigs, 0.05) is not None:
+                    try:
+                        sys.stderr.write("bench watchdog: terminated by the launcher (another rank failed)\n")
+                        self._on_timeout("terminated by the launcher: another rank failed (its message is on stderr)")
+                        sys.stdout.flush()
+                    finally:
+                        os._exit(4)
+            else:
+                time.sleep(0.05)
             with self._lock:
                 late = self._deadline is not None and time.monotonic() > self._deadline
                 what = self._what

@@ -34,6 +34,8 @@ class _Buf:
 
 class Context:
     def __init__(self, device):
+        if os.environ.get("GC_STUB_RANK_FAILS") == os.environ.get("RANK", "0"):  # (a rank whose device is not there)
+            raise EngineError(-5, "gc_ctx_create(%d): stub: invalid device ordinal" % device)
         self.device = device
 
     def random_u8(self, shape, mod, seed=0):

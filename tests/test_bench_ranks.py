@@ -67,3 +67,14 @@ def test_bench_missing_rank_ends_with_one_error_line(tmp_path):
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0].get("error") and lines[0]["value"] is None and lines[0]["n_gpus"] == 2, r.stdout[-2000:]
     assert "communicator" in lines[0]["stage"]
+
+
+def test_bench_rank_that_dies_early_still_leaves_one_error_line(tmp_path):
+    """rank 1 cannot open its device (what a 2-rank launch on a 1-GPU box does): it fails at once, the launcher sends SIGTERM
+    to rank 0 — which may be inside a C call —, and rank 0 still prints its ONE error line before it leaves"""
+    t0 = time.time()
+    r = _launch(2, ["--init-timeout", "30"], {"GC_STUB_RANK_FAILS": "1"}, tmp_path, timeout=120)
+    assert time.time() - t0 < 60 and r.returncode != 0
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0].get("error") and lines[0]["n_gpus"] == 2, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 1 failed at stage 'context'" in r.stderr
