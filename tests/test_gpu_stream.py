@@ -1,5 +1,7 @@
 """GPU streaming garbler (gc_stream_*, config 5 shape): the byte stream must equal the oracle's
 restatement of circuit/stream_garble.go byte for byte, for a sequence of per-step circuits."""
+import os
+
 import numpy as np
 import pytest
 
@@ -924,8 +926,9 @@ def test_stream_deep_lanes_match_oracle(base, keylen, lanes, by_handle, monkeypa
     deep_steps, nlanes = gg.deep_stats()
     # (with the threshold at 100 barriers the 64-bit multiplier — 179 — is a deep step as well)
     ndeep = sum(1 for c, _, _ in steps if c.name in ("adder128", "subtractor128", "adder256", "multiplier64"))
-    if lanes == "0":
+    if lanes == "0" or (lanes is None and os.environ.get("GC_STREAM_DEEP_LANES") == "0"):  # (also: the suite run with lanes off)
         assert (deep_steps, nlanes) == (0, 0)
+        lanes = "0"
     elif nofollow:
         assert nlanes >= 1 and deep_steps == ndeep, (deep_steps, ndeep, nlanes)
     else:  # (short steps that depend on a deep step in flight follow it onto its lane: they count as well)
@@ -1022,7 +1025,9 @@ def test_stream_ed25519like_matches_oracle():
             issued += 1
         assert gg.garble_finish() == want[k], "step %d (%s)" % (k, steps[k][0].name)
     groups, grouped, bigs = gg.stats()
-    assert bigs == 0 and groups < len(steps) // 4, (groups, grouped, bigs)  # the hundred products of a FeMul share launches
+    assert bigs == 0
+    if not os.environ.get("GC_STREAM_OPEN_GROUPS"):  # (the default window: the hundred products of a FeMul share launches)
+        assert groups < len(steps) // 4, (groups, grouped, bigs)
     ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
     bits = np.frombuffer(drbg("edbits", len(prim)), np.uint8) & 1
     for w, b in zip(prim, bits):
