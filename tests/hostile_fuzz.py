@@ -260,7 +260,7 @@ def run(mutants=200, seed=1, big=False, log=None, deep=False):
             log("%6d mutants: %s  parsed / matched blocks %s" % (m + 1, stats, ge.stats()))
     parsed, matched = ge.stats()
     if deep:
-        assert ge.deep_stats()[0] > 0, "no block ran on a deep lane"
+        assert ge.deep_stats()[0] > 0 or os.environ.get("GC_STREAM_DEEP_LANES") == "0", "no block ran on a deep lane"
         os.environ.pop("GC_STREAM_DEEP_STEPS", None)
     ge.close()
     ctx.close()

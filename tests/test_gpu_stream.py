@@ -988,7 +988,8 @@ def test_stream_deep_steps_in_flight_while_circuits_are_evicted(monkeypatch):
             gg.garble_begin(c.Gates, c.NumWires, in_, out_)
             issued += 1
         assert gg.garble_finish() == want[k], "step %d (%s)" % (k, steps[k][0].name)
-    assert gg.deep_stats()[0] > 10
+    if os.environ.get("GC_STREAM_DEEP_LANES") != "0":  # (the suite also runs with the lanes switched off)
+        assert gg.deep_stats()[0] > 10
     ge, oe = engine.StreamEval(ctx, key), oracle.StreamEval(key)
     for w in prim:
         ge.set(w, og.get(w)["l0"])
