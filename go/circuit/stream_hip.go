@@ -29,7 +29,6 @@ type Streaming struct {
 	conn    *p2p.Conn
 	ctx     *C.gc_ctx
 	h       *C.gc_stream
-	buf     []byte              // serialised gates of one circuit
 	handles map[*Circuit]streamHandle // gc_stream_intern: a compiled circuit is recognised by content once, not per call
 	pending []int               // gate counts of the circuits queued by Begin and not yet written out by Finish
 }
@@ -177,16 +176,15 @@ func (stream *Streaming) Finish() error {
 	if ngates == 0 {
 		return nil
 	}
-	need := 61*ngates + 16 // upper bound: 13 header bytes + 3 rows per gate
-	if len(stream.buf) < need {
-		stream.buf = make([]byte, need+need/2)
-	}
+	// the bytes are read IN PLACE from the engine's pinned staging (valid until the next Finish): the copy into conn.WriteBuf
+	// below is the only one
+	var ptr *C.uint8_t
 	var written C.size_t
-	st := C.gc_stream_garble_finish(stream.h, (*C.uint8_t)(unsafe.Pointer(&stream.buf[0])), C.size_t(len(stream.buf)), &written)
+	st := C.gc_stream_garble_finish_view(stream.h, &ptr, &written)
 	if st != C.GC_OK {
 		return statusError(st)
 	}
-	data := stream.buf[:int(written)]
+	data := unsafe.Slice((*byte)(unsafe.Pointer(ptr)), int(written))
 	for len(data) > 0 { // conn.NeedSpace(512) + direct writes into conn.WriteBuf in the reference (:177-185)
 		if err := stream.conn.NeedSpace(512); err != nil {
 			return err

@@ -268,6 +268,11 @@ int gc_stream_garble(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_
 int gc_stream_garble_begin(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                            uint32_t nin, const uint32_t *out, uint32_t nout);
 int gc_stream_garble_finish(gc_stream *, uint8_t *buf, size_t cap, size_t *written);
+/* The same without the copy (additive): *bytes points into the engine's pinned staging and stays valid until the next
+ * gc_stream_garble_finish / _finish_view / gc_stream_free on this stream — for a caller that moves the bytes on itself
+ * (the Go shim copies them into conn.WriteBuf, stream_garble.go:177-185: one copy instead of two; on a program of 13 000-gate
+ * multipliers the copy out of the staging was most of the host's time per step). */
+int gc_stream_garble_finish_view(gc_stream *, const uint8_t **bytes, size_t *len);
 int gc_stream_garble_flush(gc_stream *);
 /* A driver garbles the same few circuits over and over (the streamer keeps one compiled circuit per SSA instruction
  * shape: 23 for Ed25519 sign.mpcl, benchmarks.md:698), and gc_stream_garble_begin has to recognise the gate list by

@@ -706,6 +706,11 @@ struct gc_stream {
     gc_circ *held_circ = nullptr;
     gc_batch *held = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
+    // gc_stream_garble_finish_view: the slot whose pinned bytes the caller is still reading (given back by the next finish),
+    // and pinned staging for the bytes of a big step
+    uint32_t view_slot = 0xffffffffu;
+    uint8_t *view_buf = nullptr;
+    size_t view_cap = 0;
 };
 
 namespace {
@@ -1375,6 +1380,7 @@ void gc_stream_free(gc_stream *s) {
     if (s->held) gc_circ_release_batch(s->held_circ, s->held);
     for (auto &kv : s->cache) gc_circ_free(kv.second.circ);
     for (auto &sl : s->slots) sl->release();
+    if (s->ctx) gc::ctx_buf_put(s->ctx, true, s->view_buf, s->view_cap);
     if (s->d_rk) (void)hipFree(s->d_rk);
     if (s->d_R) (void)hipFree(s->d_R);
     s->store.release();
@@ -1826,9 +1832,18 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
 
 extern "C" {
 
-int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
-    if (!s || !buf || !written || s->queue.empty()) return GC_E_ARG;
+// The bytes of the oldest circuit in flight: copied into buf (view == nullptr), or handed out in place (*view = a pointer
+// into the engine's pinned staging, valid until the next finish / free call on the stream: the slot it belongs to is only
+// given back then)
+static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written, const uint8_t **view) {
+    if (!s || (!buf && !view) || !written || s->queue.empty()) return GC_E_ARG;
     StreamTrace tr;
+    if (s->view_slot != 0xffffffffu) {  // the slot whose bytes the last view pointed into
+        Slot &v = *s->slots[s->view_slot];
+        if (v.deep_id) s->deep.retire(v.lane, v.deep_id);
+        v.reset();
+        s->view_slot = 0xffffffffu;
+    }
     const StepRef ref = s->queue.front();
     Slot &g = *s->slots[ref.slot];
     while (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in an open group: launch up to that one
@@ -1856,7 +1871,7 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
             rc = GC_E_HIP;
         }
         g.synced = true;
-        if (rc == GC_OK) rc = gc_ctx_coop_check(ctx);  // a big step as one cooperative launch: did every workgroup stay?
+        if (rc == GC_OK) rc = gc_ctx_coop_check(ctx);  // (a cooperative pass that lost a workgroup is noted here)
     }
     if (g.kind == Slot::kGroup) {
         if (rc == GC_OK) {
@@ -1864,23 +1879,39 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
             const size_t sizes_bytes = up256(g.jobs.size() * sizeof(uint32_t));
             const uint32_t need = ((const uint32_t *)g.h_down)[ref.job];
             *written = need;
-            if (need > cap) rc = GC_E_ARG;
+            if (view) *view = g.h_down + sizes_bytes + j.off_bytes;
+            else if (need > cap) rc = GC_E_ARG;
             else if (need) std::memcpy(buf, g.h_down + sizes_bytes + j.off_bytes, need);
         }
         if (++g.handed == g.jobs.size()) {
-            if (g.deep_id) s->deep.retire(g.lane, g.deep_id);  // (its kernel has run: `done` sits behind it)
-            g.reset();
+            if (view && rc == GC_OK) {
+                s->view_slot = ref.slot;  // (given back by the next finish: the caller still reads its bytes)
+            } else {
+                if (g.deep_id) s->deep.retire(g.lane, g.deep_id);  // (its kernel has run: `done` sits behind it)
+                g.reset();
+            }
         }
         tr.lap("wait + copy out");
         return rc;
     }
-    // a big step: its bytes come straight into the caller's buffer
+    // a big step: its bytes come straight into the caller's buffer (a view: into the stream's pinned staging)
     if (rc == GC_OK) {
         const uint64_t need = *g.need;
         *written = (size_t)need;
-        if (need > cap) rc = GC_E_ARG;
-        else if (need) {  // on its own stream: the next circuit's kernels are already queued on the ctx stream
-            hipError_t e = hipMemcpyAsync(buf, g.d_bytes, (size_t)need, hipMemcpyDeviceToHost, s->copy_stream);
+        uint8_t *dst = buf;
+        if (view) {
+            hipError_t e = grow_pin(ctx, &s->view_buf, &s->view_cap, (size_t)need + 16);
+            if (e != hipSuccess) {
+                set_error("gc_stream_garble_finish_view", e);
+                rc = GC_E_NOMEM;
+            }
+            dst = s->view_buf;
+            *view = dst;
+        } else if (need > cap) {
+            rc = GC_E_ARG;
+        }
+        if (rc == GC_OK && need) {  // on its own stream: the next circuit's kernels are already queued on the ctx stream
+            hipError_t e = hipMemcpyAsync(dst, g.d_bytes, (size_t)need, hipMemcpyDeviceToHost, s->copy_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(s->copy_stream);
             if (e != hipSuccess) {
                 set_error("gc_stream_garble_finish", e);
@@ -1891,6 +1922,19 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
     g.reset();
     tr.lap("wait + d2h");
     return rc;
+}
+
+int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
+    if (!buf) return GC_E_ARG;
+    return stream_finish(s, buf, cap, written, nullptr);
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_garble_finish_view(gc_stream *s, const uint8_t **bytes, size_t *len) try {
+    if (!bytes) return GC_E_ARG;
+    *bytes = nullptr;
+    return stream_finish(s, nullptr, 0, len, bytes);
 } catch (...) {
     return gc::on_exception();
 }

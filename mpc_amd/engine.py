@@ -91,6 +91,7 @@ def lib():
         "gc_stream_garble_flush": (i32, [vp]),
         "gc_stream_intern": (i32, [vp, vp, u32, u32, u32, u32, C.POINTER(C.c_uint32)]),
         "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
+        "gc_stream_garble_finish_view": (i32, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
@@ -713,6 +714,13 @@ class Stream:
         n = C.c_size_t(0)
         _check(lib().gc_stream_garble_finish(self.h, _p(self._buf), len(self._buf), C.byref(n)), "gc_stream_garble_finish")
         return self._buf[: n.value].tobytes()
+
+    def garble_finish_view(self):
+        """gc_stream_garble_finish_view: the same bytes without the engine's copy — read in place from its pinned staging
+        (the pointer is valid until the next finish call; the copy made here is the caller's own)"""
+        ptr, n = C.c_void_p(None), C.c_size_t(0)
+        _check(lib().gc_stream_garble_finish_view(self.h, C.byref(ptr), C.byref(n)), "gc_stream_garble_finish_view")
+        return C.string_at(ptr, n.value) if n.value else b""
 
     def close(self):
         if self.h:

@@ -251,7 +251,7 @@ def test_go_shim_names_only_declared_entry_points_and_covers_the_table():
         used |= set(re.findall(r"\bC\.(gc_[a-z0-9_]+)\(", text))
     assert used and used <= names, sorted(used - names)
     must = {"gc_ctx_create", "gc_circ_load", "gc_garble", "gc_eval", "gc_garble_wire", "gc_eval_wire", "gc_stream_create",
-            "gc_stream_get_wire", "gc_stream_intern", "gc_stream_garble_begin_h", "gc_stream_garble_finish",
+            "gc_stream_get_wire", "gc_stream_intern", "gc_stream_garble_begin_h", "gc_stream_garble_finish_view",
             "gc_stream_eval_create", "gc_stream_eval_set_wire",
             "gc_stream_eval_get_wire", "gc_stream_eval_circuit", "gc_iknp_receiver_create", "gc_iknp_sender_create",
             "gc_iknp_receive", "gc_iknp_send", "gc_iknp_receive_bits", "gc_iknp_send_bits", "gc_kos_receiver_tags",

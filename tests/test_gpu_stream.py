@@ -1113,3 +1113,28 @@ def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     assert stats["accepted"] + stats["rejected"] + stats["rejected_stricter"] == n and len(kinds) >= (5 if big else 8)
     assert stats["accepted"] > 0 and stats["rejected"] + stats["rejected_stricter"] > 0
     assert matched > 0 and parsed > 0
+
+
+def test_stream_finish_view_hands_out_the_same_bytes(monkeypatch):
+    """gc_stream_garble_finish_view (no copy: a pointer into the pinned staging, valid until the next finish) against the oracle
+    on a program with grouped, deep and big steps, mixed with copying finishes; the slot a view points into is only given back
+    by the next call"""
+    monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    ctx = engine.Context(0)
+    steps, prim = _deep_dependency_program(0x20000)
+    key = drbg("viewkey", 32)
+    rnd = drbg("viewrnd", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    issued = 0
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + 20:
+            c, in_, out_ = steps[issued]
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        got = gg.garble_finish() if k % 5 == 4 else gg.garble_finish_view()
+        assert got == want[k], "step %d (%s)" % (k, steps[k][0].name)
+    for c, in_, out_ in steps[-10:]:
+        for o in out_[::9]:
+            assert gg.get(o) == og.get(o)
+    gg.close(); ctx.close()
