@@ -21,6 +21,13 @@
 // memory.  A step that conflicts with the open group closes it (stream order then carries the dependency); the bytes
 // still leave in program order through gc_stream_garble_finish.  Steps of more than kSmallGates gates keep the
 // per-step path (level launches spread over the chip).  The evaluator groups its blocks the same way.
+//
+// Deep lanes (round 4).  A step whose one-workgroup pass is LONG (a 128- / 256-bit multiplier, a 256- / 512-bit adder: 0.5 -
+// 2 ms on one CU) runs on one of a few extra HIP streams of the ctx, beside the groups, ordered against them by events only
+// where two steps share a wire (DeepLanes below); short steps that depend on such a step follow it onto its lane.  The open
+// groups form a window of up to 16 (an add chain interleaved with independent products needs a group per link); the caller's
+// finish launches what is behind the group it waits for.  A circuit met in the middle of a stream gets its LDS plan from a
+// thread of its own while its first passes run on the kernels that need none (gc_circ_flat_poll).
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -42,9 +49,13 @@ using namespace gc;
 namespace {
 // developer aid: GC_TRACE=1 prints the wall-clock laps of a streaming step to stderr
 struct StreamTrace {
+    static bool enabled() {  // (asked once: two getenv walks per streamed step were measurable on 512-gate steps)
+        static const bool v = std::getenv("GC_TRACE") != nullptr;
+        return v;
+    }
     bool on;
     std::chrono::steady_clock::time_point last;
-    StreamTrace() : on(std::getenv("GC_TRACE") != nullptr) {
+    StreamTrace() : on(enabled()) {
         if (on) last = std::chrono::steady_clock::now();
     }
     void lap(const char *what) {
