@@ -1138,3 +1138,56 @@ def test_stream_finish_view_hands_out_the_same_bytes(monkeypatch):
         for o in out_[::9]:
             assert gg.get(o) == og.get(o)
     gg.close(); ctx.close()
+
+
+def test_stream_deep_lanes_three_contexts_concurrently(monkeypatch):
+    """three contexts on three threads run the deep-lane program at once — garbler and evaluator each (lanes, probes and
+    buffer lists are per context; what the process shares is the runtime's hardware queues): every stream's bytes and every
+    evaluator's labels are the oracle's"""
+    import hashlib
+    import threading
+    monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    steps, prim = _deep_dependency_program(0x20000)
+    key = drbg("c3key", 32)
+    rnd = drbg("c3rnd", 16 * (len(prim) + 1))
+    og, oe = oracle.Stream(key, rnd, prim), oracle.StreamEval(key)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    labels0 = {w: (int(og.get(w)["l0"]["d0"]), int(og.get(w)["l0"]["d1"])) for w in prim}
+    for w in prim:
+        oe.set(w, labels0[w])
+    for (c, in_, out_), data in zip(steps, want):
+        oe.circuit(c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1, data)
+    probe = [o for _, _, out_ in steps[-12:] for o in out_[::11]]
+    want_eval = [oe.get(o) for o in probe]
+    res = [None] * 3
+
+    def run(i):
+        try:
+            ctx = engine.Context(0)
+            gg, ge = engine.Stream(ctx, key, rnd, prim), engine.StreamEval(ctx, key)
+            for w in prim:
+                ge.set(w, labels0[w])
+            issued, ok = 0, True
+            for k in range(len(steps)):
+                while issued < len(steps) and issued < k + 24:
+                    c, in_, out_ = steps[issued]
+                    gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+                    issued += 1
+                b = gg.garble_finish_view() if (k + i) % 2 else gg.garble_finish()
+                ok = ok and b == want[k]
+                c, in_, out_ = steps[k]
+                ok = ok and ge.circuit(c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1, b) == len(b)
+            ok = ok and [ge.get(o) for o in probe] == want_eval
+            lanes = gg.deep_stats()[1]
+            ctx.sync()
+            gg.close(); ge.close(); ctx.close()
+            res[i] = "ok" if ok else "mismatch (lanes %d)" % lanes
+        except Exception as e:  # noqa: BLE001 - reported through the assertion below
+            res[i] = "error: %s" % e
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert res == ["ok"] * 3, res
