@@ -569,6 +569,17 @@ struct DeepLanes {
             wr.resize(n, 0);
         }
     }
+    // the id of the next deep step (ascending in program order; after 4e9 of them: the lanes are drained and the per-wire
+    // records start over)
+    uint32_t new_id() {
+        if (next_id >= 0xfffffff0u) {
+            drain();
+            std::fill(rd.begin(), rd.end(), 0);
+            std::fill(wr.begin(), wr.end(), 0);
+            next_id = 1;
+        }
+        return next_id++;
+    }
     // every id up to this one is known to be done
     uint32_t floor() const {
         uint32_t f = next_id - 1;
@@ -1617,7 +1628,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            ng->deep_id = s->deep.next_id++;
+            ng->deep_id = s->deep.new_id();
             ng->lane = follow_lane >= 0 ? follow_lane : s->deep.pick();
             ng->deps = s->deep.conflicts(in, nin, s->skip_scratch.data(), nout);
             deep_after(s->win, s->slots, s->win.last_conflict(in, nin, s->skip_scratch.data(), nout), ng);
@@ -2726,7 +2737,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             if (!ng) return GC_E_NOMEM;
             ng->reset();
             ng->kind = Slot::kGroup;
-            ng->deep_id = e->deep.next_id++;
+            ng->deep_id = e->deep.new_id();
             ng->lane = follow_lane >= 0 ? follow_lane : e->deep.pick();
             ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
             deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
