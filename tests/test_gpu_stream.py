@@ -1191,3 +1191,20 @@ def test_stream_deep_lanes_three_contexts_concurrently(monkeypatch):
     for t in th:
         t.join()
     assert res == ["ok"] * 3, res
+
+
+def test_host_api_cooperative_pass_that_loses_a_workgroup_is_repeated(monkeypatch):
+    """the same stand-by outside the streams: ONE instance of a wide circuit through the host-buffer calls (gc_garble /
+    gc_eval: label exchange by separate kernels, no StoreXchg) with the first cooperative pass forced to lose a workgroup —
+    R, tables, every wire and the evaluated labels are the oracle's, nothing fails"""
+    from mpc_amd.circuit import synthetic_levelised
+    from tests.test_gpu_garble_eval import check_garble_eval
+    monkeypatch.setenv("GC_COOP_FORCE_TIMEOUT", "1")
+    ctx = engine.Context(0)
+    c = synthetic_levelised(16, 4096, 0.3, seed=77, ninputs=128, inv_frac=0.05, or_frac=0.02)
+    check_garble_eval(ctx, c, drbg("coop-host", 32), 1, "coophost", check_all_wires=True, schedule=1)
+    state, timeouts = ctx.coop_stats()
+    if state != 0:  # (0: the cooperative passes are not in use on this box)
+        assert timeouts >= 1 and state == -1, (state, timeouts)
+    check_garble_eval(ctx, c, drbg("coop-host", 32), 1, "coophost2", check_all_wires=False, schedule=1)  # level launches now
+    ctx.close()
