@@ -43,6 +43,7 @@
 #include <cstdlib>
 
 #include "engine.h"
+#include "skel_match.h"
 
 using namespace gc;
 
@@ -1978,14 +1979,8 @@ int gc_stream_garble(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
 // way every time: the same op / flag bytes and tmp ids at the same offsets, only the table rows and the global ids
 // differ.  A new block that equals a skeleton on every other byte, and whose global ids repeat in the same pattern, IS
 // that circuit: no gate is decoded, the rows are copied out, the global ids are read at their known offsets.
-static inline uint64_t skel_load_be64(const uint8_t *p) {
-    uint64_t v;
-    std::memcpy(&v, p, 8);
-    return __builtin_bswap64(v);
-}
-
 struct EvalSkel {
-    struct Chunk {
+    struct Chunk {       // what the parser records on its way through a block
         uint32_t cmp;    // bytes that must equal the reference block
         uint16_t skip;   // then a global id field (2 / 4 bytes), 0: none
         uint16_t nrows;  // then table rows (16 bytes each)
@@ -1993,78 +1988,48 @@ struct EvalSkel {
     size_t nbytes = 0;
     uint32_t nrows = 0, nin = 0, nout = 0;
     CircEntry *ent = nullptr;                // owned by the stream's circuit cache (dropped with it on eviction)
-    std::vector<uint8_t> bytes;              // the reference block
-    std::vector<Chunk> chunks;
+    std::vector<uint8_t> bytes;              // the reference block ...
+    std::vector<uint8_t> mask;               // ... and which of its bytes a block of this circuit must repeat (0xff / 0)
+    std::vector<uint32_t> row_off;           // byte offset of every table row, in stream order
+    std::vector<Chunk> chunks;               // (only in the parser's recording skeleton: build() turns it into mask + row_off)
     std::vector<uint32_t> gf_off;            // global id fields in stream order: byte offset | 1 << 31 for 4-byte ids
     std::vector<uint32_t> gf_canon;          // index of the first field that names the same wire (the repeat pattern)
     std::vector<uint32_t> in_gf, out_gf;     // field of input k (its first read) / of the k-th global write
     std::vector<uint8_t> out_live;           // 0: a later gate of the block writes the same wire (streaming.Set: last wins)
-    // the chunk list cut into segments of about equal length with their start positions, so that several threads can
-    // compare / copy side by side (SkelPool)
+    // the block cut into segments of about equal length, so that several threads can compare / copy side by side (SkelPool)
     struct Seg {
-        uint32_t c0, c1;   // chunks [c0, c1)
-        size_t byte_off;   // where c0 starts in the block
-        uint32_t row_off;  // rows in front of c0
+        size_t b0, b1;     // bytes [b0, b1)
+        uint32_t r0, r1;   // rows [r0, r1): the rows that start inside [b0, b1)
     };
     std::vector<Seg> segs;
-    void build_segs() {
+    size_t held() const { return bytes.size() + mask.size() + row_off.size() * sizeof(uint32_t); }
+    // mask, row offsets and segments from the parser's chunk list (bytes already holds the block)
+    void build(const std::vector<Chunk> &ch) {
+        mask.assign(bytes.size(), 0);
+        row_off.clear();
         segs.clear();
-        const uint32_t n = (uint32_t)chunks.size(), per = n / 8 >= 2048 ? n / 8 : n ? n : 1;
+        const uint32_t n = (uint32_t)ch.size(), per = n / 8 >= 2048 ? n / 8 : n ? n : 1;
         size_t off = 0;
-        uint32_t rows = 0;
         for (uint32_t c = 0; c < n; c++) {
             if (c % per == 0 && (segs.empty() || n - c >= per / 2)) {
-                if (!segs.empty()) segs.back().c1 = c;
-                segs.push_back(Seg{c, n, off, rows});
+                if (!segs.empty()) segs.back().b1 = off, segs.back().r1 = (uint32_t)row_off.size();
+                segs.push_back(Seg{off, bytes.size(), (uint32_t)row_off.size(), 0});
             }
-            off += (size_t)chunks[c].cmp + chunks[c].skip + 16u * (size_t)chunks[c].nrows;
-            rows += chunks[c].nrows;
+            std::memset(mask.data() + off, 0xff, ch[c].cmp);
+            off += (size_t)ch[c].cmp + ch[c].skip;
+            for (uint32_t r = 0; r < ch[c].nrows; r++, off += 16) row_off.push_back((uint32_t)off);
         }
-        if (segs.empty()) segs.push_back(Seg{0, 0, 0, 0});
+        if (segs.empty()) segs.push_back(Seg{0, bytes.size(), 0, 0});
+        segs.back().b1 = bytes.size(), segs.back().r1 = (uint32_t)row_off.size();
     }
-    // chunks [c0, c1) of `buf` against the reference: equal outside the global ids and the rows?  rows -> slab
+    // segment sg of `buf` against the reference: equal outside the global ids and the rows?  rows -> slab
     bool match_seg(const Seg &sg, const uint8_t *buf, gc_label *slab) const {
-        const uint8_t *p = buf + sg.byte_off, *q = bytes.data() + sg.byte_off;
-        size_t nr = sg.row_off;
-        for (uint32_t ci = sg.c0; ci < sg.c1; ci++) {
-            const Chunk &c = chunks[ci];
-            uint64_t acc = 0;
-            uint32_t i = 0;
-            for (; i + 8 <= c.cmp; i += 8) {
-                uint64_t x, y;
-                std::memcpy(&x, p + i, 8);
-                std::memcpy(&y, q + i, 8);
-                acc |= x ^ y;
-            }
-            if (i < c.cmp) {
-                if (c.cmp >= 8) {  // the last, partial word: re-read the run's final 8 bytes
-                    uint64_t x, y;
-                    std::memcpy(&x, p + c.cmp - 8, 8);
-                    std::memcpy(&y, q + c.cmp - 8, 8);
-                    acc |= x ^ y;
-                } else {
-                    for (; i < c.cmp; i++) acc |= (uint64_t)(p[i] ^ q[i]);
-                }
-            }
-            if (acc) return false;
-            p += c.cmp + c.skip;
-            q += c.cmp + c.skip;
-            if (slab)
-                for (uint32_t r = 0; r < c.nrows; r++, p += 16) slab[nr++] = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
-            else
-                p += 16u * c.nrows;
-            q += 16u * c.nrows;
-        }
+        if (!skel_simd::same(buf + sg.b0, bytes.data() + sg.b0, mask.data() + sg.b0, sg.b1 - sg.b0)) return false;
+        if (slab) skel_simd::rows(buf, row_off.data() + sg.r0, sg.r1 - sg.r0, slab + sg.r0);
         return true;
     }
     // the table rows of a block that matched this skeleton with slab == nullptr, into dst (host order)
-    void copy_rows(const uint8_t *buf, gc_label *dst) const {
-        const uint8_t *p = buf;
-        for (const Chunk &c : chunks) {
-            p += c.cmp + c.skip;
-            for (uint32_t r = 0; r < c.nrows; r++, p += 16) *dst++ = gc_label{skel_load_be64(p), skel_load_be64(p + 8)};
-        }
-    }
+    void copy_rows(const uint8_t *buf, gc_label *dst) const { skel_simd::rows(buf, row_off.data(), row_off.size(), dst); }
 };
 
 // Helper threads for the skeleton match of a big block (a 131 072-gate block is ~33 000 compare runs and 43 000 rows: 0.42 ms
@@ -2631,7 +2596,7 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
                     std::vector<EvalSkel> &v = kv.second;
                     for (size_t i = v.size(); i-- > 0;)
                         if (v[i].ent && v[i].ent->circ == gone) {
-                            e->skel_bytes -= std::min(e->skel_bytes, v[i].bytes.size());
+                            e->skel_bytes -= std::min(e->skel_bytes, v[i].held());
                             v.erase(v.begin() + (long)i);
                         }
                 }
@@ -2675,12 +2640,12 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     e->n_parsed++;
     constexpr size_t kSkelVariants = 32;
     constexpr size_t kSkelCap = (size_t)1 << 30;  // beyond 1 GiB of reference blocks every new circuit is parsed each time
-    if (e->use_skels && rec_ok && e->skel_bytes + pos <= kSkelCap) {
+    if (e->use_skels && rec_ok && e->skel_bytes + 2 * pos <= kSkelCap) {
         std::vector<EvalSkel> &v = e->skels[((uint64_t)ngates << 32) | ntmp];
         // one circuit serialises differently with the widths of the ids it is bound to (per gate: 16-bit ids if all of the
         // gate's are <= 0xffff) and with operands that repeat: an adder of a mixed program shows up in a dozen forms
         if (v.size() >= kSkelVariants) {
-            e->skel_bytes -= v.back().bytes.size();
+            e->skel_bytes -= std::min(e->skel_bytes, v.back().held());
             v.pop_back();
         }
         EvalSkel sk;
@@ -2688,12 +2653,11 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         sk.nrows = (uint32_t)nrows, sk.nin = nin, sk.nout = nout;
         sk.ent = ent;
         sk.bytes.assign(buf, buf + pos);
-        sk.chunks = rec.chunks;
-        sk.build_segs();
+        sk.build(rec.chunks);
         sk.gf_off = rec.gf_off;
         sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
         if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) {
-            e->skel_bytes += sk.bytes.size();
+            e->skel_bytes += sk.held();
             v.insert(v.begin(), std::move(sk));
         }
     }
