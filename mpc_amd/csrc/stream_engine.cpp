@@ -2300,9 +2300,9 @@ void gc_stream_eval_free(gc_stream_eval *e) {
     }
     for (int i = 0; i < (int)gc_stream_eval::kEvalRing; i++) {
         if (e->up_ev[i]) (void)hipEventDestroy(e->up_ev[i]);
-        if (e->slab_pin[i]) (void)hipHostFree(e->slab_pin[i]);
+        gc::ctx_buf_put(e->ctx, true, e->slab_pin[i], e->slab_cap[i] * sizeof(gc_label));
         if (e->slab_ev[i]) (void)hipEventDestroy(e->slab_ev[i]);
-        if (e->io_pin[i]) (void)hipHostFree(e->io_pin[i]);
+        gc::ctx_buf_put(e->ctx, true, e->io_pin[i], e->io_pin_cap[i] * sizeof(uint32_t));
         if (e->io_dev[i]) (void)hipFree(e->io_dev[i]);
     }
     e->store.release();
@@ -2383,12 +2383,13 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
         if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
         else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the pass of the block kEvalRing calls ago (long done)
         const size_t want = (size_t)ngates * 3 + 1;
-        if (e->slab_cap[sb] < want) {
-            if (e->slab_pin[sb]) (void)hipHostFree(e->slab_pin[sb]);
-            e->slab_pin[sb] = nullptr;
-            e->slab_cap[sb] = 0;
-            GC_HIP(hipHostMalloc((void **)&e->slab_pin[sb], (want + want / 2) * sizeof(gc_label), hipHostMallocDefault));
-            e->slab_cap[sb] = want + want / 2;
+        if (e->slab_cap[sb] < want) {  // (from the ctx's lists: a stream's evaluator finds the buffers of the one before it)
+            uint8_t *p = (uint8_t *)e->slab_pin[sb];
+            size_t cap = e->slab_cap[sb] * sizeof(gc_label);
+            const hipError_t eg = grow_pin(e->ctx, &p, &cap, want * sizeof(gc_label));
+            e->slab_pin[sb] = (gc_label *)p;
+            e->slab_cap[sb] = cap / sizeof(gc_label);
+            GC_HIP(eg);
         }
     }
     gc_label *slab = small_block ? e->rows_scratch.data() : e->slab_pin[sb];
@@ -2845,11 +2846,11 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             // this ring entry's pinned staging and device copy (free: slab_ev[sb] was waited for above); rows and wire maps
             // go up on the upload stream, behind the last pass that read this table buffer, and the ctx stream waits for them
             if (e->io_pin_cap[sb] < nio_alloc) {
-                if (e->io_pin[sb]) (void)hipHostFree(e->io_pin[sb]);
-                e->io_pin[sb] = nullptr;
-                e->io_pin_cap[sb] = 0;
-                er = hipHostMalloc((void **)&e->io_pin[sb], (nio_alloc + nio_alloc / 2) * sizeof(uint32_t), hipHostMallocDefault);
-                if (er == hipSuccess) e->io_pin_cap[sb] = nio_alloc + nio_alloc / 2;
+                uint8_t *p = (uint8_t *)e->io_pin[sb];
+                size_t cap = e->io_pin_cap[sb] * sizeof(uint32_t);
+                er = grow_pin(ctx, &p, &cap, nio_alloc * sizeof(uint32_t));
+                e->io_pin[sb] = (uint32_t *)p;
+                e->io_pin_cap[sb] = cap / sizeof(uint32_t);
             }
             if (er == hipSuccess) er = grow(&e->io_dev[sb], &e->io_dev_cap[sb], nio_alloc);
             if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
