@@ -1,0 +1,35 @@
+"""The reference's TestDeterministicTranscript (sha2pc/sha2pc_test.go:73-130) with the HIP engine as `Circuit.Garble`: the
+SHA-256 of the encoded round 3 — garbling key, all 42 914 table labels of sha256xor.mpclc, input labels, output wires, OT
+ciphertexts — must be the constants the Go tests hold (`expRound3`, :123; `idemRound3Hash`, :415).  No oracle in between: GPU bytes against Go's."""
+import pytest
+
+from mpc_amd import engine
+
+import go_transcript as gt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("case,schedule", [("transcript", None), ("transcript", 0), ("transcript", 1), ("transcript", 2),
+                                           ("idempotency", None)])
+def test_round3_bytes_equal_the_go_constant(ctx, sha_circ, case, schedule):
+    dc = engine.DeviceCircuit(ctx, sha_circ, schedule=schedule)
+
+    def garble(key, rnd):
+        g = dc.garble(key, rnd, batch=1)  # gc_garble: the C ABI under Circuit.Garble (include/gcengine.h)
+        io = g["io"][0]
+        return {"in": io[:512], "out": io[512:]}, g["slab"][0]
+
+    t = gt.transcript(sha_circ, garble, case)
+    dc.close()
+    want = gt.CASES[case][1]
+    assert (t["round1"], t["round2"]) == want[:2]
+    assert len(t["round3_bytes"]) == gt.ROUND3_LEN
+    assert t["round3"] == want[2]
