@@ -16,9 +16,14 @@
  * vectors of ot/mitccrh_test.go:23-30, the label arithmetic values of
  * ot/label_test.go:40-92, mul128 identities of ot/mul128_test.go, the decoded
  * digest of sha2pc/sha2pc_test.go:124 and the slab size of sha2pc/params.go:26.
- * The reference's transcript hashes (sha2pc_test.go:121-124) need Go's
- * math/rand + P-256 and are NOT reproducible here: table bytes are pinned by
- * construction + the KATs above, not by a Go-generated transcript.
+ * Garbled-table BYTES are pinned by the reference's own transcript hashes
+ * (sha2pc/sha2pc_test.go:121-123 and :413-415: SHA-256 of the encoded round 3 —
+ * key, all 42 914 table labels of sha256xor.mpclc, input labels, output wires,
+ * OT ciphertexts — of two deterministic runs): tests/go_transcript.py replays
+ * those tests without Go (math/rand's seed table recomputed from its
+ * definition, crypto/rand.Int, P-256, the sha2pc encodings) with orc_garble as
+ * Circuit.Garble, and both constants come out (tests/test_go_transcript.py);
+ * tests/test_gpu_go_transcript.py does the same with the HIP engine.
  */
 #ifndef GC_ORACLE_H
 #define GC_ORACLE_H

@@ -286,3 +286,37 @@ def transcript(circ, garble, case="transcript", cooked=None):
     h = lambda x: hashlib.sha256(x).hexdigest()
     return {"round1": h(r1), "round2": h(r2), "round3": h(r3), "round3_bytes": r3, "key": key, "ciphertexts": cts,
             "scalars": scalars, "A": session["A"]}
+
+
+def evaluator_round4(t, evaluate):
+    """EvaluatorRound4 (evaluator.go:64-113) on the encoded round 3 of transcript(): DecodeRound3, DecryptCOCiphertexts
+    (co_helpers.go:194-219), Circuit.Eval, BitFromLabel against the output hints -> the digest (hex).
+    evaluate(key, slab {d0, d1}[42914], inputs {d0, d1}[512]) -> output labels {d0, d1}[256]"""
+    label = np.dtype([("d0", "<u8"), ("d1", "<u8")])
+
+    def labels(raw):
+        be = np.frombuffer(raw, ">u8").reshape(-1, 2)
+        out = np.zeros(len(be), label)
+        out["d0"], out["d1"] = be[:, 0], be[:, 1]
+        return out
+
+    r3 = t["round3_bytes"]
+    assert r3[:2] == b"R3" and len(r3) == ROUND3_LEN
+    key, off = r3[10:42], 42
+    slab = labels(r3[off:off + 42914 * 16])
+    off += 42914 * 16
+    inputs = np.zeros(512, label)
+    inputs[:256] = labels(r3[off:off + 4096])
+    hints = labels(r3[off + 4096:off + 4096 + 8192]).reshape(256, 2)
+    cts = r3[off + 4096 + 8192:]
+    b_bits = bits_little(bytes(32 - i for i in range(32)))
+    for idx in range(256):
+        mask = derive_mask(scalar_mult(t["A"], t["scalars"][idx]), idx)
+        ct = cts[32 * idx + 16:32 * idx + 32] if b_bits[idx] else cts[32 * idx:32 * idx + 16]
+        inputs[256 + idx] = labels(bytes(x ^ y for x, y in zip(mask[:16], ct)))[0]
+    out = evaluate(key, slab, inputs)
+    bits = []
+    for j in range(256):
+        assert out[j] == hints[j, 0] or out[j] == hints[j, 1], "output label %d is neither of the wire's labels" % j
+        bits.append(1 if out[j] == hints[j, 1] else 0)
+    return bytes(sum(bits[8 * i + k] << k for k in range(8)) for i in range(32)).hex()

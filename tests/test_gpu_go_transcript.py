@@ -28,8 +28,10 @@ def test_round3_bytes_equal_the_go_constant(ctx, sha_circ, case, schedule):
         return {"in": io[:512], "out": io[512:]}, g["slab"][0]
 
     t = gt.transcript(sha_circ, garble, case)
-    dc.close()
     want = gt.CASES[case][1]
     assert (t["round1"], t["round2"]) == want[:2]
     assert len(t["round3_bytes"]) == gt.ROUND3_LEN
     assert t["round3"] == want[2]
+    # EvaluatorRound4 with gc_eval as Circuit.Eval: the digest the Go tests expect (`expFinal`, :124)
+    assert gt.evaluator_round4(t, lambda key, slab, inputs: dc.eval(key, slab, inputs=inputs[None, :], batch=1)[0]) == gt.EXP_FINAL
+    dc.close()
