@@ -19,7 +19,8 @@ import (
 // SOURCE ONLY (no Go toolchain in the build image).  Device twin of circuit.StreamEval
 // (circuit/stream_evaluator.go:29-96) and of the per-gate loop of StreamEvaluator's OpCircuit case
 // (stream_evaluator.go:270-432).  StreamEvaluator itself (framing, OT, OpResult / OpReturn handling) is unchanged: it
-// keeps calling NewStreamEval, Set, SetInputs, Get, and — in place of InitCircuit + the gate loop — evalBlock.
+// keeps calling NewStreamEval, Set, SetInputs, Get, and — in place of InitCircuit + the gate loop — evalBlock; with one more
+// line at the top of its loop (evalBuffered) whole buffers of blocks go to the device at once.
 
 // StreamEval is a streaming garbled circuit evaluator.
 type StreamEval struct {
@@ -132,6 +133,40 @@ func (stream *StreamEval) evalBlock(conn *p2p.Conn, numGates, numTmpWires, numWi
 		return statusError(st)
 	}
 	return nil
+}
+
+// evalBuffered is the faster front of the OpCircuit case: called where StreamEvaluator is about to read the next operation
+// word (stream_evaluator.go:227), it hands everything the connection has buffered to gc_stream_eval_blocks, which evaluates
+// the whole OpCircuit blocks in it (their 20-byte headers included) and says how far it got; the loop then continues with
+// whatever operation is next — OpReturn, or an OpCircuit block that did not fit (evalBlock collects that one gate by gate).
+// lastStep is the step number of the last block evaluated, for the progress report (:251-268).
+func (stream *StreamEval) evalBuffered(conn *p2p.Conn) (blocks int, err error) {
+	for {
+		have := conn.ReadEnd - conn.ReadStart
+		if have < 4 {
+			return blocks, nil // (the caller's ReceiveUint32 fills the buffer)
+		}
+		var consumed C.size_t
+		var n C.uint32_t
+		var more C.int
+		st := C.gc_stream_eval_blocks(stream.h, (*C.uint8_t)(unsafe.Pointer(&conn.ReadBuf[conn.ReadStart])), C.size_t(have),
+			&consumed, &n, &more)
+		conn.ReadStart += int(consumed)
+		blocks += int(n)
+		if st != C.GC_OK {
+			return blocks, statusError(st)
+		}
+		if more == 0 {
+			return blocks, nil // the next operation is not an OpCircuit block
+		}
+		if consumed == 0 && have == len(conn.ReadBuf) {
+			return blocks, nil // a block larger than the read buffer: evalBlock takes it
+		}
+		// a block that ends beyond the buffered bytes: move it to the front and read on (p2p/protocol.go:150-170)
+		if err := conn.Fill(conn.ReadEnd - conn.ReadStart + 1); err != nil {
+			return blocks, err
+		}
+	}
 }
 
 // Stats reports how many OpCircuit blocks were decoded gate by gate and how many were recognised as a block seen before

@@ -317,6 +317,18 @@ int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /*
  * nothing is sized by it before these checks, and allocation failures come back as GC_E_NOMEM. */
 int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
                            size_t len, size_t *consumed);
+/* The framing loop of StreamEvaluator around that (stream_evaluator.go:226-270) for as many WHOLE OpCircuit blocks as buf holds
+ * (additive).  buf starts at an operation word: 4 bytes big-endian, OpCircuit = 1, then step, numGates, numTmpWires, numWires
+ * (compiler/ssa/streamer.go:679-693), then the gates.  Block after block is evaluated as gc_stream_eval_circuit would; the call
+ * stops in front of the first operation that is not OpCircuit (OpReturn: the caller reads the result wires) and in front of
+ * a block that ends beyond len — then *more = 1: bring more bytes and call again from *consumed, or, if none can come, the
+ * stream is truncated (what gc_stream_eval_circuit reports as GC_E_ROWS).  *consumed = bytes used, *nblocks = blocks
+ * evaluated (both also when an error is returned: the blocks before the bad one are done); nblocks / more may be NULL.
+ * A Go host hands over conn.ReadBuf[ReadStart:ReadEnd] (p2p/protocol.go:29-35, 1 MiB) instead of collecting one block gate
+ * by gate; buf is only read during the call.  (A thread comparing the blocks ahead with their byte skeletons while this one
+ * queues the ones before was built and measured: +7 % with the whole stream in one call, -25 % in 1 MiB pieces — the rows
+ * then reach the queueing thread from another core's cache — and removed.) */
+int gc_stream_eval_blocks(gc_stream_eval *, const uint8_t *buf, size_t len, size_t *consumed, uint32_t *nblocks, int *more);
 /* Blocks handed to gc_stream_eval_circuit so far: parsed[0] gate by gate, parsed[1] recognised as a block seen before up
  * to its table rows and the global wires it is bound to (same op / flag bytes and tmp ids at the same offsets, global ids
  * repeating in the same pattern): those are not decoded again.  Either pointer may be NULL.  (GC_STREAM_NO_SKELETON in the

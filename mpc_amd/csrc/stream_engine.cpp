@@ -2152,7 +2152,8 @@ struct gc_stream_eval {
     std::vector<CircKey> keys;        // the block's gates as packed records {in0, in1, out, op}
     std::vector<uint64_t> dst_pack;   // per gate: destination index | tmp flag << 32 (parser scratch, kept across calls)
     std::vector<uint32_t> in_idx, id_of;
-    std::unordered_map<uint64_t, std::vector<EvalSkel>> skels;  // by (ngates, ntmp); a few byte layouts per key
+    // by (ngates, ntmp); a few byte layouts per key, most recently matched first (behind pointers: the order changes often)
+    std::unordered_map<uint64_t, std::vector<std::unique_ptr<EvalSkel>>> skels;
     std::vector<uint32_t> gf_ids, wr_ids;   // scratch: the block's global ids by field / the wires it writes
     EvalSkel rec;                           // skeleton of the block being parsed (kept when the parse succeeds)
     bool use_skels = true;                  // GC_STREAM_NO_SKELETON (read at creation): every block is parsed
@@ -2346,9 +2347,13 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
     return gc::on_exception();
 }
 
-int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
-                           size_t len, size_t *consumed) try {
-    if (!e || (!buf && len) || !consumed) return GC_E_ARG;
+}  // extern "C"
+
+namespace {
+
+// One OpCircuit block (gc_stream_eval_circuit; block after block in gc_stream_eval_blocks)
+int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf, size_t len,
+               size_t *consumed) {
     *consumed = 0;
     // The block comes from the peer: bound it before anything is sized by it.  A gate is at least 5 bytes (op + two
     // 16-bit ids), so a header that announces more gates than the bytes can hold is a truncated stream; global wire
@@ -2437,32 +2442,37 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     std::vector<uint32_t> &gf_ids = e->gf_ids, &wr_ids = e->wr_ids;
     // ---- a block seen before, up to its rows and global ids?
     {
-        auto it = e->skels.find(((uint64_t)ngates << 32) | ntmp);
-        if (e->use_skels && it != e->skels.end())
+        // the skeleton's bookkeeping for a block that equals it byte-wise: the ids at their known offsets, in the skeleton's
+        // repeat pattern?
+        auto adopt = [&](const EvalSkel &sk) {
+            if (!canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) return false;
+            ent = sk.ent;
+            nin = sk.nin, nout = sk.nout;
+            nrows = sk.nrows;
+            pos = sk.nbytes;
+            e->io_host.resize((size_t)nin + nout + 1);
+            for (uint32_t k = 0; k < nin; k++) e->io_host[k] = gf_ids[sk.in_gf[k]];
+            wr_ids.resize(nout);
+            for (uint32_t k = 0; k < nout; k++) {
+                wr_ids[k] = gf_ids[sk.out_gf[k]];
+                e->io_host[nin + k] = sk.out_live[k] ? wr_ids[k] : 0xffffffffu;
+            }
+            // (a small block's rows are copied ONCE, into the upload region of the group it joins — below)
+            if (small_block) rows_from = &sk;
+            return true;
+        };
+        auto it = e->skels.end();
+        if (e->use_skels && (it = e->skels.find(((uint64_t)ngates << 32) | ntmp)) != e->skels.end()) {
             for (size_t si = 0; si < it->second.size(); si++) {
-                const EvalSkel &sk = it->second[si];
+                const EvalSkel &sk = *it->second[si];
                 if (sk.nbytes > len) continue;
-                // (a small block's rows are copied ONCE, into the upload region of the group it joins — below)
-                const bool same = e->pool.match(sk, buf, small_block ? nullptr : slab);
-                const size_t nr = sk.nrows;
-                if (!same || !canon_of(sk.gf_off, &gf_ids, sk.gf_canon.data(), nullptr)) continue;
-                ent = sk.ent;
-                nin = sk.nin, nout = sk.nout;
-                nrows = nr;
-                pos = sk.nbytes;
-                e->io_host.resize((size_t)nin + nout + 1);
-                for (uint32_t k = 0; k < nin; k++) e->io_host[k] = gf_ids[sk.in_gf[k]];
-                wr_ids.resize(nout);
-                for (uint32_t k = 0; k < nout; k++) {
-                    wr_ids[k] = gf_ids[sk.out_gf[k]];
-                    e->io_host[nin + k] = sk.out_live[k] ? wr_ids[k] : 0xffffffffu;
-                }
+                if (!e->pool.match(sk, buf, small_block ? nullptr : slab) || !adopt(sk)) continue;
                 // most recently matched first: the variants of a circuit (which operands have 16-bit ids, which repeat) are
                 // tried in that order and the least recently matched one goes when there are too many
                 if (si) std::rotate(it->second.begin(), it->second.begin() + (long)si, it->second.begin() + (long)si + 1);
-                if (small_block) rows_from = &it->second[0];
                 break;
             }
+        }
     }
     if (ent) {
         e->n_matched++;
@@ -2594,10 +2604,10 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
             for (auto &rb : e->ring_batch) rb = nullptr;
             cache_make_room(e->cache, &e->cache_gates, e->cache_budget, (size_t)ngates + 1, [&](gc_circ *gone) {
                 for (auto &kv : e->skels) {
-                    std::vector<EvalSkel> &v = kv.second;
+                    auto &v = kv.second;
                     for (size_t i = v.size(); i-- > 0;)
-                        if (v[i].ent && v[i].ent->circ == gone) {
-                            e->skel_bytes -= std::min(e->skel_bytes, v[i].held());
+                        if (v[i]->ent && v[i]->ent->circ == gone) {
+                            e->skel_bytes -= std::min(e->skel_bytes, v[i]->held());
                             v.erase(v.begin() + (long)i);
                         }
                 }
@@ -2642,23 +2652,23 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     constexpr size_t kSkelVariants = 32;
     constexpr size_t kSkelCap = (size_t)1 << 30;  // beyond 1 GiB of reference blocks every new circuit is parsed each time
     if (e->use_skels && rec_ok && e->skel_bytes + 2 * pos <= kSkelCap) {
-        std::vector<EvalSkel> &v = e->skels[((uint64_t)ngates << 32) | ntmp];
+        auto &v = e->skels[((uint64_t)ngates << 32) | ntmp];
         // one circuit serialises differently with the widths of the ids it is bound to (per gate: 16-bit ids if all of the
         // gate's are <= 0xffff) and with operands that repeat: an adder of a mixed program shows up in a dozen forms
         if (v.size() >= kSkelVariants) {
-            e->skel_bytes -= std::min(e->skel_bytes, v.back().held());
+            e->skel_bytes -= std::min(e->skel_bytes, v.back()->held());
             v.pop_back();
         }
-        EvalSkel sk;
-        sk.nbytes = pos;
-        sk.nrows = (uint32_t)nrows, sk.nin = nin, sk.nout = nout;
-        sk.ent = ent;
-        sk.bytes.assign(buf, buf + pos);
-        sk.build(rec.chunks);
-        sk.gf_off = rec.gf_off;
-        sk.in_gf = rec.in_gf, sk.out_gf = rec.out_gf, sk.out_live = rec.out_live;
-        if (canon_of(sk.gf_off, &gf_ids, nullptr, &sk.gf_canon)) {
-            e->skel_bytes += sk.held();
+        std::unique_ptr<EvalSkel> sk(new EvalSkel);
+        sk->nbytes = pos;
+        sk->nrows = (uint32_t)nrows, sk->nin = nin, sk->nout = nout;
+        sk->ent = ent;
+        sk->bytes.assign(buf, buf + pos);
+        sk->build(rec.chunks);
+        sk->gf_off = rec.gf_off;
+        sk->in_gf = rec.in_gf, sk->out_gf = rec.out_gf, sk->out_live = rec.out_live;
+        if (canon_of(sk->gf_off, &gf_ids, nullptr, &sk->gf_canon)) {
+            e->skel_bytes += sk->held();
             v.insert(v.begin(), std::move(sk));
         }
     }
@@ -2908,6 +2918,67 @@ int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, ui
     tr.lap("eval: enqueue");
     *consumed = pos;
     return GC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gc_stream_eval_circuit(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
+                           size_t len, size_t *consumed) try {
+    if (!e || (!buf && len) || !consumed) return GC_E_ARG;
+    return eval_block(e, ngates, ntmp, nwires, buf, len, consumed);
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_eval_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, size_t *consumed, uint32_t *nblocks,
+                          int *more) try {
+    if (!e || (!buf && len) || !consumed) return GC_E_ARG;
+    *consumed = 0;
+    if (nblocks) *nblocks = 0;
+    if (more) *more = 0;
+    auto be32 = [](const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; };
+    size_t pos = 0;
+    uint32_t n = 0;
+    int rc = GC_OK;
+    bool cut = false;
+    while (len - pos >= 20 && be32(buf + pos) == 1 /* OpCircuit, stream_evaluator.go:22-26 */) {
+        const uint32_t ngates = be32(buf + pos + 8), ntmp = be32(buf + pos + 12), nwires = be32(buf + pos + 16);
+        const uint8_t *body = buf + pos + 20;
+        const size_t avail = len - pos - 20;
+        // The last block of a buffer is, as a rule, cut off.  Finding that out by parsing it gate by gate until the bytes run
+        // out costs more than evaluating a whole block: when every known layout of this (gates, tmp wires) key is longer
+        // than what is here and what is here equals the head of one of them, the block is a known one that is not complete.
+        // (A NEW layout that is complete in fewer bytes and shares that head is taken for incomplete as well: the caller
+        // comes back with more bytes — in a well-formed stream something always follows a block — and it is parsed then.)
+        auto it = e->use_skels ? e->skels.find(((uint64_t)ngates << 32) | ntmp) : e->skels.end();
+        if (it != e->skels.end()) {
+            bool fits = false, head = false;
+            for (const auto &sk : it->second) fits = fits || sk->nbytes <= avail;
+            if (!fits)
+                for (const auto &sk : it->second) head = head || skel_simd::same(body, sk->bytes.data(), sk->mask.data(), avail);
+            if (head) {
+                cut = true;
+                break;
+            }
+        }
+        size_t used = 0;
+        rc = eval_block(e, ngates, ntmp, nwires, body, avail, &used);
+        if (rc != GC_OK) break;
+        pos += 20 + used;
+        n++;
+    }
+    // a block that ends beyond the buffer is not an error of this call: the caller brings more bytes, or knows that none come
+    if (rc == GC_E_ROWS) {
+        cut = true;
+        rc = GC_OK;
+    }
+    if (rc == GC_OK && pos < len && (len - pos < 4 || (len - pos < 20 && be32(buf + pos) == 1))) cut = true;  // a header cut in two
+    if (more && cut) *more = 1;
+    *consumed = pos;
+    if (nblocks) *nblocks = n;
+    return rc;
 } catch (...) {
     return gc::on_exception();
 }

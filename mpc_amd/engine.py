@@ -101,6 +101,7 @@ def lib():
         "gc_stream_eval_set_wire": (i32, [vp, u32, vp]),
         "gc_stream_eval_get_wire": (i32, [vp, u32, vp]),
         "gc_stream_eval_circuit": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_eval_blocks": (i32, [vp, vp, sz, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
         "gc_stream_eval_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_batch_create": (vp, [vp, u32, ip]),
         "gc_batch_free": (None, [vp]),
@@ -752,6 +753,15 @@ class StreamEval:
         _check(lib().gc_stream_eval_circuit(self.h, ngates, ntmp, nwires, _p(b), len(data), C.byref(n)),
                "gc_stream_eval_circuit")
         return n.value
+
+    def blocks(self, data):
+        """gc_stream_eval_blocks: framed OpCircuit blocks (20-byte headers included) -> (bytes used, blocks evaluated, more)"""
+        b = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+        n, nb, more = C.c_size_t(0), C.c_uint32(0), C.c_int(0)
+        rc = lib().gc_stream_eval_blocks(self.h, _p(b), len(data), C.byref(n), C.byref(nb), C.byref(more))
+        self.last_blocks = (n.value, nb.value, bool(more.value))  # (also when a block is refused: the ones before it are done)
+        _check(rc, "gc_stream_eval_blocks")
+        return self.last_blocks
 
     def stats(self):
         """(blocks parsed gate by gate, blocks recognised by their byte skeleton)"""

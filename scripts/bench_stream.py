@@ -576,6 +576,9 @@ def run_native(name, key=bytes(range(32)), window=64):
     return {"program": name, "host": "tools/stream_driver (C)", "steps": r["steps"], "window": window, "gates": gates,
             "garble_gates_per_s": gates / r["garble_s"], "garble_us_per_step": r["garble_s"] / r["steps"] * 1e6,
             "eval_gates_per_s": gates / r["eval_s"], "eval_us_per_step": r["eval_s"] / r["steps"] * 1e6,
+            # the framed stream through gc_stream_eval_blocks in pieces of a p2p.Conn read buffer (a helper thread compares ahead)
+            "eval_blocks_gates_per_s": gates / r["eval_blocks_s"] if r.get("eval_blocks_s") else None,
+            "eval_blocks_chunk": r.get("eval_blocks_chunk"),
             "eval_blocks_matched": r["eval_blocks_matched"], "sha256": r["sha256"],
             "eval_steady_us_per_step": r["eval_steady_s"] / max(r["eval_steady_steps"], 1) * 1e6,
             "eval_steady_gates_per_s": gates / r["steps"] * r["eval_steady_steps"] / max(r["eval_steady_s"], 1e-9),
@@ -613,7 +616,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
             r = {"error": str(e)[:200]}
         if r is not None:
-            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
+            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s",
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
                                                       "window", "sha256_ok", "error")}
     if native:

@@ -1208,3 +1208,108 @@ def test_host_api_cooperative_pass_that_loses_a_workgroup_is_repeated(monkeypatc
         assert timeouts >= 1 and state == -1, (state, timeouts)
     check_garble_eval(ctx, c, drbg("coop-host", 32), 1, "coophost2", check_all_wires=False, schedule=1)  # level launches now
     ctx.close()
+
+
+def _framed(steps, blocks):
+    """the stream as the peer frames it (compiler/ssa/streamer.go:679-693): OpCircuit, step, numGates, numTmpWires, numWires"""
+    import struct
+    out, starts = bytearray(), []
+    for k, ((c, in_, out_), data) in enumerate(zip(steps, blocks)):
+        starts.append(len(out))
+        out += struct.pack(">5I", 1, k, c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1) + bytes(data)
+    return bytes(out), starts
+
+
+@pytest.mark.parametrize("threads,piece", [("3", None), ("3", 1 << 20), ("3", 40000), ("0", 70000), ("3", 999)])
+def test_stream_eval_blocks_equals_block_by_block(threads, piece, monkeypatch):
+    """gc_stream_eval_blocks over the framed stream — in one call, in pieces of a conn read buffer, in pieces shorter than most
+    blocks, with and without the thread that compares ahead — leaves the labels of the per-block calls and of the oracle's
+    StreamEval on every wire; a piece that ends inside a block reports `more` and nothing of that block is consumed"""
+    monkeypatch.setenv("GC_STREAM_DEEP_STEPS", "100")
+    monkeypatch.setenv("GC_STREAM_THREADS", threads)
+    ctx = engine.Context(0)
+    steps, prim = _deep_dependency_program(0x300)
+    steps = steps * 3  # (every block form comes back: the later ones are matched by skeleton, ahead of the calling thread)
+    key = drbg("blockskey", 32)
+    rnd = drbg("blocks", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    blocks = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    framed, starts = _framed(steps, blocks)
+    ge, gb, oe = engine.StreamEval(ctx, key), engine.StreamEval(ctx, key), oracle.StreamEval(key)
+    bits = np.frombuffer(drbg("blocksbits", len(prim)), np.uint8) & 1
+    for w, b in zip(prim, bits):
+        wire = og.get(w)
+        lab = wire["l1"] if b else wire["l0"]
+        for ev in (ge, gb, oe):
+            ev.set(w, lab)
+    for (c, in_, out_), data in zip(steps, blocks):
+        nw = max(max(in_), max(out_)) + 1
+        assert ge.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+        assert oe.circuit(c.NumGates, c.NumWires, nw, data) == len(data)
+    # the framed stream + an OpReturn word (2) behind it: the call stops in front of it
+    stream = framed + b"\x00\x00\x00\x02" + b"\x00\x00\x00\x07"
+    pos, done, win, calls = 0, 0, piece or len(stream), 0
+    while done < len(steps):
+        used, nb, more = gb.blocks(stream[pos:pos + win])
+        calls += 1
+        assert pos + used in starts + [len(framed)], "stopped inside a block"
+        if used == 0:
+            assert more, "no progress and no request for more bytes"
+            win *= 2
+        else:
+            win = piece or len(stream)
+        pos, done = pos + used, done + nb
+        assert calls < 100000
+    assert (pos, done) == (len(framed), len(steps))
+    assert gb.blocks(stream[pos:]) == (0, 0, False)  # OpReturn: the caller's
+    for k, (c, in_, out_) in enumerate(steps):
+        for o in out_[::5]:
+            want = oe.get(o)
+            assert ge.get(o) == want and gb.get(o) == want, "step %d (%s) wire %d" % (k, c.name, o)
+    assert sum(gb.stats()) == len(steps) and gb.stats()[1] > 0
+    ctx.sync()
+    ge.close(); gb.close(); ctx.close()
+
+
+def test_stream_eval_blocks_refuses_what_the_block_calls_refuse():
+    """a bad block in the middle of the buffer: the blocks in front of it are evaluated, the error is the per-block call's,
+    *consumed stops at the bad block; a truncated tail is `more`, not an error"""
+    ctx = engine.Context(0)
+    steps, prim = _dependency_program(0)
+    key = drbg("blocksbad", 16)
+    rnd = drbg("blocksbadr", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    blocks = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    framed, starts = _framed(steps, blocks)
+
+    def fresh():
+        ev = engine.StreamEval(ctx, key)
+        for w in prim:
+            ev.set(w, og.get(w)["l0"])
+        return ev
+
+    k = len(steps) // 2
+    bad = bytearray(framed)
+    bad[starts[k] + 20] = (bad[starts[k] + 20] & 0xf0) | 0x0f  # the first gate's operation: none of XOR .. INV
+    ev = fresh()
+    ev.blocks(framed)  # (every block form is known now: the second run matches ahead)
+    with pytest.raises(engine.EngineError) as ei:
+        ev.blocks(bytes(bad))
+    assert ei.value.code == engine.GC_E_GATE
+    assert ev.last_blocks[:2] == (starts[k], k)
+    ev.close()
+    ev = fresh()
+    cut = starts[k] + 20 + len(blocks[k]) // 2
+    assert ev.blocks(framed[:cut]) == (starts[k], k, True)
+    assert ev.blocks(framed[starts[k]:]) == (len(framed) - starts[k], len(steps) - k, False)
+    good = fresh()
+    good.blocks(framed)
+    for c, in_, out_ in steps:
+        for o in out_[::3]:
+            assert ev.get(o) == good.get(o)
+    # a header cut in two, a lone byte
+    assert fresh().blocks(framed[:starts[1] + 7]) == (starts[1], 1, True)
+    assert fresh().blocks(framed[:1]) == (0, 0, True)
+    assert fresh().blocks(b"") == (0, 0, False)
+    ctx.sync()
+    ctx.close()

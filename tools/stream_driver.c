@@ -220,11 +220,66 @@ int main(int argc, char **argv) {
         gc_stream_eval_stats(e, &parsed, &matched);
         gc_stream_eval_free(e);
     }
+    /* The same stream as the peer frames it (compiler/ssa/streamer.go:679-693: OpCircuit, step, numGates, numTmpWires, numWires
+     * in front of every block), handed to gc_stream_eval_blocks in pieces of a p2p.Conn read buffer (1 MiB, p2p/protocol.go:25;
+     * GC_DRIVER_CHUNK bytes): what a Go host does with conn.ReadBuf[ReadStart:ReadEnd] instead of collecting a block gate by
+     * gate.  A piece that ends inside a block is followed by one that starts at that block (a real reader moves the rest to
+     * the front of its buffer and reads on). */
+    double eval_blocks_s = 0;
+    size_t chunk = (size_t)1 << 20;
+    if (getenv("GC_DRIVER_CHUNK")) chunk = (size_t)strtoull(getenv("GC_DRIVER_CHUNK"), NULL, 0);
+    if (chunk < 64) chunk = 64;
+    {
+        const size_t ftotal = total + 20 * (size_t)nsteps;
+        uint8_t *framed = malloc(ftotal ? ftotal : 1);
+        size_t fo = 0, off = 0;
+        for (uint32_t k = 0; k < nsteps; k++) {
+            const circ_t *c = &circ[step[k].circ];
+            const uint32_t hdr[5] = {1u /* OpCircuit */, k, c->ngates, c->nwires, max_wire + 1};
+            for (int i = 0; i < 5; i++) {
+                framed[fo++] = (uint8_t)(hdr[i] >> 24), framed[fo++] = (uint8_t)(hdr[i] >> 16);
+                framed[fo++] = (uint8_t)(hdr[i] >> 8), framed[fo++] = (uint8_t)hdr[i];
+            }
+            memcpy(framed + fo, bytes + off, sizes[k]);
+            fo += sizes[k], off += sizes[k];
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            gc_stream_eval *e = gc_stream_eval_create(ctx, key, keylen, &st);
+            if (!e) DIE("gc_stream_eval_create: %d", st);
+            for (uint32_t i = 0; i < nprim; i++)
+                if (gc_stream_eval_set_wire(e, prim[i], &in0[i])) DIE("gc_stream_eval_set_wire");
+            const double t0 = now_s();
+            size_t pos = 0, win = chunk;
+            uint64_t done = 0;
+            while (pos < ftotal) {
+                const size_t n = ftotal - pos < win ? ftotal - pos : win;
+                size_t used = 0;
+                uint32_t nb = 0;
+                int more = 0;
+                if ((st = gc_stream_eval_blocks(e, framed + pos, n, &used, &nb, &more))) DIE("gc_stream_eval_blocks at byte %zu: %d", pos, st);
+                pos += used, done += nb;
+                if (used == 0) {
+                    if (!more || n == ftotal - pos) DIE("gc_stream_eval_blocks makes no progress at byte %zu (more %d)", pos, more);
+                    win *= 2; /* a block larger than the piece */
+                } else {
+                    win = chunk;
+                }
+            }
+            if (done != nsteps) DIE("gc_stream_eval_blocks evaluated %llu of %u blocks", (unsigned long long)done, nsteps);
+            gc_label probe2 = {0, 0};
+            if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe2)) DIE("gc_stream_eval_get_wire");
+            eval_blocks_s = now_s() - t0;
+            if (probe2.d0 != probe.d0 || probe2.d1 != probe.d1) DIE("gc_stream_eval_blocks: another label than block by block");
+            gc_stream_eval_free(e);
+        }
+        free(framed);
+    }
     printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
+           "\"eval_blocks_s\": %.6f, \"eval_blocks_chunk\": %zu, "
            "\"eval_steady_steps\": %u, \"bytes\": %zu, \"sha256\": \"%s\", "
            "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\", "
            "\"garble_t0\": %.6f, \"garble_t1\": %.6f, \"eval_t0\": %.6f, \"eval_t1\": %.6f}\n",
-           nsteps, window, garble_s, eval_s, eval_steady_s, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
+           nsteps, window, garble_s, eval_s, eval_steady_s, eval_blocks_s, chunk, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
            (unsigned long long)probe.d0, g_t0, g_t1, e_t0, e_t1);
     gc_ctx_destroy(ctx);
     return 0;
