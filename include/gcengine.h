@@ -313,7 +313,8 @@ int gc_stream_eval_set_wire(gc_stream_eval *, uint32_t w, const gc_label *l); /*
 int gc_stream_eval_get_wire(gc_stream_eval *, uint32_t w, gc_label *l);       /* OpReturn / OpResult reads */
 /* *consumed = bytes of buf used by the ngates gates; GC_E_GATE "invalid operation", GC_E_ROWS truncated stream (also:
  * more gates announced than len / 5 bytes can hold), GC_E_ARG a tmp wire read before this block wrote it (tmp wires are
- * private to their OpCircuit block), a tmp id >= ntmp or a global wire id >= nwires.  The block is the peer's data:
+ * private to their OpCircuit block), a tmp id >= ntmp or a global wire id >= nwires, and header sizes no compiler
+ * produces: ntmp > 64 ngates + 2^20, nwires > GC_STREAM_MAX_WIRES (default 2^28) — both size arrays.  The block is the peer's data:
  * nothing is sized by it before these checks, and allocation failures come back as GC_E_NOMEM. */
 int gc_stream_eval_circuit(gc_stream_eval *, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf,
                            size_t len, size_t *consumed);

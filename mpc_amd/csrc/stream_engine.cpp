@@ -2351,6 +2351,15 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
 
 namespace {
 
+uint32_t stream_max_wires() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("GC_STREAM_MAX_WIRES");
+        const unsigned long long n = e ? std::strtoull(e, nullptr, 0) : 0;
+        return n ? (uint32_t)std::min<unsigned long long>(n, 0xffffffffull) : (1u << 28);
+    }();
+    return v;
+}
+
 // One OpCircuit block (gc_stream_eval_circuit; block after block in gc_stream_eval_blocks)
 int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf, size_t len,
                size_t *consumed) {
@@ -2360,6 +2369,11 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
     // ids must stay below the numWires of the block's own header (the reference indexes its store with them,
     // stream_evaluator.go:29-96: an id beyond it panics there) and tmp ids below numTmpWires.
     if ((size_t)ngates > len / 5) return GC_E_ROWS;
+    // The header's two sizes are the peer's as well, and both size arrays (the reference's InitCircuit allocates numWires and
+    // numTmpWires labels on the spot, stream_evaluator.go:52-59): a block of n gates names at most 3 n wires, so a numTmpWires
+    // far beyond that is not a compiler's; the global store is bounded by GC_STREAM_MAX_WIRES (default 2^28 wires = 4 GiB of
+    // labels on each side of the bus).
+    if ((uint64_t)ntmp > 64ull * ngates + (1u << 20) || nwires > stream_max_wires()) return GC_E_ARG;
     e->store.ensure(nwires);  // InitCircuit(numWires, numTmpWires)
     if (ngates == 0) return GC_OK;
     StreamTrace tr;

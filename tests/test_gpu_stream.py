@@ -1307,6 +1307,17 @@ def test_stream_eval_blocks_refuses_what_the_block_calls_refuse():
     for c, in_, out_ in steps:
         for o in out_[::3]:
             assert ev.get(o) == good.get(o)
+    # header sizes that would size arrays by the peer's word: refused before anything is allocated
+    import struct
+    for ntmp, nwires in ((0xffffffff, 100), (100, 0xffffffff), (64 * 3 + (1 << 20) + 1, 100)):
+        ev = fresh()
+        with pytest.raises(engine.EngineError) as ei:
+            ev.blocks(struct.pack(">5I", 1, 0, 3, ntmp, nwires) + bytes(64))
+        assert ei.value.code == engine.GC_E_ARG and ev.last_blocks[:2] == (0, 0)
+        with pytest.raises(engine.EngineError) as ei:
+            ev.circuit(3, ntmp, nwires, bytes(64))
+        assert ei.value.code == engine.GC_E_ARG
+        ev.close()
     # a header cut in two, a lone byte
     assert fresh().blocks(framed[:starts[1] + 7]) == (starts[1], 1, True)
     assert fresh().blocks(framed[:1]) == (0, 0, True)
