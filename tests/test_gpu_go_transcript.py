@@ -35,3 +35,33 @@ def test_round3_bytes_equal_the_go_constant(ctx, sha_circ, case, schedule):
     # EvaluatorRound4 with gc_eval as Circuit.Eval: the digest the Go tests expect (`expFinal`, :124)
     assert gt.evaluator_round4(t, lambda key, slab, inputs: dc.eval(key, slab, inputs=inputs[None, :], batch=1)[0]) == gt.EXP_FINAL
     dc.close()
+
+
+def test_round3_from_the_device_pipeline(ctx, sha_circ):
+    """The same constant through the device-resident calls: gc_batch_garble on a device random stream, the table section of
+    round 3 written by gc_batch_egress_tables_dense (sha2pc's encodeGarbledTables, encoding.go:363-411, as a kernel)."""
+    import numpy as np
+    from oracle import LABEL
+    c = sha_circ
+    dc = engine.DeviceCircuit(ctx, c)
+    gb = engine.Batch(dc, 1)
+    gb.set_store_all(True)
+    nbytes = 16 * 42914
+    seen = {}
+
+    def garble(key, rnd):
+        gb.garble(key, ctx.to_device(rnd))
+        d_out = ctx.zeros(nbytes)
+        gb.egress_tables_dense(d_out, nbytes)
+        raw = d_out.numpy().tobytes()
+        seen["raw"] = raw
+        be = np.frombuffer(raw, ">u8").reshape(-1, 2)
+        slab = np.zeros(len(be), LABEL)
+        slab["d0"], slab["d1"] = be[:, 0], be[:, 1]
+        w = gb.read_wires()[0]
+        return {"in": w[:512], "out": w[c.NumWires - 256:]}, slab
+
+    t = gt.transcript(c, garble, "transcript")
+    assert t["round3_bytes"][42:42 + nbytes] == seen["raw"]  # (the device's bytes are what was hashed)
+    assert t["round3"] == gt.CASES["transcript"][1][2]
+    gb.close(); dc.close()
