@@ -163,6 +163,17 @@ func (stream *Streaming) Begin(c *Circuit, in, out []Wire) error {
 	return nil
 }
 
+// Forget gives a circuit's interned device copy back to the engine's bounded cache and lets the *Circuit itself be collected
+// (additive; gc_stream_release).  compiler/ssa's streamer keeps one compiled circuit per instruction shape for the whole run
+// (streamer.go:467-506), so it never needs this; a host that compiles circuits on the fly and drops them does — without it
+// the handles map keeps every Circuit it has ever seen alive and its device copy exempt from eviction.
+func (stream *Streaming) Forget(c *Circuit) {
+	if h, ok := stream.handles[c]; ok {
+		C.gc_stream_release(stream.h, C.uint32_t(h.id))
+		delete(stream.handles, c)
+	}
+}
+
 // Pending is the number of circuits queued by Begin whose bytes Finish has not written out yet.
 func (stream *Streaming) Pending() int { return len(stream.pending) }
 

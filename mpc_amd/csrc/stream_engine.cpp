@@ -1432,20 +1432,33 @@ int gc_stream_intern(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32
         if (b0) gc_circ_release_batch(ent->circ, b0);
         if (b1) gc_circ_release_batch(ent->circ, b1);
     }
-    for (uint32_t i = 0; i < s->handles.size(); i++)
+    uint32_t spare = (uint32_t)s->handles.size();
+    for (uint32_t i = 0; i < s->handles.size(); i++) {
         if (s->handles[i] == ent) {
             *handle = i;
             return GC_OK;
         }
-    s->handles.push_back(ent);
-    *handle = (uint32_t)s->handles.size() - 1;
+        if (!s->handles[i] && spare == s->handles.size()) spare = i;  // (a released handle's number is used again)
+    }
+    if (spare == s->handles.size()) s->handles.push_back(nullptr);
+    s->handles[spare] = ent;
+    *handle = spare;
+    return GC_OK;
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_release(gc_stream *s, uint32_t handle) try {
+    if (!s || handle >= s->handles.size() || !s->handles[handle]) return GC_E_ARG;
+    s->handles[handle]->pinned = false;  // an ordinary cache entry from here on (steps in flight keep using it: eviction
+    s->handles[handle] = nullptr;        // waits for them, stream_find_or_load)
     return GC_OK;
 } catch (...) {
     return gc::on_exception();
 }
 
 int gc_stream_garble_begin_h(gc_stream *s, uint32_t handle, const uint32_t *in, const uint32_t *out) try {
-    if (!s || handle >= s->handles.size()) return GC_E_ARG;
+    if (!s || handle >= s->handles.size() || !s->handles[handle]) return GC_E_ARG;
     CircEntry *ent = s->handles[handle];
     return stream_begin(s, nullptr, (uint32_t)ent->gates.size(), ent->nwires, in, ent->nin, out, ent->nout, ent);
 } catch (...) {

@@ -91,6 +91,7 @@ def lib():
         "gc_stream_garble_flush": (i32, [vp]),
         "gc_stream_intern": (i32, [vp, vp, u32, u32, u32, u32, C.POINTER(C.c_uint32)]),
         "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
+        "gc_stream_release": (i32, [vp, u32]),
         "gc_stream_garble_finish_view": (i32, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
@@ -674,6 +675,10 @@ class Stream:
         if buf is None or len(buf) < need:
             self._buf = np.empty(need + need // 2, np.uint8)
         return h.value
+
+    def release(self, handle):
+        """gc_stream_release: the interned circuit goes back to the bounded cache, the handle is invalid afterwards"""
+        _check(lib().gc_stream_release(self.h, handle), "gc_stream_release")
 
     def garble_begin_h(self, handle, in_, out_):
         """gc_stream_garble_begin_h: queue an interned circuit"""

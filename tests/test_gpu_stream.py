@@ -1324,3 +1324,34 @@ def test_stream_eval_blocks_refuses_what_the_block_calls_refuse():
     assert fresh().blocks(b"") == (0, 0, False)
     ctx.sync()
     ctx.close()
+
+
+def test_stream_released_handles():
+    """gc_stream_release: the circuit goes back to the bounded cache, the handle is refused afterwards and its number is handed
+    out again; a step queued before the release is unaffected"""
+    from mpc_amd.circuit import adder
+    ctx = engine.Context(0)
+    c1, c2 = adder(16), adder(24)
+    prim = list(range(100))
+    key, rnd = drbg("relkey", 16), drbg("rel", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    h1 = gg.intern(c1.Gates, c1.NumWires, c1.num_inputs, c1.num_outputs)
+    h2 = gg.intern(c2.Gates, c2.NumWires, c2.num_inputs, c2.num_outputs)
+    in1, out1 = list(range(c1.num_inputs)), list(range(200, 200 + c1.num_outputs))
+    in2, out2 = list(range(40, 40 + c2.num_inputs)), list(range(300, 300 + c2.num_outputs))
+    gg.garble_begin_h(h1, in1, out1)
+    gg.release(h1)  # (with the step still queued)
+    with pytest.raises(engine.EngineError) as ei:
+        gg.garble_begin_h(h1, in1, out1)
+    assert ei.value.code == engine.GC_E_ARG
+    with pytest.raises(engine.EngineError):
+        gg.release(h1)
+    gg.garble_begin_h(h2, in2, out2)
+    assert gg.garble_finish() == og.garble(c1.Gates, c1.NumWires, in1, out1)
+    assert gg.garble_finish() == og.garble(c2.Gates, c2.NumWires, in2, out2)
+    h3 = gg.intern(c1.Gates, c1.NumWires, c1.num_inputs, c1.num_outputs)  # the same circuit again: found in the cache, a handle of its own
+    assert h3 == h1
+    gg.garble_begin_h(h3, in1, [o + 500 for o in out1])
+    assert gg.garble_finish() == og.garble(c1.Gates, c1.NumWires, in1, [o + 500 for o in out1])
+    ctx.sync()
+    gg.close(); ctx.close()
