@@ -2381,12 +2381,12 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
     // 16-bit ids), so a header that announces more gates than the bytes can hold is a truncated stream; global wire
     // ids must stay below the numWires of the block's own header (the reference indexes its store with them,
     // stream_evaluator.go:29-96: an id beyond it panics there) and tmp ids below numTmpWires.
-    if ((size_t)ngates > len / 5) return GC_E_ROWS;
     // The header's two sizes are the peer's as well, and both size arrays (the reference's InitCircuit allocates numWires and
     // numTmpWires labels on the spot, stream_evaluator.go:52-59): a block of n gates names at most 3 n wires, so a numTmpWires
     // far beyond that is not a compiler's; the global store is bounded by GC_STREAM_MAX_WIRES (default 2^28 wires = 4 GiB of
-    // labels on each side of the bus).
+    // labels on each side of the bus).  (Before the length test: such a block is refused however many of its bytes are here.)
     if ((uint64_t)ntmp > 64ull * ngates + (1u << 20) || nwires > stream_max_wires()) return GC_E_ARG;
+    if ((size_t)ngates > len / 5) return GC_E_ROWS;
     e->store.ensure(nwires);  // InitCircuit(numWires, numTmpWires)
     if (ngates == 0) return GC_OK;
     StreamTrace tr;
@@ -2979,6 +2979,10 @@ int gc_stream_eval_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, siz
         // than what is here and what is here equals the head of one of them, the block is a known one that is not complete.
         // (A NEW layout that is complete in fewer bytes and shares that head is taken for incomplete as well: the caller
         // comes back with more bytes — in a well-formed stream something always follows a block — and it is parsed then.)
+        if ((uint64_t)ntmp > 64ull * ngates + (1u << 20) || nwires > stream_max_wires()) {
+            rc = GC_E_ARG;  // (eval_block's own test, in front of the look at what is here of the block)
+            break;
+        }
         auto it = e->use_skels ? e->skels.find(((uint64_t)ngates << 32) | ntmp) : e->skels.end();
         if (it != e->skels.end()) {
             bool fits = false, head = false;

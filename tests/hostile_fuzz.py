@@ -168,8 +168,12 @@ def programs(big=False, deep=False):
     return out
 
 
-def run(mutants=200, seed=1, big=False, log=None, deep=False):
-    """returns (mutants run, accepted, rejected, by kind) — raises AssertionError on the first violation"""
+def run(mutants=200, seed=1, big=False, log=None, deep=False, framed=False):
+    """returns (mutants run, accepted, rejected, by kind) — raises AssertionError on the first violation.
+    framed: every mutant goes through gc_stream_eval_blocks instead — the 20-byte header (OpCircuit, step, numGates,
+    numTmpWires, numWires) in front, an OpReturn word behind — and one mutant in six also has a header size changed (0, off by
+    a few, 2^31, 2^32 - 1: numTmpWires and numWires size arrays)"""
+    import struct
     rng = np.random.default_rng(seed)
     key = drbg("hostile-key", 32)
     ctx = engine.Context(0)
@@ -221,12 +225,45 @@ def run(mutants=200, seed=1, big=False, log=None, deep=False):
         for q in parse(mut, mng)[0]:
             named |= {v for v in q[4] if v < nw + 64}
         named = sorted(w for w in named if w < (1 << 22))
-        orc, oused, oafter = oracle_on(mut, mng, ntmp, nw, named)
+        tail = b""
+        if framed:
+            tail = struct.pack(">I", 2) + bytes(16)  # OpReturn: the call stops in front of it
+            if rng.integers(0, 6) == 0:
+                if rng.integers(0, 2):
+                    ntmp = int(rng.choice([0, 1, max(ntmp - 1, 0), ntmp + 7, 64 * mng + (1 << 20) + 1, 1 << 31, 0xffffffff]))
+                    what += " + numTmpWires"
+                else:
+                    nw = int(rng.choice([0, max(nw - 1, 0), nw + 1000, (1 << 28) + 1, 0xffffffff]))
+                    what += " + numWires"
+        sized = ntmp > 64 * mng + (1 << 20) or nw > (1 << 28)  # refused by the engine before anything is sized (GC_E_ARG)
+        named = [w for w in named if w < nw]
+        # (the reference reads on from the connection: what follows the mutant belongs to the bytes both sides see)
+        orc, oused, oafter = (-5, None, None) if sized else oracle_on(mut + tail, mng, ntmp, nw, named)
         try:
-            used = ge.circuit(mng, ntmp, nw, mut)
-            erc = 0
+            if framed:
+                used, nb, more = ge.blocks(struct.pack(">5I", 1, m, mng, ntmp, nw) + mut + tail)
+                if more and nb == 0:
+                    erc, used = engine.GC_E_ROWS, None  # (a block that ends beyond the buffer: the per-block call's truncation)
+                elif nb != 1 or more or used - 20 != oused:
+                    # the mutant ends elsewhere than its bytes and what follows reads as another operation word: no reference
+                    # behaviour to compare with beyond "the first block was taken as the oracle takes it"
+                    assert nb >= 1 and orc == 0, "mutant %d (%s): blocks() = %s, oracle %s" % (m, what, (used, nb, more), (orc, oused))
+                    kinds[what + " (ran on)"] = kinds.get(what + " (ran on)", 0) + 1
+                    for w in named:
+                        if w in oafter:
+                            model[w] = ge.get(w)  # (a second pseudo-block may have written it)
+                    continue
+                else:
+                    used, erc = used - 20, 0
+            else:
+                used = ge.circuit(mng, ntmp, nw, mut)
+                erc = 0
         except engine.EngineError as e:
             erc, used = e.code, None
+            if framed and ge.last_blocks[1] > 0:  # the mutant itself was taken; the error is of the bytes behind it
+                erc, used = 0, oused
+        if sized:
+            assert erc == engine.GC_E_ARG, "mutant %d (%s): header sizes beyond the bounds were not refused (%d)" % (m, what, erc)
         kinds[what] = kinds.get(what, 0) + 1
         if erc == 0:
             stats["accepted"] += 1
@@ -238,7 +275,7 @@ def run(mutants=200, seed=1, big=False, log=None, deep=False):
                     assert got == oafter[w], "mutant %d (%s): wire %d differs from the oracle's" % (m, what, w)
                     model[w] = oafter[w]
         else:
-            why = stricter(mut, mng, ntmp, nw)
+            why = "header sizes" if sized else stricter(mut + tail, mng, ntmp, nw)
             if orc != 0:
                 stats["rejected"] += 1
             else:
@@ -279,3 +316,5 @@ if __name__ == "__main__":
         print("threads=%s big blocks (helper-thread skeleton match): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
         r = run(max(50, n // 50), seed + 2, deep=True, log=say)
         print("threads=%s deep blocks (lanes; rows through the upload region / from the pinned ring): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
+        r = run(n // 4, seed + 3, framed=True, log=say)
+        print("threads=%s framed blocks through gc_stream_eval_blocks (header sizes mutated too): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)

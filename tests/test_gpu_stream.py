@@ -1098,7 +1098,7 @@ def test_stream_cooperative_pass_that_loses_a_workgroup_is_repeated(drop_at, mon
     g2.close(); gg.close(); ge.close(); ctx.close()
 
 
-@pytest.mark.parametrize("threads,big", [("0", False), ("3", False), ("3", True), ("0", True), ("3", "deep")])
+@pytest.mark.parametrize("threads,big", [("0", False), ("3", False), ("3", True), ("0", True), ("3", "deep"), ("3", "framed")])
 def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     """a slice of tests/hostile_fuzz.py (10 000 mutants logged in profiles/r04_hostile_fuzz.log): mutated OpCircuit blocks — bit
     flips, truncation, id-width / tmp-flag flips, swapped and replaced ids, row bytes only, gate counts off — through the
@@ -1108,6 +1108,10 @@ def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     monkeypatch.setenv("GC_STREAM_THREADS", threads)
     if big == "deep":  # blocks that run on the deep lanes
         n, stats, kinds, (parsed, matched) = hostile_fuzz.run(30, seed=11, deep=True)
+    elif big == "framed":  # through gc_stream_eval_blocks, header sizes mutated as well
+        n, stats, kinds, (parsed, matched) = hostile_fuzz.run(150, seed=13, framed=True)
+        n = stats["accepted"] + stats["rejected"] + stats["rejected_stricter"]  # (mutants that ran on into the tail are not counted)
+        big = False
     else:
         n, stats, kinds, (parsed, matched) = hostile_fuzz.run(24 if big else 100, seed=7 + int(threads), big=big)
     assert stats["accepted"] + stats["rejected"] + stats["rejected_stricter"] == n and len(kinds) >= (5 if big else 8)
