@@ -350,6 +350,8 @@ def test_stream_evaluator_recognises_repeated_blocks():
     to its rows and global ids (byte skeleton, gc_stream_eval_stats) — a binding with another repeat pattern among
     the ids, other id widths, or a changed byte must take the gate-by-gate path, and every label must equal the
     oracle's StreamEval either way"""
+    if os.environ.get("GC_STREAM_NO_SKELETON"):
+        pytest.skip("the byte skeletons are switched off (GC_STREAM_NO_SKELETON)")
     import os
     from mpc_amd.circuit import synthetic_levelised
     ctx = engine.Context(0)
@@ -1201,6 +1203,8 @@ def test_host_api_cooperative_pass_that_loses_a_workgroup_is_repeated(monkeypatc
     """the same stand-by outside the streams: ONE instance of a wide circuit through the host-buffer calls (gc_garble /
     gc_eval: label exchange by separate kernels, no StoreXchg) with the first cooperative pass forced to lose a workgroup —
     R, tables, every wire and the evaluated labels are the oracle's, nothing fails"""
+    if os.environ.get("GC_NO_COOP"):
+        pytest.skip("the cooperative passes are switched off (GC_NO_COOP)")
     from mpc_amd.circuit import synthetic_levelised
     from tests.test_gpu_garble_eval import check_garble_eval
     monkeypatch.setenv("GC_COOP_FORCE_TIMEOUT", "1")
