@@ -471,7 +471,10 @@ def run(stage):
             "gather_us": gather_us,
             "gather_GBs_per_gpu_received": (int(d_acc.nbytes) * (world - 1) / (gather_us * 1e-6) / 1e9) if gather_us and world > 1 else None,
             "gathers_in_timed_region": loop.gathers,
-            "collective": "ncclAllGather (gc_comm_allgather, RCCL over xGMI), one per %d steps" % K,
+            # (GC_RCCL_PATH: another library under gc_comm_* — tests/standin_rccl puts N ranks on one GPU; its times mean nothing)
+            "collective": ("ncclAllGather (gc_comm_allgather, RCCL over xGMI), one per %d steps" % K) if not os.environ.get("GC_RCCL_PATH")
+                          else "gc_comm_allgather over the library of GC_RCCL_PATH (%s) — NOT RCCL, one per %d steps"
+                               % (os.path.basename(os.environ["GC_RCCL_PATH"]), K),
             "gathered_outputs_ok": ok,
         }
     gb.close()
