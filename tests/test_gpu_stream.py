@@ -352,7 +352,6 @@ def test_stream_evaluator_recognises_repeated_blocks():
     oracle's StreamEval either way"""
     if os.environ.get("GC_STREAM_NO_SKELETON"):
         pytest.skip("the byte skeletons are switched off (GC_STREAM_NO_SKELETON)")
-    import os
     from mpc_amd.circuit import synthetic_levelised
     ctx = engine.Context(0)
     c = synthetic_levelised(6, 40, 0.4, seed=77, ninputs=12, inv_frac=0.1, xnor_frac=0.1)
