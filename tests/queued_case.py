@@ -70,8 +70,9 @@ def run_case(seed, **over):
         rnd = drbg("qr%d" % seed, 16 * (len(prim) + 1))
         og, gg = oracle.Stream(key, rnd, prim), engine.Stream(cx, key, rnd, prim)
         oe, ge = oracle.StreamEval(key), engine.StreamEval(cx, key)
+        first = {}  # (the labels the program starts from: later steps overwrite live wires)
         for w in prim:
-            l = gg.get(w)["l0"]
+            l = first[w] = gg.get(w)["l0"]
             ge.set(w, l); oe.set(w, l)
         want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
         got, issued, handles = [], 0, {}
@@ -96,8 +97,28 @@ def run_case(seed, **over):
             assert oe.circuit(c.NumGates, c.NumWires, nw, b) == len(b)
         for o in pool[::3]:
             assert ge.get(o) == oe.get(o), "%s: evaluated label of wire %d" % (what, o)
+        # the same stream as the peer frames it, through gc_stream_eval_blocks in pieces of a size drawn per case (from "most
+        # blocks are cut" to "all in one call"): the same labels
+        import struct
+        import numpy as np
+        gb = engine.StreamEval(cx, key)
+        for w in prim:
+            gb.set(w, first[w])
+        framed = b"".join(struct.pack(">5I", 1, k, c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1) + bytes(b)
+                          for k, ((c, in_, out_), b) in enumerate(zip(steps, got))) + struct.pack(">I", 2)
+        rng = np.random.default_rng(seed)
+        piece = int(rng.choice([700, 5000, 70000, 1 << 20, len(framed)]))
+        pos, done, win = 0, 0, piece
+        while done < len(steps):
+            used, nb, more = gb.blocks(framed[pos:pos + win])
+            assert used or more, "%s: gc_stream_eval_blocks stopped at byte %d of %d without asking for more" % (what, pos, len(framed))
+            win = piece if used else win * 2
+            pos, done = pos + used, done + nb
+        assert pos == len(framed) - 4, "%s: %d bytes of the framed stream consumed, %d expected" % (what, pos, len(framed) - 4)
+        for o in pool[::3]:
+            assert gb.get(o) == oe.get(o), "%s: label of wire %d after gc_stream_eval_blocks" % (what, o)
         cx.sync()
-        gg.close(); ge.close()
+        gg.close(); ge.close(); gb.close()
     finally:
         cx.close()
         os.environ.pop("GC_STREAM_DEEP_STEPS", None)
