@@ -284,7 +284,8 @@ def transcript(circ, garble, case="transcript", cooked=None):
     r2, points, scalars = evaluator_round2(DeterministicReader(n2, cooked), session["sid"], session["A"], b)
     r3, key, cts = garbler_round3(DeterministicReader(n3, cooked), session, a, points, circ, garble)
     h = lambda x: hashlib.sha256(x).hexdigest()
-    return {"round1": h(r1), "round2": h(r2), "round3": h(r3), "round3_bytes": r3, "key": key, "ciphertexts": cts,
+    return {"round1": h(r1), "round2": h(r2), "round3": h(r3), "round1_len": len(r1), "round2_len": len(r2),
+            "round3_bytes": r3, "key": key, "ciphertexts": cts,
             "scalars": scalars, "A": session["A"]}
 
 
