@@ -1362,3 +1362,15 @@ def test_stream_released_handles():
     assert gg.garble_finish() == og.garble(c1.Gates, c1.NumWires, in1, [o + 500 for o in out1])
     ctx.sync()
     gg.close(); ctx.close()
+
+
+def test_c_host_drives_both_sides_of_a_streamed_program():
+    """tools/stream_driver.c — a plain C host over include/gcengine.h, the calls a cgo shim makes: garbler by handle with a
+    window, evaluator block by block AND the framed stream through gc_stream_eval_blocks in 1 MiB pieces (the driver itself
+    compares the two evaluators' labels); the stream's SHA-256 is the oracle's (tests/golden/stream_bench_golden.json)"""
+    from scripts import bench_stream
+    if not os.path.exists(bench_stream.NATIVE):
+        pytest.skip("tools/stream_driver is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    r = bench_stream.run_native("uniform512", bytes(range(32)), 64)
+    assert r["sha256_ok"] is True and r["steps"] == 4000
+    assert r["eval_blocks_matched"] > 3900 and r["eval_blocks_gates_per_s"] and r["eval_blocks_chunk"] == 1 << 20
