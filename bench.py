@@ -224,7 +224,10 @@ def run(stage):
     stage[0] = "context"
     # one process per GPU: this rank's device, its own HIP stream (GC_BENCH_DEVICE: a probe that puts every rank on one
     # device to see how far the N > 1 path gets on a one-GPU box — RCCL refuses such a communicator)
-    ctx = engine.Context(int(os.environ.get("GC_BENCH_DEVICE", local_rank)))
+    # (a launcher that gives every rank its own HIP_VISIBLE_DEVICES shows each process ONE device, number 0: the local rank is
+    # taken modulo what this process can see)
+    ndev = engine.device_count() if hasattr(engine, "device_count") else 0
+    ctx = engine.Context(int(os.environ.get("GC_BENCH_DEVICE", local_rank % ndev if ndev > 0 else local_rank)))
     collective = world > 1 or args.force_collective
     comm = None
     if collective:  # gc_comm_init_rank: RCCL, one rank per GPU
