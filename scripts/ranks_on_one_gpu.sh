@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/ranks_one_gpu
 mkdir -p $OUT
 SO=/tmp/librccl_standin.so
-hipcc -shared -fPIC -O2 -o $SO $REPO/tests/standin_rccl/standin_rccl.cpp -lrt || exit 1
+hipcc -shared -fPIC -O2 -o $SO $REPO/tests/standin_rccl/standin_rccl.cpp || exit 1
 RDV=$(mktemp -d)
 export WORLD_SIZE=$N MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 TORCHELASTIC_RUN_ID=one_gpu_$$ GC_RENDEZVOUS_DIR=$RDV GC_RCCL_PATH=$SO GC_BENCH_DEVICE=0
 pids=()

@@ -2,11 +2,12 @@
 // environment, id hand-over, gc_comm_init_rank, the gathers behind the decode on the ctx stream, barrier, max-over-ranks,
 // the JSON line — on a box with ONE GPU, where RCCL itself refuses a communicator ("Duplicate GPU detected").  TEST
 // INFRASTRUCTURE (tests/test_gpu_two_ranks.py selects it with GC_RCCL_PATH): it implements the ten entry points comm.cpp binds,
-// for the ranks of one node, through a POSIX shared-memory segment named by the unique id; every collective is synchronous
+// for the ranks of one node, through a shared mapping of a file under TMPDIR named by the unique id (a file, not /dev/shm:
+// containers keep that one small); every collective is synchronous
 // (stream sync, device -> segment, barrier, segment -> device, barrier), so its TIMES mean nothing — what it shows is that
 // everything around the collective library works with more than one rank.  Not RCCL, not a transport: no xGMI involved.
 //
-//   hipcc -shared -fPIC -O2 -o tests/standin_rccl/librccl_standin.so tests/standin_rccl/standin_rccl.cpp
+//   hipcc -shared -fPIC -O2 -o /tmp/librccl_standin.so tests/standin_rccl/standin_rccl.cpp
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -16,6 +17,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -34,7 +36,7 @@ struct Comm {
     Seg *seg = nullptr;
     size_t bytes = 0;
     int rank = 0, nranks = 0;
-    char name[64] = "";
+    char name[256] = "";
 };
 
 bool wait_until(const std::atomic<uint32_t> &v, uint32_t not_equal_to_then_go, bool until_changes) {
@@ -93,9 +95,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     c->rank = rank, c->nranks = nranks;
     char hex[25];
     for (int i = 0; i < 12; i++) std::snprintf(hex + 2 * i, 3, "%02x", (unsigned char)id.internal[i]);
-    std::snprintf(c->name, sizeof c->name, "/gc_standin_%s", hex);
+    const char *tmp = std::getenv("TMPDIR");
+    std::snprintf(c->name, sizeof c->name, "%s/gc_standin_%s", tmp && *tmp ? tmp : "/tmp", hex);
     c->bytes = offsetof(Seg, data) + kSlot * (size_t)nranks;
-    const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    const int fd = open(c->name, O_CREAT | O_RDWR | O_NOFOLLOW, 0600);
     if (fd < 0 || ftruncate(fd, (off_t)c->bytes) != 0) {
         if (fd >= 0) close(fd);
         delete c;
@@ -112,7 +115,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     c->seg->attached.fetch_add(1, std::memory_order_acq_rel);
     if (!wait_until(c->seg->attached, (uint32_t)nranks, false)) {  // every rank of the communicator has to show up
         munmap(p, c->bytes);
-        shm_unlink(c->name);
+        unlink(c->name);
         delete c;
         return ncclSystemError;
     }
@@ -127,7 +130,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     if (!c) return ncclSuccess;
     const bool last = c->seg->left.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->nranks;
     munmap(c->seg, c->bytes);
-    if (last) shm_unlink(c->name);
+    if (last) unlink(c->name);
     delete c;
     return ncclSuccess;
 }

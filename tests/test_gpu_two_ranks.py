@@ -24,14 +24,14 @@ def standin(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc to build the stand-in collective library")
     so = str(tmp_path_factory.mktemp("standin") / "librccl_standin.so")
-    subprocess.check_call([hipcc, "-shared", "-fPIC", "-O2", "-o", so, SRC, "-lrt"])
+    subprocess.check_call([hipcc, "-shared", "-fPIC", "-O2", "-o", so, SRC])
     return so
 
 
 def _ranks(world, args, standin, tmp_path, timeout=600):
     env = dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
                TORCHELASTIC_RUN_ID="standin%d" % os.getpid(), GC_RENDEZVOUS_DIR=str(tmp_path), GC_RCCL_PATH=standin,
-               GC_BENCH_DEVICE="0")
+               GC_BENCH_DEVICE="0", TMPDIR=str(tmp_path))  # (TMPDIR: where the stand-in keeps its shared file)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + args,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
@@ -67,7 +67,8 @@ def test_a_rank_that_never_arrives_ends_the_other_with_the_error_line(standin, t
     """world 2 announced, one process started: gc_comm_init_rank cannot complete; the watchdog ends rank 0 with ONE JSON
     error line and a non-zero exit inside the init timeout"""
     env = dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29518",
-               TORCHELASTIC_RUN_ID="alone%d" % os.getpid(), GC_RENDEZVOUS_DIR=str(tmp_path), GC_RCCL_PATH=standin, GC_BENCH_DEVICE="0")
+               TORCHELASTIC_RUN_ID="alone%d" % os.getpid(), GC_RENDEZVOUS_DIR=str(tmp_path), GC_RCCL_PATH=standin, GC_BENCH_DEVICE="0",
+               TMPDIR=str(tmp_path))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256",
                         "--no-cpu-baseline", "--init-timeout", "8"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
