@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_sq
 mkdir -p $OUT
 cd /tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-iknp --no-graph --no-stream --no-config3 --no-host-api --no-synthetic"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-iknp --no-graph --no-stream --no-config3 --no-host-api --no-synthetic --no-extra-rows"
 for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" \
            "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" \
