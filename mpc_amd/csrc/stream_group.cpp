@@ -1,0 +1,283 @@
+// stream_group.cpp — shared by the streaming garbler and evaluator: the per-stream circuit cache, which circuits one
+// workgroup can run (small / deep), launch slots, and the launch sequence of a step group (see stream_garble.cpp's head).
+#include "stream_internal.h"
+
+namespace gcs {
+
+uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout) {
+    CircuitHash ch(ngates, nwires, nin, nout);
+    uint32_t i = 0;
+    for (; i + 4 <= ngates; i += 4) {  // four independent lanes: the multiplies of consecutive gates overlap
+        ch.mix(0, gates[i]);
+        ch.mix(1, gates[i + 1]);
+        ch.mix(2, gates[i + 2]);
+        ch.mix(3, gates[i + 3]);
+    }
+    for (; i < ngates; i++) ch.mix(i, gates[i]);
+    return ch.done();
+}
+
+CircEntry *cache_find(CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin,
+                      uint32_t nout) {
+    auto range = cache.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        CircEntry &e = it->second;
+        if (e.gates.size() != ngates || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
+        bool same = true;
+        for (uint32_t i = 0; i < ngates && same; i++)
+            same = e.gates[i].in0 == gates[i].in0 && e.gates[i].in1 == gates[i].in1 && e.gates[i].out == gates[i].out &&
+                   e.gates[i].op == gates[i].op;
+        if (same) return &e;
+    }
+    return nullptr;
+}
+
+// the same on the evaluator's packed gate records (16 bytes, no padding: one memcmp)
+CircEntry *cache_find_keys(CircCache &cache, uint64_t h, const std::vector<CircKey> &keys, uint32_t nwires, uint32_t nin,
+                           uint32_t nout) {
+    static_assert(sizeof(CircKey) == 16, "CircKey must be four packed words");
+    auto range = cache.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        CircEntry &e = it->second;
+        if (e.gates.size() != keys.size() || e.nwires != nwires || e.nin != nin || e.nout != nout) continue;
+        if (std::memcmp(e.gates.data(), keys.data(), keys.size() * sizeof(CircKey)) == 0) return &e;
+    }
+    return nullptr;
+}
+
+CircEntry *cache_put_keys(CircCache &cache, uint64_t h, gc_circ *circ, const std::vector<CircKey> &keys, uint32_t nwires,
+                          uint32_t nin, uint32_t nout) {
+    CircEntry e;
+    e.circ = circ;
+    e.nwires = nwires, e.nin = nin, e.nout = nout;
+    e.gates = keys;
+    e.cost = keys.size() + 1;
+    return &cache.emplace(h, std::move(e))->second;
+}
+
+CircEntry *cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+                     uint32_t nin, uint32_t nout) {
+    CircEntry e;
+    e.circ = circ;
+    e.nwires = nwires, e.nin = nin, e.nout = nout;
+    e.gates.resize(ngates);
+    uint64_t ser = 0;
+    for (uint32_t i = 0; i < ngates; i++) {
+        e.gates[i] = CircKey{gates[i].in0, gates[i].in1, gates[i].out, gates[i].op};
+        const uint32_t op = gates[i].op;
+        ser += 1 + 4u * (op == GC_INV ? 2 : 3) + 16u * (op == GC_AND ? 2 : op == GC_OR ? 3 : op == GC_INV ? 1 : 0);
+    }
+    e.ser_long = (uint32_t)std::min<uint64_t>(ser, 0xffffffffu);
+    e.cost = (size_t)ngates + 1;
+    return &cache.emplace(h, std::move(e))->second;
+}
+
+size_t cache_budget_from_env() {
+    const char *v = std::getenv("GC_STREAM_CACHE_GATES");
+    if (v && *v) {
+        const long long n = std::atoll(v);
+        if (n > 0) return (size_t)n;
+    }
+    return kCacheGatesDefault;
+}
+
+// can ONE workgroup run this cached circuit from LDS (step groups)?  asked once per entry
+bool entry_is_small(CircEntry *e) {
+    if (e->small < 0) {
+        e->small = 0;
+        if (e->gates.size() <= kSmallGates && gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or) &&
+            (e->gates.size() <= kSmallWideGates || !wide_for_one_instance(e->circ->plan.p, false)))
+            e->small = 1;
+    }
+    return e->small == 1;
+}
+
+// does ONE workgroup run this circuit from LDS, and LONG enough for a lane of its own (DeepLanes)?  Either a step that is too
+// big for a group but has a one-workgroup plan (a 128- / 256-bit multiplier on the late schedule), or a small one whose pass
+// has at least min_steps barriers (a 256- / 512-bit adder).  A wide circuit is asked nothing: its level launches never need
+// the flattened plan (building it for a 131 072-gate step costs more than the step).
+// in_stream: the circuit is met in the middle of a stream (the evaluator's blocks; a garbler step that was not interned) —
+// the plan of a big one (0.13 s of planning for a 256-bit multiplier) is then built by a thread of the circuit's own, and
+// until it is there the answer is "not yet": the step takes the path of the big steps, on kernels that need no LDS plan.
+bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream) {
+    if (e->deep < 0) {
+        const size_t n = e->gates.size();
+        if (n > kDeepMaxGates || (n > kSmallWideGates && wide_for_one_instance(e->circ->plan.p, false))) {
+            e->deep = 0;
+            return false;
+        }
+        if (in_stream && n > kSmallGates && !gc_circ_flat_poll(e->circ, true)) return false;
+        e->deep = 0;
+        const bool ok = e->small == 1 || gc_circ_flat_job(e->circ, &e->job, &e->lds, &e->has_or);
+        if (ok && (n > kSmallGates || e->circ->plan.p.n_flat_steps >= min_steps)) e->deep = 1;
+    }
+    return e->deep == 1;
+}
+
+// a free slot; big: for a deep step (megabytes of wire / table arrays) — a free slot that has grown that far already is
+// preferred for those and avoided for groups of small steps, so that not every slot of a stream ends up with big regions
+Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big) {
+    constexpr size_t kBigArena = (size_t)2 << 20;
+    int other = -1;
+    for (uint32_t i = 0; i < slots.size(); i++)
+        if (slots[i]->kind == Slot::kFree) {
+            if ((slots[i]->arena_cap >= kBigArena) == big) {
+                *index = i;
+                return slots[i].get();
+            }
+            if (other < 0) other = (int)i;
+        }
+    if (other >= 0 && (!big || slots.size() >= 64)) {
+        *index = (uint32_t)other;
+        return slots[(size_t)other].get();
+    }
+    std::unique_ptr<Slot> sl(new Slot);
+    sl->ctx = ctx;
+    if (hipEventCreateWithFlags(&sl->kdone, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        sl->release();
+        return nullptr;
+    }
+    slots.push_back(std::move(sl));
+    *index = (uint32_t)slots.size() - 1;
+    return slots.back().get();
+}
+
+// Which launch of the ctx stream does a deep step have to follow on its lane?  cs: sequence number of the latest group with a
+// step it conflicts with (GroupWindow::last_conflict; the open ones among them have just been launched).
+void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng) {
+    if (cs == 0) return;
+    const GroupWindow::Launched &l = win.ring[cs & 63u];
+    if (l.seq != cs || l.slot == 0xffffffffu) {  // launched too long ago to know, or a pass without an event of its own
+        ng->after_tail = true;
+        return;
+    }
+    const Slot &g = *slots[l.slot];
+    // (a slot that has been given back or re-used meanwhile: that group was done long ago)
+    if (g.kind == Slot::kGroup && g.launched && g.launch_no == l.launch_no && g.error == GC_OK) ng->after_ev = g.kernel_ev;
+}
+
+// Launch sequence of a group (see the head of this file).  eval: the jobs' table rows are part of the upload region and
+// nothing comes back.  On return the slot is `launched`; a failure is kept in slot.error for the group's steps.
+// A deep step (g.deep_id != 0, one job) takes the same sequence on its lane, behind an event recorded on the ctx stream here
+// and behind the deep steps of the other lanes named by g.deps; a group of small steps on the ctx stream waits for the deep
+// steps of g.deps (DeepLanes).
+int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
+                 hipStream_t copy_stream, DeepLanes &deep) {
+    const bool on_lane = g.deep_id != 0;
+    hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : ctx->stream;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    g.launched = true;
+    static std::atomic<uint64_t> launches{0};
+    g.launch_no = ++launches;
+    auto fail = [&](const char *what, hipError_t e) {
+        set_error(what, e);
+        g.error = e == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        return g.error;
+    };
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail("launch_group", e);
+    int rcs = store.flush(ctx);  // host-set labels go up first; the store may move (its pointer is taken below)
+    if (rcs != GC_OK) return g.error = rcs;
+    if (on_lane) {
+        if (store.up_ev) e = hipStreamWaitEvent(st, store.up_ev, 0);  // host-set labels it may read (long done, as a rule)
+        if (e == hipSuccess && g.after_tail) {
+            if (!g.dep) e = hipEventCreateWithFlags(&g.dep, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(g.dep, ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, g.dep, 0);
+        } else if (e == hipSuccess && g.after_ev) {
+            e = hipStreamWaitEvent(st, g.after_ev, 0);
+        }
+        if (e == hipSuccess && g.deps.any()) e = deep.wait_deps(st, g.deps, g.lane);
+    } else if (g.deps.any()) {
+        deep.poll();
+        e = deep.wait_deps(st, g.deps, -1);
+    }
+    if (e != hipSuccess) return fail("launch_group (order)", e);
+    const uint32_t n = (uint32_t)g.jobs.size();
+    const size_t off_fj = up16(g.up_used), off_fin = off_fj + (size_t)n * sizeof(FlatJob);
+    const size_t total_up = off_fin + (size_t)n * sizeof(FinJob);
+    const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
+    if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
+    if ((e = grow_dev(ctx, &g.d_up, &g.d_up_cap, total_up)) != hipSuccess) return fail("launch_group (upload)", e);
+    if ((e = grow_dev(ctx, &g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
+    if (!eval) {
+        if ((e = grow_dev(ctx, &g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
+        if ((e = grow_pin(ctx, &g.h_down, &g.h_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (pinned bytes)", e);
+    }
+    FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
+    FinJob *fin = (FinJob *)(g.h_up + off_fin);
+    for (uint32_t k = 0; k < n; k++) {
+        const JobRec &j = g.jobs[k];
+        const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
+        FlatJob f = j.ent->job;
+        f.W = (uint4 *)(g.d_arena + j.off_w);
+        f.T = eval && !j.rows_in_arena ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
+        f.R = d_R;
+        f.Rout = nullptr;
+        f.rk = d_rk;
+        f.store = store.d;
+        f.in_idx = d_io;
+        f.out_slots = j.ent->circ->d_out_slots;
+        f.out_idx = eval ? d_io + j.nin : d_io + j.nin + j.nout;
+        f.nout = j.nout;
+        fj[k] = f;
+        FinJob q{};
+        if (!eval) {
+            q.a.gw = j.ent->circ->d_gwires;
+            q.a.ops = j.ent->circ->d_ops;
+            q.a.row_of_gate = j.ent->circ->d_row_of_gate;
+            q.a.in = d_io;
+            q.a.out = d_io + j.nin;
+            q.a.ngates = j.ngates;
+            q.a.first_tmp = j.first_tmp;
+            q.a.first_out = j.first_out;
+            q.bytes = g.d_down + sizes_bytes + j.off_bytes;
+            q.size_out = (uint32_t *)g.d_down + k;
+        }
+        q.T = f.T;
+        fin[k] = q;
+    }
+    e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
+    if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
+    if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
+    // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
+    // done itself for the evaluator (nothing follows)
+    g.kernel_ev = eval ? g.done : g.kdone;
+    if (e == hipSuccess) e = hipEventRecord(g.kernel_ev, st);
+    if (e == hipSuccess && on_lane) {
+        deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
+        deep.n_inflight++;
+        deep.n_steps++;
+    }
+    if (e == hipSuccess && !eval) {
+        // serialiser and bytes on the copy stream: the next group's garbling need not wait for either
+        e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (e == hipSuccess && on_lane && n == 1 && g.jobs[0].ngates > 4 * kSerGates) {
+            // a deep step of many gates: the serialiser of the big steps, spread over the chip (one workgroup would write
+            // megabytes byte by byte: 1 - 2 ms on the copy stream, more than the step's pass)
+            const FinJob &q = fin[0];
+            const uint32_t nblocks = (q.a.ngates + kSerGates - 1) / kSerGates;
+            if (g.lane_boff_cap < ((size_t)nblocks + 1) * sizeof(uint64_t))
+                e = grow_dev(ctx, &g.d_lane_boff, &g.lane_boff_cap, ((size_t)nblocks + 1) * sizeof(uint64_t));
+            uint64_t *boff = (uint64_t *)g.d_lane_boff;
+            if (e == hipSuccess) {
+                const Layout dense{0, 0, 1, 0};
+                ser_sizes_scan(q.a, boff, nblocks, q.size_out, copy_stream);
+                ser_write(q.a, boff, nblocks, q.T, dense, q.bytes, copy_stream);
+                e = hipGetLastError();
+            }
+        } else if (e == hipSuccess) {
+            ser_group((const FinJob *)(g.d_up + off_fin), n, copy_stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(g.h_down, g.d_down, sizes_bytes + g.down_used, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(g.done, copy_stream);
+    }
+    if (e != hipSuccess) return fail("launch_group", e);
+    return GC_OK;
+}
+
+}  // namespace gcs

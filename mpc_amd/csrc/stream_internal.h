@@ -1,0 +1,721 @@
+// stream_internal.h — what the translation units of the streaming engine share (stream_garble.cpp, stream_eval.cpp,
+// stream_group.cpp, stream_serialise.cpp, stream_lanes.cpp): the circuit cache, the device-resident wire store, launch
+// slots, the window of open groups, the deep lanes and the argument records of the device-side serialiser.  Internal:
+// nothing here crosses the C ABI.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <new>
+#include <thread>
+#include <unordered_map>
+
+#include "engine.h"
+
+namespace gcs {
+using namespace gc;
+
+// developer aid: GC_TRACE=1 prints the wall-clock laps of a streaming step to stderr
+struct StreamTrace {
+    static bool enabled() {  // (asked once: two getenv walks per streamed step were measurable on 512-gate steps)
+        static const bool v = std::getenv("GC_TRACE") != nullptr;
+        return v;
+    }
+    bool on;
+    std::chrono::steady_clock::time_point last;
+    StreamTrace() : on(enabled()) {
+        if (on) last = std::chrono::steady_clock::now();
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gc trace] stream: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+// A cached device circuit with the gate list it was built from.  The key is a 64-bit non-cryptographic hash: a hit is
+// only taken after the gates compare equal (an accidental — or, on the evaluator side, peer-crafted — collision would
+// otherwise select a plan with other input / output counts: wrong results or out-of-bounds label arrays).
+struct CircKey {
+    uint32_t in0, in1, out, op;
+};
+struct CircEntry {
+    gc_circ *circ = nullptr;
+    std::vector<CircKey> gates;
+    uint32_t nwires = 0, nin = 0, nout = 0;
+    // step groups: can ONE workgroup run this circuit from LDS (-1: not asked yet), and if so the circuit-constant part
+    // of its job record
+    int small = -1;
+    int deep = -1;          // ... and is its pass long enough for a lane of its own (DeepLanes; -1: not asked yet)
+    gc::FlatJob job{};
+    size_t lds = 0;
+    bool has_or = false;
+    uint32_t ser_long = 0;  // bytes of the serialised gates with every id in the 4-byte form (an upper bound)
+    uint64_t last_use = 0;  // LRU stamp (cache eviction)
+    bool pinned = false;    // interned by the caller (gc_stream_intern): never evicted
+    size_t cost = 0;        // gates held (host copy + device plan): what the cache budget counts
+};
+using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
+
+// Global wire store of a stream (Streaming.wires / StreamEval.wires, stream_garble.go:27-38, stream_evaluator.go:29-34) in
+// HBM: the circuits of consecutive steps hand labels to each other on the device (gather before / scatter after every
+// pass), so a step does not wait for the GPU at all and the host work of step k + 1 (hashing, cache look-up, parsing)
+// overlaps the kernels of step k.  Labels the HOST sets (the stream's inputs) live in a host shadow until the next pass
+// uploads them; labels a circuit wrote are read back on demand (GetInput / OpReturn are rare).
+struct DevStore {
+    std::vector<gc_label> host;   // valid where !on_dev
+    std::vector<uint8_t> on_dev;  // 1: the current label was written by a circuit on the device
+    std::vector<uint32_t> dirty;  // host-set wires not uploaded yet
+    uint4 *d = nullptr;
+    size_t cap = 0;
+    hipEvent_t up_ev = nullptr;  // behind the latest upload of host-set labels (on the ctx stream): a deep step on a lane of
+                                 // its own waits for it (DeepLanes); null until the first upload
+
+    void ensure(size_t n) {
+        if (host.size() < n) {
+            host.resize(n, gc_label{0, 0});
+            on_dev.resize(n, 0);
+        }
+    }
+    void set(uint32_t w, const gc_label &l) {
+        ensure((size_t)w + 1);
+        host[w] = l;
+        on_dev[w] = 0;
+        dirty.push_back(w);
+    }
+    // device array covers every wire, host-set labels are uploaded (runs of consecutive indices as one copy)
+    int flush(gc_ctx *ctx) {
+        hipStream_t st = ctx->stream;
+        if (host.size() > cap) {
+            const size_t ncap = std::max(host.size(), cap * 2);
+            uint4 *nd = nullptr;
+            GC_HIP(hipMalloc((void **)&nd, ncap * sizeof(uint4)));
+            // the store moves: nothing may still be writing the old array (deep steps run on lanes of their own, DeepLanes)
+            if (d) GC_HIP(hipDeviceSynchronize());
+            GC_HIP(hipMemsetAsync(nd, 0, ncap * sizeof(uint4), st));  // a never-set wire reads as the zero label
+            if (d) GC_HIP(hipMemcpyAsync(nd, d, cap * sizeof(uint4), hipMemcpyDeviceToDevice, st));
+            GC_HIP(hipStreamSynchronize(st));
+            if (d) (void)hipFree(d);
+            d = nd;
+            cap = ncap;
+        }
+        for (size_t i = 0; i < dirty.size();) {
+            size_t j = i + 1;
+            while (j < dirty.size() && dirty[j] == dirty[j - 1] + 1) j++;
+            // a wire set twice keeps its last value in host[]; one that a circuit overwrote meanwhile is skipped
+            bool all_host = true;
+            for (size_t k = i; k < j; k++) all_host = all_host && !on_dev[dirty[k]];
+            if (all_host)
+                GC_HIP(hipMemcpyAsync(d + dirty[i], &host[dirty[i]], (j - i) * sizeof(gc_label), hipMemcpyHostToDevice, st));
+            else
+                for (size_t k = i; k < j; k++)
+                    if (!on_dev[dirty[k]])
+                        GC_HIP(hipMemcpyAsync(d + dirty[k], &host[dirty[k]], sizeof(gc_label), hipMemcpyHostToDevice, st));
+            i = j;
+        }
+        if (!dirty.empty()) {
+            if (!up_ev) GC_HIP(hipEventCreateWithFlags(&up_ev, hipEventDisableTiming));
+            GC_HIP(hipEventRecord(up_ev, st));
+        }
+        dirty.clear();
+        return GC_OK;
+    }
+    int get(gc_ctx *ctx, uint32_t w, gc_label *out) {
+        if (w >= host.size()) return GC_E_ARG;
+        if (!on_dev[w]) {
+            *out = host[w];
+            return GC_OK;
+        }
+        GC_HIP(hipSetDevice(ctx->device));
+        GC_HIP(hipMemcpyAsync(out, d + w, sizeof(gc_label), hipMemcpyDeviceToHost, ctx->stream));
+        GC_HIP(hipStreamSynchronize(ctx->stream));
+        host[w] = *out;  // cache: unchanged until a circuit writes the wire again
+        on_dev[w] = 0;
+        return GC_OK;
+    }
+    void release() {
+        if (d) (void)hipFree(d);
+        if (up_ev) (void)hipEventDestroy(up_ev);
+        up_ev = nullptr;
+        d = nullptr;
+        cap = 0;
+    }
+};
+
+// ---- step groups: staging shared by the garbler and the evaluator ----------------------------------------------------
+constexpr uint32_t kSmallGates = 32768;          // a step of at most this many gates may join a group (one workgroup, LDS plan)
+constexpr uint32_t kSmallWideGates = 8192;       // ... unless it is WIDE (levels of >= 2.5 passes) and larger than this: level
+                                                 // launches spread such a circuit over the chip, one workgroup would crawl
+constexpr uint32_t kGroupJobs = 256;             // steps per group at most: one workgroup each = one wave of the chip's 256 CUs
+constexpr size_t kGroupBytes = (size_t)96 << 20; // wire / table arrays + bytes of one group at most
+constexpr uint32_t kMaxPending = 4096;           // circuits queued and not yet finished, at most
+constexpr size_t kCacheGatesDefault = (size_t)8 << 20;  // gates the per-stream circuit cache may hold (LRU beyond it)
+
+static inline size_t up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
+static inline size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+// one queued small step, host side
+struct JobRec {
+    CircEntry *ent = nullptr;
+    uint32_t nin = 0, nout = 0, ngates = 0, first_tmp = 0, first_out = 0;
+    size_t off_io = 0;            // upload region: in[nin], out[nout], out-or-skip[nout] (u32 each)
+    size_t off_rows = 0;          // evaluator: the block's table rows in the upload region
+    size_t off_w = 0, off_t = 0;  // arena: wire array [nslots], table array [rows]
+    size_t off_bytes = 0;         // download region: where the serialised gates go (garbler)
+    // evaluator, a deep block of many gates: its rows went up from where the parser put them (pinned ring), on the upload
+    // stream, into the slot's arena at off_t (no pass through h_up; the slot's rows_ev says when they are there)
+    bool rows_in_arena = false;
+};
+
+// the deep steps in flight (DeepLanes) that a step — or a group of steps — has to follow
+struct DeepDeps {
+    uint32_t ids[6] = {};  // exactly these: the latest deep writers of wires it reads or writes
+    uint32_t n = 0;
+    uint32_t upto = 0;     // ... and every deep step up to this id: the deep READERS of a wire it writes (the per-wire record
+                           // names only the latest of them), or writers beyond what ids[] holds
+    bool any() const { return n != 0 || upto != 0; }
+    void add(uint32_t id) {
+        for (uint32_t i = 0; i < n; i++)
+            if (ids[i] == id) return;
+        if (n < 6) ids[n++] = id;
+        else upto = std::max(upto, id);
+    }
+    void merge(const DeepDeps &o) {
+        for (uint32_t i = 0; i < o.n; i++) add(o.ids[i]);
+        upto = std::max(upto, o.upto);
+    }
+};
+
+struct Slot {
+    enum Kind { kFree, kGroup, kBig } kind = kFree;
+    gc_ctx *ctx = nullptr;   // the upload / arena / download regions come from (and go back to) the ctx's buffer lists
+    bool launched = false, synced = false;
+    uint64_t launch_no = 0;  // order of the launches (the evaluator waits for its OLDEST group when it runs out of slots)
+    // deep lanes: deep_id != 0: the slot's one job runs on lane `lane` (DeepLanes); deps: the deep steps in flight that the
+    // slot's steps have a dependency on (its kernel waits for them)
+    uint32_t deep_id = 0;
+    DeepDeps deps;
+    int lane = -1;
+    hipEvent_t dep = nullptr;   // deep: "everything launched on the ctx stream before this step" (the lane waits for it) ...
+    hipEvent_t rows_ev = nullptr;   // evaluator, deep: the block's rows are in the arena (JobRec::rows_in_arena; not owned)
+    bool after_tail = false;    // ... when the step must follow a pass of the ctx stream that has no event of its own;
+    hipEvent_t after_ev = nullptr;  // else the kernel of the latest group it conflicts with (null: none, or done already)
+    int error = GC_OK;          // close failed: the group's steps report it
+    uint32_t handed = 0;        // steps whose bytes have been handed out
+    hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
+    hipEvent_t kernel_ev = nullptr;              // whichever of the two says "the group's kernel has run" (set at launch)
+    std::vector<JobRec> jobs;
+    size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
+    bool has_or = false;
+    uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr, *d_lane_boff = nullptr;
+    size_t h_up_cap = 0, d_up_cap = 0, arena_cap = 0, d_down_cap = 0, h_down_cap = 0, lane_boff_cap = 0;
+    // a big step (more than kSmallGates gates): its own wire maps, block offsets, byte buffer and size word
+    uint32_t *h_io = nullptr, *d_io = nullptr;  // h_io pinned: the upload is a true asynchronous copy
+    size_t h_io_cap = 0, io_cap = 0;
+    uint64_t *d_boff = nullptr;
+    size_t boff_cap = 0;
+    uint8_t *d_bytes = nullptr;
+    size_t bytes_cap = 0;
+    uint64_t *need = nullptr;   // pinned
+
+    void reset() {
+        kind = kFree;
+        launched = synced = false;
+        error = GC_OK;
+        handed = 0;
+        deep_id = 0;
+        deps = DeepDeps{};
+        after_tail = false;
+        after_ev = nullptr;
+        rows_ev = nullptr;
+        lane = -1;
+        jobs.clear();
+        up_used = arena_used = down_used = lds = 0;
+        has_or = false;
+    }
+    void release() {
+        if (ctx) {
+            gc::ctx_buf_put(ctx, true, h_up, h_up_cap);
+            gc::ctx_buf_put(ctx, false, d_up, d_up_cap);
+            gc::ctx_buf_put(ctx, false, d_arena, arena_cap);
+            gc::ctx_buf_put(ctx, false, d_down, d_down_cap);
+            gc::ctx_buf_put(ctx, true, h_down, h_down_cap);
+            gc::ctx_buf_put(ctx, false, d_lane_boff, lane_boff_cap);
+        }
+        if (h_io) (void)hipHostFree(h_io);
+        if (d_io) (void)hipFree(d_io);
+        if (d_boff) (void)hipFree(d_boff);
+        if (d_bytes) (void)hipFree(d_bytes);
+        if (need) (void)hipHostFree(need);
+        if (kdone) (void)hipEventDestroy(kdone);
+        if (done) (void)hipEventDestroy(done);
+        if (dep) (void)hipEventDestroy(dep);
+    }
+    // pinned upload region with room for `more` further bytes (contents preserved)
+    hipError_t reserve_up(size_t more) {
+        const size_t need_cap = up_used + more;
+        if (need_cap <= h_up_cap) return hipSuccess;
+        // (64 KiB to start with: a driver that queues a long chain of dependent small steps gets one slot per step — up to
+        // kMaxPending of them —, and a MiB of pinned memory each was gigabytes)
+        size_t ncap = std::max<size_t>((size_t)64 << 10, h_up_cap * 2);
+        while (ncap < need_cap) ncap *= 2;
+        void *n = nullptr;
+        hipError_t e = gc::ctx_buf_get(ctx, true, ncap, &n, &ncap);
+        if (e != hipSuccess) return e;
+        if (up_used) std::memcpy(n, h_up, up_used);
+        gc::ctx_buf_put(ctx, true, h_up, h_up_cap);
+        h_up = (uint8_t *)n;
+        h_up_cap = ncap;
+        return hipSuccess;
+    }
+};
+
+// a slot's region of at least `need` bytes (contents not kept); from the ctx's buffer lists: no hipFree (it would wait for
+// every queue of the device) and, after the first stream of a ctx, no hipMalloc either
+inline hipError_t grow_buf(gc_ctx *ctx, bool pinned, uint8_t **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    gc::ctx_buf_put(ctx, pinned, *p, *cap);
+    *p = nullptr;
+    *cap = 0;
+    void *n = nullptr;
+    size_t ncap = 0;
+    hipError_t e = gc::ctx_buf_get(ctx, pinned, need + need / 4, &n, &ncap);
+    if (e == hipSuccess) {
+        *p = (uint8_t *)n;
+        *cap = ncap;
+    }
+    return e;
+}
+inline hipError_t grow_dev(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) { return grow_buf(ctx, false, p, cap, need); }
+inline hipError_t grow_pin(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) { return grow_buf(ctx, true, p, cap, need); }
+
+// The open groups of a stream, oldest first: a small window of launch sequences that have not been launched yet, filled
+// by list scheduling.  Group i of the window carries sequence number first_seq + i; per global wire the window remembers
+// the sequence number of the latest open group that reads / writes it.  A new step (later in program order than
+// everything queued) may join group i only if it conflicts with no step of groups i .. last (it then runs before the
+// groups behind i, beside the steps of group i): the earliest such group is one past the latest group it has a
+// read-after-write, write-after-write or write-after-read relation with.  Groups are launched in sequence order on one
+// HIP stream, so "later group" = "later in time".
+// How many groups may be open at once.  A chain of dependent steps interleaved with independent ones — an expression like
+// f0*g0 + f1*g9 + ... compiles to mul, mul, add, mul, add, ...: every add follows the add before it — needs one open group per
+// link of the chain while the independent steps keep joining the first: with 4 open groups the hundred products of an Ed25519
+// field multiplication left in groups of 5 (round 4: 16; GC_STREAM_OPEN_GROUPS for experiments).
+// The garbler ties the number to how far ahead its caller queues: a group that stays open keeps gathering steps, but the GPU
+// only sees it when the window is full or the caller asks for its bytes — with 64 steps in flight and steps that chain in
+// fours, sixteen open groups would hold everything the caller allows and the ctx stream would run dry between two calls of
+// gc_stream_garble_finish (ssa23, 64 in flight: 1.1e8 gates/s with 4 open groups, 0.7e8 with 16; the Ed25519 program, 1 024 in
+// flight: 0.9e8 with 4, 4.4e8 with 16).  in_flight / 16, between 4 and 16.  The evaluator has no caller waiting for
+// results: 16.
+constexpr uint32_t kOpenGroupsMin = 4, kOpenGroupsMax = 16;
+inline uint32_t open_groups_env() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("GC_STREAM_OPEN_GROUPS");
+        const int n = e && *e ? std::atoi(e) : 0;
+        return (uint32_t)std::min(std::max(n, 0), 48);
+    }();
+    return v;
+}
+inline uint32_t open_groups_limit(size_t in_flight) {
+    if (open_groups_env()) return open_groups_env();
+    return (uint32_t)std::min<size_t>(std::max<size_t>(in_flight / 16, kOpenGroupsMin), kOpenGroupsMax);
+}
+struct GroupWindow {
+    std::deque<uint32_t> open;      // slots of the open groups, oldest first
+    uint32_t first_seq = 1;         // sequence number of open.front()
+    std::vector<uint32_t> rd, wr;   // per wire: sequence number of the latest group that reads / writes it (stale if < first_seq)
+    void ensure(size_t n) {
+        if (rd.size() < n) {
+            rd.resize(n, 0);
+            wr.resize(n, 0);
+        }
+    }
+    // index into `open` of the earliest group the step may join (== open.size(): it needs a new group)
+    uint32_t place(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        uint32_t lo = first_seq;
+        for (uint32_t i = 0; i < nr; i++) {
+            const uint32_t w = wr[reads[i]];
+            if (w >= lo) lo = w + 1;  // read after write
+        }
+        for (uint32_t j = 0; j < nw; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            const uint32_t w = wr[writes[j]], r = rd[writes[j]];
+            if (w >= lo) lo = w + 1;  // write after write
+            if (r >= lo) lo = r + 1;  // write after read
+        }
+        return lo - first_seq;
+    }
+    void mark(uint32_t index, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        const uint32_t seq = first_seq + index;
+        for (uint32_t i = 0; i < nr; i++)
+            if (rd[reads[i]] < seq) rd[reads[i]] = seq;
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) wr[writes[j]] = seq;
+    }
+    // Launched groups, by sequence number (the last 64): a deep step that conflicts with a step of one of them waits for THAT
+    // group's kernel on its lane, not for everything the ctx stream holds.  slot 0xffffffff: a pass of the ctx stream that is
+    // no group (a big step): the deep step waits for the stream's tail instead.
+    struct Launched {
+        uint32_t seq = 0, slot = 0;
+        uint64_t launch_no = 0;
+    };
+    Launched ring[64];
+    void note(uint32_t seq, uint32_t slot, uint64_t launch_no) { ring[seq & 63u] = Launched{seq, slot, launch_no}; }
+    // sequence number of the latest group — open, launched or long gone — with a step that the step with these reads / writes
+    // must follow (0: none)
+    uint32_t last_conflict(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < nr; i++) q = std::max(q, wr[reads[i]]);
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) q = std::max(q, std::max(wr[writes[j]], rd[writes[j]]));
+        return q;
+    }
+    // a pass of the ctx stream that is no group (the window is empty: everything queued was launched in front of it) takes a
+    // sequence number of its own, so that later deep steps see what it reads and writes
+    void mark_pass(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        mark(0, reads, nr, writes, nw);
+        note(first_seq, 0xffffffffu, 0);
+        first_seq++;
+    }
+    // the oldest group leaves the window (it is being launched)
+    uint32_t pop() {
+        const uint32_t slot = open.front();
+        open.pop_front();
+        if (++first_seq >= 0xfffffff0u && open.empty()) {  // sequence numbers wrap after 4e9 groups: start over
+            std::fill(rd.begin(), rd.end(), 0);
+            std::fill(wr.begin(), wr.end(), 0);
+            first_seq = 1;
+        }
+        return slot;
+    }
+};
+
+struct StepRef {
+    uint32_t slot, job;
+};
+
+// Groups launched on the ctx stream whose kernels may still be running, oldest first.  The stream is HUNGRY while fewer than
+// kKeepQueued of them are.  The garbler looks at it when its caller is about to wait for bytes (gc_stream_garble_finish): the
+// open groups behind the one it waits for then go to the GPU too, so that the GPU has a group to run and one behind it while
+// the host is busy with the bytes; everything younger stays open and keeps gathering steps.
+constexpr size_t kKeepQueued = 2;
+struct CtxQueue {
+    struct E {
+        uint32_t slot;
+        uint64_t launch_no;
+    };
+    std::deque<E> q;
+    std::chrono::steady_clock::time_point last{};
+    void pushed(uint32_t slot, uint64_t launch_no) { q.push_back(E{slot, launch_no}); }
+    template <typename Slots>
+    bool hungry(const Slots &slots) {
+        if (q.size() < kKeepQueued) return true;
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last < std::chrono::microseconds(8)) return false;  // (an event query costs a microsecond or two)
+        last = now;
+        while (!q.empty()) {
+            const auto &g = *slots[q.front().slot];
+            const bool gone = !g.launched || g.launch_no != q.front().launch_no || g.error != GC_OK;  // its slot was given back
+            if (!gone && hipEventQuery(g.kernel_ev) != hipSuccess) break;
+            q.pop_front();
+        }
+        (void)hipGetLastError();  // hipErrorNotReady
+        return q.size() < kKeepQueued;
+    }
+};
+
+// ---- deep lanes ---------------------------------------------------------------------------------------------------------
+// A step whose one-workgroup plan is LONG (hundreds of dependent hash phases: a 128- / 256-bit multiplier, a 256- / 512-bit
+// adder — 0.5 to 2 ms on one CU) would hold up a whole group of short steps if it joined one, and the whole ctx stream if it
+// ran there as a pass of its own.  It runs on a LANE instead: one of a few extra HIP streams, as a group of one job (the same
+// kernels, launch sequence and serialiser as a group), beside the groups of the ctx stream and the deep steps of the other
+// lanes.  Program order is kept by events, and only where two steps share a wire:
+//   * a deep step conflicts with EARLIER small steps -> the open groups that hold them are launched first, and the lane waits
+//     for an event recorded on the ctx stream at that point (everything launched there so far: groups, big steps, uploads);
+//   * a deep step conflicts with earlier DEEP steps  -> per wire the id of the latest deep reader / writer (ids ascend in
+//     program order); the lane waits, per other lane, for that lane's latest step with an id up to the conflicting one (a lane
+//     runs in order, so that covers every earlier step of the lane — readers that the per-wire record no longer names too);
+//   * a LATER small step conflicts with a deep step   -> its group remembers which (Slot::deps) and the ctx stream
+//     waits for the lanes' steps up to it before the group's kernel; a later big step waits for every deep step in flight.
+// Every wait names work that was enqueued before the waiter, so the streams cannot deadlock.  Whether a lane really runs
+// beside the ctx stream is up to the runtime: it multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+// environment says otherwise; engine.cpp raises the default to 8 when the library is loaded before the runtime starts), and
+// two streams on one queue run one after the other.  Lanes are therefore PROBED when they are created (k_lane_probe): a
+// candidate whose kernel cannot see a flag raised by a kernel enqueued afterwards on the ctx stream (or on a lane already
+// accepted) shares a queue with it and is set aside; without a usable lane deep steps keep the path of the big steps.
+constexpr uint32_t kDeepStepsDefault = 300;  // barriers per pass (hash phases + XOR rounds) from which a step is deep: ~0.4 ms
+constexpr uint32_t kDeepLanesDefault = 3;
+constexpr uint32_t kDeepMaxGates = 1u << 20;
+constexpr uint32_t kDeepInFlight = 96;       // deep steps launched and not known to be done, at most (then the oldest is waited for)
+
+struct DeepLanes {
+    struct InFlight {
+        uint32_t id;
+        hipEvent_t ev;  // the step's kernel has run (its slot's kdone; the slot is not re-used before retire())
+    };
+    int state = 0;  // 0: not set up, 1: lanes ready, -1: off
+    uint32_t min_steps = kDeepStepsDefault;
+    bool follow = true;
+    std::vector<hipStream_t> lanes;         // the ctx's lanes (owned by the ctx: set up once, shared by its streams)
+    std::vector<std::deque<InFlight>> inflight;  // per lane, ids ascending
+    std::vector<uint32_t> rd, wr;           // per global wire: id of the latest deep step that reads / writes it
+    uint32_t next_id = 1, n_inflight = 0;
+    uint64_t n_steps = 0;
+
+    // the ctx's lanes, created and probed on first use (under ctx->mu)
+    static void setup_ctx(gc_ctx *ctx);  // stream_lanes.cpp
+    void read_env() {  // (at stream creation: the threshold is asked before the lanes are)
+        const char *v = std::getenv("GC_STREAM_DEEP_STEPS");
+        if (v && *v) min_steps = (uint32_t)std::max(1, std::atoi(v));
+        // GC_STREAM_NO_FOLLOW: short steps never follow a deep step onto its lane (they wait for it in a group)
+        follow = std::getenv("GC_STREAM_NO_FOLLOW") == nullptr;
+    }
+    bool setup(gc_ctx *ctx) {
+        if (state != 0) return state > 0;
+        state = -1;
+        setup_ctx(ctx);
+        if (ctx->lanes_state <= 0) return false;
+        lanes = ctx->lanes;
+        inflight.resize(lanes.size());
+        state = 1;
+        return true;
+    }
+    void ensure(size_t n) {
+        if (rd.size() < n) {
+            rd.resize(n, 0);
+            wr.resize(n, 0);
+        }
+    }
+    // the id of the next deep step (ascending in program order; after 4e9 of them: the lanes are drained and the per-wire
+    // records start over)
+    uint32_t new_id() {
+        if (next_id >= 0xfffffff0u) {
+            drain();
+            std::fill(rd.begin(), rd.end(), 0);
+            std::fill(wr.begin(), wr.end(), 0);
+            next_id = 1;
+        }
+        return next_id++;
+    }
+    // every id up to this one is known to be done
+    uint32_t floor() const {
+        uint32_t f = next_id - 1;
+        for (const auto &q : inflight)
+            if (!q.empty()) f = std::min(f, q.front().id - 1);
+        return f;
+    }
+    // the deep steps in flight that a step with these reads / writes depends on
+    DeepDeps conflicts(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
+        DeepDeps d;
+        if (n_inflight == 0 || rd.empty()) return d;
+        const uint32_t fl = floor();
+        for (uint32_t i = 0; i < nr; i++)
+            if (wr[reads[i]] > fl) d.add(wr[reads[i]]);  // read after write
+        for (uint32_t j = 0; j < nw; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            if (wr[writes[j]] > fl) d.add(wr[writes[j]]);                                      // write after write
+            if (rd[writes[j]] > fl && rd[writes[j]] > wr[writes[j]]) d.upto = std::max(d.upto, rd[writes[j]]);  // write after read
+        }
+        return d;
+    }
+    void mark(uint32_t id, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+        for (uint32_t i = 0; i < nr; i++) rd[reads[i]] = id;
+        for (uint32_t j = 0; j < nw; j++)
+            if (writes[j] != 0xffffffffu) wr[writes[j]] = id;
+    }
+    // steps whose kernels have run leave the lists (cheap: one query per lane head)
+    void poll() {
+        for (auto &q : inflight)
+            while (!q.empty() && hipEventQuery(q.front().ev) == hipSuccess) {
+                q.pop_front();
+                n_inflight--;
+            }
+        (void)hipGetLastError();  // hipErrorNotReady of the queries
+    }
+    // `st` waits for every deep step with an id up to x (per lane: the latest such step); skip: the lane `st` itself is
+    hipError_t wait_upto(hipStream_t st, uint32_t x, int skip) {
+        for (size_t l = 0; l < inflight.size(); l++) {
+            if ((int)l == skip) continue;
+            const auto &q = inflight[l];
+            hipEvent_t ev = nullptr;
+            for (const InFlight &f : q) {
+                if (f.id > x) break;
+                ev = f.ev;
+            }
+            if (ev) {
+                hipError_t e = hipStreamWaitEvent(st, ev, 0);
+                if (e != hipSuccess) return e;
+            }
+        }
+        return hipSuccess;
+    }
+    hipError_t wait_all(hipStream_t st) { return n_inflight ? wait_upto(st, next_id, -1) : hipSuccess; }
+    // `st` waits for the deep steps of d that are still in flight; skip: the lane `st` itself is (-1: none)
+    hipError_t wait_deps(hipStream_t st, const DeepDeps &d, int skip) {
+        for (uint32_t i = 0; i < d.n; i++)
+            for (size_t l = 0; l < inflight.size(); l++) {  // (a few dozen entries in all; ids ascend inside a lane)
+                if ((int)l == skip) continue;
+                for (const InFlight &f : inflight[l]) {
+                    if (f.id > d.ids[i]) break;
+                    if (f.id == d.ids[i]) {
+                        hipError_t e = hipStreamWaitEvent(st, f.ev, 0);
+                        if (e != hipSuccess) return e;
+                        break;
+                    }
+                }
+            }
+        return d.upto ? wait_upto(st, d.upto, skip) : hipSuccess;
+    }
+    // the step is known to be done (its slot is about to be re-used): it and everything older on its lane leave the list
+    void retire(int lane, uint32_t id) {
+        if (lane < 0 || (size_t)lane >= inflight.size()) return;
+        auto &q = inflight[(size_t)lane];
+        while (!q.empty() && q.front().id <= id) {
+            q.pop_front();
+            n_inflight--;
+        }
+    }
+    // the lane of the LATEST deep step in flight among d's (-1: d names none that is still in flight)
+    int lane_to_follow(const DeepDeps &d) const {
+        uint32_t best = 0;
+        for (uint32_t i = 0; i < d.n; i++) best = std::max(best, d.ids[i]);
+        best = std::max(best, d.upto);
+        if (best == 0 || best <= floor()) return -1;
+        // (the lane that holds the latest step in flight with an id up to `best`)
+        int lane = -1;
+        uint32_t found = 0;
+        for (size_t l = 0; l < inflight.size(); l++)
+            for (const InFlight &f : inflight[l])
+                if (f.id <= best && f.id > found) {
+                    found = f.id;
+                    lane = (int)l;
+                }
+        return lane;
+    }
+    // the least busy lane (fewest steps in flight; ties: the one whose last step is the oldest)
+    int pick() const {
+        int best = 0;
+        for (size_t l = 1; l < inflight.size(); l++) {
+            const auto &a = inflight[l], &b = inflight[(size_t)best];
+            if (a.size() < b.size() || (a.size() == b.size() && !a.empty() && a.back().id < b.back().id)) best = (int)l;
+        }
+        return best;
+    }
+    void drain() {
+        for (hipStream_t l : lanes) (void)hipStreamSynchronize(l);
+        for (auto &q : inflight) q.clear();
+        n_inflight = 0;
+    }
+    void release() { drain(); }
+};
+
+// ---- device-side serialiser (stream_serialise.cpp; stream_garble.go:391-446) ----------------------------------------------
+constexpr uint32_t kSerThreads = 256, kSerPer = 4, kSerGates = kSerThreads * kSerPer;
+
+struct SerArgs {
+    const uint32_t *gw;   // {in0, in1, out} per gate
+    const uint8_t *ops;
+    const uint32_t *row_of_gate;
+    const uint32_t *in, *out;  // wire maps of this call
+    uint32_t ngates, first_tmp, first_out;
+};
+
+// ---- the serialiser of a step group (garbler): workgroup j = job j ------------------------------------------------
+// The job's gates in the wire format (stream_garble.go:391-446), gate order, into the job's byte slot; the byte count
+// into *size_out.  Runs on the copy stream behind the group's garbling kernel, beside the NEXT group's garbling (the
+// output labels went back into the wire store in the garbling kernel's own epilogue).
+struct FinJob {
+    SerArgs a;
+    const uint4 *T;
+    uint8_t *bytes;
+    uint32_t *size_out;
+};
+
+// a big step / a deep step of many gates, spread over the chip: byte size of every block of kSerGates gates and their
+// exclusive scan into boff[0 .. nblocks] (boff[nblocks] = total, also into *total_out when given), then every gate to its
+// byte offset (T: the table rows, lt their layout)
+void ser_sizes_scan(const SerArgs &a, uint64_t *boff, uint32_t nblocks, uint32_t *total_out, hipStream_t s);
+void ser_write(const SerArgs &a, const uint64_t *boff, uint32_t nblocks, const uint4 *T, const Layout &lt, uint8_t *buf, hipStream_t s);
+// a step group: workgroup j serialises job j into its byte slot (d_jobs: device array of n records)
+void ser_group(const FinJob *d_jobs, uint32_t n, hipStream_t s);
+
+template <typename T>
+hipError_t grow(T **p, size_t *cap, size_t need) {
+    if (need <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 2 + 64;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e == hipSuccess) *cap = n;
+    return e;
+}
+
+// content hash of a circuit (cache key): four independent multiply-xor lanes over the gate words, so the
+// multiplies of consecutive gates overlap (one dependent chain was 0.2 ms per 131 072-gate step)
+struct CircuitHash {  // incremental form: the evaluator hashes while it renumbers (one pass over the gates less)
+    static constexpr uint64_t kPrime = 1099511628211ull;
+    uint64_t h[4];
+    CircuitHash(uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout)
+        : h{1469598103934665603ull ^ ngates, 0x9e3779b97f4a7c15ull ^ nwires, 0xc2b2ae3d27d4eb4full ^ nin,
+            0x165667b19e3779f9ull ^ nout} {}
+    inline void mix(uint32_t i, const gc_gate &g) {
+        uint64_t &v = h[i & 3];
+        v = (v ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
+        v = (v ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
+    }
+    inline void mix(uint32_t i, const CircKey &g) {
+        uint64_t &v = h[i & 3];
+        v = (v ^ (((uint64_t)g.in0 << 32) | g.in1)) * kPrime;
+        v = (v ^ (((uint64_t)g.out << 8) | g.op)) * kPrime;
+    }
+    uint64_t done() const {
+        uint64_t r = 0;
+        for (int l = 0; l < 4; l++) r = (r ^ h[l]) * kPrime + (r >> 29);
+        return r;
+    }
+};
+uint64_t circuit_hash(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin, uint32_t nout);
+
+// ---- circuit cache, launch slots, launch sequence of a group (stream_group.cpp) -------------------------------------------
+CircEntry *cache_find(CircCache &cache, uint64_t h, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t nin,
+                      uint32_t nout);
+CircEntry *cache_find_keys(CircCache &cache, uint64_t h, const std::vector<CircKey> &keys, uint32_t nwires, uint32_t nin,
+                           uint32_t nout);
+CircEntry *cache_put_keys(CircCache &cache, uint64_t h, gc_circ *circ, const std::vector<CircKey> &keys, uint32_t nwires,
+                          uint32_t nin, uint32_t nout);
+CircEntry *cache_put(CircCache &cache, uint64_t h, gc_circ *circ, const gc_gate *gates, uint32_t ngates, uint32_t nwires,
+                     uint32_t nin, uint32_t nout);
+size_t cache_budget_from_env();
+// Room for a circuit of `cost` gates in a cache of at most `budget`: least recently used entries go first.  The CALLER
+// has made sure nothing on the device or in a queue refers to a cached circuit any more (groups closed, streams drained).
+// dropped(circ) is told about every circuit that goes (the evaluator forgets the byte skeletons that point at it).
+template <typename F>
+void cache_make_room(CircCache &cache, size_t *held, size_t budget, size_t cost, F dropped) {
+    while (!cache.empty() && *held + cost > budget) {
+        auto victim = cache.end();
+        for (auto it = cache.begin(); it != cache.end(); ++it)
+            if (!it->second.pinned && (victim == cache.end() || it->second.last_use < victim->second.last_use)) victim = it;
+        if (victim == cache.end()) break;  // only interned circuits left
+        *held -= std::min(*held, victim->second.cost);
+        dropped(victim->second.circ);
+        gc_circ_free(victim->second.circ);
+        cache.erase(victim);
+    }
+}
+
+bool entry_is_small(CircEntry *e);
+bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream);
+Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big = false);
+void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng);
+int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
+                 hipStream_t copy_stream, DeepLanes &deep);
+
+}  // namespace gcs
