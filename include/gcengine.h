@@ -88,6 +88,15 @@ typedef struct gc_plan_info {
 
 gc_plan *gc_plan_create(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
                         uint32_t noutputs, int *status);
+/* The plan a CHAIN of streamed circuits runs on when the streaming engine fuses them into one job (round 5, chain fusion:
+ * gc_stream_fuse_stats below; mpc_amd/csrc/stream_fuse.cpp).  Step k has gates[k][0 .. ngates[k]) in its own wire ids —
+ * inputs [0, nin[k]), outputs the last nout[k] wires — and wiring[k][i] says where its input i comes from: 0xffffffff = the
+ * stream's wire store, else (m << 24 | j) = output j of the earlier step m (wiring[0] may be NULL: all from the store).  The
+ * merged circuit reads the store inputs in step order, its outputs are every step's outputs in step order, the hash tweak
+ * starts over at every step (circuit/stream_garble.go:174) and the table rows count through.  Host only; the introspection
+ * calls below apply (gc_plan_describe: gate k of step s is gate first_gate_of_step[s] + k of the merged list). */
+gc_plan *gc_plan_create_chain(const gc_gate *const *gates, const uint32_t *ngates, const uint32_t *nwires, const uint32_t *nin,
+                              const uint32_t *nout, const uint32_t *const *wiring, uint32_t nsteps, int *status);
 void gc_plan_free(gc_plan *);
 int gc_plan_get_info(const gc_plan *, gc_plan_info *out);
 /* introspection used by the parity tests (arrays sized by the caller):
@@ -299,6 +308,15 @@ int gc_stream_stats(const gc_stream *, uint64_t *groups, uint64_t *grouped_steps
  * (barriers per pass from which a step counts as deep, default 300) are read when a ctx / a stream first needs them.
  * Either pointer may be NULL. */
 int gc_stream_deep_stats(const gc_stream *, uint64_t *deep_steps, uint32_t *lanes);
+/* Chain fusion (round 5; mpc_amd/csrc/stream_fuse.cpp): a queued step whose dependencies among the steps still queued all sit
+ * in ONE launch unit is appended to that unit, and the chain — mul -> add -> add -> ... -> carry — runs as one planned job
+ * whose gates are scheduled across the step boundaries (a ten-link chain of 64-bit adders: 63 + 9 dependent hash phases
+ * instead of 10 x 63).  The hash tweak still starts over at every circuit (circuit/stream_garble.go:174) and the bytes still
+ * leave step by step in program order (:385-449): nothing on the wire or in the wire store differs.  fused_units: launch
+ * units of more than one step so far; fused_steps: the steps in them; plans_built: merged plans this stream had to build
+ * (they are cached per ctx); unfit: units whose merged plan fits no workgroup (their steps ran one launch after the other).
+ * GC_STREAM_NO_FUSE in the environment switches the fusion off.  Any pointer may be NULL. */
+int gc_stream_fuse_stats(const gc_stream *, uint64_t *fused_units, uint64_t *fused_steps, uint64_t *plans_built, uint64_t *unfit);
 
 /* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
  * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
@@ -340,6 +358,9 @@ int gc_stream_eval_blocks(gc_stream_eval *, const uint8_t *buf, size_t len, size
 int gc_stream_eval_stats(const gc_stream_eval *, uint64_t *parsed, uint64_t *matched);
 /* the evaluator's counterpart of gc_stream_deep_stats */
 int gc_stream_eval_deep_stats(const gc_stream_eval *, uint64_t *deep_blocks, uint32_t *lanes);
+/* the evaluator's counterpart of gc_stream_fuse_stats (its blocks chain exactly as the garbler's steps do) */
+int gc_stream_eval_fuse_stats(const gc_stream_eval *, uint64_t *fused_units, uint64_t *fused_blocks, uint64_t *plans_built,
+                              uint64_t *unfit);
 
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,

@@ -246,6 +246,7 @@ void gc_ctx_destroy(gc_ctx *c) {
         if (c->ev_c[b]) (void)hipEventDestroy(c->ev_c[b]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    gcs_fuse_cache_free(c);
     for (hipStream_t l : c->lanes) (void)hipStreamDestroy(l);
     for (hipStream_t l : c->lanes_aside) (void)hipStreamDestroy(l);
     for (auto &b : c->dev_cache) (void)hipFree(b.p);
@@ -424,7 +425,14 @@ void gc_graph_free(gc_graph *g) {
 // ---- circuit ---------------------------------------------------------------------------------
 
 gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
-                      uint32_t noutputs, int *status) try {
+                      uint32_t noutputs, int *status) {
+    return gc_circ_load_seg(ctx, gates, ngates, nwires, ninputs, noutputs, nullptr, 0, status);
+}
+
+}  // extern "C"
+
+gc_circ *gc_circ_load_seg(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                          uint32_t noutputs, const uint32_t *seg_first, uint32_t nseg, int *status) try {
     int rc = GC_OK;
     gc_circ *c = nullptr;
     if (!ctx) rc = GC_E_ARG;
@@ -435,7 +443,7 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
     if (rc == GC_OK) {
         c->ctx = ctx;
         // the flattened plan (70 % of the build) is deferred: ONE instance of a wide circuit never needs it
-        rc = build_plan(gates, ngates, nwires, ninputs, noutputs, &c->plan.p, /*defer_flat=*/true);
+        rc = build_plan(gates, ngates, nwires, ninputs, noutputs, &c->plan.p, /*defer_flat=*/true, seg_first, nseg);
     }
     if (rc == GC_OK) {
         const Plan &p = c->plan.p;
@@ -471,6 +479,8 @@ gc_circ *gc_circ_load(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32
     if (status) *status = rc__;
     return nullptr;
 }
+
+extern "C" {
 
 void gc_circ_free(gc_circ *c) {
     if (!c) return;

@@ -57,6 +57,9 @@ struct gc_ctx {
     //    that grows in the middle of a stream would stall every queue.
     int lanes_state = 0;
     std::vector<hipStream_t> lanes, lanes_aside;
+    //  * the merged plans of fused step chains and the registry of circuit contents they are keyed by (stream_fuse.cpp)
+    struct gcs_fuse_cache *fuse = nullptr;
+    std::mutex fuse_mu;
     struct CachedBuf {
         void *p;
         size_t cap;
@@ -65,6 +68,7 @@ struct gc_ctx {
     std::vector<CachedBuf> dev_cache, pin_cache;
     size_t dev_cached = 0, pin_cached = 0;
 };
+void gcs_fuse_cache_free(gc_ctx *);  // stream_fuse.cpp (gc_ctx_destroy: the ctx's merged plans and their planner thread)
 namespace gc {
 // a buffer of at least `need` bytes (device, or pinned host memory) from the ctx's lists or the runtime; *cap = its real size
 hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *cap);
@@ -143,6 +147,10 @@ struct gc_batch {
     uint32_t last_launches = 0;
 };
 
+// internal: gc_circ_load for a CHAIN of streamed circuits fused into one gate list (stream_fuse.cpp): the hash tweak starts
+// over at every gate index of seg_first[0 .. nseg) (plan.h: build_plan)
+gc_circ *gc_circ_load_seg(gc_ctx *ctx, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
+                          uint32_t noutputs, const uint32_t *seg_first, uint32_t nseg, int *status);
 // internal (C++ linkage): one instance garbled from explicit labels, the pooled batch kept by the caller
 // (tables in b->d_T) until gc_circ_release_batch — used by the streaming garbler's device-side serialiser
 int gc_garble_labels_keep(gc_circ *c, const uint8_t *key, size_t keylen, const gc_label *r, const gc_label *inputs,

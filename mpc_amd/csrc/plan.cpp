@@ -690,7 +690,7 @@ void finish_flat(Plan *pp) {
 }
 
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
-               Plan *out, bool defer_flat) {
+               Plan *out, bool defer_flat, const uint32_t *seg_first, uint32_t nseg) {
     if ((!gates && ngates) || !out) return GC_E_ARG;
     const bool tr__ = std::getenv("GC_TRACE") != nullptr;
     auto t__ = std::chrono::steady_clock::now();
@@ -725,9 +725,13 @@ int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t 
     std::vector<uint32_t> src0(ngates), src1(ngates);
     std::vector<uint32_t> cur(nwires, NONE);  // producer id of the wire's current value
     for (uint32_t w = 0; w < ninputs; w++) cur[w] = w;
-    uint32_t id = 0, row = 0, max_level = 0;
+    uint32_t id = 0, row = 0, max_level = 0, seg = 0;
     for (uint32_t g = 0; g < ngates; g++) {
         const gc_gate &G = gates[g];
+        while (seg < nseg && seg_first[seg] <= g) {  // the next fused circuit begins: its tweaks start over (stream_garble.go:174)
+            if (seg_first[seg] == g) id = 0;
+            seg++;
+        }
         if (G.op > GC_INV) return GC_E_GATE;
         const bool unary = (G.op == GC_INV);
         if (G.in0 >= nwires || G.out >= nwires || (!unary && G.in1 >= nwires)) return GC_E_WIRE;

@@ -151,8 +151,11 @@ struct Plan {
 };
 
 // returns GC_OK or GC_E_GATE / GC_E_WIRE / GC_E_ARG
+// seg_first / nseg: optional, ascending gate indices at which the hash tweak `id` starts over at 0 — the gate list is a
+// CHAIN of streamed circuits fused into one planned job (stream_fuse.cpp) and Streaming.Garble restarts the tweak per circuit
+// (circuit/stream_garble.go:174); table rows keep counting through the whole list.
 int build_plan(const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs, uint32_t noutputs,
-               Plan *out, bool defer_flat = false);
+               Plan *out, bool defer_flat = false, const uint32_t *seg_first = nullptr, uint32_t nseg = 0);
 // builds the flattened schedule of a plan made with defer_flat (no-op once built); not thread-safe: callers serialise
 void finish_flat(Plan *p);
 // ONE instance of this circuit is better off as one launch per level with the level's passes spread over workgroups

@@ -23,6 +23,8 @@ struct gc_stream_eval {
     DeepLanes deep;
     std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
     uint64_t n_groups = 0, n_group_blocks = 0;
+    FuseStats fuse;  // chain fusion (stream_fuse.cpp)
+    std::vector<uint32_t> wiring_scratch;
     std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
     uint32_t *d_io = nullptr;
     size_t io_cap = 0;
@@ -75,7 +77,7 @@ int eval_launch_oldest(gc_stream_eval *e) {
     Slot &g = *e->slots[slot];
     e->n_groups++;
     e->n_group_blocks += g.jobs.size();
-    const int rc = launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
+    const int rc = launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep, &e->fuse);
     e->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) e->ctxq.pushed(slot, g.launch_no);
     return rc;
@@ -206,6 +208,16 @@ int gc_stream_eval_stats(const gc_stream_eval *e, uint64_t *parsed, uint64_t *ma
     if (!e) return GC_E_ARG;
     if (parsed) *parsed = e->n_parsed;
     if (matched) *matched = e->n_matched;
+    return GC_OK;
+}
+
+int gc_stream_eval_fuse_stats(const gc_stream_eval *e, uint64_t *fused_units, uint64_t *fused_blocks, uint64_t *plans_built,
+                              uint64_t *unfit) {
+    if (!e) return GC_E_ARG;
+    if (fused_units) *fused_units = e->fuse.units;
+    if (fused_blocks) *fused_blocks = e->fuse.steps;
+    if (plans_built) *plans_built = e->fuse.built;
+    if (unfit) *unfit = e->fuse.unfit;
     return GC_OK;
 }
 
@@ -527,6 +539,8 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         if (!nc) return st;
         ent = cache_put_keys(e->cache, h, nc, gates, cw, nin, nout);
         e->cache_gates += ent->cost;
+        ent->eval_form = true;  // (chain fusion: `gates` holds the block as parsed; its ctx-wide identity)
+        ent->uid = fuse_register(e->ctx, true, h, ent->gates, cw, nin, nout);
     }
     tr.lap("eval: hash + cache");
     // Input labels are gathered from, output labels scattered into, the device-resident store: nothing waits for the
@@ -588,9 +602,39 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         e->win.ensure(e->store.host.size());
         if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
-        uint32_t gi = e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
+        // chain fusion, as in the garbler (stream_garble.cpp: stream_begin): a short block whose conflicts with the latest group
+        // it has any with all sit in ONE launch unit is appended to that unit
+        uint32_t unit = kFuseNone;
+        uint32_t gi = fuse_enabled() ? e->win.place_fuse(e->io_host.data(), nin, wr_ids.data(), nout, &unit)
+                                     : e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
+        const bool may_fuse = fuse_enabled() && !is_deep && small_block && ent->uid != 0;
+        bool fuse = false;
+        uint64_t shape = 0;
+        uint32_t n_ext = 0;
+        if (may_fuse && gi > 0 && unit < kFuseMulti && ngates <= kFuseTailGates) {
+            const Slot &fg = *e->slots[e->win.open[gi - 1]];
+            const WgRec &w = fg.wgs[unit];
+            fuse = w.open && w.n < kFuseMembers && w.gates + ngates <= kFuseGates && w.slots + ent->job.zslot + 1 <= kFuseSlots &&
+                   w.inputs + nin <= kFuseInputs && fg.jobs.size() < kGroupSteps &&
+                   fg.arena_used + fg.up_used + 2 * wbytes + 2 * nrows * 16 <= kGroupBytes;
+            if (fuse) {  // input sources, and what chains of this shape say about their depth (as in the garbler)
+                const uint32_t seq = e->win.first_seq + gi - 1;
+                e->wiring_scratch.resize(nin);
+                for (uint32_t i = 0; i < nin; i++) {
+                    const GroupWindow::WireRec &r = e->win.rec[e->io_host[i]];
+                    if (r.wr == seq && r.wrj == unit) e->wiring_scratch[i] = (fg.jobs[r.wrm >> 20].member << 24) | (r.wrm & 0xfffffu);
+                    else e->wiring_scratch[i] = kFuseNone, n_ext++;
+                }
+                shape = fuse_shape(w.shape, ent, e->wiring_scratch.data());
+                const uint32_t hint = fuse_depth_hint(ctx, shape);
+                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
+            }
+        }
         uint32_t slot_idx = 0;
-        if (is_deep) {
+        if (fuse) {
+            gi--;
+            slot_idx = e->win.open[gi];
+        } else if (is_deep) {
             for (; gi > 0; gi--) {  // the open groups this block depends on go first
                 int rcq = eval_launch_oldest(e);
                 if (rcq != GC_OK) return rcq;
@@ -613,7 +657,8 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
             deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
         } else {
             auto full = [&](const Slot &g) {
-                return g.jobs.size() >= kGroupJobs || g.arena_used + g.up_used + wbytes + nrows * 16 > kGroupBytes;
+                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
+                       g.arena_used + g.up_used + 2 * wbytes + 2 * nrows * 16 > kGroupBytes;
             };
             while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
             if (gi == e->win.open.size()) {
@@ -683,13 +728,29 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         }
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
+        j.nrows = (uint32_t)nrows;
+        const uint32_t step_idx = (uint32_t)g.jobs.size();
+        if (fuse) {  // the wiring goes with the block; outputs of earlier blocks of the unit that this one overwrites
+            const uint32_t seq = e->win.first_seq + gi;
+            j.off_wiring = g.wiring.size();
+            g.wiring.insert(g.wiring.end(), e->wiring_scratch.begin(), e->wiring_scratch.begin() + nin);
+            for (uint32_t k = 0; k < nout; k++) {
+                if (e->io_host[nin + k] == 0xffffffffu) continue;  // (superseded inside the block itself: not stored anyway)
+                const GroupWindow::WireRec &r = e->win.rec[wr_ids[k]];
+                if (r.wr == seq && r.wrj == unit) g.kills.emplace_back(r.wrm >> 20, r.wrm & 0xfffffu);
+            }
+            wg_append(g, unit, &j, ent, n_ext, shape);
+            e->fuse.appended++;
+        } else {
+            unit = wg_new(g, &j, ent, may_fuse);
+        }
         g.jobs.push_back(j);
         if (!is_deep) {
-            e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout);
+            e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout, unit, step_idx);
             if (e->deep.n_inflight) g.deps.merge(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
         }
         if (is_deep) {  // launched at once, on its lane
-            int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep);
+            int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep, &e->fuse);
             hipStream_t lane = e->deep.lanes[(size_t)g.lane];
             if (rcl != GC_OK) {
                 (void)hipStreamSynchronize(lane);

@@ -47,6 +47,7 @@ struct gc_stream {
     uint32_t gen = 0;
     std::vector<gc_gate> rewritten;            // gate list with aliased reads redirected (rare)
     std::vector<uint32_t> skip_scratch;        // out[] with 0xffffffff where nothing is stored
+    std::vector<uint32_t> wiring_scratch;      // chain fusion: the input sources of the step being queued
     // circuits in flight (gc_stream_garble_begin / _finish), oldest first, and the slots that hold them
     std::vector<std::unique_ptr<Slot>> slots;
     std::deque<StepRef> queue;
@@ -68,6 +69,7 @@ struct gc_stream {
     gc_circ *held_circ = nullptr;
     gc_batch *held = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
+    FuseStats fuse;               // chain fusion: launch units of several steps, merged plans built
     // gc_stream_garble_finish_view: the slot whose pinned bytes the caller is still reading (given back by the next finish),
     // and pinned staging for the bytes of a big step
     uint32_t view_slot = 0xffffffffu;
@@ -94,7 +96,7 @@ int launch_oldest(gc_stream *s) {
     Slot &g = *s->slots[slot];
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
-    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
+    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse);
     s->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) s->ctxq.pushed(slot, g.launch_no);
     return rc;
@@ -156,6 +158,7 @@ int stream_find_or_load(gc_stream *s, const gc_gate *gates, uint32_t ngates, uin
             }
             ent = cache_put(s->cache, h, circ, gates, ngates, nwires, nin, nout);
             s->cache_gates += ent->cost;
+            ent->uid = fuse_register(s->ctx, false, h, ent->gates, nwires, nin, nout);  // (chain fusion: its ctx-wide identity)
         }
     }
     *out_ent = ent;
@@ -309,6 +312,15 @@ int gc_stream_stats(const gc_stream *s, uint64_t *groups, uint64_t *grouped_step
     return GC_OK;
 }
 
+int gc_stream_fuse_stats(const gc_stream *s, uint64_t *fused_units, uint64_t *fused_steps, uint64_t *plans_built, uint64_t *unfit) {
+    if (!s) return GC_E_ARG;
+    if (fused_units) *fused_units = s->fuse.units;
+    if (fused_steps) *fused_steps = s->fuse.steps;
+    if (plans_built) *plans_built = s->fuse.built;
+    if (unfit) *unfit = s->fuse.unfit;
+    return GC_OK;
+}
+
 int gc_stream_deep_stats(const gc_stream *s, uint64_t *deep_steps, uint32_t *lanes) {
     if (!s) return GC_E_ARG;
     if (deep_steps) *deep_steps = s->deep.n_steps;
@@ -370,6 +382,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     // stream.wire(index) per gate (:131-157), so a gate that reads the input-mapped wire after the gate that Set the
     // output-mapped one sees the NEW label.  The device garbles from a snapshot of the inputs: redirect such reads to
     // the producing circuit wire (same global id and flags on the wire, so the serialised bytes do not change).
+    bool was_aliased = false;
     if (ngates) {
         if (s->alias_gen.size() < s->store.host.size()) {
             s->alias_gen.resize(s->store.host.size(), 0);
@@ -386,6 +399,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             }
         bool aliased = false;
         for (uint32_t i = 0; i < nin && !aliased; i++) aliased = s->alias_gen[in[i]] == s->gen;
+        was_aliased = aliased;
         if (aliased) {
             std::vector<uint8_t> set(nout, 0);
             if (known) {  // an interned circuit bound so that an output updates one of its inputs in place: rare, general path
@@ -451,9 +465,42 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         s->win.ensure(s->store.host.size());
         if (is_deep || s->deep.n_inflight) s->deep.ensure(s->store.host.size());
         const size_t wbytes = up256((size_t)ent->job.w_tile * 16) + up256((size_t)ent->job.t_tile * 16);
-        uint32_t gi = s->win.place(in, nin, s->skip_scratch.data(), nout);
+        // Chain fusion (stream_fuse.cpp): when everything the step conflicts with in the latest group it conflicts with at all
+        // (group gi - 1) is ONE launch unit, a short step is appended to that unit — the chain runs as one planned job — instead
+        // of waiting for that whole group in a later one.
+        uint32_t unit = kFuseNone;
+        const uint32_t *skip = s->skip_scratch.data();
+        uint32_t gi = fuse_enabled() ? s->win.place_fuse(in, nin, skip, nout, &unit) : s->win.place(in, nin, skip, nout);
+        const bool may_fuse = fuse_enabled() && !is_deep && !was_aliased && ent->uid != 0 && first_out >= first_tmp;
+        bool fuse = false;
+        uint64_t shape = 0;
+        uint32_t n_ext = 0;
+        if (may_fuse && gi > 0 && unit < kFuseMulti && ngates <= kFuseTailGates) {
+            const Slot &fg = *s->slots[s->win.open[gi - 1]];
+            const WgRec &w = fg.wgs[unit];
+            fuse = w.open && w.n < kFuseMembers && w.gates + ngates <= kFuseGates && w.slots + ent->job.zslot + 1 <= kFuseSlots &&
+                   w.inputs + nin <= kFuseInputs && fg.jobs.size() < kGroupSteps &&
+                   fg.arena_used + fg.down_used + wbytes + ent->ser_long <= kGroupBytes;
+            if (fuse) {
+                // where every input comes from: an earlier step of the unit (the window's record of the wire names it) or the
+                // wire store; and is a chain of this shape known to run too long for one workgroup?
+                const uint32_t seq = s->win.first_seq + gi - 1;
+                s->wiring_scratch.resize(nin);
+                for (uint32_t i = 0; i < nin; i++) {
+                    const GroupWindow::WireRec &r = s->win.rec[in[i]];
+                    if (r.wr == seq && r.wrj == unit) s->wiring_scratch[i] = (fg.jobs[r.wrm >> 20].member << 24) | (r.wrm & 0xfffffu);
+                    else s->wiring_scratch[i] = kFuseNone, n_ext++;
+                }
+                shape = fuse_shape(w.shape, ent, s->wiring_scratch.data());
+                const uint32_t hint = fuse_depth_hint(ctx, shape);
+                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
+            }
+        }
         uint32_t slot_idx = 0;
-        if (is_deep) {
+        if (fuse) {
+            gi--;
+            slot_idx = s->win.open[gi];
+        } else if (is_deep) {
             // the open groups this step depends on go to the GPU first (place(): every conflict sits in a group before gi)
             for (; gi > 0; gi--) {
                 int rcq = launch_oldest(s);
@@ -477,7 +524,8 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             deep_after(s->win, s->slots, s->win.last_conflict(in, nin, s->skip_scratch.data(), nout), ng);
         } else {
             auto full = [&](const Slot &g) {
-                return g.jobs.size() >= kGroupJobs || g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
+                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
+                       g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
             };
             while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
             if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
@@ -523,14 +571,31 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         g.down_used += up16((size_t)ent->ser_long);
         g.lds = std::max(g.lds, ent->lds);
         g.has_or = g.has_or || ent->has_or;
+        const uint32_t step_idx = (uint32_t)g.jobs.size();
+        if (fuse) {
+            // the wiring goes with the step; outputs of earlier steps of the unit that this one overwrites: their stores are
+            // dropped (launch_group)
+            const uint32_t seq = s->win.first_seq + gi;
+            j.off_wiring = g.wiring.size();
+            g.wiring.insert(g.wiring.end(), s->wiring_scratch.begin(), s->wiring_scratch.begin() + nin);
+            for (uint32_t k = 0; k < nout; k++) {
+                if (skip[k] == 0xffffffffu) continue;
+                const GroupWindow::WireRec &r = s->win.rec[out[k]];
+                if (r.wr == seq && r.wrj == unit) g.kills.emplace_back(r.wrm >> 20, r.wrm & 0xfffffu);
+            }
+            wg_append(g, unit, &j, ent, n_ext, shape);
+            s->fuse.appended++;
+        } else {
+            unit = wg_new(g, &j, ent, may_fuse);
+        }
         g.jobs.push_back(j);
         if (!is_deep) {
-            s->win.mark(gi, in, nin, s->skip_scratch.data(), nout);
+            s->win.mark(gi, in, nin, s->skip_scratch.data(), nout, unit, step_idx);
             // a deep step in flight that this one must follow: the group waits for it (and for the older ones of its lane)
             if (s->deep.n_inflight) g.deps.merge(s->deep.conflicts(in, nin, s->skip_scratch.data(), nout));
         }
         if (is_deep) {  // launched at once, on its lane
-            int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep);
+            int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse);
             if (rcl != GC_OK) {
                 (void)hipStreamSynchronize(s->deep.lanes[(size_t)g.lane]);
                 s->deep.retire(g.lane, g.deep_id);

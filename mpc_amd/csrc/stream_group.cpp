@@ -158,15 +158,73 @@ void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>>
     if (g.kind == Slot::kGroup && g.launched && g.launch_no == l.launch_no && g.error == GC_OK) ng->after_ev = g.kernel_ev;
 }
 
-// Launch sequence of a group (see the head of this file).  eval: the jobs' table rows are part of the upload region and
+// table rows of the evaluator's fused chains: every step's rows, wherever the parser put them in the group's upload region, into
+// the chain's one table array (workgroup c = copy c)
+namespace {
+struct RowCopy {
+    const uint4 *src;
+    uint4 *dst;
+    uint32_t n, pad_;
+};
+__global__ __launch_bounds__(256) void k_rows_copy(const RowCopy *rc) {
+    const RowCopy c = rc[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+}
+}  // namespace
+
+// Launch sequence of a group (see the head of stream_garble.cpp).  eval: the jobs' table rows are part of the upload region and
 // nothing comes back.  On return the slot is `launched`; a failure is kept in slot.error for the group's steps.
 // A deep step (g.deep_id != 0, one job) takes the same sequence on its lane, behind an event recorded on the ctx stream here
 // and behind the deep steps of the other lanes named by g.deps; a group of small steps on the ctx stream waits for the deep
 // steps of g.deps (DeepLanes).
+// Chain fusion (stream_fuse.cpp): a launch unit of several steps runs as ONE job on its merged plan — inputs gathered from the
+// wire store for the whole chain, every step's outputs scattered back at the end (an output that a later step of the chain
+// writes again is dropped), the garbler's serialiser finding step k's rows in the chain's table array at row_base[k].  A chain
+// without a one-workgroup plan runs its steps in successive launches of the same kernel (round r = the r-th step).
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep) {
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats) {
     const bool on_lane = g.deep_id != 0;
     hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : ctx->stream;
+    const uint32_t n = (uint32_t)g.jobs.size(), nwg = (uint32_t)g.wgs.size();
+    // ---- the merged plans of the chains (before the ctx lock: a chain met for the first time is planned here)
+    std::vector<const FusedPlan *> plans(nwg, nullptr);
+    uint32_t nrec = 0, nrounds = 1, ncopies = 0;
+    size_t extra_up = 0, extra_arena = 0;
+    size_t lds = g.lds;
+    bool has_or = g.has_or;
+    {
+        std::vector<FuseMember> mem;
+        for (uint32_t u = 0; u < nwg; u++) {
+            const WgRec &w = g.wgs[u];
+            if (w.n < 2) {
+                nrec++;
+                continue;
+            }
+            mem.clear();
+            for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next)
+                mem.push_back(FuseMember{g.jobs[(size_t)k].ent, mem.empty() ? nullptr : g.wiring.data() + g.jobs[(size_t)k].off_wiring});
+            bool built = false;
+            const FusedPlan *fp = fuse_plan(ctx, eval, mem.data(), (uint32_t)mem.size(), &built);
+            if (fstats) {
+                fstats->units++;
+                fstats->steps += w.n;
+                fstats->built += built;
+            }
+            if (fp && fp->circ) {
+                plans[u] = fp;
+                nrec++;
+                extra_up += up16(((size_t)fp->n_ext + fp->n_out) * sizeof(uint32_t));
+                extra_arena += up256(fp->job.w_tile * 16) + up256(fp->job.t_tile * 16);
+                if (eval) ncopies += w.n;
+                lds = std::max(lds, fp->lds);
+                has_or = has_or || fp->has_or;
+            } else {
+                nrec += w.n;
+                nrounds = std::max(nrounds, w.n);
+                if (fstats) (fp ? fstats->unfit : fstats->unplanned)++;
+            }
+        }
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     g.launched = true;
     static std::atomic<uint64_t> launches{0};
@@ -195,21 +253,37 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         e = deep.wait_deps(st, g.deps, -1);
     }
     if (e != hipSuccess) return fail("launch_group (order)", e);
-    const uint32_t n = (uint32_t)g.jobs.size();
-    const size_t off_fj = up16(g.up_used), off_fin = off_fj + (size_t)n * sizeof(FlatJob);
-    const size_t total_up = off_fin + (size_t)n * sizeof(FinJob);
+    // upload region: [what the steps queued] [merged wire maps of the chains] [job records] [serialiser records] [row copies]
+    const size_t off_maps = up16(g.up_used), off_fj = off_maps + extra_up, off_fin = off_fj + (size_t)nrec * sizeof(FlatJob);
+    const size_t off_rc = off_fin + (size_t)n * sizeof(FinJob);
+    const size_t total_up = off_rc + (size_t)ncopies * sizeof(RowCopy);
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
+    const size_t arena_chain = up256(g.arena_used);
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
     if ((e = grow_dev(ctx, &g.d_up, &g.d_up_cap, total_up)) != hipSuccess) return fail("launch_group (upload)", e);
-    if ((e = grow_dev(ctx, &g.d_arena, &g.arena_cap, std::max<size_t>(g.arena_used, 256))) != hipSuccess) return fail("launch_group (arena)", e);
+    if ((e = grow_dev(ctx, &g.d_arena, &g.arena_cap, std::max<size_t>(arena_chain + extra_arena, 256))) != hipSuccess) return fail("launch_group (arena)", e);
     if (!eval) {
         if ((e = grow_dev(ctx, &g.d_down, &g.d_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (bytes)", e);
         if ((e = grow_pin(ctx, &g.h_down, &g.h_down_cap, sizes_bytes + g.down_used)) != hipSuccess) return fail("launch_group (pinned bytes)", e);
     }
     FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
     FinJob *fin = (FinJob *)(g.h_up + off_fin);
-    for (uint32_t k = 0; k < n; k++) {
-        const JobRec &j = g.jobs[k];
+    RowCopy *rcp = (RowCopy *)(g.h_up + off_rc);
+    // records of round r start at rec_first[r] (round 0: every unit's job, or its first step; round r: the r-th step of a chain
+    // that runs step by step)
+    std::vector<uint32_t> rec_first(nrounds + 1, 0);
+    if (nrounds > 1) {
+        for (uint32_t u = 0; u < nwg; u++) {
+            if (g.wgs[u].n < 2 || plans[u]) rec_first[1]++;
+            else
+                for (uint32_t r = 0; r < g.wgs[u].n; r++) rec_first[r + 1]++;
+        }
+        for (uint32_t r = 0; r < nrounds; r++) rec_first[r + 1] += rec_first[r];
+    } else {
+        rec_first[1] = nrec;
+    }
+    std::vector<uint32_t> rec_next(rec_first.begin(), rec_first.end() - 1);
+    auto step_job = [&](const JobRec &j) {  // one step as a job of its own
         const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
         FlatJob f = j.ent->job;
         f.W = (uint4 *)(g.d_arena + j.off_w);
@@ -222,12 +296,15 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         f.out_slots = j.ent->circ->d_out_slots;
         f.out_idx = eval ? d_io + j.nin : d_io + j.nin + j.nout;
         f.nout = j.nout;
-        fj[k] = f;
+        return f;
+    };
+    auto step_fin = [&](const JobRec &j, uint32_t k, const uint4 *T, const uint32_t *row_of_gate) {
         FinJob q{};
         if (!eval) {
+            const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
             q.a.gw = j.ent->circ->d_gwires;
             q.a.ops = j.ent->circ->d_ops;
-            q.a.row_of_gate = j.ent->circ->d_row_of_gate;
+            q.a.row_of_gate = row_of_gate;
             q.a.in = d_io;
             q.a.out = d_io + j.nin;
             q.a.ngates = j.ngates;
@@ -236,12 +313,68 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
             q.bytes = g.d_down + sizes_bytes + j.off_bytes;
             q.size_out = (uint32_t *)g.d_down + k;
         }
-        q.T = f.T;
+        q.T = T;
         fin[k] = q;
+    };
+    size_t maps = off_maps, arena = arena_chain;
+    uint32_t ncp = 0;
+    std::vector<uint32_t> out_base;  // (chains: where each step's outputs start in the merged list; indexed by step)
+    if (!g.kills.empty()) out_base.assign(n, 0xffffffffu);
+    for (uint32_t u = 0; u < nwg; u++) {
+        const WgRec &w = g.wgs[u];
+        if (w.n < 2 || !plans[u]) {
+            uint32_t r = 0;
+            for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next, r++) {
+                const JobRec &j = g.jobs[(size_t)k];
+                const FlatJob f = step_job(j);
+                fj[rec_next[r]++] = f;
+                step_fin(j, (uint32_t)k, f.T, j.ent->circ->d_row_of_gate);
+            }
+            continue;
+        }
+        const FusedPlan &fp = *plans[u];
+        uint32_t *h_in = (uint32_t *)(g.h_up + maps), *h_out = h_in + fp.n_ext;
+        const uint32_t *d_in = (const uint32_t *)(g.d_up + maps);
+        maps += up16(((size_t)fp.n_ext + fp.n_out) * sizeof(uint32_t));
+        FlatJob f = fp.job;
+        f.W = (uint4 *)(g.d_arena + arena);
+        arena += up256(f.w_tile * 16);
+        f.T = (uint4 *)(g.d_arena + arena);
+        arena += up256(f.t_tile * 16);
+        f.R = d_R;
+        f.Rout = nullptr;
+        f.rk = d_rk;
+        f.store = store.d;
+        f.in_idx = d_in;
+        f.out_slots = fp.circ->d_out_slots;
+        f.out_idx = d_in + fp.n_ext;
+        f.nout = fp.n_out;
+        fj[rec_next[0]++] = f;
+        uint32_t ni = 0, no = 0, m = 0;
+        for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next, m++) {
+            const JobRec &j = g.jobs[(size_t)k];
+            const uint32_t *io = (const uint32_t *)(g.h_up + j.off_io);
+            const uint32_t *wiring = m ? g.wiring.data() + j.off_wiring : nullptr;
+            for (uint32_t i = 0; i < j.nin; i++)
+                if (!wiring || wiring[i] == kFuseNone) h_in[ni++] = io[i];
+            const uint32_t *skip = eval ? io + j.nin : io + j.nin + j.nout;
+            if (j.nout) std::memcpy(h_out + no, skip, (size_t)j.nout * sizeof(uint32_t));
+            if (!out_base.empty()) out_base[(size_t)k] = (uint32_t)(h_out + no - (uint32_t *)g.h_up);
+            no += j.nout;
+            step_fin(j, (uint32_t)k, f.T, fp.circ->d_row_of_gate + fp.gate_base[m]);
+            if (eval && j.nrows) rcp[ncp++] = RowCopy{(const uint4 *)(g.d_up + j.off_rows), f.T + fp.row_base[m], j.nrows, 0};
+        }
     }
+    for (const auto &kl : g.kills)  // an output a later step of the same chain writes again
+        if (kl.first < n && out_base[kl.first] != 0xffffffffu) ((uint32_t *)g.h_up)[out_base[kl.first] + kl.second] = 0xffffffffu;
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
     if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
-    if (e == hipSuccess) e = launch_fused_flat_jobs(eval, rounds, g.has_or, (const FlatJob *)(g.d_up + off_fj), n, g.lds, st);
+    if (e == hipSuccess && ncp) {
+        hipLaunchKernelGGL(k_rows_copy, dim3(ncp), dim3(256), 0, st, (const RowCopy *)(g.d_up + off_rc));
+        e = hipGetLastError();
+    }
+    for (uint32_t r = 0; r < nrounds && e == hipSuccess; r++)
+        e = launch_fused_flat_jobs(eval, rounds, has_or, (const FlatJob *)(g.d_up + off_fj) + rec_first[r], rec_first[r + 1] - rec_first[r], lds, st);
     // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
     // done itself for the evaluator (nothing follows)
     g.kernel_ev = eval ? g.done : g.kdone;

@@ -62,6 +62,10 @@ struct CircEntry {
     uint64_t last_use = 0;  // LRU stamp (cache eviction)
     bool pinned = false;    // interned by the caller (gc_stream_intern): never evicted
     size_t cost = 0;        // gates held (host copy + device plan): what the cache budget counts
+    // chain fusion (stream_fuse.cpp): the ctx-wide identity of the circuit's content (0: not registered — never part of a
+    // fused chain), whether `gates` holds the evaluator's parsed form, and the gates written in the wire format's own ids
+    uint32_t uid = 0;
+    bool eval_form = false;
 };
 using CircCache = std::unordered_multimap<uint64_t, CircEntry>;
 
@@ -159,6 +163,19 @@ constexpr size_t kGroupBytes = (size_t)96 << 20; // wire / table arrays + bytes 
 constexpr uint32_t kMaxPending = 4096;           // circuits queued and not yet finished, at most
 constexpr size_t kCacheGatesDefault = (size_t)8 << 20;  // gates the per-stream circuit cache may hold (LRU beyond it)
 
+// Chain fusion (stream_fuse.cpp): a queued step whose dependencies inside the window all sit in ONE job of the latest group
+// it conflicts with is appended to that job instead of opening a later group — the chain (mul -> add -> add -> ... -> carry)
+// then runs as ONE planned circuit whose gates are scheduled across the step boundaries.
+constexpr uint32_t kFuseTailGates = 1024;   // a step of at most this many gates may be appended to a chain ...
+constexpr uint32_t kFuseMembers = 48;       // ... of at most this many steps,
+constexpr uint32_t kFuseGates = 40960;      //     gates,
+constexpr uint32_t kFuseSlots = 2600;       //     live labels (the sum of the members' own LDS plans: an estimate),
+constexpr uint32_t kFuseInputs = 2048;      //     and labels read from the wire store
+constexpr uint32_t kFuseDepth = 320;        // ... and dependent hash phases, as far as earlier chains of the same shape tell (fuse_depth_hint);
+constexpr uint32_t kFuseDepthSum = 640;     //     for a shape nobody has planned yet: the sum of the steps' own depths (no overlap assumed)
+constexpr uint32_t kGroupSteps = 4096;      // steps per group at most (fused or not)
+constexpr uint32_t kFuseMulti = 0xfffffffeu, kFuseNone = 0xffffffffu;
+
 static inline size_t up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
 static inline size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 
@@ -173,6 +190,21 @@ struct JobRec {
     // evaluator, a deep block of many gates: its rows went up from where the parser put them (pinned ring), on the upload
     // stream, into the slot's arena at off_t (no pass through h_up; the slot's rows_ev says when they are there)
     bool rows_in_arena = false;
+    // chain fusion: the launch unit (Slot::wgs) this step belongs to, the next step of the same unit (-1: the last) and, for
+    // every step but a unit's first, where Slot::wiring holds the source of each of its inputs (kFuseNone: read from the wire
+    // store; else member << 24 | output index of an earlier step of the unit)
+    uint32_t wg = 0, member = 0;  // (member: its position in the unit)
+    int32_t next = -1;
+    size_t off_wiring = 0;
+    uint32_t nrows = 0;           // evaluator: table rows of the block
+};
+
+// one launch unit of a group = one workgroup of its kernel: ONE step, or a chain of dependent steps (chain fusion)
+struct WgRec {
+    uint32_t head = 0, tail = 0, n = 0;   // steps of the unit (indices into Slot::jobs), linked through JobRec::next
+    uint32_t gates = 0, slots = 0, inputs = 0, depth_sum = 0;  // what the caps of the fusion count
+    uint64_t shape = 0;                   // running hash of (circuits, wiring) of its steps: what the depth hints are kept by
+    bool open = true;                     // may take further steps (a unit whose head cannot be fused is closed from the start)
 };
 
 // the deep steps in flight (DeepLanes) that a step — or a group of steps — has to follow
@@ -213,6 +245,11 @@ struct Slot {
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
     hipEvent_t kernel_ev = nullptr;              // whichever of the two says "the group's kernel has run" (set at launch)
     std::vector<JobRec> jobs;
+    std::vector<WgRec> wgs;          // launch units, in the order their first steps were queued
+    std::vector<uint32_t> wiring;    // chain fusion: input sources of the appended steps (JobRec::off_wiring)
+    // ... and outputs a LATER step of the same unit writes again: (step, output index) pairs whose store is dropped (in a
+    // fused job every output goes back to the wire store at the end, side by side: the last writer must be the only one)
+    std::vector<std::pair<uint32_t, uint32_t>> kills;
     size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
     bool has_or = false;
     uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr, *d_lane_boff = nullptr;
@@ -238,6 +275,9 @@ struct Slot {
         rows_ev = nullptr;
         lane = -1;
         jobs.clear();
+        wgs.clear();
+        wiring.clear();
+        kills.clear();
         up_used = arena_used = down_used = lds = 0;
         has_or = false;
     }
@@ -330,34 +370,68 @@ inline uint32_t open_groups_limit(size_t in_flight) {
 struct GroupWindow {
     std::deque<uint32_t> open;      // slots of the open groups, oldest first
     uint32_t first_seq = 1;         // sequence number of open.front()
-    std::vector<uint32_t> rd, wr;   // per wire: sequence number of the latest group that reads / writes it (stale if < first_seq)
+    // per wire: sequence number of the latest group that reads / writes it (stale if < first_seq); chain fusion: which launch
+    // unit of that group writes it (wrj) as which output of which of the group's steps (wrm = step << 20 | output index), and
+    // which unit reads it (rdj; kFuseMulti: several)
+    struct WireRec {
+        uint32_t wr = 0, rd = 0, wrj = 0, rdj = 0, wrm = 0;
+    };
+    std::vector<WireRec> rec;
     void ensure(size_t n) {
-        if (rd.size() < n) {
-            rd.resize(n, 0);
-            wr.resize(n, 0);
-        }
+        if (rec.size() < n) rec.resize(n);
     }
     // index into `open` of the earliest group the step may join (== open.size(): it needs a new group)
     uint32_t place(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
         uint32_t lo = first_seq;
         for (uint32_t i = 0; i < nr; i++) {
-            const uint32_t w = wr[reads[i]];
+            const uint32_t w = rec[reads[i]].wr;
             if (w >= lo) lo = w + 1;  // read after write
         }
         for (uint32_t j = 0; j < nw; j++) {
             if (writes[j] == 0xffffffffu) continue;
-            const uint32_t w = wr[writes[j]], r = rd[writes[j]];
+            const uint32_t w = rec[writes[j]].wr, r = rec[writes[j]].rd;
             if (w >= lo) lo = w + 1;  // write after write
             if (r >= lo) lo = r + 1;  // write after read
         }
         return lo - first_seq;
     }
-    void mark(uint32_t index, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) {
+    // place(), and chain fusion's question in the same walk: do ALL the step's conflicts with the latest open group it has any
+    // with (the group before the one place() names) sit in ONE launch unit?  *unit = that unit, kFuseMulti if there are
+    // several, kFuseNone if the step conflicts with nothing in the window.
+    uint32_t place_fuse(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw, uint32_t *unit) const {
+        uint32_t best = 0, bj = kFuseNone;
+        auto consider = [&](uint32_t seq, uint32_t job) {
+            if (seq < first_seq) return;
+            if (seq > best) best = seq, bj = job;
+            else if (seq == best && job != bj) bj = kFuseMulti;
+        };
+        for (uint32_t i = 0; i < nr; i++) {
+            const WireRec &r = rec[reads[i]];
+            consider(r.wr, r.wrj);
+        }
+        for (uint32_t j = 0; j < nw; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            const WireRec &r = rec[writes[j]];
+            consider(r.wr, r.wrj);
+            consider(r.rd, r.rdj);
+        }
+        *unit = bj;
+        return best ? best + 1 - first_seq : 0;
+    }
+    // unit / step: the launch unit of the group that the step is (part of), and its index among the group's steps
+    void mark(uint32_t index, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw, uint32_t unit = 0,
+              uint32_t step = 0) {
         const uint32_t seq = first_seq + index;
-        for (uint32_t i = 0; i < nr; i++)
-            if (rd[reads[i]] < seq) rd[reads[i]] = seq;
+        for (uint32_t i = 0; i < nr; i++) {
+            WireRec &r = rec[reads[i]];
+            if (r.rd < seq) r.rd = seq, r.rdj = unit;
+            else if (r.rd == seq && r.rdj != unit) r.rdj = kFuseMulti;
+        }
         for (uint32_t j = 0; j < nw; j++)
-            if (writes[j] != 0xffffffffu) wr[writes[j]] = seq;
+            if (writes[j] != 0xffffffffu) {
+                WireRec &r = rec[writes[j]];
+                r.wr = seq, r.wrj = unit, r.wrm = (step << 20) | j;
+            }
     }
     // Launched groups, by sequence number (the last 64): a deep step that conflicts with a step of one of them waits for THAT
     // group's kernel on its lane, not for everything the ctx stream holds.  slot 0xffffffff: a pass of the ctx stream that is
@@ -372,9 +446,9 @@ struct GroupWindow {
     // must follow (0: none)
     uint32_t last_conflict(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {
         uint32_t q = 0;
-        for (uint32_t i = 0; i < nr; i++) q = std::max(q, wr[reads[i]]);
+        for (uint32_t i = 0; i < nr; i++) q = std::max(q, rec[reads[i]].wr);
         for (uint32_t j = 0; j < nw; j++)
-            if (writes[j] != 0xffffffffu) q = std::max(q, std::max(wr[writes[j]], rd[writes[j]]));
+            if (writes[j] != 0xffffffffu) q = std::max(q, std::max(rec[writes[j]].wr, rec[writes[j]].rd));
         return q;
     }
     // a pass of the ctx stream that is no group (the window is empty: everything queued was launched in front of it) takes a
@@ -389,8 +463,7 @@ struct GroupWindow {
         const uint32_t slot = open.front();
         open.pop_front();
         if (++first_seq >= 0xfffffff0u && open.empty()) {  // sequence numbers wrap after 4e9 groups: start over
-            std::fill(rd.begin(), rd.end(), 0);
-            std::fill(wr.begin(), wr.end(), 0);
+            std::fill(rec.begin(), rec.end(), WireRec{});
             first_seq = 1;
         }
         return slot;
@@ -711,11 +784,70 @@ void cache_make_room(CircCache &cache, size_t *held, size_t budget, size_t cost,
     }
 }
 
+// ---- chain fusion (stream_fuse.cpp) ------------------------------------------------------------------------------------------
+// The merged plan of a chain of steps: their gate lists concatenated with the wires re-named — an input that an earlier step
+// of the chain produces IS that step's output wire; the others become the merged circuit's inputs, in order; every step's
+// outputs are outputs of the merged circuit — the hash tweak starting over at every step (stream_garble.go:174) and the table
+// rows counted through (step k's rows: [row_base[k], row_base[k + 1])).  Cached per ctx by (circuits, wiring): a compiled
+// program repeats its chains (the ten sums and the carry chain of a field multiplication) thousands of times.
+struct FusedPlan {
+    gc_circ *circ = nullptr;     // the merged circuit (owned by the ctx's cache; null: the chain has no one-workgroup plan)
+    gc::FlatJob job{};           // its circuit-constant job record, LDS need, OR gates
+    size_t lds = 0;
+    bool has_or = false;
+    uint32_t n_ext = 0, n_out = 0, n_steps = 0;  // merged inputs / outputs; barriers of its pass
+    std::vector<uint32_t> gate_base, row_base;   // per step (+ the totals at the end)
+    std::vector<uint32_t> key;                   // what it was built from (compared on a hit)
+};
+// one step of a chain as merge_chain sees it: its gates in its own wire ids (inputs [0, nin), outputs the last nout wires) and
+// the source of every input (null: all from the wire store)
+struct ChainStep {
+    const gc_gate *gates;
+    uint32_t ngates, nwires, nin, nout;
+    const uint32_t *wiring;
+};
+// the chain as ONE gate list: wires [0, n_ext) the inputs read from the wire store (in step order), then every step's
+// private wires, then every step's outputs (in step order: the merged circuit's outputs); gate_base[k] = first gate of step k
+// (+ the total): where the hash tweak starts over
+int merge_chain(const ChainStep *steps, uint32_t n, std::vector<gc_gate> *all, std::vector<uint32_t> *gate_base, uint32_t *n_ext,
+                uint32_t *n_tmp, uint32_t *n_out);
+struct FuseStats {
+    uint64_t units = 0, steps = 0;  // launch units of several steps, and the steps in them
+    uint64_t appended = 0;          // steps appended to a unit when they were queued
+    uint64_t unplanned = 0;         // units that ran step by step because their chain was met for the first time (or the cache is full)
+    uint64_t built = 0, unfit = 0;  // merged plans this stream had to build; units that ran step by step (no one-workgroup plan)
+};
+struct FuseMember {
+    const CircEntry *ent;
+    const uint32_t *wiring;  // per input: kFuseNone (from the wire store) or member << 24 | output index; null: all from the store
+};
+// the merged plan of the chain (built, by the ctx's planner thread, when the chain has been met a few times; plan->circ == nullptr when it does not fit
+// one workgroup); nullptr: not planned (yet) / no memory / the cache is full — the caller then runs the steps one after the
+// other.  *built: this call planned it.
+const FusedPlan *fuse_plan(gc_ctx *ctx, bool eval_form, const FuseMember *members, uint32_t n, bool *built);
+// the ctx-wide identity of a circuit's content (what the merged plans are keyed by): 0 when the registry is full or the
+// circuit too big to be part of a chain
+uint32_t fuse_register(gc_ctx *ctx, bool eval_form, uint64_t hash, const std::vector<CircKey> &gates, uint32_t nwires, uint32_t nin,
+                       uint32_t nout);
+// chain fusion is on (GC_STREAM_NO_FUSE switches it off: every step its own launch unit, as before round 5)
+bool fuse_enabled();
+// the step joins unit `unit` of group g (its index there is jobs.size(): the caller pushes the JobRec next); n_ext: how many
+// of its inputs come from the wire store
+void wg_append(Slot &g, uint32_t unit, JobRec *j, const CircEntry *ent, uint32_t n_ext, uint64_t shape);
+// The running hash of a unit's shape when a step with this circuit and wiring joins it, and what earlier chains of that shape
+// say about its DEPTH (dependent hash phases of the merged plan up to and including that step; 0: not known yet).  A unit
+// is one workgroup: a chain that would run for a thousand phases holds up its whole group, so the caller stops appending
+// where the hint exceeds kFuseDepth — the first chain of a shape runs as long as the other caps allow, and tells.
+uint64_t fuse_shape(uint64_t shape, const CircEntry *ent, const uint32_t *wiring);
+uint32_t fuse_depth_hint(gc_ctx *ctx, uint64_t shape);
+// a new launch unit for a step about to be pushed to g.jobs; returns its index
+uint32_t wg_new(Slot &g, JobRec *j, const CircEntry *ent, bool may_fuse);
+
 bool entry_is_small(CircEntry *e);
 bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream);
 Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big = false);
 void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng);
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep);
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats);
 
 }  // namespace gcs

@@ -66,6 +66,7 @@ def lib():
         "gc_last_error": (C.c_char_p, []),
         "gc_abi_version": (i32, []),
         "gc_plan_create": (vp, [vp, u32, u32, u32, u32, ip]),
+        "gc_plan_create_chain": (vp, [vp, vp, vp, vp, vp, vp, u32, ip]),
         "gc_plan_free": (None, [vp]),
         "gc_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
         "gc_plan_simulate": (i32, [vp, vp, vp]),
@@ -95,6 +96,8 @@ def lib():
         "gc_stream_garble_finish_view": (i32, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+        "gc_stream_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
+        "gc_stream_eval_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
         "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
         "gc_stream_eval_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
@@ -266,15 +269,43 @@ class Plan:
         self.h = L.gc_plan_create(_p(g), len(g), nwires, ninputs, noutputs, C.byref(st))
         if not self.h:
             raise EngineError(st.value, "gc_plan_create")
+        self._describe(len(g))
+
+    def _describe(self, n):
+        L = lib()
         self.info = PlanInfo()
         _check(L.gc_plan_get_info(self.h, C.byref(self.info)), "gc_plan_get_info")
-        n = len(g)
         self.level_of_gate = np.zeros(n, np.uint32)
         self.tweak_of_gate = np.zeros(n, np.uint32)
         self.row_of_gate = np.zeros(n + 1, np.uint32)
         self.slot_of_gate = np.zeros(n, np.uint32)
         _check(L.gc_plan_describe(self.h, _p(self.level_of_gate), _p(self.tweak_of_gate), _p(self.row_of_gate),
                                   _p(self.slot_of_gate)), "gc_plan_describe")
+
+    @classmethod
+    def chain(cls, steps):
+        """the merged plan of a fused chain (gc_plan_create_chain).  steps: [(gates, nwires, nin, nout, wiring)], wiring per
+        input 0xffffffff (wire store) or m << 24 | j (output j of step m); None for a step that reads the store only"""
+        L = lib()
+        n = len(steps)
+        keep = []
+        gp, wp = (C.c_void_p * n)(), (C.c_void_p * n)()
+        ng, nw, ni, no = (np.zeros(n, np.uint32) for _ in range(4))
+        for k, (gates, nwires, nin, nout, wiring) in enumerate(steps):
+            g = np.ascontiguousarray(gates, dtype=GATE)
+            w = np.full(nin, 0xFFFFFFFF, np.uint32) if wiring is None else np.ascontiguousarray(wiring, dtype=np.uint32)
+            assert len(w) == nin
+            keep += [g, w]
+            gp[k], wp[k] = g.ctypes.data, w.ctypes.data
+            ng[k], nw[k], ni[k], no[k] = len(g), nwires, nin, nout
+        st = C.c_int(0)
+        self = cls.__new__(cls)
+        self.h = L.gc_plan_create_chain(gp, _p(ng), _p(nw), _p(ni), _p(no), wp, n, C.byref(st))
+        if not self.h:
+            raise EngineError(st.value, "gc_plan_create_chain")
+        self._describe(int(ng.sum()))
+        self.gate_base = np.concatenate([[0], np.cumsum(ng)]).astype(np.uint32)
+        return self
 
     def simulate(self, in_bits):
         """plaintext walk of the flattened unit program (gc_plan_simulate): output bits"""
@@ -702,6 +733,13 @@ class Stream:
         _check(lib().gc_stream_deep_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_deep_stats")
         return a.value, b.value
 
+    def fuse_stats(self):
+        """chain fusion (gc_stream_fuse_stats): (launch units of several steps, steps in them, merged plans built, units that
+        ran step by step for want of a one-workgroup plan)"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        _check(lib().gc_stream_fuse_stats(self.h, *[C.byref(x) for x in v]), "gc_stream_fuse_stats")
+        return tuple(x.value for x in v)
+
     def garble_begin(self, gates, nwires, in_, out_):
         """gc_stream_garble_begin: queue one circuit, do not wait (up to 4 096 in flight; small independent circuits
         share a launch sequence)"""
@@ -779,6 +817,12 @@ class StreamEval:
         a, b = C.c_uint64(0), C.c_uint32(0)
         _check(lib().gc_stream_eval_deep_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_deep_stats")
         return a.value, b.value
+
+    def fuse_stats(self):
+        """chain fusion on the evaluator's side (gc_stream_eval_fuse_stats)"""
+        v = [C.c_uint64(0) for _ in range(4)]
+        _check(lib().gc_stream_eval_fuse_stats(self.h, *[C.byref(x) for x in v]), "gc_stream_eval_fuse_stats")
+        return tuple(x.value for x in v)
 
     def close(self):
         if self.h:

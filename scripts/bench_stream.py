@@ -394,7 +394,7 @@ class _Args:
         return out
 
 
-def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True):
+def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True, view=False):
     """returns (stream bytes as one array, per-step byte counts, seconds, stats, the Stream — still open); g.inputs0 =
     the zero labels of the primary inputs as they were BEFORE the program ran (a program may overwrite its inputs)"""
     L = engine.lib()
@@ -414,6 +414,10 @@ def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True):
         begin, bargs = L.gc_stream_garble_begin_h, a.interned(g)
     off = 0
     issued = 0
+    if view:  # experiment: the bytes are handed out in place (gc_stream_garble_finish_view) and nobody reads them
+        vptr = C.c_void_p(0)
+        pv = C.byref(vptr)
+        fview = L.gc_stream_garble_finish_view
     t0 = time.perf_counter()
     for k in range(n):
         lim = min(n, k + window)
@@ -422,7 +426,7 @@ def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True):
             if rc:
                 raise engine.EngineError(rc, "gc_stream_garble_begin(step %d)" % issued)
             issued += 1
-        rc = finish(h, C.c_void_p(base + off), cap - off, pnb)
+        rc = fview(h, pv, pnb) if view else finish(h, C.c_void_p(base + off), cap - off, pnb)
         if rc:
             raise engine.EngineError(rc, "gc_stream_garble_finish(step %d)" % k)
         sizes[k] = nb.value
@@ -480,7 +484,7 @@ def golden_sha(name, key):
         return None
 
 
-def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, repeats=2, intern=True):
+def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, repeats=2, intern=True, view=False):
     steps, prim = PROGRAMS[name]()
     rnd = stream_rnd(name, len(prim))
     own = ctx is None
@@ -490,7 +494,7 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
     ands = sum(c.stats()["AND"] for c, _, _ in steps)
     best = None
     for rep in range(repeats):  # the first pass builds and caches the plans: report the second as the steady state
-        stream, sizes, dt, stats, g = garble_program(ctx, key, steps, prim, rnd, window, intern)
+        stream, sizes, dt, stats, g = garble_program(ctx, key, steps, prim, rnd, window, intern, view)
         sha = hashlib.sha256(stream.tobytes() if len(stream) < (1 << 30) else memoryview(stream)).hexdigest()
         res = {"program": name, "steps": len(steps), "gates": gates, "and": ands, "window": window, "interned": intern,
                "garble_s": dt, "garble_gates_per_s": gates / dt, "garble_us_per_step": dt / len(steps) * 1e6,
@@ -501,11 +505,14 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
             first = dt
         else:
             res["first_pass_s"] = first
-        want = golden_sha(name, key)
+        res["fuse"] = g.fuse_stats()
+        want = golden_sha(name, key) if not view else None
         if want is not None and want != sha:
             raise AssertionError("%s: stream SHA-256 %s != oracle's %s" % (name, sha, want))
-        if evaluate and rep == repeats - 1:
-            edt, est = eval_program(ctx, key, steps, prim, g, stream, sizes)
+        if evaluate and rep == repeats - 1 and not view:
+            # (twice, as the garbler: the merged plans of fused chains are cached per ctx — the second evaluator finds them)
+            for _ in range(2):
+                edt, est = eval_program(ctx, key, steps, prim, g, stream, sizes)
             res.update({"eval_s": edt, "eval_gates_per_s": gates / edt, "eval_us_per_step": edt / len(steps) * 1e6,
                         "eval_blocks_parsed": est[0], "eval_blocks_matched": est[1]})
             sdt, sn = eval_program.steady
@@ -514,7 +521,7 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
                             "eval_steady_gates_per_s": gates / len(steps) * sn / sdt, "eval_first_blocks_s": edt - sdt})
         g.close()
         best = res
-    want = golden_sha(name, key)
+    want = golden_sha(name, key) if not view else None
     best["sha256_golden"] = want
     best["sha256_ok"] = None if want is None else bool(want == best["sha256"])
     if want is not None and want != best["sha256"]:
@@ -642,4 +649,4 @@ if __name__ == "__main__":
             print(json.dumps(run_native(nm, window=2 if nm.startswith("big") and win == 64 else win)), flush=True)
             continue
         print(json.dumps(run_program(nm, window=2 if nm.startswith("big") and win == 64 else win,
-                                     intern=not (len(parts) > 2 and parts[2] == "noh"))), flush=True)
+                                     intern=not (len(parts) > 2 and parts[2] == "noh"), view=len(parts) > 2 and parts[2] == "view")), flush=True)

@@ -1,0 +1,6 @@
+import sys, json
+for l in sys.stdin:
+    try: d=json.loads(l)
+    except Exception:
+        print(l[:300].rstrip()); continue
+    print(d["program"], "win", d.get("window"), "garble %.3g eval %.3g groups %d fuse %s garble_s %.3f first %.3f" % (d["garble_gates_per_s"], d.get("eval_gates_per_s",0), d["launch_groups"], d.get("fuse"), d["garble_s"], d.get("first_pass_s",0)))

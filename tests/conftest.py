@@ -16,6 +16,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Chain fusion of the streaming engine (mpc_amd/csrc/stream_fuse.cpp) plans a chain of steps when it meets it the second
+    # time, on a thread of its own: in a product run nobody waits for a plan.  The parity tests want the fused kernels on
+    # EVERY chain, deterministically: plans at first sight, on the calling thread (tests that check the default unset it).
+    os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")
 
 
 def pytest_sessionfinish(session, exitstatus):
