@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per gate per side (SURVEY.md §8d / DESIGN.md): 16-byte labels, L1 never stored
 ALG_BYTES = {"xor": 48, "xnor": 48, "and": 80, "inv": 48, "or": 96}
 GATHER_EVERY = 8  # steps per all_gather of the decoded outputs (N > 1)
+PREWARM_STEPS = 100  # untimed launches of the step ahead of the warm-up steps: the GPU at its sustained clocks (see run())
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 # Secondary bound (SURVEY.md §8d "LDS bandwidth / VALU issue on AND-dense levels"): the fixed-key hash is a
 # T-table AES out of LDS.  tools/aes_ubench measures the production AES core alone at 10.28 cycles per block per
@@ -125,6 +126,62 @@ def sweep_rows_for_line(batch, key, ctx):
     return [{k: r[k] for k in SWEEP_KEEP if k in r} for r in rows]
 
 
+def level_launch_row(batch, circ, key, ctx):
+    """The north star's literal schedule beside the production one (SURVEY §7 hard part 4): schedule 0 —
+    one data-parallel launch per dependency level (308 garbling + 308 evaluating launches for aes_128, thread = (gate,
+    instance), wires in HBM), the step's launches recorded in a hipGraph — on the headline's workload, timed like the
+    headline (wall time between two device syncs) with the passes' HIP-event times beside it."""
+    dc = engine.DeviceCircuit(ctx, circ)
+    info = dc.info
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    for b in (gb, ev):
+        b.set_schedule(0)
+        b.set_graph(True)
+    d_rnd = ctx.random_u8((batch, circ.num_inputs + 1, 16), 256, seed=77)
+    d_bits = ctx.random_u8((batch, circ.num_inputs), 2, seed=78)
+    d_out = ctx.zeros((batch, circ.num_outputs))
+    d_mis = ctx.zeros(1, np.int32)
+
+    def step():
+        gb.garble(key, d_rnd)
+        ev.select_inputs(gb, d_bits)
+        ev.eval(key, gb)
+        gb.decode(ev, d_out, d_mis)
+
+    for _ in range(3):
+        step()
+    ctx.sync()
+    steps = 6
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    g_ms, e_ms = [], []
+    for _ in range(4):
+        gb.garble(key, d_rnd)
+        g_ms.append(gb.last_ms)
+        ev.select_inputs(gb, d_bits)
+        ev.eval(key, gb)
+        e_ms.append(ev.last_ms)
+    ctx.sync()
+    algb = alg_bytes_per_instance(info)
+    row = {"schedule": "level-launch (schedule 0): one launch per dependency level, recorded in a hipGraph",
+           "workload": "%s x %d instances, %d-byte key" % (circ.name, batch, len(key)),
+           "launches_per_garble": int(gb.last_launches), "levels": int(info.nlevels), "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "and_gates_per_s": info.n_and * batch * steps / dt,
+           "garble_ms": float(np.mean(g_ms)), "eval_ms": float(np.mean(e_ms)),
+           "hbm_alg_GBs_garble": algb * batch / (float(np.mean(g_ms)) * 1e-3) / 1e9,
+           "hbm_roofline_frac_garble": algb * batch / (float(np.mean(g_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "outputs_ok": int(d_mis.numpy()[0]) == 0}
+    gb.close()
+    ev.close()
+    dc.close()
+    for d in (d_rnd, d_bits, d_out, d_mis):
+        d.close()
+    return row
+
+
 def reference_bench_rows(batch, circ, ctx):
     """SURVEY §8d's remaining rows, under the reference's own benchmark key (circuit/garble_bench_test.go:35, 16 bytes =
     AES-128): config 2 again (`key16`) and buildANDChain(10000) (:19-33, :39 — depth 10 000, width 1: the worst case)"""
@@ -182,6 +239,7 @@ def run(stage):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-iknp", action="store_true", help="skip the IKNP OT-extension side measurement")
     ap.add_argument("--no-host-api", action="store_true", help="skip the PCIe-inclusive gc_garble / gc_eval side measurement")
+    ap.add_argument("--no-prewarm", action="store_true", help="no untimed launches ahead of the warm-up steps (the GPU's clocks then ramp inside the timed region)")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming (config 5 shape) side measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the sha256xor x 256 + 65 536 OTs pipeline (config 3) side measurement")
     ap.add_argument("--no-synthetic", action="store_true", help="skip the five synthetic levelised rows (SURVEY §8d)")
@@ -313,6 +371,13 @@ def run(stage):
             print("bench: hipGraph capture unavailable (%s); launching directly" % e, file=sys.stderr)
             graphs = None
             ctx.sync()
+    # The GPU's clocks fall back after ~10 ms without work and take a few ms of load to come up again (scripts/probe_fixed_cost.py:
+    # 20 graph launches behind a 20 ms pause take 1.4 ms longer than behind a 2 ms pause; the set-up above — circuit upload,
+    # graph capture — leaves the GPU idle for far longer, and W = 5 warm-up steps are 5 ms).  Untimed launches of the same step
+    # bring it to its sustained state before the warm-up steps; nothing is waited for in between, so the warm-up starts behind them.
+    if not args.no_prewarm:
+        for _ in range(PREWARM_STEPS):
+            launch(0)
     stage[0] = "timed steps"
     loop = gdist.StepLoop(K, launch, gather if collective else None)
     elapsed = gdist.run_timed(loop, fence, args.steps, args.warmup,
@@ -465,7 +530,18 @@ def run(stage):
         },
     }
     if collective:
+        # which GPU every rank really ran on (one process per GPU: each may see its own as device 0), as the ranks say
+        # themselves: 96 bytes per rank through the communicator's own all-gather
+        me = ("%s|%s|%d" % (ctx.pci_bus_id() if hasattr(ctx, "pci_bus_id") else "?", os.environ.get("HIP_VISIBLE_DEVICES", ""),
+                            ctx.device)).encode()[:95]
+        cards = comm.allgather_host(np.frombuffer(me.ljust(96, b"\0"), np.uint8))
+        rank_devices = []
+        for r in range(world):
+            bus, vis, dev = (bytes(cards[r]).rstrip(b"\0").decode(errors="replace").split("|") + ["", "", ""])[:3]
+            rank_devices.append({"rank": r, "pci_bus_id": bus, "HIP_VISIBLE_DEVICES": vis or None, "device_index": dev})
         res["config4"] = {
+            "rank_devices": rank_devices,
+            "distinct_gpus": len({d["pci_bus_id"] for d in rank_devices}),
             "workload": "aes_128 x %d instances = %d per GPU x %d GPUs (BASELINE config 4 is 8 192 x 8), outputs of %d steps per "
                         "gather" % (batch * world, batch, world, K),
             "instances_total": batch * world,
@@ -493,6 +569,7 @@ def run(stage):
             res["synthetic"] = sweep_rows_for_line(batch, key, ctx)
         if not args.no_extra_rows and aes:
             res.update(reference_bench_rows(batch, circ, ctx))
+            res["level_launch"] = level_launch_row(batch, circ, key, ctx)
         if not args.no_iknp:
             # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):
             # device-resident API, 4 Mi OTs

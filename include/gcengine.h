@@ -130,6 +130,10 @@ int gc_ctx_sync(gc_ctx *);
  * state: 0 not used yet, 1 in use, -1 off (GC_NO_COOP, the self-test failed, or after a timeout); timeouts: passes that were
  * done again.  Either pointer may be NULL.  (GC_COOP_FORCE_TIMEOUT=n makes the n-th pass of every ctx lose a workgroup.) */
 int gc_ctx_coop_stats(gc_ctx *, int *state, uint64_t *timeouts);
+/* which device the ctx really sits on: its PCI bus id as text ("0000:75:00.0", hipDeviceGetPCIBusId) — a multi-GPU launcher
+ * that hands every rank its own HIP_VISIBLE_DEVICES shows each process ONE device, number 0; the bus id tells the ranks'
+ * devices apart (bench.py --gpus N records it per rank in its config4 block).  len >= 16. */
+int gc_ctx_pci_bus_id(gc_ctx *, char *buf, size_t len);
 /* the ctx's HIP stream as an opaque pointer (hipStream_t) for callers that enqueue their own work */
 void *gc_ctx_stream(gc_ctx *);
 

@@ -12,7 +12,6 @@
 // librccl is opened lazily (dlopen "librccl.so.1"; a copy the process already holds — e.g. PyTorch's — is reused, its
 // soname is the same), so libgcengine.so itself loads on hosts without RCCL and the single-GPU path never maps it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -22,24 +21,11 @@
 #include <vector>
 
 #include "engine.h"
+#include "rccl_binding.h"
 
 namespace {
 
-struct Rccl {
-    void *h = nullptr;
-    ncclResult_t (*GetVersion)(int *) = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    bool ok = false;
-    char why[256] = "";
-};
+using gc_rccl::Rccl;
 
 Rccl &rccl() {
     static Rccl r;

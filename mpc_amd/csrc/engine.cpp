@@ -366,6 +366,12 @@ int gc_ctx_sync(gc_ctx *c) {
 
 void *gc_ctx_stream(gc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+int gc_ctx_pci_bus_id(gc_ctx *c, char *buf, size_t len) {
+    if (!c || !buf || len < 16) return GC_E_ARG;
+    GC_HIP(hipDeviceGetPCIBusId(buf, (int)len, c->device));
+    return GC_OK;
+}
+
 int gc_ctx_coop_stats(gc_ctx *c, int *state, uint64_t *timeouts) {
     if (!c) return GC_E_ARG;
     (void)gc_ctx_coop_check(c);  // (a pass that has raised the word since the last look)

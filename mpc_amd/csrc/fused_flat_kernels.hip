@@ -426,13 +426,15 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
     const uint32_t ustride = a.ustride;                                                                      \
     uint4 *rl = smem + kStageOff + 2 * ustride;                                                              \
     uint4 *wl = rl + TI;                                                                                     \
-    load_te_dual(te, a.te0);                                                                                 \
+    /* (a workgroup that runs a CHAIN of jobs, one after the other, keeps the AES table and the column keys of the first) */ \
+    const bool first_job = !MULTI || a.pad2_ == 0;                                                           \
+    if (first_job) load_te_dual(te, a.te0);                                                                  \
     uint32_t rkr[4 * (NR + 1)];                                                                              \
     uint32_t vz;                                                                                             \
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));                                                              \
     load_round_keys_split<NR, (4 * (NR + 1) > 32 ? 4 * (NR + 1) - 32 : 4 * (NR + 1))>(rkr, a.rk, vz);        \
     fold_last_round_key<NR>(rkr); /* the hashes run on whitened blocks (hash_dual_whitened) */              \
-    if (threadIdx.x < 4 * (NR + 1)) { /* the same keys, column-addressable, for hash_col_whitened */          \
+    if (first_job && threadIdx.x < 4 * (NR + 1)) { /* the same keys, column-addressable, for hash_col_whitened */ \
         uint32_t kv = a.rk[threadIdx.x];                                                                     \
         if (threadIdx.x >= 4 * NR) kv ^= a.rk[threadIdx.x - 4 * NR];                                         \
         ((uint32_t *)smem)[kKeyTab / 4 + threadIdx.x] = kv;                                                  \
@@ -614,10 +616,10 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
 // this workgroup's job record, word by word through v_readfirstlane: wave-uniform values the compiler keeps in SGPRs
 // (a plain struct copy from global memory lands in VGPRs — the kernel has stores it cannot prove disjoint — and with
 // them the 128-VGPR budget of a 1024-thread workgroup spills)
-__device__ __forceinline__ FlArgs load_job(const FlArgs *jobs) {
+__device__ __forceinline__ FlArgs load_job(const FlArgs *job) {
     constexpr int kWords = sizeof(FlArgs) / 4;
     static_assert(sizeof(FlArgs) % 4 == 0, "FlatJob is a whole number of dwords");
-    const uint32_t *p = (const uint32_t *)(jobs + blockIdx.x);
+    const uint32_t *p = (const uint32_t *)job;
     uint32_t w[kWords];
 #pragma unroll
     for (int i = 0; i < kWords; i++) w[i] = __builtin_amdgcn_readfirstlane(p[i]);
@@ -630,11 +632,28 @@ template <int NR, bool PROF, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
     garble_flat_body<NR, PROF, HAS_OR, false>(a);
 }
-// step groups of the streaming engine: workgroup j = job j (a whole, independent one-instance circuit)
-template <int NR, bool HAS_OR>
-__global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs) {
-    const FlArgs a = load_job(jobs);
-    garble_flat_body<NR, false, HAS_OR, true>(a);
+// step groups of the streaming engine: workgroup u = launch unit u — one job (a whole, independent one-instance circuit: a
+// step, or a chain of steps on its merged plan).  CHAIN: some unit of the launch is a chain of dependent steps that has no
+// merged plan (yet): the workgroup runs its jobs one after the other (records first[u] .. first[u] + jobs[first[u]].pad_; each
+// job's outputs go back into the wire store before the next one gathers its inputs from there).  A build of its own: the
+// loop's state costs the registers the single-job build just fits into (0 against 14 spilled VGPRs).
+template <int NR, bool HAS_OR, bool CHAIN>
+__global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs, const uint32_t *first) {
+    if constexpr (!CHAIN) {
+        const FlArgs a = load_job(jobs + blockIdx.x);
+        garble_flat_body<NR, false, HAS_OR, true>(a);
+    } else {
+        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[blockIdx.x]);
+        const uint32_t more = __builtin_amdgcn_readfirstlane(jobs[j0].pad_);
+        for (uint32_t j = j0; j <= j0 + more; j++) {
+            const FlArgs a = load_job(jobs + j);
+            garble_flat_body<NR, false, HAS_OR, true>(a);
+            if (j != j0 + more) {  // the next job of the chain reads what this one has just stored
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    }
 }
 
 template <int NR, bool PROF, bool HAS_OR, bool MULTI>
@@ -735,10 +754,23 @@ template <int NR, bool PROF, bool HAS_OR>
 __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     eval_flat_body<NR, PROF, HAS_OR, false>(a);
 }
-template <int NR, bool HAS_OR>
-__global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs) {
-    const FlArgs a = load_job(jobs);
-    eval_flat_body<NR, false, HAS_OR, true>(a);
+template <int NR, bool HAS_OR, bool CHAIN>
+__global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs, const uint32_t *first) {
+    if constexpr (!CHAIN) {
+        const FlArgs a = load_job(jobs + blockIdx.x);
+        eval_flat_body<NR, false, HAS_OR, true>(a);
+    } else {
+        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[blockIdx.x]);
+        const uint32_t more = __builtin_amdgcn_readfirstlane(jobs[j0].pad_);
+        for (uint32_t j = j0; j <= j0 + more; j++) {
+            const FlArgs a = load_job(jobs + j);
+            eval_flat_body<NR, false, HAS_OR, true>(a);
+            if (j != j0 + more) {
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    }
 }
 
 size_t fused_flat_bytes(uint32_t nls, uint32_t ti_log2, uint32_t ustride) {
@@ -790,21 +822,24 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
 }
 
 template <typename K>
-static hipError_t launch_jobs(K kern, const FlatJob *jobs, uint32_t njobs, size_t lds, hipStream_t s) {
+static hipError_t launch_jobs(K kern, const FlatJob *jobs, const uint32_t *first, uint32_t nunits, size_t lds, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(njobs), dim3(TF), lds, s, jobs);
+    hipLaunchKernelGGL(kern, dim3(nunits), dim3(TF), lds, s, jobs, first);
     return hipGetLastError();
 }
 
-hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, uint32_t njobs,
+hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
                                   size_t lds_bytes, hipStream_t s) {
-    if (njobs == 0) return hipSuccess;
-#define GC_J3(KERN, NR) (has_or ? launch_jobs(KERN<NR, true>, d_jobs, njobs, lds_bytes, s) : launch_jobs(KERN<NR, false>, d_jobs, njobs, lds_bytes, s))
+    if (nunits == 0) return hipSuccess;
+    const bool chain = d_first != nullptr;  // (nullptr: unit u is record u)
+#define GC_J4(KERN, NR, OR) (chain ? launch_jobs(KERN<NR, OR, true>, d_jobs, d_first, nunits, lds_bytes, s) : launch_jobs(KERN<NR, OR, false>, d_jobs, d_first, nunits, lds_bytes, s))
+#define GC_J3(KERN, NR) (has_or ? GC_J4(KERN, NR, true) : GC_J4(KERN, NR, false))
 #define GC_J2(KERN) (rounds == 10 ? GC_J3(KERN, 10) : rounds == 12 ? GC_J3(KERN, 12) : GC_J3(KERN, 14))
     return eval ? GC_J2(k_eval_flat_jobs) : GC_J2(k_garble_flat_jobs);
 #undef GC_J2
 #undef GC_J3
+#undef GC_J4
 }
 
 }  // namespace gc

@@ -191,10 +191,12 @@ struct FlatJob {
     const uint32_t *out_idx;     //     0xffffffff: not stored), written back by the workgroup itself when it is done
     uint32_t nout, pad2_;
 };
-// d_jobs: device array of njobs records (ti_log2 = 0, batch = 1, rnd = prof = nullptr); lds_bytes = the largest
-// fused_flat_bytes(nls, 0, ustride) of the group; has_or: some job's circuit has an OR gate; rounds: 10 / 12 / 14 (one
-// key per stream)
-hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, uint32_t njobs,
+// d_jobs: device array of records (ti_log2 = 0, batch = 1, rnd = prof = nullptr); d_first == nullptr: workgroup u runs record
+// u; else the records d_first[u] .. d_first[u] + d_jobs[d_first[u]].pad_ one after the other (pad2_ = a record's position in
+// that run: 0 loads the AES table) — several for a chain of dependent steps without a merged plan (stream_fuse.cpp);
+// lds_bytes = the largest fused_flat_bytes(nls, 0, ustride) of the group; has_or: some job's circuit has an OR gate; rounds:
+// 10 / 12 / 14 (one key per stream)
+hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
                                   size_t lds_bytes, hipStream_t s);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void k_rows_copy(const RowCopy *rc) {
 // Chain fusion (stream_fuse.cpp): a launch unit of several steps runs as ONE job on its merged plan — inputs gathered from the
 // wire store for the whole chain, every step's outputs scattered back at the end (an output that a later step of the chain
 // writes again is dropped), the garbler's serialiser finding step k's rows in the chain's table array at row_base[k].  A chain
-// without a one-workgroup plan runs its steps in successive launches of the same kernel (round r = the r-th step).
+// without a merged plan (not met often enough yet, or none fits a workgroup) still is ONE workgroup: it runs its steps' own
+// jobs one after the other, through the wire store (fused_flat_kernels.hip: k_*_flat_jobs).
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
                  hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats) {
     const bool on_lane = g.deep_id != 0;
@@ -188,7 +189,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     const uint32_t n = (uint32_t)g.jobs.size(), nwg = (uint32_t)g.wgs.size();
     // ---- the merged plans of the chains (before the ctx lock: a chain met for the first time is planned here)
     std::vector<const FusedPlan *> plans(nwg, nullptr);
-    uint32_t nrec = 0, nrounds = 1, ncopies = 0;
+    uint32_t nrec = 0, ncopies = 0;
     size_t extra_up = 0, extra_arena = 0;
     size_t lds = g.lds;
     bool has_or = g.has_or;
@@ -220,7 +221,6 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
                 has_or = has_or || fp->has_or;
             } else {
                 nrec += w.n;
-                nrounds = std::max(nrounds, w.n);
                 if (fstats) (fp ? fstats->unfit : fstats->unplanned)++;
             }
         }
@@ -254,9 +254,11 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     }
     if (e != hipSuccess) return fail("launch_group (order)", e);
     // upload region: [what the steps queued] [merged wire maps of the chains] [job records] [serialiser records] [row copies]
+    // [first job record of every unit]
     const size_t off_maps = up16(g.up_used), off_fj = off_maps + extra_up, off_fin = off_fj + (size_t)nrec * sizeof(FlatJob);
     const size_t off_rc = off_fin + (size_t)n * sizeof(FinJob);
-    const size_t total_up = off_rc + (size_t)ncopies * sizeof(RowCopy);
+    const size_t off_first = off_rc + (size_t)ncopies * sizeof(RowCopy);
+    const size_t total_up = off_first + up16((size_t)nwg * sizeof(uint32_t));
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
     const size_t arena_chain = up256(g.arena_used);
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
@@ -269,20 +271,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
     FinJob *fin = (FinJob *)(g.h_up + off_fin);
     RowCopy *rcp = (RowCopy *)(g.h_up + off_rc);
-    // records of round r start at rec_first[r] (round 0: every unit's job, or its first step; round r: the r-th step of a chain
-    // that runs step by step)
-    std::vector<uint32_t> rec_first(nrounds + 1, 0);
-    if (nrounds > 1) {
-        for (uint32_t u = 0; u < nwg; u++) {
-            if (g.wgs[u].n < 2 || plans[u]) rec_first[1]++;
-            else
-                for (uint32_t r = 0; r < g.wgs[u].n; r++) rec_first[r + 1]++;
-        }
-        for (uint32_t r = 0; r < nrounds; r++) rec_first[r + 1] += rec_first[r];
-    } else {
-        rec_first[1] = nrec;
-    }
-    std::vector<uint32_t> rec_next(rec_first.begin(), rec_first.end() - 1);
+    uint32_t *first = (uint32_t *)(g.h_up + off_first);
+    uint32_t rec = 0;
     auto step_job = [&](const JobRec &j) {  // one step as a job of its own
         const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
         FlatJob f = j.ent->job;
@@ -322,12 +312,15 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (!g.kills.empty()) out_base.assign(n, 0xffffffffu);
     for (uint32_t u = 0; u < nwg; u++) {
         const WgRec &w = g.wgs[u];
-        if (w.n < 2 || !plans[u]) {
+        first[u] = rec;
+        if (w.n < 2 || !plans[u]) {  // one step — or a chain without a merged plan: its steps' jobs, one after the other
             uint32_t r = 0;
             for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next, r++) {
                 const JobRec &j = g.jobs[(size_t)k];
-                const FlatJob f = step_job(j);
-                fj[rec_next[r]++] = f;
+                FlatJob f = step_job(j);
+                f.pad_ = r == 0 ? w.n - 1 : 0;
+                f.pad2_ = r;
+                fj[rec++] = f;
                 step_fin(j, (uint32_t)k, f.T, j.ent->circ->d_row_of_gate);
             }
             continue;
@@ -349,7 +342,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         f.out_slots = fp.circ->d_out_slots;
         f.out_idx = d_in + fp.n_ext;
         f.nout = fp.n_out;
-        fj[rec_next[0]++] = f;
+        f.pad_ = f.pad2_ = 0;
+        fj[rec++] = f;
         uint32_t ni = 0, no = 0, m = 0;
         for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next, m++) {
             const JobRec &j = g.jobs[(size_t)k];
@@ -373,8 +367,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         hipLaunchKernelGGL(k_rows_copy, dim3(ncp), dim3(256), 0, st, (const RowCopy *)(g.d_up + off_rc));
         e = hipGetLastError();
     }
-    for (uint32_t r = 0; r < nrounds && e == hipSuccess; r++)
-        e = launch_fused_flat_jobs(eval, rounds, has_or, (const FlatJob *)(g.d_up + off_fj) + rec_first[r], rec_first[r + 1] - rec_first[r], lds, st);
+    if (e == hipSuccess)
+        e = launch_fused_flat_jobs(eval, rounds, has_or, (const FlatJob *)(g.d_up + off_fj), nrec != nwg ? (const uint32_t *)(g.d_up + off_first) : nullptr,
+                                   nwg, lds, st);
     // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
     // done itself for the evaluator (nothing follows)
     g.kernel_ev = eval ? g.done : g.kdone;

@@ -99,6 +99,7 @@ def lib():
         "gc_stream_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
         "gc_stream_eval_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
         "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+        "gc_ctx_pci_bus_id": (i32, [vp, C.c_char_p, sz]),
         "gc_stream_eval_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_eval_create": (vp, [vp, vp, sz, ip]),
         "gc_stream_eval_free": (None, [vp]),
@@ -338,6 +339,12 @@ class Context:
         a, b = C.c_int(0), C.c_uint64(0)
         _check(lib().gc_ctx_coop_stats(self.h, C.byref(a), C.byref(b)), "gc_ctx_coop_stats")
         return a.value, b.value
+
+    def pci_bus_id(self):
+        """the device's PCI bus id ("0000:75:00.0"): tells the ranks' GPUs apart when every process sees its own as device 0"""
+        b = C.create_string_buffer(32)
+        _check(lib().gc_ctx_pci_bus_id(self.h, b, 32), "gc_ctx_pci_bus_id")
+        return b.value.decode()
 
     def sync(self):
         _check(lib().gc_ctx_sync(self.h), "gc_ctx_sync")

@@ -614,6 +614,18 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                                        "eval_us_per_step", "eval_steady_gates_per_s", "launch_groups", "grouped_steps", "big_steps",
                                        "deep_steps", "lanes", "sha256", "sha256_ok") if k in r}
         out[name]["shape"] = SHAPES[name]
+    # The UNCHANGED caller: compiler/ssa/streamer.go:694 calls Streaming.Garble one instruction at a time —
+    # begin + finish per step, nothing queued ahead (window 1).  Every row above queues 64 - 1 024 instructions ahead, which
+    # needs the three-edit patch of the streamer (go/ssa/stream_window_hip.go).
+    r = run_program("ed25519like", key, ctx, window=1, evaluate=False)
+    out["ed25519like_window1"] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "launch_groups",
+                                                    "sha256", "sha256_ok") if k in r}
+    out["ed25519like_window1"]["caller"] = "unchanged: Streaming.Garble per instruction (gc_stream_garble_begin + _finish, nothing in flight)"
+    # ... and the engine's rate when the bytes are consumed IN PLACE (gc_stream_garble_finish_view, as go/circuit/stream_hip.go
+    # does: a pointer into the engine's pinned staging, no copy into a second buffer)
+    r = run_program("ed25519like", key, ctx, window=WINDOWS["ed25519like"], view=True)
+    out["ed25519like"]["garble_view_gates_per_s"] = r["garble_gates_per_s"]
+    out["ed25519like"]["fuse"] = dict(zip(("fused_units", "fused_steps", "plans_asked", "unfit"), r.get("fuse", ())))
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
     for name, win in (("big130", 2), ("ed25519like", WINDOWS["ed25519like"]), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64),

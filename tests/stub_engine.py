@@ -133,6 +133,12 @@ class Comm:
             out[:] = t
         d_recv.a.reshape(-1).view(np.uint8)[: self.nranks * nbytes] = out.numpy()
 
+    def allgather_host(self, local):
+        a = np.ascontiguousarray(local)
+        send, recv = _Buf(a.copy()), _Buf(np.zeros((self.nranks,) + a.shape, a.dtype))
+        self.allgather(send, recv, a.nbytes)
+        return recv.a
+
     def allreduce_max(self, v):
         import torch
         import torch.distributed as dist
