@@ -362,6 +362,15 @@ int gc_stream_eval_blocks(gc_stream_eval *, const uint8_t *buf, size_t len, size
 int gc_stream_eval_stats(const gc_stream_eval *, uint64_t *parsed, uint64_t *matched);
 /* the evaluator's counterpart of gc_stream_deep_stats */
 int gc_stream_eval_deep_stats(const gc_stream_eval *, uint64_t *deep_blocks, uint32_t *lanes);
+/* Device-side match (round 5; mpc_amd/csrc/stream_eval_dev.cpp): gc_stream_eval_blocks sends a read buffer of 64 KiB or more
+ * to the GPU as it is — one DMA, straight from the caller's memory when that is pinned (gc_host_alloc / gc_host_register), else
+ * through pinned staging — where one workgroup recognises the blocks by their byte skeletons and reads their global wire ids;
+ * the table rows are gathered from the device copy by the launch that needs them.  The host reads 20 bytes of header and the
+ * ids of a block instead of every byte twice.  blocks: blocks recognised that way so far; fallbacks: blocks among them whose
+ * ids repeated in another pattern than the skeleton's, parsed by the host after all.  Blocks the device does not know (met
+ * for the first time, cut off by the end of the buffer) take the host path as before.  GC_STREAM_NO_DEVICE_MATCH switches it
+ * off.  Either pointer may be NULL. */
+int gc_stream_eval_dev_stats(const gc_stream_eval *, uint64_t *blocks, uint64_t *fallbacks);
 /* the evaluator's counterpart of gc_stream_fuse_stats (its blocks chain exactly as the garbler's steps do) */
 int gc_stream_eval_fuse_stats(const gc_stream_eval *, uint64_t *fused_units, uint64_t *fused_blocks, uint64_t *plans_built,
                               uint64_t *unfit);

@@ -2,72 +2,9 @@
 // (the wire store) and :226-432 (one OpCircuit block: parse, evaluate, Set the global outputs).  Blocks are grouped, laned and
 // launched like the garbler's steps (stream_garble.cpp's head, stream_group.cpp); a block seen before is recognised by its byte
 // skeleton (stream_skel.h).
-#include "stream_internal.h"
-#include "stream_skel.h"
+#include "stream_eval_internal.h"
 
 using namespace gcs;
-
-struct gc_stream_eval {
-    gc_ctx *ctx = nullptr;
-    std::vector<uint8_t> key;
-    int rounds = 0;
-    uint32_t *d_rk = nullptr;  // expanded key on the device (step groups)
-    DevStore store;  // StreamEval.wires (global store), device-resident
-    CircCache cache;
-    size_t cache_gates = 0, cache_budget = kCacheGatesDefault;
-    uint64_t tick = 0;
-    // step groups (see the head of this file): small blocks that share no global wire are evaluated by ONE launch sequence
-    std::vector<std::unique_ptr<Slot>> slots;
-    GroupWindow win;
-    CtxQueue ctxq;
-    DeepLanes deep;
-    std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
-    uint64_t n_groups = 0, n_group_blocks = 0;
-    FuseStats fuse;  // chain fusion (stream_fuse.cpp)
-    std::vector<uint32_t> wiring_scratch;
-    std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
-    uint32_t *d_io = nullptr;
-    size_t io_cap = 0;
-    // per-circuit scratch, kept across calls: last writer of every tmp / global wire with a generation stamp
-    std::vector<uint64_t> last_t, last_w;  // per tmp / global wire: generation stamp << 32 | current id (one load per look-up)
-    uint32_t gen = 0;
-    std::vector<gc_gate> gates;       // only materialised for a circuit the cache does not know
-    std::vector<CircKey> keys;        // the block's gates as packed records {in0, in1, out, op}
-    std::vector<uint64_t> dst_pack;   // per gate: destination index | tmp flag << 32 (parser scratch, kept across calls)
-    std::vector<uint32_t> in_idx, id_of;
-    // by (ngates, ntmp); a few byte layouts per key, most recently matched first (behind pointers: the order changes often)
-    std::unordered_map<uint64_t, std::vector<std::unique_ptr<EvalSkel>>> skels;
-    std::vector<uint32_t> gf_ids, wr_ids;   // scratch: the block's global ids by field / the wires it writes
-    EvalSkel rec;                           // skeleton of the block being parsed (kept when the parse succeeds)
-    bool use_skels = true;                  // GC_STREAM_NO_SKELETON (read at creation): every block is parsed
-    SkelPool pool;                          // helper threads of the skeleton match (started by the first big block)
-    uint64_t n_parsed = 0, n_matched = 0;
-    size_t skel_bytes = 0;                  // reference bytes held by skels (capped: the blocks are the peer's data)
-    // table rows of the block being parsed, in pinned memory (true asynchronous H2D); two buffers: the copy of block k
-    // may still be in flight while block k + 1 is parsed
-    // (kEvalRing buffers: a block's set is re-used once the pass of the block kEvalRing calls ago has run)
-    static constexpr uint32_t kEvalRing = 4;
-    gc_label *slab_pin[kEvalRing] = {};
-    size_t slab_cap[kEvalRing] = {};
-    hipEvent_t slab_ev[kEvalRing] = {};
-    // ... and its wire maps (inputs, then global outputs): pinned staging + a device copy per ring entry — from pageable
-    // memory the upload is synchronous with the stream (the host would wait for the previous block's kernels at every
-    // block: the evaluator ran at host time PLUS GPU time per big block), and one device copy would be overwritten under
-    // the pass still reading it
-    uint32_t *io_pin[kEvalRing] = {};
-    uint32_t *io_dev[kEvalRing] = {};
-    size_t io_pin_cap[kEvalRing] = {}, io_dev_cap[kEvalRing] = {};
-    uint32_t slab_turn = 0;
-    // The uploads of a big block (rows, wire maps) run on a stream of their own, under the kernels of the block before:
-    // up_ev[i] = this entry's uploads done (the ctx stream waits for it); ring_batch[i] = the pooled batch whose table
-    // buffer they went into (an upload into it waits for slab_ev[i]: the pass that last read it); held = the batch of the
-    // last block, kept out of the pool until the next block has taken its own (two passes in flight, two table buffers)
-    hipStream_t up_stream = nullptr;
-    hipEvent_t up_ev[kEvalRing] = {};
-    gc_batch *ring_batch[kEvalRing] = {};
-    gc_circ *held_circ = nullptr;
-    gc_batch *held = nullptr;
-};
 
 namespace {
 
@@ -77,7 +14,10 @@ int eval_launch_oldest(gc_stream_eval *e) {
     Slot &g = *e->slots[slot];
     e->n_groups++;
     e->n_group_blocks += g.jobs.size();
+    e->prof.lap(StageProf::kOther);
     const int rc = launch_group(e->ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep, &e->fuse);
+    e->prof.lap(StageProf::kLaunch);
+    if (!g.chunk_refs.empty()) evdev_launched(e, g, slot);
     e->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) e->ctxq.pushed(slot, g.launch_no);
     return rc;
@@ -168,11 +108,13 @@ gc_stream_eval *gc_stream_eval_create(gc_ctx *ctx, const uint8_t *key, size_t ke
 
 void gc_stream_eval_free(gc_stream_eval *e) {
     if (!e) return;
+    e->prof.print("evaluator", e->n_blocks_total);
     if (e->ctx) {
         (void)hipSetDevice(e->ctx->device);
         (void)hipStreamSynchronize(e->ctx->stream);
     }
     e->deep.release();
+    evdev_free(e);
     if (e->held) gc_circ_release_batch(e->held_circ, e->held);
     for (auto &kv : e->cache) gc_circ_free(kv.second.circ);
     for (auto &sl : e->slots) sl->release();
@@ -211,6 +153,12 @@ int gc_stream_eval_stats(const gc_stream_eval *e, uint64_t *parsed, uint64_t *ma
     return GC_OK;
 }
 
+int gc_stream_eval_dev_stats(const gc_stream_eval *e, uint64_t *blocks, uint64_t *fallbacks) {
+    if (!e) return GC_E_ARG;
+    evdev_stats(e, blocks, fallbacks);
+    return GC_OK;
+}
+
 int gc_stream_eval_fuse_stats(const gc_stream_eval *e, uint64_t *fused_units, uint64_t *fused_blocks, uint64_t *plans_built,
                               uint64_t *unfit) {
     if (!e) return GC_E_ARG;
@@ -242,7 +190,7 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
 
 }  // extern "C"
 
-namespace {
+namespace gcs {
 
 uint32_t stream_max_wires() {
     static const uint32_t v = [] {
@@ -253,7 +201,384 @@ uint32_t stream_max_wires() {
     return v;
 }
 
+bool eval_adopt_ids(gc_stream_eval *e, const EvalSkel &sk, const uint32_t *ids, uint32_t nwires) {
+    if (++e->gen == 0) {
+        std::fill(e->last_t.begin(), e->last_t.end(), 0);
+        std::fill(e->last_w.begin(), e->last_w.end(), 0);
+        e->gen = 1;
+    }
+    const uint64_t stamp = (uint64_t)e->gen << 32;
+    const uint32_t nf = (uint32_t)sk.gf_off.size();
+    for (uint32_t f = 0; f < nf; f++) {
+        const uint32_t id = ids[f];
+        if (id >= nwires) return false;
+        if (id >= e->last_w.size()) e->last_w.resize((size_t)id + 1 + e->last_w.size() / 2, 0);
+        uint32_t first = f;
+        if ((e->last_w[id] >> 32) == e->gen) first = (uint32_t)e->last_w[id];
+        else e->last_w[id] = stamp | f;
+        if (sk.gf_canon[f] != first) return false;
+    }
+    const uint32_t nin = sk.nin, nout = sk.nout;
+    e->io_host.resize((size_t)nin + nout + 1);
+    for (uint32_t k = 0; k < nin; k++) e->io_host[k] = ids[sk.in_gf[k]];
+    e->wr_ids.resize(nout);
+    for (uint32_t k = 0; k < nout; k++) {
+        e->wr_ids[k] = ids[sk.out_gf[k]];
+        e->io_host[nin + k] = sk.out_live[k] ? e->wr_ids[k] : 0xffffffffu;
+    }
+    return true;
+}
+
 // One OpCircuit block (gc_stream_eval_circuit; block after block in gc_stream_eval_blocks)
+// the row buffer of the block being taken in: a small block (candidate for a step group) parses its rows into plain host
+// scratch — they are copied into the group's pinned upload region when the block is queued —, a big block uses the next entry
+// of the pinned ring
+int eval_rows_buffer(gc_stream_eval *e, uint32_t ngates, bool *small_block_out, uint32_t *sb_out, gc_label **slab_out) {
+    const bool small_block = ngates <= kSmallGates;
+    const uint32_t sb = e->slab_turn % gc_stream_eval::kEvalRing;
+    if (small_block) {
+        if (e->rows_scratch.size() < (size_t)ngates * 3 + 1) e->rows_scratch.resize((size_t)ngates * 3 + 1);
+        GC_HIP(hipSetDevice(e->ctx->device));
+    } else {
+        e->slab_turn++;
+        GC_HIP(hipSetDevice(e->ctx->device));
+        if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
+        else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the pass of the block kEvalRing calls ago (long done)
+        const size_t want = (size_t)ngates * 3 + 1;
+        if (e->slab_cap[sb] < want) {  // (from the ctx's lists: a stream's evaluator finds the buffers of the one before it)
+            uint8_t *p = (uint8_t *)e->slab_pin[sb];
+            size_t cap = e->slab_cap[sb] * sizeof(gc_label);
+            const hipError_t eg = grow_pin(e->ctx, &p, &cap, want * sizeof(gc_label));
+            e->slab_pin[sb] = (gc_label *)p;
+            e->slab_cap[sb] = cap / sizeof(gc_label);
+            GC_HIP(eg);
+        }
+    }
+    gc_label *slab = small_block ? e->rows_scratch.data() : e->slab_pin[sb];
+    *small_block_out = small_block, *sb_out = sb, *slab_out = slab;
+    return GC_OK;
+}
+
+// The block joins a group / takes a lane / runs as a pass of its own (see the head of stream_garble.cpp)
+int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
+    CircEntry *ent = in.ent;
+    const uint32_t ngates = in.ngates, nin = in.nin, nout = in.nout, sb = in.sb;
+    const size_t nrows = in.nrows, pos = in.pos;
+    const bool small_block = in.small_block;
+    gc_label *slab = in.slab;
+    const EvalSkel *rows_from = in.rows_from;
+    const uint8_t *buf = in.buf;
+    std::vector<uint32_t> &wr_ids = e->wr_ids;
+    StreamTrace tr;
+    ent->last_use = ++e->tick;
+    gc_ctx *ctx = e->ctx;
+    // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence; a deep
+    //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
+    bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
+    int follow_lane = -1;  // a short block that depends on a deep block in flight follows it onto its lane (see the garbler)
+    if (!is_deep && small_block && e->deep.n_inflight && e->deep.follow && entry_is_small(ent)) {
+        e->deep.ensure(e->store.host.size());
+        follow_lane = e->deep.lane_to_follow(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
+        is_deep = follow_lane >= 0;
+    }
+    e->n_blocks_total++;
+    e->prof.lap(StageProf::kOther);
+    if (is_deep || (small_block && entry_is_small(ent))) {
+        if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned (and before
+            std::lock_guard<std::mutex> lk(ctx->mu);  // the block is put anywhere: a failure leaves nothing half-queued)
+            int rcs = e->store.flush(ctx);
+            if (rcs != GC_OK) return rcs;
+        }
+        e->win.ensure(e->store.host.size());
+        if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
+        const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
+        // chain fusion, as in the garbler (stream_garble.cpp: stream_begin): a short block whose conflicts with the latest group
+        // it has any with all sit in ONE launch unit is appended to that unit
+        uint32_t unit = kFuseNone;
+        uint32_t gi = fuse_enabled() ? e->win.place_fuse(e->io_host.data(), nin, wr_ids.data(), nout, &unit)
+                                     : e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
+        const bool may_fuse = fuse_enabled() && !is_deep && small_block && ent->uid != 0;
+        bool fuse = false;
+        uint64_t shape = 0;
+        uint32_t n_ext = 0;
+        if (may_fuse && gi > 0 && unit < kFuseMulti && ngates <= kFuseTailGates) {
+            const Slot &fg = *e->slots[e->win.open[gi - 1]];
+            const WgRec &w = fg.wgs[unit];
+            fuse = w.open && w.n < kFuseMembers && w.gates + ngates <= kFuseGates && w.slots + ent->job.zslot + 1 <= kFuseSlots &&
+                   w.inputs + nin <= kFuseInputs && fg.jobs.size() < kGroupSteps &&
+                   fg.arena_used + fg.up_used + 2 * wbytes + 2 * nrows * 16 <= kGroupBytes;
+            if (fuse) {  // input sources, and what chains of this shape say about their depth (as in the garbler)
+                const uint32_t seq = e->win.first_seq + gi - 1;
+                e->wiring_scratch.resize(nin);
+                for (uint32_t i = 0; i < nin; i++) {
+                    const GroupWindow::WireRec &r = e->win.rec[e->io_host[i]];
+                    if (r.wr == seq && r.wrj == unit) e->wiring_scratch[i] = (fg.jobs[r.wrm >> 20].member << 24) | (r.wrm & 0xfffffu);
+                    else e->wiring_scratch[i] = kFuseNone, n_ext++;
+                }
+                shape = fuse_shape(w.shape, ent, e->wiring_scratch.data());
+                const uint32_t hint = fuse_depth_hint(ctx, shape);
+                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
+            }
+        }
+        uint32_t slot_idx = 0;
+        e->prof.lap(StageProf::kPlace);
+        if (fuse) {
+            gi--;
+            slot_idx = e->win.open[gi];
+        } else if (is_deep) {
+            for (; gi > 0; gi--) {  // the open groups this block depends on go first
+                int rcq = eval_launch_oldest(e);
+                if (rcq != GC_OK) return rcq;
+            }
+            e->deep.poll();
+            if (e->deep.n_inflight >= kDeepInFlight) {
+                size_t l = 0;
+                for (size_t k = 1; k < e->deep.inflight.size(); k++)
+                    if (e->deep.inflight[k].size() > e->deep.inflight[l].size()) l = k;
+                (void)hipEventSynchronize(e->deep.inflight[l].front().ev);
+                e->deep.poll();
+            }
+            Slot *ng = eval_slot(e, &slot_idx, follow_lane < 0);
+            if (!ng) return GC_E_NOMEM;
+            ng->reset();
+            ng->kind = Slot::kGroup;
+            ng->deep_id = e->deep.new_id();
+            ng->lane = follow_lane >= 0 ? follow_lane : e->deep.pick();
+            ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
+            deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
+        } else {
+            auto full = [&](const Slot &g) {
+                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
+                       g.arena_used + g.up_used + 2 * wbytes + 2 * nrows * 16 > kGroupBytes;
+            };
+            while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
+            if (gi == e->win.open.size()) {
+                if (e->win.open.size() >= open_groups_limit((size_t)kOpenGroupsMax * 16)) {
+                    int rcq = eval_launch_oldest(e);
+                    if (rcq != GC_OK) return rcq;
+                    gi--;
+                }
+                uint32_t idx = 0;
+                Slot *ng = eval_slot(e, &idx);
+                tr.lap("eval: launch + free slot");
+                if (!ng) return GC_E_NOMEM;
+                ng->reset();
+                ng->kind = Slot::kGroup;
+                e->win.open.push_back(idx);
+            }
+            slot_idx = e->win.open[gi];
+        }
+        Slot &g = *e->slots[slot_idx];
+        // the rows of a block of many gates were parsed into the pinned ring: they go up from there (launch_group); the rows of
+        // a block the DEVICE matched are in device memory already: the launch sequence gathers them into the job's table array
+        const bool ext_rows = is_deep && !small_block;
+        const bool dev_rows = in.d_block != nullptr && !ext_rows;
+        const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = ext_rows || dev_rows ? 0 : up16(nrows * sizeof(gc_label));
+        hipError_t er = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes + row_bytes + 16);
+        if (er != hipSuccess) {
+            set_error("gc_stream_eval_circuit (pinned)", er);
+            if (is_deep) g.reset();
+            return GC_E_NOMEM;
+        }
+        JobRec j;
+        j.ent = ent;
+        j.nin = nin, j.nout = nout;
+        g.up_used = up16(g.up_used);
+        j.off_io = g.up_used;
+        if (nin + nout) std::memcpy(g.h_up + g.up_used, e->io_host.data(), ((size_t)nin + nout) * sizeof(uint32_t));
+        g.up_used += io_bytes;
+        j.off_rows = g.up_used;
+        if (!ext_rows && !dev_rows && nrows) {
+            if (rows_from) rows_from->copy_rows(buf, (gc_label *)(g.h_up + g.up_used));
+            else std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
+        }
+        g.up_used += row_bytes;
+        j.off_w = g.arena_used;
+        g.arena_used += wbytes;
+        if (dev_rows) {
+            j.d_block = in.d_block, j.d_row_off = in.d_row_off, j.chunk = in.chunk;
+            j.off_t = g.arena_used;
+            g.arena_used += up256(nrows * sizeof(gc_label));
+            g.chunk_refs.push_back(in.chunk);
+            evdev_ref(e, in.chunk);
+        }
+        if (ext_rows) {
+            // the rows go up NOW, on the upload stream, from the pinned ring entry into the slot's arena: the entry is free
+            // again as soon as that copy has run (on the lane it would wait for the deep blocks queued there, and the parser
+            // for the entry)
+            j.rows_in_arena = true;
+            j.off_t = g.arena_used;
+            g.arena_used += up256(nrows * sizeof(gc_label));
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            er = grow_dev(ctx, &g.d_arena, &g.arena_cap, g.arena_used);
+            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
+            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
+            if (er == hipSuccess && nrows)
+                er = hipMemcpyAsync(g.d_arena + j.off_t, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
+            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
+            (void)hipEventRecord(e->slab_ev[sb], e->up_stream);
+            e->ring_batch[sb] = nullptr;
+            if (er != hipSuccess) {
+                set_error("gc_stream_eval_circuit (rows)", er);
+                (void)hipStreamSynchronize(e->up_stream);
+                g.reset();
+                return er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+            }
+            g.rows_ev = e->up_ev[sb];
+        }
+        g.lds = std::max(g.lds, ent->lds);
+        g.has_or = g.has_or || ent->has_or;
+        j.nrows = (uint32_t)nrows;
+        const uint32_t step_idx = (uint32_t)g.jobs.size();
+        if (fuse) {  // the wiring goes with the block; outputs of earlier blocks of the unit that this one overwrites
+            const uint32_t seq = e->win.first_seq + gi;
+            j.off_wiring = g.wiring.size();
+            g.wiring.insert(g.wiring.end(), e->wiring_scratch.begin(), e->wiring_scratch.begin() + nin);
+            for (uint32_t k = 0; k < nout; k++) {
+                if (e->io_host[nin + k] == 0xffffffffu) continue;  // (superseded inside the block itself: not stored anyway)
+                const GroupWindow::WireRec &r = e->win.rec[wr_ids[k]];
+                if (r.wr == seq && r.wrj == unit) g.kills.emplace_back(r.wrm >> 20, r.wrm & 0xfffffu);
+            }
+            wg_append(g, unit, &j, ent, n_ext, shape);
+            e->fuse.appended++;
+        } else {
+            unit = wg_new(g, &j, ent, may_fuse);
+        }
+        g.jobs.push_back(j);
+        e->prof.lap(StageProf::kQueue);
+        if (!is_deep) {
+            e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout, unit, step_idx);
+            if (e->deep.n_inflight) g.deps.merge(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
+        }
+        if (is_deep) {  // launched at once, on its lane
+            int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep, &e->fuse);
+            if (!g.chunk_refs.empty()) evdev_launched(e, g, slot_idx);
+            hipStream_t lane = e->deep.lanes[(size_t)g.lane];
+            if (rcl != GC_OK) {
+                (void)hipStreamSynchronize(lane);
+                e->deep.retire(g.lane, g.deep_id);
+                g.reset();
+                return rcl;
+            }
+            e->deep.mark(g.deep_id, e->io_host.data(), nin, wr_ids.data(), nout);
+            e->n_groups++;
+            e->n_group_blocks++;
+        }
+        for (uint32_t k = 0; k < nout; k++) e->store.on_dev[wr_ids[k]] = 1;
+        e->prof.lap(StageProf::kMark);
+        tr.lap(is_deep ? "eval: launched on a lane" : "eval: queued in group");
+        *consumed = pos;
+        return GC_OK;
+    }
+    // ---- a big block: its own launch sequence, behind everything queued -------------------------------------------
+    {
+        int rcq = eval_close_group(e);
+        if (rcq != GC_OK) return rcq;
+        if (e->deep.n_inflight) {  // a pass on the ctx stream: behind every deep block in flight (DeepLanes)
+            e->deep.poll();
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            GC_HIP(e->deep.wait_all(ctx->stream));
+        }
+        {  // ... and later deep blocks must see what it reads and writes
+            e->win.ensure(e->store.host.size());
+            e->win.mark_pass(e->io_host.data(), nin, wr_ids.data(), nout);
+        }
+    }
+    gc_circ *circ = ent->circ;
+    uint32_t *d_io = nullptr;
+    const gc::StoreXchg *d_xchg = nullptr;
+    gc_batch *b = nullptr;
+    if (rows_from) {  // (a matched small block without a one-workgroup plan: rare — its rows into the scratch after all)
+        rows_from->copy_rows(buf, slab);
+        rows_from = nullptr;
+    }
+    const gc_label *slab_arg = slab;
+    if (!small_block) {
+        // the batch (its table buffer) first: not the one of the block before (held), so its pass may still be running
+        // while this block's rows are copied in
+        int rcb = gc_pass_batch(circ, &b);
+        if (rcb != GC_OK) return rcb;
+        slab_arg = nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipError_t er = hipSetDevice(ctx->device);
+        int rcs = er == hipSuccess ? e->store.flush(ctx) : GC_E_HIP;
+        const size_t nio = e->io_host.size();
+        const size_t x_off = (nio + 1) & ~(size_t)1, nio_alloc = x_off + sizeof(gc::StoreXchg) / 4;
+        if (rcs != GC_OK) {
+        } else if (small_block) {  // (without an LDS plan: rare; the pass is waited for below)
+            er = grow(&e->d_io, &e->io_cap, nio);
+            if (er == hipSuccess) er = hipMemcpyAsync(e->d_io, e->io_host.data(), nio * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+            d_io = e->d_io;
+        } else {
+            // this ring entry's pinned staging and device copy (free: slab_ev[sb] was waited for above); rows and wire maps
+            // go up on the upload stream, behind the last pass that read this table buffer, and the ctx stream waits for them
+            if (e->io_pin_cap[sb] < nio_alloc) {
+                uint8_t *p = (uint8_t *)e->io_pin[sb];
+                size_t cap = e->io_pin_cap[sb] * sizeof(uint32_t);
+                er = grow_pin(ctx, &p, &cap, nio_alloc * sizeof(uint32_t));
+                e->io_pin[sb] = (uint32_t *)p;
+                e->io_pin_cap[sb] = cap / sizeof(uint32_t);
+            }
+            if (er == hipSuccess) er = grow(&e->io_dev[sb], &e->io_dev_cap[sb], nio_alloc);
+            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
+            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
+            for (uint32_t i = 0; i < gc_stream_eval::kEvalRing && er == hipSuccess; i++)
+                if (e->ring_batch[i] == b && i != sb && e->slab_ev[i]) er = hipStreamWaitEvent(e->up_stream, e->slab_ev[i], 0);
+            if (er == hipSuccess && nrows)
+                er = hipMemcpyAsync(b->d_T, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
+            if (er == hipSuccess) {
+                std::memcpy(e->io_pin[sb], e->io_host.data(), nio * sizeof(uint32_t));
+                // ... and the pass's label exchange record behind them (a cooperative pass gathers and scatters itself)
+                const gc::StoreXchg x = gc_pass_xchg(circ, e->store.d, e->io_dev[sb], e->io_dev[sb] + nin);
+                std::memcpy(e->io_pin[sb] + x_off, &x, sizeof x);
+                d_xchg = (const gc::StoreXchg *)(e->io_dev[sb] + x_off);
+                er = hipMemcpyAsync(e->io_dev[sb], e->io_pin[sb], nio_alloc * sizeof(uint32_t), hipMemcpyHostToDevice, e->up_stream);
+            }
+            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
+            if (er == hipSuccess) er = hipStreamWaitEvent(ctx->stream, e->up_ev[sb], 0);
+            d_io = e->io_dev[sb];
+        }
+        if (rcs != GC_OK || er != hipSuccess) {
+            if (er != hipSuccess) set_error("gc_stream_eval_circuit", er);
+            if (b) {
+                // a copy into the batch's buffers may be in flight: nothing else may use it before that has run
+                (void)hipStreamSynchronize(e->up_stream);
+                gc_circ_release_batch(circ, b);
+            }
+            return rcs != GC_OK ? rcs : er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
+        }
+    }
+    int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, d_io, d_io + nin, slab_arg, nrows, &b, d_xchg);
+
+    // the pinned slab (and this entry's buffers) may be overwritten once what was enqueued from it has run: also when the
+    // pass failed half-way (the uploads are in flight)
+    if (!small_block) {
+        (void)hipEventRecord(e->slab_ev[sb], ctx->stream);
+        for (auto &rb : e->ring_batch)
+            if (rb == b) rb = nullptr;
+        e->ring_batch[sb] = b;  // (null when the pass failed: gc_pass_dev has put the batch back)
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);  // rows in plain host scratch (a small block without an LDS plan: rare)
+    }
+    if (rc != GC_OK) {
+        if (!small_block) (void)hipStreamSynchronize(e->up_stream);
+        return rc;
+    }
+    if (small_block) {
+        gc_circ_release_batch(circ, b);
+    } else {
+        if (e->held) gc_circ_release_batch(e->held_circ, e->held);
+        e->held = b;
+        e->held_circ = circ;
+    }
+    for (uint32_t k = 0; k < nout; k++) e->store.on_dev[e->wr_ids[k]] = 1;
+    tr.lap("eval: enqueue");
+    *consumed = pos;
+    return GC_OK;
+}
+
 int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwires, const uint8_t *buf, size_t len,
                size_t *consumed) {
     *consumed = 0;
@@ -282,29 +607,13 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         e->last_t.resize(ntmp, 0);
     }
     std::vector<CircKey> &gates = e->keys;
-    // a small block (candidate for a step group) parses its rows into plain host scratch: they are copied into the
-    // group's pinned upload region when the block is queued; a big block uses the double-buffered pinned slab
-    const bool small_block = ngates <= kSmallGates;
-    const uint32_t sb = e->slab_turn % gc_stream_eval::kEvalRing;
-    if (small_block) {
-        if (e->rows_scratch.size() < (size_t)ngates * 3 + 1) e->rows_scratch.resize((size_t)ngates * 3 + 1);
-        GC_HIP(hipSetDevice(e->ctx->device));
-    } else {
-        e->slab_turn++;
-        GC_HIP(hipSetDevice(e->ctx->device));
-        if (!e->slab_ev[sb]) GC_HIP(hipEventCreateWithFlags(&e->slab_ev[sb], hipEventDisableTiming));
-        else GC_HIP(hipEventSynchronize(e->slab_ev[sb]));  // the pass of the block kEvalRing calls ago (long done)
-        const size_t want = (size_t)ngates * 3 + 1;
-        if (e->slab_cap[sb] < want) {  // (from the ctx's lists: a stream's evaluator finds the buffers of the one before it)
-            uint8_t *p = (uint8_t *)e->slab_pin[sb];
-            size_t cap = e->slab_cap[sb] * sizeof(gc_label);
-            const hipError_t eg = grow_pin(e->ctx, &p, &cap, want * sizeof(gc_label));
-            e->slab_pin[sb] = (gc_label *)p;
-            e->slab_cap[sb] = cap / sizeof(gc_label);
-            GC_HIP(eg);
-        }
+    bool small_block = false;
+    uint32_t sb = 0;
+    gc_label *slab = nullptr;
+    {
+        int rcb = eval_rows_buffer(e, ngates, &small_block, &sb, &slab);
+        if (rcb != GC_OK) return rcb;
     }
-    gc_label *slab = small_block ? e->rows_scratch.data() : e->slab_pin[sb];
     size_t nrows = 0;
     tr.lap("eval: row buffer free");
     auto load_be64 = [](const uint8_t *p) {
@@ -514,6 +823,7 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
                     auto &v = kv.second;
                     for (size_t i = v.size(); i-- > 0;)
                         if (v[i]->ent && v[i]->ent->circ == gone) {
+                            evdev_drop(e, v[i].get());
                             e->skel_bytes -= std::min(e->skel_bytes, v[i]->held());
                             v.erase(v.begin() + (long)i);
                         }
@@ -565,11 +875,13 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         // one circuit serialises differently with the widths of the ids it is bound to (per gate: 16-bit ids if all of the
         // gate's are <= 0xffff) and with operands that repeat: an adder of a mixed program shows up in a dozen forms
         if (v.size() >= kSkelVariants) {
+            evdev_drop(e, v.back().get());
             e->skel_bytes -= std::min(e->skel_bytes, v.back()->held());
             v.pop_back();
         }
         std::unique_ptr<EvalSkel> sk(new EvalSkel);
         sk->nbytes = pos;
+        sk->key = ((uint64_t)ngates << 32) | ntmp;
         sk->nrows = (uint32_t)nrows, sk->nin = nin, sk->nout = nout;
         sk->ent = ent;
         sk->bytes.assign(buf, buf + pos);
@@ -577,306 +889,17 @@ int eval_block(gc_stream_eval *e, uint32_t ngates, uint32_t ntmp, uint32_t nwire
         sk->gf_off = rec.gf_off;
         sk->in_gf = rec.in_gf, sk->out_gf = rec.out_gf, sk->out_live = rec.out_live;
         if (canon_of(sk->gf_off, &gf_ids, nullptr, &sk->gf_canon)) {
+            sk->shape_hash();
             e->skel_bytes += sk->held();
+            evdev_add(e, sk.get());
             v.insert(v.begin(), std::move(sk));
         }
     }
     }  // parsed
-    ent->last_use = ++e->tick;
-    gc_ctx *ctx = e->ctx;
-    // ---- a small block joins the open group: independent blocks are evaluated side by side in one launch sequence; a deep
-    //      block (a long one-workgroup pass, DeepLanes) takes a lane ----------------------------------------------------------
-    bool is_deep = entry_is_deep(ent, e->deep.min_steps, true) && e->deep.setup(ctx);
-    int follow_lane = -1;  // a short block that depends on a deep block in flight follows it onto its lane (see the garbler)
-    if (!is_deep && small_block && e->deep.n_inflight && e->deep.follow && entry_is_small(ent)) {
-        e->deep.ensure(e->store.host.size());
-        follow_lane = e->deep.lane_to_follow(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
-        is_deep = follow_lane >= 0;
-    }
-    if (is_deep || (small_block && entry_is_small(ent))) {
-        if (!e->store.dirty.empty()) {  // host-set labels go up before the block's outputs are marked device-owned (and before
-            std::lock_guard<std::mutex> lk(ctx->mu);  // the block is put anywhere: a failure leaves nothing half-queued)
-            int rcs = e->store.flush(ctx);
-            if (rcs != GC_OK) return rcs;
-        }
-        e->win.ensure(e->store.host.size());
-        if (is_deep || e->deep.n_inflight) e->deep.ensure(e->store.host.size());
-        const size_t wbytes = up256((size_t)ent->job.w_tile * 16);
-        // chain fusion, as in the garbler (stream_garble.cpp: stream_begin): a short block whose conflicts with the latest group
-        // it has any with all sit in ONE launch unit is appended to that unit
-        uint32_t unit = kFuseNone;
-        uint32_t gi = fuse_enabled() ? e->win.place_fuse(e->io_host.data(), nin, wr_ids.data(), nout, &unit)
-                                     : e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
-        const bool may_fuse = fuse_enabled() && !is_deep && small_block && ent->uid != 0;
-        bool fuse = false;
-        uint64_t shape = 0;
-        uint32_t n_ext = 0;
-        if (may_fuse && gi > 0 && unit < kFuseMulti && ngates <= kFuseTailGates) {
-            const Slot &fg = *e->slots[e->win.open[gi - 1]];
-            const WgRec &w = fg.wgs[unit];
-            fuse = w.open && w.n < kFuseMembers && w.gates + ngates <= kFuseGates && w.slots + ent->job.zslot + 1 <= kFuseSlots &&
-                   w.inputs + nin <= kFuseInputs && fg.jobs.size() < kGroupSteps &&
-                   fg.arena_used + fg.up_used + 2 * wbytes + 2 * nrows * 16 <= kGroupBytes;
-            if (fuse) {  // input sources, and what chains of this shape say about their depth (as in the garbler)
-                const uint32_t seq = e->win.first_seq + gi - 1;
-                e->wiring_scratch.resize(nin);
-                for (uint32_t i = 0; i < nin; i++) {
-                    const GroupWindow::WireRec &r = e->win.rec[e->io_host[i]];
-                    if (r.wr == seq && r.wrj == unit) e->wiring_scratch[i] = (fg.jobs[r.wrm >> 20].member << 24) | (r.wrm & 0xfffffu);
-                    else e->wiring_scratch[i] = kFuseNone, n_ext++;
-                }
-                shape = fuse_shape(w.shape, ent, e->wiring_scratch.data());
-                const uint32_t hint = fuse_depth_hint(ctx, shape);
-                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
-            }
-        }
-        uint32_t slot_idx = 0;
-        if (fuse) {
-            gi--;
-            slot_idx = e->win.open[gi];
-        } else if (is_deep) {
-            for (; gi > 0; gi--) {  // the open groups this block depends on go first
-                int rcq = eval_launch_oldest(e);
-                if (rcq != GC_OK) return rcq;
-            }
-            e->deep.poll();
-            if (e->deep.n_inflight >= kDeepInFlight) {
-                size_t l = 0;
-                for (size_t k = 1; k < e->deep.inflight.size(); k++)
-                    if (e->deep.inflight[k].size() > e->deep.inflight[l].size()) l = k;
-                (void)hipEventSynchronize(e->deep.inflight[l].front().ev);
-                e->deep.poll();
-            }
-            Slot *ng = eval_slot(e, &slot_idx, follow_lane < 0);
-            if (!ng) return GC_E_NOMEM;
-            ng->reset();
-            ng->kind = Slot::kGroup;
-            ng->deep_id = e->deep.new_id();
-            ng->lane = follow_lane >= 0 ? follow_lane : e->deep.pick();
-            ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
-            deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
-        } else {
-            auto full = [&](const Slot &g) {
-                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
-                       g.arena_used + g.up_used + 2 * wbytes + 2 * nrows * 16 > kGroupBytes;
-            };
-            while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
-            if (gi == e->win.open.size()) {
-                if (e->win.open.size() >= open_groups_limit((size_t)kOpenGroupsMax * 16)) {
-                    int rcq = eval_launch_oldest(e);
-                    if (rcq != GC_OK) return rcq;
-                    gi--;
-                }
-                uint32_t idx = 0;
-                Slot *ng = eval_slot(e, &idx);
-                tr.lap("eval: launch + free slot");
-                if (!ng) return GC_E_NOMEM;
-                ng->reset();
-                ng->kind = Slot::kGroup;
-                e->win.open.push_back(idx);
-            }
-            slot_idx = e->win.open[gi];
-        }
-        Slot &g = *e->slots[slot_idx];
-        // the rows of a block of many gates were parsed into the pinned ring: they go up from there (launch_group)
-        const bool ext_rows = is_deep && !small_block;
-        const size_t io_bytes = up16(((size_t)nin + nout) * sizeof(uint32_t)), row_bytes = ext_rows ? 0 : up16(nrows * sizeof(gc_label));
-        hipError_t er = g.reserve_up(up16(g.up_used) - g.up_used + io_bytes + row_bytes + 16);
-        if (er != hipSuccess) {
-            set_error("gc_stream_eval_circuit (pinned)", er);
-            if (is_deep) g.reset();
-            return GC_E_NOMEM;
-        }
-        JobRec j;
-        j.ent = ent;
-        j.nin = nin, j.nout = nout;
-        g.up_used = up16(g.up_used);
-        j.off_io = g.up_used;
-        if (nin + nout) std::memcpy(g.h_up + g.up_used, e->io_host.data(), ((size_t)nin + nout) * sizeof(uint32_t));
-        g.up_used += io_bytes;
-        j.off_rows = g.up_used;
-        if (!ext_rows && nrows) {
-            if (rows_from) rows_from->copy_rows(buf, (gc_label *)(g.h_up + g.up_used));
-            else std::memcpy(g.h_up + g.up_used, slab, nrows * sizeof(gc_label));
-        }
-        g.up_used += row_bytes;
-        j.off_w = g.arena_used;
-        g.arena_used += wbytes;
-        if (ext_rows) {
-            // the rows go up NOW, on the upload stream, from the pinned ring entry into the slot's arena: the entry is free
-            // again as soon as that copy has run (on the lane it would wait for the deep blocks queued there, and the parser
-            // for the entry)
-            j.rows_in_arena = true;
-            j.off_t = g.arena_used;
-            g.arena_used += up256(nrows * sizeof(gc_label));
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            er = grow_dev(ctx, &g.d_arena, &g.arena_cap, g.arena_used);
-            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
-            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
-            if (er == hipSuccess && nrows)
-                er = hipMemcpyAsync(g.d_arena + j.off_t, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
-            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
-            (void)hipEventRecord(e->slab_ev[sb], e->up_stream);
-            e->ring_batch[sb] = nullptr;
-            if (er != hipSuccess) {
-                set_error("gc_stream_eval_circuit (rows)", er);
-                (void)hipStreamSynchronize(e->up_stream);
-                g.reset();
-                return er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
-            }
-            g.rows_ev = e->up_ev[sb];
-        }
-        g.lds = std::max(g.lds, ent->lds);
-        g.has_or = g.has_or || ent->has_or;
-        j.nrows = (uint32_t)nrows;
-        const uint32_t step_idx = (uint32_t)g.jobs.size();
-        if (fuse) {  // the wiring goes with the block; outputs of earlier blocks of the unit that this one overwrites
-            const uint32_t seq = e->win.first_seq + gi;
-            j.off_wiring = g.wiring.size();
-            g.wiring.insert(g.wiring.end(), e->wiring_scratch.begin(), e->wiring_scratch.begin() + nin);
-            for (uint32_t k = 0; k < nout; k++) {
-                if (e->io_host[nin + k] == 0xffffffffu) continue;  // (superseded inside the block itself: not stored anyway)
-                const GroupWindow::WireRec &r = e->win.rec[wr_ids[k]];
-                if (r.wr == seq && r.wrj == unit) g.kills.emplace_back(r.wrm >> 20, r.wrm & 0xfffffu);
-            }
-            wg_append(g, unit, &j, ent, n_ext, shape);
-            e->fuse.appended++;
-        } else {
-            unit = wg_new(g, &j, ent, may_fuse);
-        }
-        g.jobs.push_back(j);
-        if (!is_deep) {
-            e->win.mark(gi, e->io_host.data(), nin, wr_ids.data(), nout, unit, step_idx);
-            if (e->deep.n_inflight) g.deps.merge(e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout));
-        }
-        if (is_deep) {  // launched at once, on its lane
-            int rcl = launch_group(ctx, g, true, e->store, e->d_rk, nullptr, e->rounds, nullptr, e->deep, &e->fuse);
-            hipStream_t lane = e->deep.lanes[(size_t)g.lane];
-            if (rcl != GC_OK) {
-                (void)hipStreamSynchronize(lane);
-                e->deep.retire(g.lane, g.deep_id);
-                g.reset();
-                return rcl;
-            }
-            e->deep.mark(g.deep_id, e->io_host.data(), nin, wr_ids.data(), nout);
-            e->n_groups++;
-            e->n_group_blocks++;
-        }
-        for (uint32_t k = 0; k < nout; k++) e->store.on_dev[wr_ids[k]] = 1;
-        tr.lap(is_deep ? "eval: launched on a lane" : "eval: queued in group");
-        *consumed = pos;
-        return GC_OK;
-    }
-    // ---- a big block: its own launch sequence, behind everything queued -------------------------------------------
-    {
-        int rcq = eval_close_group(e);
-        if (rcq != GC_OK) return rcq;
-        if (e->deep.n_inflight) {  // a pass on the ctx stream: behind every deep block in flight (DeepLanes)
-            e->deep.poll();
-            std::lock_guard<std::mutex> lk(ctx->mu);
-            GC_HIP(e->deep.wait_all(ctx->stream));
-        }
-        {  // ... and later deep blocks must see what it reads and writes
-            e->win.ensure(e->store.host.size());
-            e->win.mark_pass(e->io_host.data(), nin, wr_ids.data(), nout);
-        }
-    }
-    gc_circ *circ = ent->circ;
-    uint32_t *d_io = nullptr;
-    const gc::StoreXchg *d_xchg = nullptr;
-    gc_batch *b = nullptr;
-    if (rows_from) {  // (a matched small block without a one-workgroup plan: rare — its rows into the scratch after all)
-        rows_from->copy_rows(buf, slab);
-        rows_from = nullptr;
-    }
-    const gc_label *slab_arg = slab;
-    if (!small_block) {
-        // the batch (its table buffer) first: not the one of the block before (held), so its pass may still be running
-        // while this block's rows are copied in
-        int rcb = gc_pass_batch(circ, &b);
-        if (rcb != GC_OK) return rcb;
-        slab_arg = nullptr;
-    }
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        hipError_t er = hipSetDevice(ctx->device);
-        int rcs = er == hipSuccess ? e->store.flush(ctx) : GC_E_HIP;
-        const size_t nio = e->io_host.size();
-        const size_t x_off = (nio + 1) & ~(size_t)1, nio_alloc = x_off + sizeof(gc::StoreXchg) / 4;
-        if (rcs != GC_OK) {
-        } else if (small_block) {  // (without an LDS plan: rare; the pass is waited for below)
-            er = grow(&e->d_io, &e->io_cap, nio);
-            if (er == hipSuccess) er = hipMemcpyAsync(e->d_io, e->io_host.data(), nio * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-            d_io = e->d_io;
-        } else {
-            // this ring entry's pinned staging and device copy (free: slab_ev[sb] was waited for above); rows and wire maps
-            // go up on the upload stream, behind the last pass that read this table buffer, and the ctx stream waits for them
-            if (e->io_pin_cap[sb] < nio_alloc) {
-                uint8_t *p = (uint8_t *)e->io_pin[sb];
-                size_t cap = e->io_pin_cap[sb] * sizeof(uint32_t);
-                er = grow_pin(ctx, &p, &cap, nio_alloc * sizeof(uint32_t));
-                e->io_pin[sb] = (uint32_t *)p;
-                e->io_pin_cap[sb] = cap / sizeof(uint32_t);
-            }
-            if (er == hipSuccess) er = grow(&e->io_dev[sb], &e->io_dev_cap[sb], nio_alloc);
-            if (er == hipSuccess && !e->up_stream) er = hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking);
-            if (er == hipSuccess && !e->up_ev[sb]) er = hipEventCreateWithFlags(&e->up_ev[sb], hipEventDisableTiming);
-            for (uint32_t i = 0; i < gc_stream_eval::kEvalRing && er == hipSuccess; i++)
-                if (e->ring_batch[i] == b && i != sb && e->slab_ev[i]) er = hipStreamWaitEvent(e->up_stream, e->slab_ev[i], 0);
-            if (er == hipSuccess && nrows)
-                er = hipMemcpyAsync(b->d_T, slab, nrows * sizeof(gc_label), hipMemcpyHostToDevice, e->up_stream);
-            if (er == hipSuccess) {
-                std::memcpy(e->io_pin[sb], e->io_host.data(), nio * sizeof(uint32_t));
-                // ... and the pass's label exchange record behind them (a cooperative pass gathers and scatters itself)
-                const gc::StoreXchg x = gc_pass_xchg(circ, e->store.d, e->io_dev[sb], e->io_dev[sb] + nin);
-                std::memcpy(e->io_pin[sb] + x_off, &x, sizeof x);
-                d_xchg = (const gc::StoreXchg *)(e->io_dev[sb] + x_off);
-                er = hipMemcpyAsync(e->io_dev[sb], e->io_pin[sb], nio_alloc * sizeof(uint32_t), hipMemcpyHostToDevice, e->up_stream);
-            }
-            if (er == hipSuccess) er = hipEventRecord(e->up_ev[sb], e->up_stream);
-            if (er == hipSuccess) er = hipStreamWaitEvent(ctx->stream, e->up_ev[sb], 0);
-            d_io = e->io_dev[sb];
-        }
-        if (rcs != GC_OK || er != hipSuccess) {
-            if (er != hipSuccess) set_error("gc_stream_eval_circuit", er);
-            if (b) {
-                // a copy into the batch's buffers may be in flight: nothing else may use it before that has run
-                (void)hipStreamSynchronize(e->up_stream);
-                gc_circ_release_batch(circ, b);
-            }
-            return rcs != GC_OK ? rcs : er == hipErrorOutOfMemory ? GC_E_NOMEM : GC_E_HIP;
-        }
-    }
-    int rc = gc_pass_dev(circ, true, e->key.data(), e->key.size(), nullptr, e->store.d, d_io, d_io + nin, slab_arg, nrows, &b, d_xchg);
-
-    // the pinned slab (and this entry's buffers) may be overwritten once what was enqueued from it has run: also when the
-    // pass failed half-way (the uploads are in flight)
-    if (!small_block) {
-        (void)hipEventRecord(e->slab_ev[sb], ctx->stream);
-        for (auto &rb : e->ring_batch)
-            if (rb == b) rb = nullptr;
-        e->ring_batch[sb] = b;  // (null when the pass failed: gc_pass_dev has put the batch back)
-    } else {
-        (void)hipStreamSynchronize(ctx->stream);  // rows in plain host scratch (a small block without an LDS plan: rare)
-    }
-    if (rc != GC_OK) {
-        if (!small_block) (void)hipStreamSynchronize(e->up_stream);
-        return rc;
-    }
-    if (small_block) {
-        gc_circ_release_batch(circ, b);
-    } else {
-        if (e->held) gc_circ_release_batch(e->held_circ, e->held);
-        e->held = b;
-        e->held_circ = circ;
-    }
-    for (uint32_t k = 0; k < nout; k++) e->store.on_dev[e->wr_ids[k]] = 1;
-    tr.lap("eval: enqueue");
-    *consumed = pos;
-    return GC_OK;
+    return eval_schedule(e, BlockIn{ent, ngates, nin, nout, nrows, pos, small_block, sb, slab, rows_from, buf}, consumed);
 }
 
-}  // namespace
+}  // namespace gcs
 
 extern "C" {
 
@@ -899,7 +922,17 @@ int gc_stream_eval_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, siz
     uint32_t n = 0;
     int rc = GC_OK;
     bool cut = false;
-    while (len - pos >= 20 && be32(buf + pos) == 1 /* OpCircuit, stream_evaluator.go:22-26 */) {
+    // a read buffer of many blocks: the device recognises them (stream_eval_dev.cpp) — what it leaves (a cut-off last block,
+    // a block nobody has seen yet that is not all here, another operation) goes through the loop below
+    // (the device's turn again behind every block the host had to take: it only stops where it cannot place a block)
+    auto device_turn = [&]() {
+        size_t used = 0;
+        uint32_t nb = 0;
+        rc = evdev_blocks(e, buf + pos, len - pos, &used, &nb);
+        pos += used, n += nb;
+    };
+    device_turn();
+    while (rc == GC_OK && len - pos >= 20 && be32(buf + pos) == 1 /* OpCircuit, stream_evaluator.go:22-26 */) {
         const uint32_t ngates = be32(buf + pos + 8), ntmp = be32(buf + pos + 12), nwires = be32(buf + pos + 16);
         const uint8_t *body = buf + pos + 20;
         const size_t avail = len - pos - 20;
@@ -928,6 +961,7 @@ int gc_stream_eval_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, siz
         if (rc != GC_OK) break;
         pos += 20 + used;
         n++;
+        device_turn();
     }
     // a block that ends beyond the buffer is not an error of this call: the caller brings more bytes, or knows that none come
     if (rc == GC_E_ROWS) {

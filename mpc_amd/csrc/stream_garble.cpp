@@ -70,6 +70,8 @@ struct gc_stream {
     gc_batch *held = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
     FuseStats fuse;               // chain fusion: launch units of several steps, merged plans built
+    StageProf prof;
+    uint64_t n_steps_total = 0;
     // gc_stream_garble_finish_view: the slot whose pinned bytes the caller is still reading (given back by the next finish),
     // and pinned staging for the bytes of a big step
     uint32_t view_slot = 0xffffffffu;
@@ -96,7 +98,9 @@ int launch_oldest(gc_stream *s) {
     Slot &g = *s->slots[slot];
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
+    s->prof.lap(StageProf::kOther);
     const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse);
+    s->prof.lap(StageProf::kLaunch);
     s->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) s->ctxq.pushed(slot, g.launch_no);
     return rc;
@@ -217,6 +221,7 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
 
 void gc_stream_free(gc_stream *s) {
     if (!s) return;
+    s->prof.print("garbler", s->n_steps_total);
     if (s->ctx) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
@@ -363,16 +368,22 @@ namespace {
 int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t nwires, const uint32_t *in,
                  uint32_t nin, const uint32_t *out, uint32_t nout, CircEntry *known) {
     if (!s || (nin && !in) || (nout && !out)) return GC_E_ARG;
+    s->prof.start();
+    s->n_steps_total++;
     if (s->queue.size() >= kMaxPending) return GC_E_ARG;
     // in[] and out[] may overlap (a circuit whose last wires are input wires): initCircuit (:102-114) takes both as they
     // are, Get / Set resolve a wire through in[] first (:131-157), so such an output id is simply never written
     if (nin > nwires || nout > nwires) return GC_E_ARG;
     const uint32_t first_tmp = nin, first_out = nwires - nout;
     // initCircuit (:102-114)
-    uint32_t mx = 0;
-    for (uint32_t i = 0; i < nin; i++) mx = std::max(mx, in[i]);
-    for (uint32_t i = 0; i < nout; i++) mx = std::max(mx, out[i]);
+    uint32_t mx = 0, in_lo = 0xffffffffu, in_hi = 0, out_lo = 0xffffffffu, out_hi = 0;
+    for (uint32_t i = 0; i < nin; i++) in_lo = std::min(in_lo, in[i]), in_hi = std::max(in_hi, in[i]);
+    for (uint32_t i = 0; i < nout; i++) out_lo = std::min(out_lo, out[i]), out_hi = std::max(out_hi, out[i]);
+    mx = std::max(in_hi, out_hi);
     ensure(s, mx);
+    // (in[] and out[] can only name a common wire where their id ranges overlap: as a rule they do not, and the per-wire look of
+    // the aliasing check below — two passes over tables the size of the wire store — is skipped)
+    const bool ranges_overlap = nin && nout && in_lo <= out_hi && out_lo <= in_hi;
     gc_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     GC_HIP(hipSetDevice(ctx->device));
@@ -383,7 +394,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     // output-mapped one sees the NEW label.  The device garbles from a snapshot of the inputs: redirect such reads to
     // the producing circuit wire (same global id and flags on the wire, so the serialised bytes do not change).
     bool was_aliased = false;
-    if (ngates) {
+    if (ngates && ranges_overlap) {
         if (s->alias_gen.size() < s->store.host.size()) {
             s->alias_gen.resize(s->store.host.size(), 0);
             s->alias_j.resize(s->store.host.size(), 0);
@@ -440,6 +451,11 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     s->skip_scratch.resize(nout);
     for (uint32_t j = 0; j < nout; j++) s->skip_scratch[j] = first_out + j >= first_tmp ? out[j] : 0xffffffffu;
 
+    if (ngates && s->win.rec.size() >= s->store.host.size()) {
+        s->win.prefetch(in, nin);
+        s->win.prefetch(out, nout);
+    }
+    s->prof.lap(StageProf::kGuess);  // (alias check, look-up, skip marks)
     // ---- a small step joins the earliest open group it has no dependency on (or behind); a deep one takes a lane ---------
     bool is_deep = ngates && entry_is_deep(ent, s->deep.min_steps, known == nullptr) && s->deep.setup(ctx);
     // A SHORT step that reads or overwrites what a deep step in flight writes or reads FOLLOWS that step onto its lane (as a
@@ -497,6 +513,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             }
         }
         uint32_t slot_idx = 0;
+        s->prof.lap(StageProf::kPlace);
         if (fuse) {
             gi--;
             slot_idx = s->win.open[gi];
@@ -589,6 +606,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             unit = wg_new(g, &j, ent, may_fuse);
         }
         g.jobs.push_back(j);
+        s->prof.lap(StageProf::kQueue);
         if (!is_deep) {
             s->win.mark(gi, in, nin, s->skip_scratch.data(), nout, unit, step_idx);
             // a deep step in flight that this one must follow: the group waits for it (and for the older ones of its lane)
@@ -609,6 +627,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         for (uint32_t k = 0; k < nout; k++)
             if (s->skip_scratch[k] != 0xffffffffu) s->store.on_dev[out[k]] = 1;
         s->queue.push_back(StepRef{slot_idx, (uint32_t)g.jobs.size() - 1});
+        s->prof.lap(StageProf::kMark);
         tr.lap(is_deep ? "launched on a lane" : "queued in group");
         return GC_OK;
     }
@@ -766,6 +785,7 @@ extern "C" {
 // given back then)
 static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written, const uint8_t **view) {
     if (!s || (!buf && !view) || !written || s->queue.empty()) return GC_E_ARG;
+    s->prof.start();
     StreamTrace tr;
     if (s->view_slot != 0xffffffffu) {  // the slot whose bytes the last view pointed into
         Slot &v = *s->slots[s->view_slot];
@@ -794,7 +814,9 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
             if (rcq != GC_OK) break;
         }
         (void)hipGetLastError();
+        s->prof.lap(StageProf::kOther);
         hipError_t e = hipEventSynchronize(g.done);
+        s->prof.lap(StageProf::kWait);
         if (e != hipSuccess) {
             set_error("gc_stream_garble_finish", e);
             rc = GC_E_HIP;
@@ -820,6 +842,7 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
                 g.reset();
             }
         }
+        s->prof.lap(StageProf::kFinish);
         tr.lap("wait + copy out");
         return rc;
     }

@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void k_rows_copy(const RowCopy *rc) {
     const RowCopy c = rc[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
 }
+// ... and the rows of blocks the DEVICE matched (stream_eval_dev.cpp): still in the peer's bytes, in device memory — row r of
+// the block is the 16 bytes BE(D0) || BE(D1) at src + row_off[r] (any alignment), its label in host order goes to dst[r]
+struct RowGather {
+    const uint8_t *src;
+    const uint32_t *row_off;
+    uint4 *dst;
+    uint32_t n, pad_;
+};
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__global__ __launch_bounds__(256) void k_rows_gather(const RowGather *rg) {
+    const RowGather c = rg[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < c.n; i += 256) {
+        const u32_unaligned *p = (const u32_unaligned *)(c.src + c.row_off[i]);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+        // uint4 label: (x, y) = D0 low / high, (z, w) = D1 low / high
+        c.dst[i] = make_uint4(__builtin_bswap32(w1), __builtin_bswap32(w0), __builtin_bswap32(w3), __builtin_bswap32(w2));
+    }
+}
 }  // namespace
 
 // Launch sequence of a group (see the head of stream_garble.cpp).  eval: the jobs' table rows are part of the upload region and
@@ -189,7 +207,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     const uint32_t n = (uint32_t)g.jobs.size(), nwg = (uint32_t)g.wgs.size();
     // ---- the merged plans of the chains (before the ctx lock: a chain met for the first time is planned here)
     std::vector<const FusedPlan *> plans(nwg, nullptr);
-    uint32_t nrec = 0, ncopies = 0;
+    uint32_t nrec = 0, ncopies = 0, ngathers = 0;
+    if (eval)
+        for (const JobRec &j : g.jobs) ngathers += j.d_block != nullptr && j.nrows != 0;
     size_t extra_up = 0, extra_arena = 0;
     size_t lds = g.lds;
     bool has_or = g.has_or;
@@ -257,7 +277,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     // [first job record of every unit]
     const size_t off_maps = up16(g.up_used), off_fj = off_maps + extra_up, off_fin = off_fj + (size_t)nrec * sizeof(FlatJob);
     const size_t off_rc = off_fin + (size_t)n * sizeof(FinJob);
-    const size_t off_first = off_rc + (size_t)ncopies * sizeof(RowCopy);
+    const size_t off_rg = off_rc + (size_t)ncopies * sizeof(RowCopy);
+    const size_t off_first = off_rg + (size_t)ngathers * sizeof(RowGather);
     const size_t total_up = off_first + up16((size_t)nwg * sizeof(uint32_t));
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
     const size_t arena_chain = up256(g.arena_used);
@@ -271,13 +292,15 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     FlatJob *fj = (FlatJob *)(g.h_up + off_fj);
     FinJob *fin = (FinJob *)(g.h_up + off_fin);
     RowCopy *rcp = (RowCopy *)(g.h_up + off_rc);
+    RowGather *rgp = (RowGather *)(g.h_up + off_rg);
+    uint32_t ngt = 0;
     uint32_t *first = (uint32_t *)(g.h_up + off_first);
     uint32_t rec = 0;
     auto step_job = [&](const JobRec &j) {  // one step as a job of its own
         const uint32_t *d_io = (const uint32_t *)(g.d_up + j.off_io);
         FlatJob f = j.ent->job;
         f.W = (uint4 *)(g.d_arena + j.off_w);
-        f.T = eval && !j.rows_in_arena ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
+        f.T = eval && !j.rows_in_arena && !j.d_block ? (uint4 *)(g.d_up + j.off_rows) : (uint4 *)(g.d_arena + j.off_t);
         f.R = d_R;
         f.Rout = nullptr;
         f.rk = d_rk;
@@ -321,6 +344,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
                 f.pad_ = r == 0 ? w.n - 1 : 0;
                 f.pad2_ = r;
                 fj[rec++] = f;
+                if (eval && j.d_block && j.nrows) rgp[ngt++] = RowGather{j.d_block, j.d_row_off, f.T, j.nrows, 0};
                 step_fin(j, (uint32_t)k, f.T, j.ent->circ->d_row_of_gate);
             }
             continue;
@@ -356,7 +380,10 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
             if (!out_base.empty()) out_base[(size_t)k] = (uint32_t)(h_out + no - (uint32_t *)g.h_up);
             no += j.nout;
             step_fin(j, (uint32_t)k, f.T, fp.circ->d_row_of_gate + fp.gate_base[m]);
-            if (eval && j.nrows) rcp[ncp++] = RowCopy{(const uint4 *)(g.d_up + j.off_rows), f.T + fp.row_base[m], j.nrows, 0};
+            if (eval && j.nrows) {
+                if (j.d_block) rgp[ngt++] = RowGather{j.d_block, j.d_row_off, f.T + fp.row_base[m], j.nrows, 0};
+                else rcp[ncp++] = RowCopy{(const uint4 *)(g.d_up + j.off_rows), f.T + fp.row_base[m], j.nrows, 0};
+            }
         }
     }
     for (const auto &kl : g.kills)  // an output a later step of the same chain writes again
@@ -365,6 +392,10 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
     if (e == hipSuccess && ncp) {
         hipLaunchKernelGGL(k_rows_copy, dim3(ncp), dim3(256), 0, st, (const RowCopy *)(g.d_up + off_rc));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && ngt) {
+        hipLaunchKernelGGL(k_rows_gather, dim3(ngt), dim3(256), 0, st, (const RowGather *)(g.d_up + off_rg));
         e = hipGetLastError();
     }
     if (e == hipSuccess)

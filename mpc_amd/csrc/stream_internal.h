@@ -22,6 +22,29 @@
 namespace gcs {
 using namespace gc;
 
+// developer aid: where the host's share of a stream goes (cycle counters per stage, printed when the stream is freed under
+// GC_TRACE; a reading costs ~20 cycles)
+struct StageProf {
+    enum { kGuess, kWait, kAdopt, kPlace, kQueue, kMark, kLaunch, kFinish, kOther, kN };
+    uint64_t cyc[kN] = {}, last = 0;
+    static uint64_t now() { return __builtin_ia32_rdtsc(); }
+    void start() { last = now(); }
+    void lap(int stage) {
+        const uint64_t t = now();
+        cyc[stage] += t - last;
+        last = t;
+    }
+    void print(const char *who, uint64_t steps) const {
+        if (!std::getenv("GC_TRACE") || !steps) return;
+        static const char *names[kN] = {"guess", "wait", "adopt", "place", "queue", "mark", "launch", "finish", "other"};
+        uint64_t tot = 0;
+        for (uint64_t c : cyc) tot += c;
+        std::fprintf(stderr, "[gc trace] %s: host cycles per step (%llu steps):", who, (unsigned long long)steps);
+        for (int i = 0; i < kN; i++) std::fprintf(stderr, " %s %.0f", names[i], (double)cyc[i] / (double)steps);
+        std::fprintf(stderr, " | total %.0f\n", (double)tot / (double)steps);
+    }
+};
+
 // developer aid: GC_TRACE=1 prints the wall-clock laps of a streaming step to stderr
 struct StreamTrace {
     static bool enabled() {  // (asked once: two getenv walks per streamed step were measurable on 512-gate steps)
@@ -197,6 +220,12 @@ struct JobRec {
     int32_t next = -1;
     size_t off_wiring = 0;
     uint32_t nrows = 0;           // evaluator: table rows of the block
+    // evaluator, a block the DEVICE matched (stream_eval_dev.cpp): its bytes are in device memory — a chunk of the peer's
+    // stream — and the launch sequence gathers its rows from there (d_row_off: the skeleton's row offsets, a device array)
+    // into the job's table array (arena, off_t)
+    const uint8_t *d_block = nullptr;
+    const uint32_t *d_row_off = nullptr;
+    uint32_t chunk = 0;
 };
 
 // one launch unit of a group = one workgroup of its kernel: ONE step, or a chain of dependent steps (chain fusion)
@@ -250,6 +279,7 @@ struct Slot {
     // ... and outputs a LATER step of the same unit writes again: (step, output index) pairs whose store is dropped (in a
     // fused job every output goes back to the wire store at the end, side by side: the last writer must be the only one)
     std::vector<std::pair<uint32_t, uint32_t>> kills;
+    std::vector<uint32_t> chunk_refs;  // evaluator: the chunks of the peer's stream the slot's jobs gather their rows from (one per job)
     size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
     bool has_or = false;
     uint8_t *h_up = nullptr, *d_up = nullptr, *d_arena = nullptr, *d_down = nullptr, *h_down = nullptr, *d_lane_boff = nullptr;
@@ -278,6 +308,7 @@ struct Slot {
         wgs.clear();
         wiring.clear();
         kills.clear();
+        chunk_refs.clear();
         up_used = arena_used = down_used = lds = 0;
         has_or = false;
     }
@@ -379,6 +410,12 @@ struct GroupWindow {
     std::vector<WireRec> rec;
     void ensure(size_t n) {
         if (rec.size() < n) rec.resize(n);
+    }
+    // the records of these wires on their way into the cache (a step names a few hundred wires spread over a table of tens of
+    // megabytes: the look-ups below are a chain of cache misses unless the loads are in flight together)
+    void prefetch(const uint32_t *wires, uint32_t n) const {
+        for (uint32_t i = 0; i < n; i += 3)  // (consecutive ids share cache lines: every third record is enough)
+            if (wires[i] < rec.size()) __builtin_prefetch(&rec[wires[i]]);
     }
     // index into `open` of the earliest group the step may join (== open.size(): it needs a new group)
     uint32_t place(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw) const {

@@ -33,6 +33,23 @@ struct EvalSkel {
     std::vector<uint32_t> gf_canon;          // index of the first field that names the same wire (the repeat pattern)
     std::vector<uint32_t> in_gf, out_gf;     // field of input k (its first read) / of the k-th global write
     std::vector<uint8_t> out_live;           // 0: a later gate of the block writes the same wire (streaming.Set: last wins)
+    int dev_index = -1;                      // its copy in the device-side matcher's table (stream_eval_dev.cpp; -1: none)
+    const uint32_t *d_row_off = nullptr;     // ... and its row offsets there (a device array)
+    uint32_t n_uniq = 0;                     // distinct global wires the block names; which of them input / output k is (the
+    std::vector<uint32_t> in_u, out_u;       // device's verdict brings the distinct ids in order of first occurrence)
+    uint64_t key = 0;                        // gates << 32 | tmp wires: what the skeletons are looked up by
+    // what a block must equal byte-wise, as a hash: the reference bytes under the mask, the mask, the id fields, the row offsets.
+    // Skeletons of ONE shape differ only in how the global ids repeat (an adder bound to another constant): a byte-wise
+    // verdict on one of them holds for all, and only the cheap check of the repeat pattern has to be done per candidate.
+    uint64_t shape = 0;
+    void shape_hash() {
+        uint64_t h = 1469598103934665603ull ^ bytes.size();
+        auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+        for (size_t i = 0; i < bytes.size(); i++) mix((uint64_t)(bytes[i] & mask[i]) | ((uint64_t)mask[i] << 8));
+        for (uint32_t f : gf_off) mix(f);
+        for (uint32_t r : row_off) mix(0x100000000ull | r);
+        shape = h ^ (h >> 31);
+    }
     // the block cut into segments of about equal length, so that several threads can compare / copy side by side (SkelPool)
     struct Seg {
         size_t b0, b1;     // bytes [b0, b1)

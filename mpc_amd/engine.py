@@ -98,6 +98,7 @@ def lib():
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
         "gc_stream_eval_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
+        "gc_stream_eval_dev_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 2),
         "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
         "gc_ctx_pci_bus_id": (i32, [vp, C.c_char_p, sz]),
         "gc_stream_eval_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
@@ -824,6 +825,20 @@ class StreamEval:
         a, b = C.c_uint64(0), C.c_uint32(0)
         _check(lib().gc_stream_eval_deep_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_deep_stats")
         return a.value, b.value
+
+    def dev_stats(self):
+        """(blocks the DEVICE recognised in read buffers handed to gc_stream_eval_blocks, of those: parsed by the host after all)"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().gc_stream_eval_dev_stats(self.h, C.byref(a), C.byref(b)), "gc_stream_eval_dev_stats")
+        return a.value, b.value
+
+    def blocks_at(self, address, nbytes):
+        """gc_stream_eval_blocks on caller memory given by address (a piece of a pinned read buffer: no copy)"""
+        n, nb, more = C.c_size_t(0), C.c_uint32(0), C.c_int(0)
+        rc = lib().gc_stream_eval_blocks(self.h, C.c_void_p(address), nbytes, C.byref(n), C.byref(nb), C.byref(more))
+        self.last_blocks = (n.value, nb.value, bool(more.value))
+        _check(rc, "gc_stream_eval_blocks")
+        return self.last_blocks
 
     def fuse_stats(self):
         """chain fusion on the evaluator's side (gc_stream_eval_fuse_stats)"""

@@ -476,6 +476,58 @@ def eval_program(ctx, key, steps, prim, g, stream, sizes):
     return dt, st
 
 
+def eval_program_blocks(ctx, key, steps, prim, g, stream, sizes, piece=32 << 20, pinned=True):
+    """the evaluator over the FRAMED stream (20-byte OpCircuit headers + blocks, as the peer's p2p.Conn delivers it) through
+    gc_stream_eval_blocks in pieces of `piece` bytes of a read buffer — pinned (gc_host_alloc: the DMA reads it in place) or
+    pageable.  Whole read buffers go to the GPU, which recognises the blocks itself (mpc_amd/csrc/stream_eval_dev.cpp).
+    Returns seconds, (parsed, matched); checks the last outputs against the garbler's wires."""
+    import struct
+    L = engine.lib()
+    n = len(steps)
+    total = int(sizes.sum()) + 20 * n + 4
+    hold = engine.PinnedArray((total,), np.uint8) if pinned else None
+    framed = hold.a if pinned else np.empty(total, np.uint8)
+    pos, off = 0, 0
+    for k, (c, i, o) in enumerate(steps):  # (outside the timed region: this is the peer's work)
+        framed[pos:pos + 20] = np.frombuffer(struct.pack(">5I", 1, k & 0xffffffff, c.NumGates, c.NumWires, max(max(i), max(o)) + 1), np.uint8)
+        framed[pos + 20:pos + 20 + sizes[k]] = stream[off:off + sizes[k]]
+        pos += 20 + int(sizes[k])
+        off += int(sizes[k])
+    framed[pos:pos + 4] = np.frombuffer(struct.pack(">I", 2), np.uint8)
+    ev = engine.StreamEval(ctx, key)
+    for w, l0 in zip(prim, g.inputs0):
+        ev.set(w, (int(l0["d0"]), int(l0["d1"])))
+    call = L.gc_stream_eval_blocks
+    used, nb, more = C.c_size_t(0), C.c_uint32(0), C.c_int(0)
+    pu, pn, pm = C.byref(used), C.byref(nb), C.byref(more)
+    base = framed.ctypes.data
+    end = total - 4
+    at, done, win = 0, 0, piece
+    t0 = time.perf_counter()
+    while done < n:
+        rc = call(ev.h, C.c_void_p(base + at), min(win, total - at), pu, pn, pm)
+        if rc:
+            raise engine.EngineError(rc, "gc_stream_eval_blocks(at byte %d)" % at)
+        if not used.value and not more.value:
+            raise RuntimeError("gc_stream_eval_blocks stopped at byte %d of %d" % (at, total))
+        win = piece if used.value else win * 2  # (a block longer than the piece: come back with more)
+        at += used.value
+        done += nb.value
+    outs = steps[-1][2][:8]
+    got = [ev.get(o) for o in outs]  # waits for everything
+    dt = time.perf_counter() - t0
+    assert at == end, (at, end)
+    for o, lab in zip(outs, got):
+        wire = g.get(o)
+        assert lab in ((int(wire["l0"]["d0"]), int(wire["l0"]["d1"])), (int(wire["l1"]["d0"]), int(wire["l1"]["d1"]))), o
+    st = ev.stats()
+    fz = ev.fuse_stats() + ev.dev_stats()
+    ev.close()
+    if hold is not None:
+        hold.close()
+    return dt, st, fz
+
+
 def golden_sha(name, key):
     try:
         with open(GOLDEN) as f:
@@ -515,6 +567,11 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
                 edt, est = eval_program(ctx, key, steps, prim, g, stream, sizes)
             res.update({"eval_s": edt, "eval_gates_per_s": gates / edt, "eval_us_per_step": edt / len(steps) * 1e6,
                         "eval_blocks_parsed": est[0], "eval_blocks_matched": est[1]})
+            # ... and over the framed stream, whole read buffers at a time (the device recognises the blocks)
+            for _ in range(2):
+                bdt, bst, bfz = eval_program_blocks(ctx, key, steps, prim, g, stream, sizes)
+            res.update({"eval_blocks_s": bdt, "eval_blocks_gates_per_s": gates / bdt, "eval_blocks_parsed": bst[0], "eval_blocks_matched": bst[1],
+                        "eval_blocks_piece": 32 << 20, "eval_blocks_buffer": "pinned (gc_host_alloc)", "eval_fuse": list(bfz)})
             sdt, sn = eval_program.steady
             if sn:  # after the last block the evaluator had not seen before
                 res.update({"eval_steady_us_per_step": sdt / sn * 1e6, "eval_steady_steps": sn,
@@ -585,6 +642,9 @@ def run_native(name, key=bytes(range(32)), window=64):
             "eval_gates_per_s": gates / r["eval_s"], "eval_us_per_step": r["eval_s"] / r["steps"] * 1e6,
             # the framed stream through gc_stream_eval_blocks in pieces of a p2p.Conn read buffer (a helper thread compares ahead)
             "eval_blocks_gates_per_s": gates / r["eval_blocks_s"] if r.get("eval_blocks_s") else None,
+            # ... the bytes handed out in place (no copy into a second buffer) / read buffers of 32 MiB in pinned memory
+            "garble_view_gates_per_s": gates / r["garble_view_s"] if r.get("garble_view_s") else None,
+            "eval_blocks_pinned_gates_per_s": gates / r["eval_blocks_pinned_s"] if r.get("eval_blocks_pinned_s") else None,
             "eval_blocks_chunk": r.get("eval_blocks_chunk"),
             "eval_blocks_matched": r["eval_blocks_matched"], "sha256": r["sha256"],
             "eval_steady_us_per_step": r["eval_steady_s"] / max(r["eval_steady_steps"], 1) * 1e6,
@@ -611,7 +671,8 @@ def run_for_line(key=bytes(range(32)), ctx=None):
     for name in ("ed25519like", "ssa23", "mixed", "uniform512", "uniform4096"):
         r = run_program(name, key, ctx, window=WINDOWS.get(name, 64))
         out[name] = {k: r[k] for k in ("steps", "gates", "and", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
-                                       "eval_us_per_step", "eval_steady_gates_per_s", "launch_groups", "grouped_steps", "big_steps",
+                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_buffer",
+                                       "eval_blocks_piece", "eval_fuse", "launch_groups", "grouped_steps", "big_steps",
                                        "deep_steps", "lanes", "sha256", "sha256_ok") if k in r}
         out[name]["shape"] = SHAPES[name]
     # The UNCHANGED caller: compiler/ssa/streamer.go:694 calls Streaming.Garble one instruction at a time —
@@ -635,7 +696,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
             r = {"error": str(e)[:200]}
         if r is not None:
-            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s",
+            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_view_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_pinned_gates_per_s",
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
                                                       "window", "sha256_ok", "error")}
     if native:

@@ -221,3 +221,54 @@ def test_default_planning_in_the_background_keeps_the_bytes(monkeypatch):
     _, gf, ef = _run(ctx, steps, prim, key, rnd, 300)
     assert gf[2] == 0 and ef[2] == 0  # everything that repeats is planned by now
     ctx.close()
+
+
+def _framed_stream(steps, blocks):
+    import struct
+    return b"".join(struct.pack(">5I", 1, k, c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1) + bytes(b)
+                    for k, ((c, in_, out_), b) in enumerate(zip(steps, blocks))) + struct.pack(">I", 2)
+
+
+@pytest.mark.parametrize("pinned,piece", [(True, 1 << 20), (False, 1 << 20), (True, 150_000), (False, 70_000)])
+def test_read_buffers_matched_on_the_device(pinned, piece):
+    """gc_stream_eval_blocks on read buffers of many blocks: the DEVICE recognises the blocks (stream_eval_dev.cpp), the host
+    reads headers and ids, the rows are gathered from the device copy of the stream — pinned buffers by DMA in place, pageable
+    ones through staging; pieces that cut blocks in two; the labels are the oracle's, whichever path a block takes"""
+    ctx = engine.Context(0)
+    steps, prim = _chain_program(0x8000)
+    steps = steps * 4  # (the same instructions again: wires are overwritten, every block is known from the second round on)
+    key, rnd = drbg("devm", 32), drbg("devm-r", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    first = {w: og.get(w)["l0"] for w in prim}
+    blocks = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    framed = _framed_stream(steps, blocks)
+    oe = oracle.StreamEval(key)
+    for w in prim:
+        oe.set(w, first[w])
+    for (c, in_, out_), b in zip(steps, blocks):
+        assert oe.circuit(c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1, b) == len(b)
+    wires = sorted({o for _, _, out_ in steps for o in out_} | set(prim))
+    hold = engine.PinnedArray((len(framed),), np.uint8) if pinned else None
+    buf = hold.a if pinned else np.frombuffer(framed, np.uint8).copy()
+    buf[:] = np.frombuffer(framed, np.uint8)
+    for rep in range(2):  # (the second evaluator of the ctx finds the merged plans of the chains)
+        ge = engine.StreamEval(ctx, key)
+        for w in prim:
+            ge.set(w, first[w])
+        at, done, win = 0, 0, piece
+        while done < len(steps):
+            used, nb, more = ge.blocks_at(buf.ctypes.data + at, min(win, len(framed) - at))
+            assert used or more, (at, win)
+            win = piece if used else win * 2
+            at, done = at + used, done + nb
+        assert at == len(framed) - 4
+        for o in wires:
+            assert ge.get(o) == oe.get(o), "label of wire %d" % o
+        dev_blocks, fallbacks = ge.dev_stats()
+        parsed, matched = ge.stats()
+        if not os.environ.get("GC_STREAM_NO_DEVICE_MATCH") and piece >= 150_000:  # (a buffer of fewer than four blocks stays on the host)
+            assert dev_blocks >= len(steps) // 2, (dev_blocks, fallbacks, parsed, matched)
+        ge.close()
+    if hold is not None:
+        hold.close()
+    ctx.close()

@@ -182,6 +182,33 @@ int main(int argc, char **argv) {
         total = off;
         gc_stream_free(g);
     }
+    /* the same program with the bytes consumed IN PLACE (gc_stream_garble_finish_view: a pointer into the engine's pinned staging,
+     * valid until the next finish — what go/circuit/stream_hip.go does: the copy into conn.WriteBuf is the transport's) */
+    double garble_view_s = 0;
+    {
+        gc_stream *g = gc_stream_create(ctx, key, keylen, rnd, rndlen, prim, nprim, &st);
+        if (!g) DIE("gc_stream_create: %d", st);
+        for (uint32_t c = 0; c < ncirc; c++)
+            if ((st = gc_stream_intern(g, circ[c].gates, circ[c].ngates, circ[c].nwires, circ[c].nin, circ[c].nout, &circ[c].handle)))
+                DIE("gc_stream_intern: %d", st);
+        uint32_t issued = 0;
+        size_t seen = 0;
+        const double t0 = now_s();
+        for (uint32_t k = 0; k < nsteps; k++) {
+            const uint32_t lim = k + window < nsteps ? k + window : nsteps;
+            for (; issued < lim; issued++)
+                if ((st = gc_stream_garble_begin_h(g, circ[step[issued].circ].handle, step[issued].in, step[issued].out)))
+                    DIE("gc_stream_garble_begin_h(step %u): %d", issued, st);
+            const uint8_t *view = NULL;
+            size_t n = 0;
+            if ((st = gc_stream_garble_finish_view(g, &view, &n))) DIE("gc_stream_garble_finish_view(step %u): %d", k, st);
+            if (n != sizes[k]) DIE("gc_stream_garble_finish_view(step %u): %zu bytes, %zu when copied", k, n, sizes[k]);
+            seen += n;
+        }
+        garble_view_s = now_s() - t0;
+        if (seen != total) DIE("view pass: %zu bytes of %zu", seen, total);
+        gc_stream_free(g);
+    }
     sha256_t sh;
     sha_init(&sh);
     sha_update(&sh, bytes, total);
@@ -225,7 +252,7 @@ int main(int argc, char **argv) {
      * GC_DRIVER_CHUNK bytes): what a Go host does with conn.ReadBuf[ReadStart:ReadEnd] instead of collecting a block gate by
      * gate.  A piece that ends inside a block is followed by one that starts at that block (a real reader moves the rest to
      * the front of its buffer and reads on). */
-    double eval_blocks_s = 0;
+    double eval_blocks_s = 0, eval_blocks_pinned_s = 0;
     size_t chunk = (size_t)1 << 20;
     if (getenv("GC_DRIVER_CHUNK")) chunk = (size_t)strtoull(getenv("GC_DRIVER_CHUNK"), NULL, 0);
     if (chunk < 64) chunk = 64;
@@ -272,14 +299,51 @@ int main(int argc, char **argv) {
             if (probe2.d0 != probe.d0 || probe2.d1 != probe.d1) DIE("gc_stream_eval_blocks: another label than block by block");
             gc_stream_eval_free(e);
         }
+        /* ... and from a PINNED read buffer (gc_host_alloc: the DMA reads it in place) in pieces of 32 MiB: whole read buffers go
+         * to the GPU, which recognises the blocks itself (mpc_amd/csrc/stream_eval_dev.cpp) */
+        uint8_t *pin = (uint8_t *)gc_host_alloc(ftotal ? ftotal : 1);
+        if (pin) {
+            memcpy(pin, framed, ftotal);
+            const size_t big = (size_t)32 << 20;
+            for (int pass = 0; pass < 2; pass++) {
+                gc_stream_eval *e = gc_stream_eval_create(ctx, key, keylen, &st);
+                if (!e) DIE("gc_stream_eval_create: %d", st);
+                for (uint32_t i = 0; i < nprim; i++)
+                    if (gc_stream_eval_set_wire(e, prim[i], &in0[i])) DIE("gc_stream_eval_set_wire");
+                const double t0 = now_s();
+                size_t pos = 0, win = big;
+                uint64_t done = 0;
+                while (pos < ftotal) {
+                    const size_t n = ftotal - pos < win ? ftotal - pos : win;
+                    size_t used = 0;
+                    uint32_t nb = 0;
+                    int more = 0;
+                    if ((st = gc_stream_eval_blocks(e, pin + pos, n, &used, &nb, &more))) DIE("gc_stream_eval_blocks (pinned) at byte %zu: %d", pos, st);
+                    pos += used, done += nb;
+                    if (used == 0) {
+                        if (!more || n == ftotal - pos) DIE("gc_stream_eval_blocks (pinned) makes no progress at byte %zu", pos);
+                        win *= 2;
+                    } else {
+                        win = big;
+                    }
+                }
+                if (done != nsteps) DIE("gc_stream_eval_blocks (pinned) evaluated %llu of %u blocks", (unsigned long long)done, nsteps);
+                gc_label probe3 = {0, 0};
+                if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe3)) DIE("gc_stream_eval_get_wire");
+                eval_blocks_pinned_s = now_s() - t0;
+                if (probe3.d0 != probe.d0 || probe3.d1 != probe.d1) DIE("gc_stream_eval_blocks (pinned): another label than block by block");
+                gc_stream_eval_free(e);
+            }
+            gc_host_free(pin);
+        }
         free(framed);
     }
-    printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
-           "\"eval_blocks_s\": %.6f, \"eval_blocks_chunk\": %zu, "
+    printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"garble_view_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
+           "\"eval_blocks_s\": %.6f, \"eval_blocks_pinned_s\": %.6f, \"eval_blocks_chunk\": %zu, "
            "\"eval_steady_steps\": %u, \"bytes\": %zu, \"sha256\": \"%s\", "
            "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\", "
            "\"garble_t0\": %.6f, \"garble_t1\": %.6f, \"eval_t0\": %.6f, \"eval_t1\": %.6f}\n",
-           nsteps, window, garble_s, eval_s, eval_steady_s, eval_blocks_s, chunk, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
+           nsteps, window, garble_s, garble_view_s, eval_s, eval_steady_s, eval_blocks_s, eval_blocks_pinned_s, chunk, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
            (unsigned long long)probe.d0, g_t0, g_t1, e_t0, e_t1);
     gc_ctx_destroy(ctx);
     return 0;
