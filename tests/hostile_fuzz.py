@@ -304,6 +304,149 @@ def run(mutants=200, seed=1, big=False, log=None, deep=False, framed=False):
     return mutants, stats, kinds, (parsed, matched)
 
 
+def run_device(mutants=100, seed=1, log=None, pinned=False):
+    """The same mutants INSIDE read buffers that the device recognises (mpc_amd/csrc/stream_eval_dev.cpp: buffers of 64 KiB and
+    more through gc_stream_eval_blocks): a few valid blocks the evaluator knows, the mutant, two more valid blocks, an OpReturn
+    word.  The host only guesses where blocks are, the GPU says whether a guess holds and which repeat pattern the ids have:
+    a mutant must be caught there or fall through to the host's parser.  Required: the valid blocks in front of the mutant are
+    taken; the mutant is taken iff the oracle takes it (or refused by design: `stricter`), with the oracle's byte count; the
+    blocks behind an accepted mutant are taken too; every wire the buffer names ends on the oracle's label."""
+    import struct
+    from mpc_amd.circuit import multiplier
+    rng = np.random.default_rng(seed)
+    key = drbg("hostile-key", 32)
+    ctx = engine.Context(0)
+    steps = programs()
+    mul = multiplier(32)  # ~70 KB of block: a buffer with one of these is one the device gets
+    for base in (0, 0x11000):
+        steps.append((mul, [base + 500 + i for i in range(64)], [base + 600 + i for i in range(32)]))
+    prim = sorted({w for _, i, _ in steps for w in i})
+    rnd = drbg("hostile-rnd", 16 * (len(prim) + 1))
+    og = oracle.Stream(key, rnd, prim)
+    blocks = []
+    for c, in_, out_ in steps:
+        data = og.garble(c.Gates, c.NumWires, in_, out_)
+        blocks.append((data, c.NumGates, c.NumWires, max(max(in_), max(out_)) + 1, sorted(set(in_) | set(out_))))
+    big_ones = [k for k, b in enumerate(blocks) if len(b[0]) > 40000]
+    every = sorted({w for b in blocks for w in b[4]})
+    ge = engine.StreamEval(ctx, key)
+    model = {}
+    for w in prim:
+        model[w] = (int(og.get(w)["l0"]["d0"]), int(og.get(w)["l0"]["d1"]))
+        ge.set(w, model[w])
+
+    def fresh_oracle():
+        oe = oracle.StreamEval(key)
+        for w, l in model.items():
+            oe.set(w, l)
+        return oe
+
+    oe = fresh_oracle()
+    for data, ng, ntmp, nw, wires in blocks:  # the evaluator sees every valid block first
+        assert ge.circuit(ng, ntmp, nw, data) == oe.circuit(ng, ntmp, nw, data) == len(data)
+    for w in every:
+        model[w] = oe.get(w)
+    hold = engine.PinnedArray((1 << 22,), np.uint8) if pinned else None
+    stats = {"accepted": 0, "rejected": 0, "rejected_stricter": 0, "ran_on": 0}
+    kinds = {}
+    for m in range(mutants):
+        pre = [int(rng.integers(0, len(blocks))) for _ in range(int(rng.integers(3, 7)))]
+        pre.insert(int(rng.integers(0, len(pre) + 1)), big_ones[int(rng.integers(0, len(big_ones)))])
+        if rng.integers(0, 3) == 0:
+            pre.append(big_ones[int(rng.integers(0, len(big_ones)))])
+        post = [int(rng.integers(0, len(blocks))) for _ in range(2)]
+        mi = int(rng.integers(0, len(blocks)))
+        data, ng, ntmp, nw, wires = blocks[mi]
+        mut, mng, what = mutate(rng, data, ng)
+        mnt, mnw = ntmp, nw
+        if rng.integers(0, 8) == 0:
+            if rng.integers(0, 2):
+                mnt = int(rng.choice([0, 1, max(ntmp - 1, 0), ntmp + 7, 64 * mng + (1 << 20) + 1, 1 << 31, 0xffffffff]))
+                what += " + numTmpWires"
+            else:
+                mnw = int(rng.choice([0, max(nw - 1, 0), nw + 1000, (1 << 28) + 1, 0xffffffff]))
+                what += " + numWires"
+        sized = mnt > 64 * mng + (1 << 20) or mnw > (1 << 28)
+        frame = lambda k, b: struct.pack(">5I", 1, k, b[1], b[2], b[3]) + bytes(b[0])
+        buf = b"".join(frame(k, blocks[k]) for k in pre)
+        j = len(pre)
+        buf += struct.pack(">5I", 1, m, mng, mnt, mnw) + mut
+        buf += b"".join(frame(k, blocks[k]) for k in post) + struct.pack(">I", 2) + bytes(16)
+        # the oracle: block after block; where does it stop?
+        oe = fresh_oracle()
+        for k in pre:
+            b = blocks[k]
+            assert oe.circuit(b[1], b[2], b[3], b[0]) == len(b[0])
+        orc, oused = 0, None
+        # (the reference reads on from the connection: what follows the mutant belongs to the bytes both sides see)
+        following = buf[len(buf) - 20 - sum(len(blocks[k][0]) + 20 for k in post):]
+        if sized:
+            orc = -5
+        else:
+            try:
+                oused = oe.circuit(mng, mnt, mnw, mut + following)
+            except oracle.OracleError as e:
+                orc = e.code
+        try:
+            if pinned:
+                hold.a[:len(buf)] = np.frombuffer(buf, np.uint8)
+                used, nb, more = ge.blocks_at(hold.a.ctypes.data, len(buf))
+            else:
+                used, nb, more = ge.blocks(buf)
+            erc = 0
+        except engine.EngineError as e:
+            erc = e.code
+            used, nb, more = ge.last_blocks
+        kinds[what] = kinds.get(what, 0) + 1
+        assert nb >= j, "mutant %d (%s): only %d of the %d valid blocks in front of it were taken (%d)" % (m, what, nb, j, erc)
+        took = nb > j
+        if sized:
+            assert not took and erc == engine.GC_E_ARG, "mutant %d (%s): header sizes beyond the bounds were not refused" % (m, what)
+        ran_on = took and (orc != 0 or oused != len(mut))
+        if took and not ran_on:
+            stats["accepted"] += 1
+            for k in post:
+                b = blocks[k]
+                assert oe.circuit(b[1], b[2], b[3], b[0]) == len(b[0])
+            assert nb == j + 3 and erc == 0, "mutant %d (%s): %d blocks taken of %d, status %d" % (m, what, nb, j + 3, erc)
+        elif ran_on:
+            # the mutant ends elsewhere than its bytes and what follows read as further operations: no reference behaviour to
+            # compare with beyond "it was taken as the oracle takes it" — both stores start over from the engine's
+            assert orc == 0, "mutant %d (%s): the engine took what the oracle rejects (%d)" % (m, what, orc)
+            stats["ran_on"] += 1
+            for w in every:
+                model[w] = ge.get(w)
+            continue
+        else:
+            if orc != 0:
+                stats["rejected"] += 1
+            else:
+                why = "header sizes" if sized else stricter(mut + following, mng, mnt, mnw)
+                cut = erc == 0 and more  # (the block "ends beyond the buffer": only if it really is longer than its bytes)
+                assert why or cut, "mutant %d (%s): the engine rejects (%d) what the reference's loop walks" % (m, what, erc)
+                stats["rejected_stricter"] += 1
+            # nothing of a refused block may have reached the store (the reference's loop stops half-way through such a block:
+            # the comparison is with the blocks in front of it)
+            oe = fresh_oracle()
+            for k in pre:
+                b = blocks[k]
+                oe.circuit(b[1], b[2], b[3], b[0])
+        named = [w for w in every if w < (1 << 22)]
+        for w in named[:: max(1, len(named) // 60)] + [w for w in wires if w < mnw]:
+            assert ge.get(w) == oe.get(w), "mutant %d (%s): wire %d differs from the oracle's (taken %s, status %d, oracle %d, blocks %d of %d + 3, numWires %d of %d, block %d pre %s post %s)" % (
+                m, what, w, took, erc, orc, nb, j, mnw, nw, mi, pre, post)
+        for w in every:
+            model[w] = oe.get(w)
+        if log and m % 100 == 99:
+            log("%6d mutants in device-matched buffers: %s  device blocks / fallbacks %s" % (m + 1, stats, ge.dev_stats()))
+    dev = ge.dev_stats()
+    ge.close()
+    if hold is not None:
+        hold.close()
+    ctx.close()
+    return mutants, stats, kinds, dev
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -318,3 +461,7 @@ if __name__ == "__main__":
         print("threads=%s deep blocks (lanes; rows through the upload region / from the pinned ring): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
         r = run(n // 4, seed + 3, framed=True, log=say)
         print("threads=%s framed blocks through gc_stream_eval_blocks (header sizes mutated too): %d mutants, %s, kinds %s, parsed/matched %s — no violation" % ((threads,) + r), flush=True)
+    for pinned in (False, True):
+        r = run_device(n // 4, seed + 4, log=print, pinned=pinned)
+        print("read buffers matched on the device (%s): %d mutants, %s, kinds %s, device blocks / fallbacks %s — no violation" % (
+            ("pinned" if pinned else "pageable",) + r), flush=True)

@@ -1120,6 +1120,16 @@ def test_stream_evaluator_survives_hostile_blocks(threads, big, monkeypatch):
     assert matched > 0 and parsed > 0
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_stream_evaluator_survives_hostile_blocks_in_device_matched_buffers(pinned):
+    """tests/hostile_fuzz.py: run_device — the mutants inside read buffers of 64 KiB and more, whose blocks the GPU recognises
+    (stream_eval_dev.cpp): guessed boundaries, verdicts and repeat-pattern checks on the device, the host's parser behind them"""
+    from tests import hostile_fuzz
+    n, stats, kinds, dev = hostile_fuzz.run_device(60, seed=21 + int(pinned), pinned=pinned)
+    assert stats["accepted"] > 0 and stats["rejected"] + stats["rejected_stricter"] > 0 and len(kinds) >= 8
+    assert dev[0] > 100  # (the buffers really went to the device)
+
+
 def test_stream_finish_view_hands_out_the_same_bytes(monkeypatch):
     """gc_stream_garble_finish_view (no copy: a pointer into the pinned staging, valid until the next finish) against the oracle
     on a program with grouped, deep and big steps, mixed with copying finishes; the slot a view points into is only given back
