@@ -8,10 +8,21 @@ package circuit
 import "C"
 
 import (
+	"os"
 	"unsafe"
 
 	"github.com/markkurossi/mpc/ot"
 )
+
+// A streaming host wants eight hardware queues: the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES of
+// them (4 by default) and streams that share one run one after the other (mpc_amd/csrc/engine.cpp).  The runtime reads the
+// variable on the first HIP call of the process, so it is set here, before any — by the HOST: libgcengine.so does not touch
+// the environment.  A value the operator has set is kept.
+func init() {
+	if _, ok := os.LookupEnv("GPU_MAX_HW_QUEUES"); !ok {
+		os.Setenv("GPU_MAX_HW_QUEUES", "8")
+	}
+}
 
 // SOURCE ONLY (no Go toolchain in the build image).  The reference pools its garble scratch on the Go heap
 // (garbleScratchPool, circuit/garble.go:195-225).  Backing the slab of that pool with pinned memory (gc_host_alloc =

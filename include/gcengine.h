@@ -296,8 +296,9 @@ int gc_stream_garble_flush(gc_stream *);
 int gc_stream_intern(gc_stream *, const gc_gate *gates, uint32_t ngates, uint32_t nwires, uint32_t ninputs,
                      uint32_t noutputs, uint32_t *handle);
 int gc_stream_garble_begin_h(gc_stream *, uint32_t handle, const uint32_t *in, const uint32_t *out);
-/* gives an interned circuit back to the bounded cache (a host that drops a compiled circuit; the Go shim does it from the
- * *Circuit's finalizer): the handle is invalid afterwards (GC_E_ARG) and its number may be handed out again */
+/* gives an interned circuit back to the bounded cache (a host that drops a compiled circuit; the Go shim's
+ * (*Streaming).Forget(c) does it — an explicit call: the shim's handle map keeps the *Circuit alive, so no finalizer could):
+ * the handle is invalid afterwards (GC_E_ARG) and its number may be handed out again */
 int gc_stream_release(gc_stream *, uint32_t handle);
 /* launch sequences so far: groups of small circuits, circuits that ran in them, circuits with a sequence of their own
  * (any pointer may be NULL) */

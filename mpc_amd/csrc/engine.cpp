@@ -43,15 +43,13 @@ int on_exception() noexcept {
 }  // namespace gc
 
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (4 by default), and two
-// streams that share a queue run one after the other.  A garbler / evaluator stream of this engine uses up to seven HIP
-// streams that are meant to run side by side (ctx stream, copy / serialiser / upload streams, the deep lanes of
-// stream_engine.cpp), so the default becomes 8 — when the library is loaded before the runtime has read its settings (it
-// reads them on the first HIP call of the process), and only if the environment does not say otherwise (GC_KEEP_HW_QUEUES
-// leaves the runtime's default).  Without it the engine still works: lanes that share the ctx stream's queue are detected and
-// not used (DeepLanes::setup).
-__attribute__((constructor(101))) static void gc_default_hw_queues() {
-    if (!std::getenv("GC_KEEP_HW_QUEUES")) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
-}
+// streams that share a queue run one after the other.  A garbler / evaluator stream of this engine uses up to seven HIP streams
+// that are meant to run side by side (ctx stream, copy / serialiser / upload streams, the deep lanes of stream_lanes.cpp): a host
+// that streams should start with GPU_MAX_HW_QUEUES=8 in its environment (the runtime reads it on the first HIP call of the
+// process).  The library does NOT set it: changing the environment of a host process from a constructor races
+// with its other threads and changes the runtime for everybody in it.  Without it the engine still works: lanes that
+// share the ctx stream's queue are detected and not used (DeepLanes::setup_ctx).  mpc_amd/engine.py, bench.py's children and
+// tools/stream_driver.c set it for themselves, before their first HIP call.
 
 using namespace gc;
 
@@ -119,7 +117,35 @@ static bool coop_ready(gc_ctx *c) {
 
 namespace gc {
 constexpr size_t kBufMin = (size_t)64 << 10;
-constexpr size_t kDevCacheMax = (size_t)6 << 30, kPinCacheMax = (size_t)2 << 30;
+// what a ctx's lists may hold (idle buffers; GC_CTX_CACHE_MIB = "<device MiB>,<pinned MiB>" overrides it)
+static void cache_caps(size_t *dev, size_t *pin) {
+    static size_t d = 0, p = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        d = (size_t)4 << 30, p = (size_t)1 << 30;
+        if (const char *v = std::getenv("GC_CTX_CACHE_MIB")) {
+            unsigned long long a = 0, b = 0;
+            const int n = std::sscanf(v, "%llu,%llu", &a, &b);
+            if (n >= 1) d = (size_t)a << 20;
+            if (n >= 2) p = (size_t)b << 20;
+        }
+    });
+    *dev = d, *pin = p;
+}
+// every idle buffer of the kind back to the runtime (an allocation has failed: memory parked here — outgrown size classes,
+// the lists of a stream long gone — is the first thing to give back)
+static void ctx_buf_trim(gc_ctx *c, bool pinned) {
+    std::vector<gc_ctx::CachedBuf> drop;
+    {
+        std::lock_guard<std::mutex> lk(c->cache_mu);
+        drop.swap(pinned ? c->pin_cache : c->dev_cache);
+        (pinned ? c->pin_cached : c->dev_cached) = 0;
+    }
+    for (auto &b : drop) {
+        if (pinned) (void)hipHostFree(b.p);
+        else (void)hipFree(b.p);
+    }
+}
 hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *cap) {
     size_t want = kBufMin;
     while (want < need) want *= 2;
@@ -137,6 +163,12 @@ hipError_t ctx_buf_get(gc_ctx *c, bool pinned, size_t need, void **p, size_t *ca
     }
     void *q = nullptr;
     hipError_t e = pinned ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want);
+    if (e != hipSuccess) {  // no memory while this ctx sits on idle buffers of other sizes: give them back and ask again
+        (void)hipGetLastError();
+        ctx_buf_trim(c, pinned);
+        if (!pinned) ctx_buf_trim(c, true);  // (pinned pages count against the host, but a device allocation may need staging too)
+        e = pinned ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want);
+    }
     if (e != hipSuccess) return e;
     *p = q;
     *cap = want;
@@ -147,7 +179,9 @@ void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap) {
     {
         std::lock_guard<std::mutex> lk(c->cache_mu);
         size_t &held = pinned ? c->pin_cached : c->dev_cached;
-        if (held + cap <= (pinned ? kPinCacheMax : kDevCacheMax)) {
+        size_t dev_max = 0, pin_max = 0;
+        cache_caps(&dev_max, &pin_max);
+        if (held + cap <= (pinned ? pin_max : dev_max)) {
             (pinned ? c->pin_cache : c->dev_cache).push_back(gc_ctx::CachedBuf{p, cap});
             held += cap;
             return;
@@ -158,14 +192,21 @@ void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap) {
 }
 }  // namespace gc
 
-// A cooperative pass that lost a workgroup (its bounded wait ran out) has been done again on the device by k_coop_repair, on
-// the same stream and before anything that follows it: results are never wrong and nothing has to fail.  What is left for the
-// host, when it sees the pinned word raised: count it and keep to the level launches from here on (a ctx whose passes do not
-// stay resident together — three or more streams on one GPU — would pay 36 ms per pass).  Always GC_OK.
+// A cooperative pass that lost a workgroup (its bounded wait ran out) is done again on the device by the stand-by workgroup of
+// the same launch, before anything that follows it on the stream — and the stand-by is who tells the host: the pinned word
+// becomes 1 when a pass HAS BEEN done again (results are good; the host counts it and keeps to the level launches from here on:
+// a ctx whose passes do not stay resident together — three or more streams on one GPU — would pay 36 ms per pass), 2 when the
+// stand-by could not do so (the pass had not ended within its ~2 s backstop, or host and device disagree on the pass count):
+// labels or table rows of that pass are garbage then, and every call that hands results out reports GC_E_HIP.
 int gc_ctx_coop_check(gc_ctx *c) {
     if (!c || !c->h_coop_err || *c->h_coop_err == 0) return GC_OK;
-    *c->h_coop_err = 0;
+    const uint32_t what = *c->h_coop_err;
     c->coop_state = -1;
+    if (what >= 2) {  // (the word stays up: the ctx's results cannot be trusted any more)
+        std::snprintf(gc::tls_error, sizeof gc::tls_error, "a cooperative one-instance pass lost a workgroup and could not be repeated on the device");
+        return GC_E_HIP;
+    }
+    *c->h_coop_err = 0;
     c->coop_timeouts++;
     if (std::getenv("GC_TRACE"))
         std::fprintf(stderr, "[gc trace] a cooperative one-instance pass lost a workgroup and was repeated on the device; level launches from here on\n");
@@ -629,9 +670,12 @@ static bool want_flat(const gc_batch *b) {
 
 static BatchGeom geom_for(const gc_batch *b) {
     const Plan &p = b->circ->plan.p;
-    const bool pend = flat_pending(b->circ);  // (no plan with the wires in LDS yet: the HBM-wire kernels)
-    const bool flat = !pend && want_flat(b);
-    const uint32_t nls = one_wide(b) || pend ? 0xffffffffu : flat ? p.n_flat_slots : p.n_lds_slots;
+    // (no plan with the wires in LDS yet — the circuit's own thread is building it: the HBM-wire kernels; none of the plan's
+    // flattened / LDS fields is read while that thread writes them: constants instead)
+    const bool pend = flat_pending(b->circ);
+    if (pend) return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, 0xffffffffu, 6u, false, 0);
+    const bool flat = want_flat(b);
+    const uint32_t nls = one_wide(b) ? 0xffffffffu : flat ? p.n_flat_slots : p.n_lds_slots;
     // an XOR list spread over 2 / 4 lanes (TI apart) is joined with DPP row shifts: parts * TI <= 16
     const uint32_t max_t = flat ? (p.fl_max_parts >= 4 ? 2u : p.fl_max_parts == 2 ? 3u : 6u) : 6u;
     return make_geom(b->g.batch, b->schedule, p.info.nslots, p.info.slab_rows, nls, max_t, flat, p.fl_unit_stride);
@@ -881,8 +925,8 @@ static int run_levels(gc_batch *b, bool eval, const uint4 *T, const uint4 *rnd =
                     // until gc_ctx_coop_check (gc_ctx_sync, gc_pass_dev, the streaming calls that hand results out) notes it
                     // (with its stand-by workgroup: a pass that loses a workgroup is done again inside the same launch)
                     launch_coop(eval, a, cx->d_coop, b->xchg, cx->coop_launched, s);
-                    if (a.nsteps) cx->coop_launched++;  // = the device's count of passes once this one has run
                     GC_HIP(hipGetLastError());
+                    if (a.nsteps) cx->coop_launched++;  // (a launch that really went out) = the device's count of passes once this one has run
                     b->last_launches = 1;
                     return GC_OK;
                 }

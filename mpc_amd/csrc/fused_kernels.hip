@@ -1056,8 +1056,8 @@ __device__ __forceinline__ void coop_wait(CoopCtl *ctl, uint32_t gen) {
             if ((++spins & 63u) == 0) {
                 if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                 if (__builtin_amdgcn_s_memtime() - t0 > kCoopTimeout) {
+                    // (the host hears of it from the stand-by: 1 once the pass has been done again, 2 if that was not possible)
                     __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (uint32_t *host_err = ctl->host_err) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -1095,16 +1095,26 @@ __device__ __noinline__ void coop_standby(CoopCtl *ctl, uint32_t seq, const Gate
                                           uint32_t nsteps, uint32_t ninputs, uint4 *__restrict__ W, const uint4 *__restrict__ Rv,
                                           uint4 *__restrict__ T, const uint32_t *__restrict__ rk, const uint32_t *__restrict__ g_te0,
                                           const StoreXchg *xp, uint32_t *te) {
+    __shared__ uint32_t ended;
     if (threadIdx.x == 0) {
-        // the last workgroup to leave counts the pass; every wait inside the pass is bounded, so this one ends (the bound here
-        // is a backstop: ~2 s)
+        // the last workgroup to leave counts the pass (ctl->passes becomes seq + 1); every wait inside the pass is bounded, so
+        // this one ends.  The bound here is a backstop (~2 s): a pass that has NOT ended by then — or a count the host and the
+        // device do not agree on — cannot be repaired from here: the host is told that the results are not to be used (2).
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while (__hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+        uint32_t ok = 1;
+        while ((int32_t)(__hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) <= 0) {
             __builtin_amdgcn_s_sleep(100);
-            if (__builtin_amdgcn_s_memtime() - t0 > 50u * kCoopTimeout) break;
+            if (__builtin_amdgcn_s_memtime() - t0 > 50u * kCoopTimeout) {
+                ok = 0;
+                break;
+            }
         }
+        if (!ok)
+            if (uint32_t *host_err = ctl->host_err) __hip_atomic_store(host_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ended = ok;
     }
     __syncthreads();
+    if (!ended) return;
     if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;  // the rule: a good pass
     load_te_tables(te, g_te0);
     if (xp)  // Get through in[] again: the failed pass left the wire store alone (it skips its scatter once the flag is up)
@@ -1129,6 +1139,8 @@ __device__ __noinline__ void coop_standby(CoopCtl *ctl, uint32_t seq, const Gate
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(&ctl->repaired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ctl->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the host: a pass lost a workgroup AND has been done again (never overwrites a 2)
+        if (uint32_t *host_err = ctl->host_err) __hip_atomic_fetch_max(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

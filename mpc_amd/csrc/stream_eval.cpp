@@ -182,8 +182,8 @@ int gc_stream_eval_get_wire(gc_stream_eval *e, uint32_t w, gc_label *l) try {
     if (rc != GC_OK) return rc;
     if (e->deep.n_inflight) e->deep.drain();  // ... or a deep block on its lane
     rc = e->store.get(e->ctx, w, l);
-    (void)gc_ctx_coop_check(e->ctx);  // (the stream was waited for: a cooperative pass that lost a workgroup is noted here)
-    return rc;
+    const int rcc = gc_ctx_coop_check(e->ctx);  // (the stream was waited for: a cooperative pass that lost a workgroup is noted here)
+    return rc != GC_OK ? rc : rcc;
 } catch (...) {
     return gc::on_exception();
 }

@@ -341,7 +341,7 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streami
     gc_label l0;
     rc = s->store.get(s->ctx, w, &l0);
     if (rc != GC_OK) return rc;
-    (void)gc_ctx_coop_check(s->ctx);  // (the stream was waited for: a cooperative pass that lost a workgroup is noted here)
+    if ((rc = gc_ctx_coop_check(s->ctx)) != GC_OK) return rc;  // (the stream was waited for: a pass that lost a workgroup is noted here)
     out->l0 = l0;
     out->l1 = gc_label{l0.d0 ^ s->r.d0, l0.d1 ^ s->r.d1};
     return GC_OK;

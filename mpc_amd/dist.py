@@ -80,7 +80,10 @@ def _rendezvous_path(directory=None):
         import stat as _stat
         if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
             raise PermissionError("rendezvous directory %s is not a private directory of this user" % directory)
-    nonce = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:32]
+    # GC_LAUNCH_NONCE: a value the launcher draws per launch and hands to every rank (scripts/ranks_on_one_gpu.sh does): launches
+    # from ONE shell share the parent pid and the port, and a run that crashed a moment ago may have left its file behind
+    nonce = os.environ.get("GC_LAUNCH_NONCE") or (os.environ.get("TORCHELASTIC_RUN_ID", "") + "r" + os.environ.get("TORCHELASTIC_RESTART_COUNT", ""))
+    nonce = "".join(ch for ch in nonce if ch.isalnum())[:48]
     return os.path.join(directory, "gc_comm_id.%d.%s.%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), nonce or "x"))
 
 
@@ -112,8 +115,9 @@ def exchange_unique_id_file(make_id, rank, world, timeout=180.0, directory=None)
             try:
                 st = os.fstat(fd)
                 import stat as _stat
-                # rank 0 starts with this process (same launcher): a file much older than this rank is a leftover
-                if _stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_size > 0 and st.st_mtime >= start - 120:
+                # rank 0 starts with this process (same launcher): a file older than this rank by more than the launcher's
+                # spread is a leftover (GC_LAUNCH_NONCE in the name rules leftovers out altogether)
+                if _stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and st.st_size > 0 and st.st_mtime >= start - 30:
                     return os.read(fd, 4096)
             finally:
                 os.close(fd)

@@ -58,6 +58,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the HIP extension is the product; there is no CPU fallback)" % LIB_PATH)
+    # A streaming host wants 8 hardware queues (the HIP runtime's default is 4: streams that share one run one after the other;
+    # mpc_amd/csrc/engine.cpp).  The HOST decides that, before its first HIP call — this binding is the host of the test-suite
+    # and of bench.py; the library itself never touches the environment.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH)
     vp, u32, sz, i32 = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
     ip = C.POINTER(C.c_int)

@@ -11,6 +11,7 @@ mkdir -p $OUT
 SO=/tmp/librccl_standin.so
 hipcc -shared -fPIC -O2 -o $SO $REPO/tests/standin_rccl/standin_rccl.cpp || exit 1
 RDV=$(mktemp -d)
+export GC_LAUNCH_NONCE=$(date +%s%N)p$$  # (one value per launch, in the name of the communicator-id file: mpc_amd/dist.py)
 export WORLD_SIZE=$N MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 TORCHELASTIC_RUN_ID=one_gpu_$$ GC_RENDEZVOUS_DIR=$RDV GC_RCCL_PATH=$SO GC_BENCH_DEVICE=0
 pids=()
 for r in $(seq 0 $((N - 1))); do

@@ -142,6 +142,9 @@ int main(int argc, char **argv) {
     const uint32_t window = rd32(f);
     fclose(f);
 
+    /* eight hardware queues for the engine's streams (the runtime's default is 4; read on the first HIP call of the process):
+     * the host's decision, as a Go host would make it in its init() — the library does not touch the environment */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int st = 0;
     gc_ctx *ctx = gc_ctx_create(0, &st);
     if (!ctx) DIE("gc_ctx_create: %d", st);
