@@ -286,6 +286,14 @@ int gc_stream_garble_finish(gc_stream *, uint8_t *buf, size_t cap, size_t *writt
  * (the Go shim copies them into conn.WriteBuf, stream_garble.go:177-185: one copy instead of two; on a program of 13 000-gate
  * multipliers the copy out of the staging was most of the host's time per step). */
 int gc_stream_garble_finish_view(gc_stream *, const uint8_t **bytes, size_t *len);
+/* gc_stream_garble_finish with the copy DEFERRED (additive, round 5): *written is known when the call returns, the bytes are in
+ * buf[0 .. *written) once gc_stream_garble_copies_wait (or gc_stream_free) has returned — a few threads of the stream do the
+ * copying (GC_STREAM_COPY_THREADS, default 3) while the caller's thread queues the next circuits.  For a host that fills a
+ * large write buffer of its own: on the Ed25519-shaped program the stream is 22 bytes per gate, so at 8e8 gates/s the copy
+ * out of the staging alone is 17 GB/s — more than the one core that also queues 26 000 circuits can move.  buf must stay
+ * valid and untouched until the wait; the three kinds of finish may be mixed (every one hands out the OLDEST circuit). */
+int gc_stream_garble_finish_async(gc_stream *, uint8_t *buf, size_t cap, size_t *written);
+int gc_stream_garble_copies_wait(gc_stream *);
 int gc_stream_garble_flush(gc_stream *);
 /* A driver garbles the same few circuits over and over (the streamer keeps one compiled circuit per SSA instruction
  * shape: 23 for Ed25519 sign.mpcl, benchmarks.md:698), and gc_stream_garble_begin has to recognise the gate list by

@@ -69,6 +69,7 @@ struct gc_stream {
     gc_circ *held_circ = nullptr;
     gc_batch *held = nullptr;
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
+    CopyPool copier;              // gc_stream_garble_finish_async: the copies into the caller's buffer, off this thread
     FuseStats fuse;               // chain fusion: launch units of several steps, merged plans built
     StageProf prof;
     uint64_t n_steps_total = 0;
@@ -221,6 +222,8 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
 
 void gc_stream_free(gc_stream *s) {
     if (!s) return;
+    s->copier.wait();  // (copies out of the slots' pinned bytes that are still under way)
+    s->copier.stop();
     s->prof.print("garbler", s->n_steps_total);
     if (s->ctx) {
         (void)hipSetDevice(s->ctx->device);
@@ -783,7 +786,16 @@ extern "C" {
 // The bytes of the oldest circuit in flight: copied into buf (view == nullptr), or handed out in place (*view = a pointer
 // into the engine's pinned staging, valid until the next finish / free call on the stream: the slot it belongs to is only
 // given back then)
-static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written, const uint8_t **view) {
+// slots whose steps have all been handed out and whose deferred copies are done go back to the free ones
+static void retire_slots(gc_stream *s) {
+    for (auto &sl : s->slots)
+        if (sl->retire && sl->copies.load(std::memory_order_acquire) == 0) {
+            if (sl->deep_id) s->deep.retire(sl->lane, sl->deep_id);
+            sl->reset();
+        }
+}
+
+static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written, const uint8_t **view, bool async = false) {
     if (!s || (!buf && !view) || !written || s->queue.empty()) return GC_E_ARG;
     s->prof.start();
     StreamTrace tr;
@@ -832,11 +844,14 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
             *written = need;
             if (view) *view = g.h_down + sizes_bytes + j.off_bytes;
             else if (need > cap) rc = GC_E_ARG;
+            else if (need && async) s->copier.submit(buf, g.h_down + sizes_bytes + j.off_bytes, need, &g.copies);
             else if (need) std::memcpy(buf, g.h_down + sizes_bytes + j.off_bytes, need);
         }
         if (++g.handed == g.jobs.size()) {
             if (view && rc == GC_OK) {
                 s->view_slot = ref.slot;  // (given back by the next finish: the caller still reads its bytes)
+            } else if (g.copies.load(std::memory_order_acquire) != 0) {
+                g.retire = true;          // (given back when its copies are done: retire_slots)
             } else {
                 if (g.deep_id) s->deep.retire(g.lane, g.deep_id);  // (its kernel has run: `done` sits behind it)
                 g.reset();
@@ -879,6 +894,23 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
 int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
     if (!buf) return GC_E_ARG;
     return stream_finish(s, buf, cap, written, nullptr);
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_garble_finish_async(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
+    if (!buf) return GC_E_ARG;
+    retire_slots(s);
+    return stream_finish(s, buf, cap, written, nullptr, true);
+} catch (...) {
+    return gc::on_exception();
+}
+
+int gc_stream_garble_copies_wait(gc_stream *s) try {
+    if (!s) return GC_E_ARG;
+    s->copier.wait();
+    retire_slots(s);
+    return GC_OK;
 } catch (...) {
     return gc::on_exception();
 }

@@ -255,6 +255,80 @@ struct DeepDeps {
     }
 };
 
+// A few threads that copy bytes for the stream's thread (the garbler's copies of finished steps into the caller's buffer: 2.3 GB
+// for the Ed25519-shaped program, more than one core moves while it also queues 26 000 steps).  Tasks are (dst, src, len) with a
+// counter to decrement when done; large ones are cut into pieces so that the threads share them.  wait() returns when every
+// task handed over so far has been done.
+class CopyPool {
+public:
+    ~CopyPool() { stop(); }
+    void submit(void *dst, const void *src, size_t len, std::atomic<uint32_t> *pending) {
+        if (th_.empty()) start();
+        constexpr size_t kPiece = (size_t)256 << 10;
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t off = 0; off < len || off == 0; off += kPiece) {
+            const size_t n = std::min(kPiece, len - off);
+            if (pending) pending->fetch_add(1, std::memory_order_relaxed);
+            q_.push_back(Task{(uint8_t *)dst + off, (const uint8_t *)src + off, n, pending});
+            issued_++;
+            if (len == 0) break;
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return done_ == issued_; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+        th_.clear();
+        quit_ = false;
+    }
+
+private:
+    struct Task {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t len;
+        std::atomic<uint32_t> *pending;
+    };
+    void start() {
+        const char *v = std::getenv("GC_STREAM_COPY_THREADS");
+        int n = v && *v ? std::atoi(v) : 3;
+        n = n < 1 ? 1 : n > 8 ? 8 : n;
+        for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return quit_ || !q_.empty(); });
+                if (q_.empty()) return;
+                t = q_.front();
+                q_.pop_front();
+            }
+            if (t.len) std::memcpy(t.dst, t.src, t.len);
+            if (t.pending) t.pending->fetch_sub(1, std::memory_order_release);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (++done_ == issued_) done_cv_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<Task> q_;
+    std::vector<std::thread> th_;
+    uint64_t issued_ = 0, done_ = 0;
+    bool quit_ = false;
+};
+
 struct Slot {
     enum Kind { kFree, kGroup, kBig } kind = kFree;
     gc_ctx *ctx = nullptr;   // the upload / arena / download regions come from (and go back to) the ctx's buffer lists
@@ -271,6 +345,10 @@ struct Slot {
     hipEvent_t after_ev = nullptr;  // else the kernel of the latest group it conflicts with (null: none, or done already)
     int error = GC_OK;          // close failed: the group's steps report it
     uint32_t handed = 0;        // steps whose bytes have been handed out
+    // gc_stream_garble_finish_async: copies out of the slot's pinned bytes still under way on the copier threads; a slot whose
+    // steps have all been handed out is only given back (retire) when they are done
+    std::atomic<uint32_t> copies{0};
+    bool retire = false;
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
     hipEvent_t kernel_ev = nullptr;              // whichever of the two says "the group's kernel has run" (set at launch)
     std::vector<JobRec> jobs;
@@ -298,6 +376,7 @@ struct Slot {
         launched = synced = false;
         error = GC_OK;
         handed = 0;
+        retire = false;
         deep_id = 0;
         deps = DeepDeps{};
         after_tail = false;

@@ -98,6 +98,8 @@ def lib():
         "gc_stream_garble_begin_h": (i32, [vp, u32, vp, vp]),
         "gc_stream_release": (i32, [vp, u32]),
         "gc_stream_garble_finish_view": (i32, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "gc_stream_garble_finish_async": (i32, [vp, vp, sz, C.POINTER(C.c_size_t)]),
+        "gc_stream_garble_copies_wait": (i32, [vp]),
         "gc_stream_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
@@ -770,6 +772,17 @@ class Stream:
         n = C.c_size_t(0)
         _check(lib().gc_stream_garble_finish(self.h, _p(self._buf), len(self._buf), C.byref(n)), "gc_stream_garble_finish")
         return self._buf[: n.value].tobytes()
+
+    def garble_finish_async(self, dst, offset):
+        """gc_stream_garble_finish_async: the bytes of the oldest circuit in flight into dst[offset:] (a numpy uint8 array the
+        caller keeps alive and untouched until copies_wait) — copied by the stream's copier threads; returns the byte count"""
+        n = C.c_size_t(0)
+        _check(lib().gc_stream_garble_finish_async(self.h, C.c_void_p(dst.ctypes.data + offset), len(dst) - offset, C.byref(n)),
+               "gc_stream_garble_finish_async")
+        return n.value
+
+    def copies_wait(self):
+        _check(lib().gc_stream_garble_copies_wait(self.h), "gc_stream_garble_copies_wait")
 
     def garble_finish_view(self):
         """gc_stream_garble_finish_view: the same bytes without the engine's copy — read in place from its pinned staging

@@ -394,7 +394,7 @@ class _Args:
         return out
 
 
-def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True, view=False):
+def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True, view=False, deferred=True):
     """returns (stream bytes as one array, per-step byte counts, seconds, stats, the Stream — still open); g.inputs0 =
     the zero labels of the primary inputs as they were BEFORE the program ran (a program may overwrite its inputs)"""
     L = engine.lib()
@@ -408,7 +408,9 @@ def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True, view=Fals
     sizes = np.zeros(n, np.int64)
     nb = C.c_size_t(0)
     pnb = C.byref(nb)
-    begin, finish, h = L.gc_stream_garble_begin, L.gc_stream_garble_finish, g.h
+    # the bytes land in `out` — copied by the stream's copier threads while this thread queues on (gc_stream_garble_finish_async
+    # + one gc_stream_garble_copies_wait at the end, inside the timed region), or by this thread (deferred=False)
+    begin, finish, h = L.gc_stream_garble_begin, (L.gc_stream_garble_finish_async if deferred else L.gc_stream_garble_finish), g.h
     bargs = a.begin
     if intern:  # circuits named by handle (gc_stream_intern, once per circuit): no per-step content hash
         begin, bargs = L.gc_stream_garble_begin_h, a.interned(g)
@@ -431,6 +433,10 @@ def garble_program(ctx, key, steps, prim, rnd, window=64, intern=True, view=Fals
             raise engine.EngineError(rc, "gc_stream_garble_finish(step %d)" % k)
         sizes[k] = nb.value
         off += nb.value
+    if deferred and not view:
+        rc = L.gc_stream_garble_copies_wait(h)
+        if rc:
+            raise engine.EngineError(rc, "gc_stream_garble_copies_wait")
     dt = time.perf_counter() - t0
     return out[:off], sizes, dt, g.stats(), g
 
@@ -644,6 +650,7 @@ def run_native(name, key=bytes(range(32)), window=64):
             "eval_blocks_gates_per_s": gates / r["eval_blocks_s"] if r.get("eval_blocks_s") else None,
             # ... the bytes handed out in place (no copy into a second buffer) / read buffers of 32 MiB in pinned memory
             "garble_view_gates_per_s": gates / r["garble_view_s"] if r.get("garble_view_s") else None,
+            "garble_async_gates_per_s": gates / r["garble_async_s"] if r.get("garble_async_s") else None,
             "eval_blocks_pinned_gates_per_s": gates / r["eval_blocks_pinned_s"] if r.get("eval_blocks_pinned_s") else None,
             "eval_blocks_chunk": r.get("eval_blocks_chunk"),
             "eval_blocks_matched": r["eval_blocks_matched"], "sha256": r["sha256"],
@@ -696,7 +703,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
             r = {"error": str(e)[:200]}
         if r is not None:
-            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_view_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_pinned_gates_per_s",
+            native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_view_gates_per_s", "garble_async_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_pinned_gates_per_s",
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
                                                       "window", "sha256_ok", "error")}
     if native:

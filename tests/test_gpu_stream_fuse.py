@@ -272,3 +272,41 @@ def test_read_buffers_matched_on_the_device(pinned, piece):
     if hold is not None:
         hold.close()
     ctx.close()
+
+
+def test_deferred_copies_hand_out_the_same_bytes():
+    """gc_stream_garble_finish_async: the copies into the caller's buffer run on the stream's copier threads; after
+    gc_stream_garble_copies_wait every byte is the oracle's — mixed with copying finishes and views, slots re-used under way"""
+    ctx = engine.Context(0)
+    steps, prim = _chain_program(0x2000)
+    steps = steps * 3
+    key, rnd = drbg("defer", 32), drbg("defer-r", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [bytes(og.garble(c.Gates, c.NumWires, in_, out_)) for c, in_, out_ in steps]
+    total = sum(len(w) for w in want)
+    out = np.zeros(total + 64, np.uint8)
+    handles, issued, off, spans, direct = {}, 0, 0, [], {}
+    for k in range(len(steps)):
+        while issued < min(len(steps), k + 40):
+            c, in_, out_ = steps[issued]
+            if id(c) not in handles:
+                handles[id(c)] = gg.intern(c.Gates, c.NumWires, len(in_), len(out_))
+            gg.garble_begin_h(handles[id(c)], in_, out_)
+            issued += 1
+        if k % 11 == 5:
+            direct[k] = gg.garble_finish()
+        elif k % 13 == 7:
+            direct[k] = gg.garble_finish_view()
+        else:
+            n = gg.garble_finish_async(out, off)
+            spans.append((k, off, n))
+            off += n
+        if k % 50 == 49:
+            gg.copies_wait()
+    gg.copies_wait()
+    for k, o, n in spans:
+        assert out[o:o + n].tobytes() == want[k], "step %d (deferred copy)" % k
+    for k, b in direct.items():
+        assert b == want[k], "step %d" % k
+    gg.close()
+    ctx.close()
