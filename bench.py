@@ -131,6 +131,8 @@ def level_launch_row(batch, circ, key, ctx):
     one data-parallel launch per dependency level (308 garbling + 308 evaluating launches for aes_128, thread = (gate,
     instance), wires in HBM), the step's launches recorded in a hipGraph — on the headline's workload, timed like the
     headline (wall time between two device syncs) with the passes' HIP-event times beside it."""
+    import numpy as np
+
     from mpc_amd import engine
     dc = engine.DeviceCircuit(ctx, circ)
     info = dc.info

@@ -140,6 +140,9 @@ func (stream *StreamEval) evalBlock(conn *p2p.Conn, numGates, numTmpWires, numWi
 // the whole OpCircuit blocks in it (their 20-byte headers included) and says how far it got; the loop then continues with
 // whatever operation is next — OpReturn, or an OpCircuit block that did not fit (evalBlock collects that one gate by gate).
 // lastStep is the step number of the last block evaluated, for the progress report (:251-268).
+// Round 5: a buffer of 64 KiB or more goes to the GPU as it is and the blocks are recognised there (DESIGN.md §5) — the more
+// the connection has buffered the better; a ReadBuf from gc_host_alloc (pinnedBytes below) is read by the DMA in place, a
+// Go-heap ReadBuf is staged by copier threads of the engine.
 func (stream *StreamEval) evalBuffered(conn *p2p.Conn) (blocks int, err error) {
 	for {
 		have := conn.ReadEnd - conn.ReadStart
@@ -186,4 +189,15 @@ func (stream *StreamEval) Close() {
 		C.gc_ctx_destroy(stream.ctx)
 		stream.h, stream.ctx = nil, nil
 	}
+}
+
+// pinnedBytes returns n bytes of pinned host memory for a connection's read buffer (p2p.Conn.ReadBuf; additive): whole read
+// buffers of OpCircuit blocks then reach the GPU by DMA straight from it (gc_stream_eval_blocks).  The reference sizes its
+// buffers at 64 KiB / 1 MiB (p2p/protocol.go:24-25); the engine is happiest with tens of MiB.
+func pinnedBytes(n int) ([]byte, func()) {
+	p := C.gc_host_alloc(C.size_t(n))
+	if p == nil {
+		return make([]byte, n), func() {}
+	}
+	return unsafe.Slice((*byte)(p), n), func() { C.gc_host_free(p) }
 }

@@ -175,8 +175,11 @@ struct EvalDev {
         std::vector<std::pair<uint32_t, uint64_t>> users;  // (slot, launch number) of the launches that read it
     };
     std::vector<Chunk> chunks;
-    uint8_t *stage = nullptr;  // pinned staging for a caller's pageable buffer
-    size_t stage_cap = 0;
+    uint8_t *stage = nullptr;  // pinned staging for a caller's pageable buffer: filled piece by piece by a few copier threads
+    size_t stage_cap = 0;      // (one core copies ~12 GB/s; the stream of the Ed25519-shaped program wants 20) while the pieces
+    CopyPool copier;           // already there go up and are looked at
+    std::unique_ptr<std::atomic<uint32_t>[]> piece_copies;
+    size_t piece_copies_cap = 0;
     uint64_t n_blocks = 0, n_fallback = 0;
 };
 
@@ -319,6 +322,8 @@ void evdev_stats(const gc_stream_eval *e, uint64_t *blocks, uint64_t *fallbacks)
 void evdev_free(gc_stream_eval *e) {
     EvalDev *d = e->dev;
     if (!d) return;
+    d->copier.wait();
+    d->copier.stop();
     if (e->ctx) (void)hipSetDevice(e->ctx->device);
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     if (d->vstream) {
@@ -445,14 +450,29 @@ int evdev_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, size_t *pos_
     }
     d->ctl->ndone = 0;
     hipError_t er = hipSuccess;
+    if (!pinned) {  // a pageable buffer: through pinned staging (the DMA cannot read it in place) — all pieces to the copier threads
+        size_t npieces = 0, piece = kPieceFirst;
+        for (size_t off = 0; off < upto; off += std::min(piece, upto - off), piece = std::min(piece * 2, kPieceMax)) npieces++;
+        if (npieces > d->piece_copies_cap) {
+            d->piece_copies.reset(new std::atomic<uint32_t>[npieces + 8]);
+            d->piece_copies_cap = npieces + 8;
+        }
+        piece = kPieceFirst;
+        size_t k = 0;
+        for (size_t off = 0, nb = 0; off < upto; off += nb, piece = std::min(piece * 2, kPieceMax), k++) {
+            nb = std::min(piece, upto - off);
+            d->piece_copies[k].store(0, std::memory_order_relaxed);
+            d->copier.submit(d->stage + off, buf + off, nb, &d->piece_copies[k]);
+        }
+    }
     {
         uint32_t first = 0, pi = 0;  // (pi: events in use — one per piece that is followed by verdicts)
-        size_t piece = kPieceFirst;
-        for (size_t off = 0, nb = 0; off < upto && er == hipSuccess; off += nb, piece = std::min(piece * 2, kPieceMax)) {
+        size_t piece = kPieceFirst, k = 0;
+        for (size_t off = 0, nb = 0; off < upto && er == hipSuccess; off += nb, piece = std::min(piece * 2, kPieceMax), k++) {
             nb = std::min(piece, upto - off);
             const uint8_t *src = buf + off;
-            if (!pinned) {  // a pageable buffer: through pinned staging (the DMA cannot read it in place)
-                std::memcpy(d->stage + off, buf + off, nb);
+            if (!pinned) {
+                while (d->piece_copies[k].load(std::memory_order_acquire) != 0) _mm_pause();  // (this piece is in the staging)
                 src = d->stage + off;
             }
             er = hipMemcpyAsync(d_buf + off, src, nb, hipMemcpyHostToDevice, st);
@@ -476,6 +496,7 @@ int evdev_blocks(gc_stream_eval *e, const uint8_t *buf, size_t len, size_t *pos_
         }
     }
     if (er != hipSuccess) {
+        if (!pinned) d->copier.wait();  // (the copier threads read the caller's buffer: not beyond this call)
         (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(d->vstream);
         d->chunks[ci].walking = false;

@@ -379,14 +379,16 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     if (nin > nwires || nout > nwires) return GC_E_ARG;
     const uint32_t first_tmp = nin, first_out = nwires - nout;
     // initCircuit (:102-114)
-    uint32_t mx = 0, in_lo = 0xffffffffu, in_hi = 0, out_lo = 0xffffffffu, out_hi = 0;
-    for (uint32_t i = 0; i < nin; i++) in_lo = std::min(in_lo, in[i]), in_hi = std::max(in_hi, in[i]);
+    uint32_t mx = 0, in_hi = 0, out_lo = 0xffffffffu, out_hi = 0;
+    for (uint32_t i = 0; i < nin; i++) in_hi = std::max(in_hi, in[i]);
     for (uint32_t i = 0; i < nout; i++) out_lo = std::min(out_lo, out[i]), out_hi = std::max(out_hi, out[i]);
     mx = std::max(in_hi, out_hi);
     ensure(s, mx);
-    // (in[] and out[] can only name a common wire where their id ranges overlap: as a rule they do not, and the per-wire look of
-    // the aliasing check below — two passes over tables the size of the wire store — is skipped)
-    const bool ranges_overlap = nin && nout && in_lo <= out_hi && out_lo <= in_hi;
+    // (in[] and out[] can only name a common wire if an input id lies inside the id range of the outputs: as a rule — results
+    // take fresh ids from the allocator, operands and constants lie elsewhere — none does, and the per-wire look of the
+    // aliasing check below, two passes over tables the size of the wire store, is skipped)
+    bool ranges_overlap = false;
+    for (uint32_t i = 0; i < nin && nout; i++) ranges_overlap |= in[i] >= out_lo && in[i] <= out_hi;
     gc_ctx *ctx = s->ctx;
     hipStream_t st = ctx->stream;
     GC_HIP(hipSetDevice(ctx->device));

@@ -273,7 +273,9 @@ public:
             issued_++;
             if (len == 0) break;
         }
-        cv_.notify_all();
+        // (a wake-up is a system call: only when a thread is really asleep — with 26 000 copies a run, most find them all busy)
+        if (idle_ >= 2 && q_.size() >= 2) cv_.notify_all();
+        else if (idle_) cv_.notify_one();
     }
     void wait() {
         std::unique_lock<std::mutex> lk(mu_);
@@ -308,7 +310,9 @@ private:
             Task t;
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                idle_++;
                 cv_.wait(lk, [&] { return quit_ || !q_.empty(); });
+                idle_--;
                 if (q_.empty()) return;
                 t = q_.front();
                 q_.pop_front();
@@ -326,6 +330,7 @@ private:
     std::deque<Task> q_;
     std::vector<std::thread> th_;
     uint64_t issued_ = 0, done_ = 0;
+    uint32_t idle_ = 0;
     bool quit_ = false;
 };
 

@@ -29,6 +29,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 import numpy as np
 
+os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")  # every chain on its merged plan, at first sight (as tests/conftest.py)
+
 import oracle
 from mpc_amd import engine
 from tests.util import drbg

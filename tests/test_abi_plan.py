@@ -344,3 +344,20 @@ def test_go_shim_calls_match_the_prototypes():
                 if pointer.match(a) and w != "ptr":
                     bad.append("%s argument %d: pointer expression %r for a scalar parameter" % (where, k + 1, a))
     assert ncalls > 100 and not bad, "\n".join(bad)
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """INTEGRATION.md's table of environment switches names every getenv of libgcengine.so (and says which are test hooks)"""
+    import glob
+    csrc = os.path.join(os.path.dirname(engine.HEADER), "..", "mpc_amd", "csrc")
+    used = set()
+    for f in glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        used |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert len(used) >= 20
+    doc = open(os.path.join(os.path.dirname(engine.HEADER), "..", "INTEGRATION.md")).read()
+    table = doc[doc.index("## Environment switches of the library"):]
+    missing = sorted(v for v in used if "`%s`" % v not in table)
+    assert not missing, "INTEGRATION.md does not document %s" % missing
+    for hook in ("GC_COOP_FORCE_TIMEOUT", "GC_STREAM_FUSE_EAGER", "GC_RCCL_PATH"):
+        line = [l for l in table.splitlines() if "`%s`" % hook in l][0]
+        assert "TEST HOOK" in line, hook
