@@ -317,7 +317,7 @@ int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
                 }
                 shape = fuse_shape(w.shape, ent, e->wiring_scratch.data());
                 const uint32_t hint = fuse_depth_hint(ctx, shape);
-                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
+                fuse = hint ? hint <= fuse_depth_cap() : w.depth_sum + ent->circ->plan.p.n_hash_phases <= 2 * fuse_depth_cap();
             }
         }
         uint32_t slot_idx = 0;

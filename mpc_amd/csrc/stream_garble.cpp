@@ -514,7 +514,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
                 }
                 shape = fuse_shape(w.shape, ent, s->wiring_scratch.data());
                 const uint32_t hint = fuse_depth_hint(ctx, shape);
-                fuse = hint ? hint <= kFuseDepth : w.depth_sum + ent->circ->plan.p.n_hash_phases <= kFuseDepthSum;
+                fuse = hint ? hint <= fuse_depth_cap() : w.depth_sum + ent->circ->plan.p.n_hash_phases <= 2 * fuse_depth_cap();
             }
         }
         uint32_t slot_idx = 0;

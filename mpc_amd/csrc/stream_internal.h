@@ -194,8 +194,17 @@ constexpr uint32_t kFuseMembers = 48;       // ... of at most this many steps,
 constexpr uint32_t kFuseGates = 40960;      //     gates,
 constexpr uint32_t kFuseSlots = 2600;       //     live labels (the sum of the members' own LDS plans: an estimate),
 constexpr uint32_t kFuseInputs = 2048;      //     and labels read from the wire store
-constexpr uint32_t kFuseDepth = 320;        // ... and dependent hash phases, as far as earlier chains of the same shape tell (fuse_depth_hint);
-constexpr uint32_t kFuseDepthSum = 640;     //     for a shape nobody has planned yet: the sum of the steps' own depths (no overlap assumed)
+constexpr uint32_t kFuseDepth = 320;        // ... and dependent hash phases, as far as earlier chains of the same shape tell (fuse_depth_hint;
+                                            //     GC_STREAM_FUSE_DEPTH overrides it); for a shape nobody has planned yet: twice that as the
+                                            //     sum of the steps' own depths (no overlap assumed)
+inline uint32_t fuse_depth_cap() {
+    static const uint32_t v = [] {
+        const char *e = std::getenv("GC_STREAM_FUSE_DEPTH");
+        const int n = e && *e ? std::atoi(e) : 0;
+        return n > 0 ? (uint32_t)n : kFuseDepth;
+    }();
+    return v;
+}
 constexpr uint32_t kGroupSteps = 4096;      // steps per group at most (fused or not)
 constexpr uint32_t kFuseMulti = 0xfffffffeu, kFuseNone = 0xffffffffu;
 
