@@ -330,6 +330,15 @@ int gc_stream_deep_stats(const gc_stream *, uint64_t *deep_steps, uint32_t *lane
  * (they are cached per ctx); unfit: units whose merged plan fits no workgroup (their steps ran one launch after the other).
  * GC_STREAM_NO_FUSE in the environment switches the fusion off.  Any pointer may be NULL. */
 int gc_stream_fuse_stats(const gc_stream *, uint64_t *fused_units, uint64_t *fused_steps, uint64_t *plans_built, uint64_t *unfit);
+/* Units that WAIT inside a launch — an experiment, off unless GC_STREAM_DEPS=1 is in the environment when the stream is
+ * created (EXPERIMENTS.md, round 5: on the programs measured it costs more chain fusion than it saves launches).  A queued step
+ * that conflicts with steps of an open group — and cannot be fused into one unit with them: it conflicts with several units,
+ * or is too large for a chain — then still joins that group: its workgroup waits, on the device, for the done-flags of exactly
+ * the units it conflicts with (mpc_amd/csrc/kernels.h: d_sync) instead of the whole step waiting for the whole group in a
+ * later launch.  Program order per wire is what the reference's serial loop gives (stream_garble.go:131-157): a reader runs
+ * behind the writer it names, a writer behind the earlier readers and writers of its wire.  waiting_units: such units so far
+ * (0 when the experiment is off). */
+int gc_stream_wait_stats(const gc_stream *, uint64_t *waiting_units);
 
 /* Streaming evaluator: the store of circuit.StreamEval (stream_evaluator.go:29-96) and the
  * per-gate loop of StreamEvaluator for ONE OpCircuit block (stream_evaluator.go:270-432).  The host driver keeps
@@ -383,6 +392,8 @@ int gc_stream_eval_dev_stats(const gc_stream_eval *, uint64_t *blocks, uint64_t 
 /* the evaluator's counterpart of gc_stream_fuse_stats (its blocks chain exactly as the garbler's steps do) */
 int gc_stream_eval_fuse_stats(const gc_stream_eval *, uint64_t *fused_units, uint64_t *fused_blocks, uint64_t *plans_built,
                               uint64_t *unfit);
+/* ... and of gc_stream_wait_stats */
+int gc_stream_eval_wait_stats(const gc_stream_eval *, uint64_t *waiting_units);
 
 /* ------------------------------------------------------------------------------------------
  * Device-resident batch API — what a Go host pipelining many instances (GarbleBatch/EvalBatch,

@@ -95,7 +95,7 @@ static bool coop_ready(gc_ctx *c) {
     c->coop_state = -1;
     if (std::getenv("GC_NO_COOP")) return false;
     if (hipMalloc((void **)&c->d_coop, sizeof(CoopCtl)) != hipSuccess) return false;
-    if (hipHostMalloc((void **)&c->h_coop_err, 256, hipHostMallocPortable) != hipSuccess) return false;
+    if (!c->h_coop_err && hipHostMalloc((void **)&c->h_coop_err, 256, hipHostMallocPortable) != hipSuccess) return false;
     CoopCtl *h = (CoopCtl *)c->h_coop_err;  // the head of the control block after the self-test
     std::memset(h, 0xff, 256);
     launch_coop_selftest(c->d_coop, c->stream);
@@ -113,6 +113,22 @@ static bool coop_ready(gc_ctx *c) {
     if (hipMemcpy(c->d_coop, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) return false;
     if (ok) c->coop_state = 1;
     return ok;
+}
+
+// The pinned word of the ctx that kernels raise when a bounded wait on the device runs out (coop_ready allocates it too):
+// its device address, nullptr if there is none to be had.  Called with ctx->mu held.
+uint32_t *gc_ctx_err_word(gc_ctx *c) {
+    if (!c->h_coop_err) {
+        if (hipHostMalloc((void **)&c->h_coop_err, 256, hipHostMallocPortable) != hipSuccess) {
+            c->h_coop_err = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::memset(c->h_coop_err, 0, 256);
+    }
+    uint32_t *d = nullptr;
+    if (hipHostGetDevicePointer((void **)&d, c->h_coop_err, 0) != hipSuccess) return nullptr;
+    return d;
 }
 
 namespace gc {
@@ -203,7 +219,9 @@ int gc_ctx_coop_check(gc_ctx *c) {
     const uint32_t what = *c->h_coop_err;
     c->coop_state = -1;
     if (what >= 2) {  // (the word stays up: the ctx's results cannot be trusted any more)
-        std::snprintf(gc::tls_error, sizeof gc::tls_error, "a cooperative one-instance pass lost a workgroup and could not be repeated on the device");
+        std::snprintf(gc::tls_error, sizeof gc::tls_error,
+                      what == 3 ? "a unit of a step group waited ~2 s for a unit of the same launch and ran without it"
+                                : "a cooperative one-instance pass lost a workgroup and could not be repeated on the device");
         return GC_E_HIP;
     }
     *c->h_coop_err = 0;

@@ -78,6 +78,8 @@ void ctx_buf_put(gc_ctx *c, bool pinned, void *p, size_t cap);
 // internal: notes a cooperative pass of this ctx that lost a workgroup (repeated on the device already) and switches the
 // cooperative passes off; GC_OK always
 int gc_ctx_coop_check(gc_ctx *c);
+// internal: device address of the ctx's pinned error word (allocated at first use); nullptr if there is none
+uint32_t *gc_ctx_err_word(gc_ctx *c);
 
 struct gc_graph {
     gc_ctx *ctx = nullptr;

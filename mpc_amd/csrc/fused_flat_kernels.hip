@@ -416,6 +416,22 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
     }
 }
 
+// The stream's wire store, as the job launches read and write it: a label may have been written by ANOTHER workgroup of the
+// same launch — a unit this one waited for (unit_enter below), on another XCD, behind another L2 — so its loads and stores
+// are agent-scope accesses (sc1: past the L1, and coherent across the XCDs' L2s), and neither side needs to write back or
+// invalidate a whole L2 (buffer_wbl2 / buffer_inv sc1: ~12 us each, measured for the cooperative passes).
+__device__ __forceinline__ uint4 store_get(const uint4 *p) {
+    const uint64_t *q = (const uint64_t *)p;
+    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ void store_put(uint4 *p, const uint4 &v) {
+    uint64_t *q = (uint64_t *)p;
+    __hip_atomic_store(q, (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // MULTI (job launches): `a` is this workgroup's own record, its tile is 0 and the input labels come from the wire store
 #define GC_FL_PROLOGUE(LOAD_R)                                                                               \
     const uint32_t tile = MULTI ? 0u : blockIdx.x;                                                           \
@@ -467,7 +483,7 @@ __device__ __forceinline__ void eval_hash_narrow(const uint4 *buf, const FUnit &
         for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                \
             const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                               \
             if constexpr (MULTI) { /* Get through in[] (stream_garble.go:131-141) on the device */           \
-                const uint4 v = a.store[a.in_idx[w]];                                                        \
+                const uint4 v = store_get(a.store + a.in_idx[w]);                                            \
                 Wt[i] = v;                                                                                   \
                 if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = v;                                      \
             } else if (ls != 0xffffu) {                                                                      \
@@ -608,7 +624,7 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
             const uint32_t idx = a.out_idx[k];
-            if (idx != 0xffffffffu) a.store[idx] = Wt[a.out_slots[k]];
+            if (idx != 0xffffffffu) store_put(a.store + idx, Wt[a.out_slots[k]]);
         }
     }
 }
@@ -637,22 +653,65 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
 // merged plan (yet): the workgroup runs its jobs one after the other (records first[u] .. first[u] + jobs[first[u]].pad_; each
 // job's outputs go back into the wire store before the next one gathers its inputs from there).  A build of its own: the
 // loop's state costs the registers the single-job build just fits into (0 against 14 spilled VGPRs).
+// Units that depend on one another inside ONE launch (kernels.h: d_sync).  unit_enter: this workgroup's unit = the next ticket;
+// then every thread polls one of the done-flags the unit waits for (a bounded wait: ~2 s, then the pinned error word goes up
+// and the unit runs anyway — garbage, reported by gc_ctx_coop_check, rather than a hung queue).
+constexpr uint32_t kDepSpins = 1u << 22;
+__device__ __forceinline__ uint32_t unit_enter(uint32_t *sync) {
+    extern __shared__ uint4 smem[];
+    uint32_t *scratch = (uint32_t *)smem;  // (the AES table's place: loaded after the barriers below)
+    if (threadIdx.x == 0) scratch[0] = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t unit = __builtin_amdgcn_readfirstlane(scratch[0]);
+    const uint32_t nun_raw = __builtin_amdgcn_readfirstlane(sync[1]), nun = nun_raw & 0x7fffffffu;
+    const uint32_t *off = sync + kSyncHead + nun, *list = off + nun + 1;
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(off[unit]), d1 = __builtin_amdgcn_readfirstlane(off[unit + 1]);
+    bool late = false;
+    for (uint32_t i = d0 + threadIdx.x; i < d1; i += TF) {
+        const uint32_t *flag = sync + kSyncHead + list[i];
+        for (uint32_t spins = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > kDepSpins) {
+                late = true;
+                break;
+            }
+        }
+    }
+    if (late) {
+        uint32_t *host_err = *(uint32_t **)(sync + 2);
+        if (host_err) __hip_atomic_fetch_max(host_err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    // what those units stored is what this one loads: store_get / store_put.  (sync[1] bit 31 — GC_STREAM_DEP_FENCES, a
+    // cross-check — has both sides write back / invalidate their L2 as a release / acquire at agent scope would.)
+    if (d1 != d0 && (nun_raw & 0x80000000u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return unit;
+}
+__device__ __forceinline__ void unit_leave(uint32_t *sync, uint32_t unit) {
+    if (__builtin_amdgcn_readfirstlane(sync[1]) & 0x80000000u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread's stores into the wire store have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(sync + kSyncHead + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NR, bool HAS_OR, bool CHAIN>
-__global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs, const uint32_t *first) {
+__global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs, const uint32_t *first, uint32_t *sync) {
     if constexpr (!CHAIN) {
         const FlArgs a = load_job(jobs + blockIdx.x);
         garble_flat_body<NR, false, HAS_OR, true>(a);
     } else {
-        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[blockIdx.x]);
+        const uint32_t unit = sync ? unit_enter(sync) : blockIdx.x;
+        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[unit]);
         const uint32_t more = __builtin_amdgcn_readfirstlane(jobs[j0].pad_);
         for (uint32_t j = j0; j <= j0 + more; j++) {
             const FlArgs a = load_job(jobs + j);
             garble_flat_body<NR, false, HAS_OR, true>(a);
             if (j != j0 + more) {  // the next job of the chain reads what this one has just stored
-                __threadfence();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (store_put / store_get: no cache to flush)
                 __syncthreads();
             }
         }
+        if (sync) unit_leave(sync, unit);
     }
 }
 
@@ -745,7 +804,7 @@ __device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
             const uint32_t idx = a.out_idx[k];
-            if (idx != 0xffffffffu) a.store[idx] = Wt[a.out_slots[k]];
+            if (idx != 0xffffffffu) store_put(a.store + idx, Wt[a.out_slots[k]]);
         }
     }
 }
@@ -755,21 +814,23 @@ __global__ __launch_bounds__(TF) void k_eval_flat(FlArgs a) {
     eval_flat_body<NR, PROF, HAS_OR, false>(a);
 }
 template <int NR, bool HAS_OR, bool CHAIN>
-__global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs, const uint32_t *first) {
+__global__ __launch_bounds__(TF) void k_eval_flat_jobs(const FlArgs *jobs, const uint32_t *first, uint32_t *sync) {
     if constexpr (!CHAIN) {
         const FlArgs a = load_job(jobs + blockIdx.x);
         eval_flat_body<NR, false, HAS_OR, true>(a);
     } else {
-        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[blockIdx.x]);
+        const uint32_t unit = sync ? unit_enter(sync) : blockIdx.x;
+        const uint32_t j0 = __builtin_amdgcn_readfirstlane(first[unit]);
         const uint32_t more = __builtin_amdgcn_readfirstlane(jobs[j0].pad_);
         for (uint32_t j = j0; j <= j0 + more; j++) {
             const FlArgs a = load_job(jobs + j);
             eval_flat_body<NR, false, HAS_OR, true>(a);
             if (j != j0 + more) {
-                __threadfence();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (store_put / store_get: no cache to flush)
                 __syncthreads();
             }
         }
+        if (sync) unit_leave(sync, unit);
     }
 }
 
@@ -822,18 +883,20 @@ hipError_t launch_fused_flat(bool eval, const FusedFlatArgs &f, const BatchGeom 
 }
 
 template <typename K>
-static hipError_t launch_jobs(K kern, const FlatJob *jobs, const uint32_t *first, uint32_t nunits, size_t lds, hipStream_t s) {
+static hipError_t launch_jobs(K kern, const FlatJob *jobs, const uint32_t *first, uint32_t *sync, uint32_t nunits, size_t lds,
+                              hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nunits), dim3(TF), lds, s, jobs, first);
+    hipLaunchKernelGGL(kern, dim3(nunits), dim3(TF), lds, s, jobs, first, sync);
     return hipGetLastError();
 }
 
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
-                                  size_t lds_bytes, hipStream_t s) {
+                                  size_t lds_bytes, hipStream_t s, uint32_t *d_sync) {
     if (nunits == 0) return hipSuccess;
+    if (d_sync && !d_first) return hipErrorInvalidValue;
     const bool chain = d_first != nullptr;  // (nullptr: unit u is record u)
-#define GC_J4(KERN, NR, OR) (chain ? launch_jobs(KERN<NR, OR, true>, d_jobs, d_first, nunits, lds_bytes, s) : launch_jobs(KERN<NR, OR, false>, d_jobs, d_first, nunits, lds_bytes, s))
+#define GC_J4(KERN, NR, OR) (chain ? launch_jobs(KERN<NR, OR, true>, d_jobs, d_first, d_sync, nunits, lds_bytes, s) : launch_jobs(KERN<NR, OR, false>, d_jobs, d_first, nullptr, nunits, lds_bytes, s))
 #define GC_J3(KERN, NR) (has_or ? GC_J4(KERN, NR, true) : GC_J4(KERN, NR, false))
 #define GC_J2(KERN) (rounds == 10 ? GC_J3(KERN, 10) : rounds == 12 ? GC_J3(KERN, 12) : GC_J3(KERN, 14))
     return eval ? GC_J2(k_eval_flat_jobs) : GC_J2(k_garble_flat_jobs);

@@ -195,9 +195,16 @@ struct FlatJob {
 // u; else the records d_first[u] .. d_first[u] + d_jobs[d_first[u]].pad_ one after the other (pad2_ = a record's position in
 // that run: 0 loads the AES table) — several for a chain of dependent steps without a merged plan (stream_fuse.cpp);
 // lds_bytes = the largest fused_flat_bytes(nls, 0, ustride) of the group; has_or: some job's circuit has an OR gate; rounds:
-// 10 / 12 / 14 (one key per stream)
+// 10 / 12 / 14 (one key per stream).
+// d_sync != nullptr (with d_first): units of the launch DEPEND on one another.  The block (device memory, uploaded with these
+// words) is [0] a ticket counter, zero; [1] nunits (bit 31: full agent-scope fences around the waits, a cross-check); [2..3] device address of a pinned host word raised to 3 when a wait runs
+// out (0: none); [kSyncHead ..) one done-flag per unit, zero; then nunits + 1 offsets into the list behind them: the units
+// that unit u waits for are list[off[u]] .. list[off[u + 1]) and ALL have a lower index than u.  A workgroup takes the next
+// ticket as its unit number (so every unit it may wait for has started: no wait can starve, whatever order the hardware
+// dispatches workgroups in), waits for the done-flags of its list, runs its records, raises its own flag.
+constexpr uint32_t kSyncHead = 4;
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
-                                  size_t lds_bytes, hipStream_t s);
+                                  size_t lds_bytes, hipStream_t s, uint32_t *d_sync = nullptr);
 
 // rnd [batch][1+ninputs] big-endian label bytes -> R[inst] (S bit set) and W[w][inst]
 void launch_init_garble(const uint4 *rnd, uint32_t ninputs, uint4 *W, uint4 *R, const BatchGeom &g, hipStream_t s);

@@ -169,6 +169,12 @@ int gc_stream_eval_fuse_stats(const gc_stream_eval *e, uint64_t *fused_units, ui
     return GC_OK;
 }
 
+int gc_stream_eval_wait_stats(const gc_stream_eval *e, uint64_t *waiting_units) {
+    if (!e) return GC_E_ARG;
+    if (waiting_units) *waiting_units = e->fuse.waiting;
+    return GC_OK;
+}
+
 int gc_stream_eval_deep_stats(const gc_stream_eval *e, uint64_t *deep_blocks, uint32_t *lanes) {
     if (!e) return GC_E_ARG;
     if (deep_blocks) *deep_blocks = e->deep.n_steps;
@@ -298,6 +304,16 @@ int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
         uint32_t gi = fuse_enabled() ? e->win.place_fuse(e->io_host.data(), nin, wr_ids.data(), nout, &unit)
                                      : e->win.place(e->io_host.data(), nin, wr_ids.data(), nout);
         const bool may_fuse = fuse_enabled() && !is_deep && small_block && ent->uid != 0;
+        // conflicts with several units of that group (as in the garbler): appended to the latest if that one starts behind all
+        // the others, else a unit that waits
+        uint32_t dep_units[kUnitDeps], ndeps = 0;
+        const bool can_wait = fuse_enabled() && e->use_deps && !is_deep && small_block && gi > 0;
+        if (can_wait && unit == kFuseMulti) {
+            ndeps = e->win.conflict_units(e->io_host.data(), nin, wr_ids.data(), nout, e->win.first_seq + gi - 1, dep_units, kUnitDeps);
+            unit = wg_covering(*e->slots[e->win.open[gi - 1]], dep_units, ndeps);
+        } else if (can_wait) {
+            dep_units[0] = unit, ndeps = 1;
+        }
         bool fuse = false;
         uint64_t shape = 0;
         uint32_t n_ext = 0;
@@ -321,9 +337,20 @@ int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
             }
         }
         uint32_t slot_idx = 0;
-        e->prof.lap(StageProf::kPlace);
-        if (fuse) {
+        auto full = [&](const Slot &g) {
+            return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
+                   g.arena_used + g.up_used + 2 * wbytes + 2 * nrows * 16 > kGroupBytes;
+        };
+        // not fused: the block still joins the group it conflicts with, as a unit that waits on the device for the units it
+        // conflicts with there (as in the garbler)
+        bool waits = false;
+        if (!fuse && can_wait && !full(*e->slots[e->win.open[gi - 1]])) {
+            waits = true;
             gi--;
+        }
+        e->prof.lap(StageProf::kPlace);
+        if (fuse || waits) {
+            if (fuse) gi--;
             slot_idx = e->win.open[gi];
         } else if (is_deep) {
             for (; gi > 0; gi--) {  // the open groups this block depends on go first
@@ -347,10 +374,6 @@ int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
             ng->deps = e->deep.conflicts(e->io_host.data(), nin, wr_ids.data(), nout);
             deep_after(e->win, e->slots, e->win.last_conflict(e->io_host.data(), nin, wr_ids.data(), nout), ng);
         } else {
-            auto full = [&](const Slot &g) {
-                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
-                       g.arena_used + g.up_used + 2 * wbytes + 2 * nrows * 16 > kGroupBytes;
-            };
             while (gi < e->win.open.size() && full(*e->slots[e->win.open[gi]])) gi++;
             if (gi == e->win.open.size()) {
                 if (e->win.open.size() >= open_groups_limit((size_t)kOpenGroupsMax * 16)) {
@@ -443,6 +466,10 @@ int eval_schedule(gc_stream_eval *e, const BlockIn &in, size_t *consumed) {
             e->fuse.appended++;
         } else {
             unit = wg_new(g, &j, ent, may_fuse);
+            if (waits) {
+                wg_wait(g, unit, dep_units, ndeps);
+                e->fuse.waiting++;
+            }
         }
         g.jobs.push_back(j);
         e->prof.lap(StageProf::kQueue);

@@ -28,6 +28,7 @@ struct gc_stream_eval {
     std::vector<gc_label> rows_scratch;  // table rows of a small block while it is parsed
     uint64_t n_groups = 0, n_group_blocks = 0;
     FuseStats fuse;  // chain fusion (stream_fuse.cpp)
+    bool use_deps = deps_wanted();  // units that wait inside a launch (stream_internal.h: kUnitDeps)
     std::vector<uint32_t> wiring_scratch;
     std::vector<uint32_t> io_host;  // indices of this block's inputs, then of its global outputs (0xffffffff: superseded)
     uint32_t *d_io = nullptr;

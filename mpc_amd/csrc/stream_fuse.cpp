@@ -379,6 +379,42 @@ uint32_t wg_new(Slot &g, JobRec *j, const CircEntry *ent, bool may_fuse) {
     return j->wg;
 }
 
+uint32_t wg_covering(const Slot &g, const uint32_t *units, uint32_t n) {
+    if (n == 0 || n == kDepsAllEarlier) return kFuseMulti;
+    uint32_t b = units[0];
+    for (uint32_t i = 1; i < n; i++) b = std::max(b, units[i]);
+    if (b >= g.wgs.size()) return kFuseMulti;
+    const WgRec &w = g.wgs[b];
+    for (uint32_t i = 0; i < n; i++)
+        if (units[i] != b && !w.behind(units[i])) return kFuseMulti;
+    return b;
+}
+
+void wg_wait(Slot &g, uint32_t unit, const uint32_t *units, uint32_t n) {
+    WgRec &w = g.wgs[unit];
+    w.dep_off = (uint32_t)g.unit_deps.size();
+    w.dep_n = 0;
+    if (n == kDepsAllEarlier) {
+        w.dep_n = n;
+        for (uint32_t u = 0; u < unit; u++) w.anc[u >> 6] |= 1ull << (u & 63u);
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            const WgRec &d = g.wgs[units[i]];
+            for (int k = 0; k < 4; k++) w.anc[k] |= d.anc[k];
+        }
+        for (uint32_t i = 0; i < n; i++) {  // (a unit that another one of the list waits for need not be named)
+            bool implied = false;
+            for (uint32_t k = 0; k < n && !implied; k++) implied = k != i && g.wgs[units[k]].behind(units[i]);
+            if (!implied) {
+                g.unit_deps.push_back(units[i]);
+                w.dep_n++;
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) w.anc[units[i] >> 6] |= 1ull << (units[i] & 63u);
+    }
+    g.has_waits = true;
+}
+
 void wg_append(Slot &g, uint32_t unit, JobRec *j, const CircEntry *ent, uint32_t n_ext, uint64_t shape) {
     WgRec &w = g.wgs[unit];
     const uint32_t idx = (uint32_t)g.jobs.size();

@@ -71,6 +71,7 @@ struct gc_stream {
     uint64_t n_groups = 0, n_group_steps = 0, n_big_steps = 0;
     CopyPool copier;              // gc_stream_garble_finish_async: the copies into the caller's buffer, off this thread
     FuseStats fuse;               // chain fusion: launch units of several steps, merged plans built
+    bool use_deps = deps_wanted();  // units that wait inside a launch (stream_internal.h: kUnitDeps)
     StageProf prof;
     uint64_t n_steps_total = 0;
     // gc_stream_garble_finish_view: the slot whose pinned bytes the caller is still reading (given back by the next finish),
@@ -329,6 +330,12 @@ int gc_stream_fuse_stats(const gc_stream *s, uint64_t *fused_units, uint64_t *fu
     return GC_OK;
 }
 
+int gc_stream_wait_stats(const gc_stream *s, uint64_t *waiting_units) {
+    if (!s) return GC_E_ARG;
+    if (waiting_units) *waiting_units = s->fuse.waiting;
+    return GC_OK;
+}
+
 int gc_stream_deep_stats(const gc_stream *s, uint64_t *deep_steps, uint32_t *lanes) {
     if (!s) return GC_E_ARG;
     if (deep_steps) *deep_steps = s->deep.n_steps;
@@ -493,6 +500,16 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         const uint32_t *skip = s->skip_scratch.data();
         uint32_t gi = fuse_enabled() ? s->win.place_fuse(in, nin, skip, nout, &unit) : s->win.place(in, nin, skip, nout);
         const bool may_fuse = fuse_enabled() && !is_deep && !was_aliased && ent->uid != 0 && first_out >= first_tmp;
+        // conflicts with SEVERAL units of that group: which ones (stream_internal.h: kUnitDeps) — a step can still be appended
+        // to the latest of them if that one starts behind all the others, else it joins the group as a unit that waits
+        uint32_t dep_units[kUnitDeps], ndeps = 0;
+        const bool can_wait = fuse_enabled() && s->use_deps && !is_deep && gi > 0;
+        if (can_wait && unit == kFuseMulti) {
+            ndeps = s->win.conflict_units(in, nin, skip, nout, s->win.first_seq + gi - 1, dep_units, kUnitDeps);
+            unit = wg_covering(*s->slots[s->win.open[gi - 1]], dep_units, ndeps);
+        } else if (can_wait) {
+            dep_units[0] = unit, ndeps = 1;
+        }
         bool fuse = false;
         uint64_t shape = 0;
         uint32_t n_ext = 0;
@@ -518,9 +535,20 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             }
         }
         uint32_t slot_idx = 0;
-        s->prof.lap(StageProf::kPlace);
-        if (fuse) {
+        auto full = [&](const Slot &g) {
+            return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
+                   g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
+        };
+        // not fused: the step still joins the group it conflicts with, as a unit that waits on the device for the units it
+        // conflicts with there (stream_internal.h: kUnitDeps) — where that group has room
+        bool waits = false;
+        if (!fuse && can_wait && !full(*s->slots[s->win.open[gi - 1]])) {
+            waits = true;
             gi--;
+        }
+        s->prof.lap(StageProf::kPlace);
+        if (fuse || waits) {
+            if (fuse) gi--;
             slot_idx = s->win.open[gi];
         } else if (is_deep) {
             // the open groups this step depends on go to the GPU first (place(): every conflict sits in a group before gi)
@@ -545,10 +573,6 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             ng->deps = s->deep.conflicts(in, nin, s->skip_scratch.data(), nout);
             deep_after(s->win, s->slots, s->win.last_conflict(in, nin, s->skip_scratch.data(), nout), ng);
         } else {
-            auto full = [&](const Slot &g) {
-                return g.wgs.size() >= kGroupJobs || g.jobs.size() >= kGroupSteps ||
-                       g.arena_used + g.down_used + wbytes + ent->ser_long > kGroupBytes;
-            };
             while (gi < s->win.open.size() && full(*s->slots[s->win.open[gi]])) gi++;
             if (gi == s->win.open.size()) {  // behind every open group: a new one (the oldest goes to the GPU when the window is full)
                 if (s->win.open.size() >= open_groups_limit(s->queue.size())) {
@@ -609,6 +633,10 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             s->fuse.appended++;
         } else {
             unit = wg_new(g, &j, ent, may_fuse);
+            if (waits) {
+                wg_wait(g, unit, dep_units, ndeps);
+                s->fuse.waiting++;
+            }
         }
         g.jobs.push_back(j);
         s->prof.lap(StageProf::kQueue);

@@ -279,7 +279,15 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     const size_t off_rc = off_fin + (size_t)n * sizeof(FinJob);
     const size_t off_rg = off_rc + (size_t)ncopies * sizeof(RowCopy);
     const size_t off_first = off_rg + (size_t)ngathers * sizeof(RowGather);
-    const size_t total_up = off_first + up16((size_t)nwg * sizeof(uint32_t));
+    // [ticket, unit count, error word, done-flags, the lists of the units that wait] (kernels.h: d_sync) where units of the
+    // group wait for one another
+    size_t sync_words = 0;
+    if (g.has_waits) {
+        sync_words = kSyncHead + (size_t)nwg + nwg + 1;
+        for (uint32_t u = 0; u < nwg; u++) sync_words += g.wgs[u].dep_n == kDepsAllEarlier ? u : g.wgs[u].dep_n;
+    }
+    const size_t off_sync = off_first + up16((size_t)nwg * sizeof(uint32_t));
+    const size_t total_up = off_sync + up16(sync_words * sizeof(uint32_t));
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
     const size_t arena_chain = up256(g.arena_used);
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
@@ -388,6 +396,33 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     }
     for (const auto &kl : g.kills)  // an output a later step of the same chain writes again
         if (kl.first < n && out_base[kl.first] != 0xffffffffu) ((uint32_t *)g.h_up)[out_base[kl.first] + kl.second] = 0xffffffffu;
+    if (g.has_waits) {
+        uint32_t *sy = (uint32_t *)(g.h_up + off_sync);
+        std::memset(sy, 0, (kSyncHead + (size_t)nwg) * sizeof(uint32_t));
+        static const bool fences = [] {
+            const char *v = std::getenv("GC_STREAM_DEP_FENCES");
+            return v && *v && std::strcmp(v, "0") != 0;
+        }();
+        sy[1] = nwg | (fences ? 0x80000000u : 0u);
+        uint32_t *d_err = gc_ctx_err_word(ctx);
+        std::memcpy(sy + 2, &d_err, sizeof d_err);
+        static_assert(sizeof(uint32_t *) == 2 * sizeof(uint32_t) && kSyncHead == 4, "layout of the sync block's head");
+        uint32_t *off = sy + kSyncHead + nwg, *list = off + nwg + 1, nl = 0;
+        for (uint32_t u = 0; u < nwg; u++) {
+            const WgRec &w = g.wgs[u];
+            off[u] = nl;
+            if (w.dep_n == kDepsAllEarlier) {
+                for (uint32_t v = 0; v < u; v++) list[nl++] = v;
+            } else {
+                for (uint32_t k = 0; k < w.dep_n; k++) {
+                    const uint32_t v = g.unit_deps[w.dep_off + k];
+                    if (v >= u) return fail("launch_group (a unit that waits for a later one)", hipErrorInvalidValue);
+                    list[nl++] = v;
+                }
+            }
+        }
+        off[nwg] = nl;
+    }
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
     if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
     if (e == hipSuccess && ncp) {
@@ -399,8 +434,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         e = hipGetLastError();
     }
     if (e == hipSuccess)
-        e = launch_fused_flat_jobs(eval, rounds, has_or, (const FlatJob *)(g.d_up + off_fj), nrec != nwg ? (const uint32_t *)(g.d_up + off_first) : nullptr,
-                                   nwg, lds, st);
+        e = launch_fused_flat_jobs(eval, rounds, has_or, (const FlatJob *)(g.d_up + off_fj),
+                                   nrec != nwg || g.has_waits ? (const uint32_t *)(g.d_up + off_first) : nullptr, nwg, lds, st,
+                                   g.has_waits ? (uint32_t *)(g.d_up + off_sync) : nullptr);
     // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
     // done itself for the evaluator (nothing follows)
     g.kernel_ev = eval ? g.done : g.kdone;

@@ -207,6 +207,19 @@ inline uint32_t fuse_depth_cap() {
 }
 constexpr uint32_t kGroupSteps = 4096;      // steps per group at most (fused or not)
 constexpr uint32_t kFuseMulti = 0xfffffffeu, kFuseNone = 0xffffffffu;
+// Dependent units in ONE launch (kernels.h: launch_fused_flat_jobs, d_sync) — an EXPERIMENT, off unless GC_STREAM_DEPS=1 is in
+// the environment when the stream is created (EXPERIMENTS.md, round 5: it did not pay).  A step whose conflicts with the
+// latest open group it has any with cannot be fused into one unit of that group still JOINS that group, as a unit that waits
+// — on the device, by done-flags — for the units it conflicts with, instead of waiting for the whole group in the next
+// launch.  A group is then as long as the longest dependency path inside it, not the sum of its longest steps level by
+// level.  kUnitDeps: the units a step may name; beyond that (or where the window's records do not tell them apart: a wire
+// several units read) it waits for every earlier unit.
+constexpr uint32_t kUnitDeps = 8;
+constexpr uint32_t kDepsAllEarlier = 0xffffffffu;
+inline bool deps_wanted() {
+    const char *e = std::getenv("GC_STREAM_DEPS");
+    return e && *e && std::strcmp(e, "0") != 0;
+}
 
 static inline size_t up16(size_t v) { return (v + 15u) & ~(size_t)15u; }
 static inline size_t up256(size_t v) { return (v + 255u) & ~(size_t)255u; }
@@ -243,6 +256,11 @@ struct WgRec {
     uint32_t gates = 0, slots = 0, inputs = 0, depth_sum = 0;  // what the caps of the fusion count
     uint64_t shape = 0;                   // running hash of (circuits, wiring) of its steps: what the depth hints are kept by
     bool open = true;                     // may take further steps (a unit whose head cannot be fused is closed from the start)
+    uint32_t dep_off = 0, dep_n = 0;      // units of the same group it waits for: Slot::unit_deps[dep_off .. dep_off + dep_n)
+                                          // (dep_n == kDepsAllEarlier: every unit before it)
+    uint64_t anc[4] = {0, 0, 0, 0};       // ... and everything those wait for in turn: the units that are DONE when this one starts
+    static_assert(kGroupJobs <= 256, "one bit per unit of a group");
+    bool behind(uint32_t u) const { return (anc[(u >> 6) & 3u] >> (u & 63u)) & 1u; }
 };
 
 // the deep steps in flight (DeepLanes) that a step — or a group of steps — has to follow
@@ -371,6 +389,8 @@ struct Slot {
     // ... and outputs a LATER step of the same unit writes again: (step, output index) pairs whose store is dropped (in a
     // fused job every output goes back to the wire store at the end, side by side: the last writer must be the only one)
     std::vector<std::pair<uint32_t, uint32_t>> kills;
+    std::vector<uint32_t> unit_deps;  // the units that the waiting units of the group wait for (WgRec::dep_off / dep_n)
+    bool has_waits = false;
     std::vector<uint32_t> chunk_refs;  // evaluator: the chunks of the peer's stream the slot's jobs gather their rows from (one per job)
     size_t up_used = 0, arena_used = 0, down_used = 0, lds = 0;
     bool has_or = false;
@@ -401,6 +421,8 @@ struct Slot {
         wgs.clear();
         wiring.clear();
         kills.clear();
+        unit_deps.clear();
+        has_waits = false;
         chunk_refs.clear();
         up_used = arena_used = down_used = lds = 0;
         has_or = false;
@@ -548,6 +570,35 @@ struct GroupWindow {
         *unit = bj;
         return best ? best + 1 - first_seq : 0;
     }
+    // The units of the open group with sequence number `seq` that the step conflicts with (distinct, at most `max`), for a
+    // step that joins that group as a unit that waits for them.  Returns their number, or kDepsAllEarlier where the records
+    // cannot name them (a wire several units read; more than `max`).
+    uint32_t conflict_units(const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw, uint32_t seq, uint32_t *units,
+                            uint32_t max) const {
+        uint32_t n = 0;
+        bool all = false;
+        auto add = [&](uint32_t u) {
+            if (u >= kFuseMulti) {
+                all = true;
+                return;
+            }
+            for (uint32_t i = 0; i < n; i++)
+                if (units[i] == u) return;
+            if (n < max) units[n++] = u;
+            else all = true;
+        };
+        for (uint32_t i = 0; i < nr && !all; i++) {
+            const WireRec &r = rec[reads[i]];
+            if (r.wr == seq) add(r.wrj);
+        }
+        for (uint32_t j = 0; j < nw && !all; j++) {
+            if (writes[j] == 0xffffffffu) continue;
+            const WireRec &r = rec[writes[j]];
+            if (r.wr == seq) add(r.wrj);
+            if (r.rd == seq) add(r.rdj);
+        }
+        return all ? kDepsAllEarlier : n;
+    }
     // unit / step: the launch unit of the group that the step is (part of), and its index among the group's steps
     void mark(uint32_t index, const uint32_t *reads, uint32_t nr, const uint32_t *writes, uint32_t nw, uint32_t unit = 0,
               uint32_t step = 0) {
@@ -561,6 +612,9 @@ struct GroupWindow {
             if (writes[j] != 0xffffffffu) {
                 WireRec &r = rec[writes[j]];
                 r.wr = seq, r.wrj = unit, r.wrm = (step << 20) | j;
+                // (who read the wire before this write is of no interest any more: whoever conflicts with them conflicts
+                // with this writer, which is behind them)
+                r.rd = 0, r.rdj = 0;
             }
     }
     // Launched groups, by sequence number (the last 64): a deep step that conflicts with a step of one of them waits for THAT
@@ -946,6 +1000,7 @@ struct FuseStats {
     uint64_t appended = 0;          // steps appended to a unit when they were queued
     uint64_t unplanned = 0;         // units that ran step by step because their chain was met for the first time (or the cache is full)
     uint64_t built = 0, unfit = 0;  // merged plans this stream had to build; units that ran step by step (no one-workgroup plan)
+    uint64_t waiting = 0;           // units that joined the group they conflict with and wait, on the device, for units of it
 };
 struct FuseMember {
     const CircEntry *ent;
@@ -972,6 +1027,11 @@ uint64_t fuse_shape(uint64_t shape, const CircEntry *ent, const uint32_t *wiring
 uint32_t fuse_depth_hint(gc_ctx *ctx, uint64_t shape);
 // a new launch unit for a step about to be pushed to g.jobs; returns its index
 uint32_t wg_new(Slot &g, JobRec *j, const CircEntry *ent, bool may_fuse);
+// Units that wait inside a launch.  wg_covering: the step conflicts with these units of group g (n of them, known); the one
+// it could be APPENDED to — the latest, if every other one is done by the time that unit starts (WgRec::behind) — or
+// kFuseMulti.  wg_wait: unit `unit` (new, the group's last) waits for these units (n == kDepsAllEarlier: for every earlier one).
+uint32_t wg_covering(const Slot &g, const uint32_t *units, uint32_t n);
+void wg_wait(Slot &g, uint32_t unit, const uint32_t *units, uint32_t n);
 
 bool entry_is_small(CircEntry *e);
 bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream);

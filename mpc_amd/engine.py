@@ -104,6 +104,8 @@ def lib():
         "gc_stream_deep_stats": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
         "gc_stream_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
         "gc_stream_eval_fuse_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 4),
+        "gc_stream_wait_stats": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "gc_stream_eval_wait_stats": (i32, [vp, C.POINTER(C.c_uint64)]),
         "gc_stream_eval_dev_stats": (i32, [vp] + [C.POINTER(C.c_uint64)] * 2),
         "gc_ctx_coop_stats": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
         "gc_ctx_pci_bus_id": (i32, [vp, C.c_char_p, sz]),
@@ -754,6 +756,12 @@ class Stream:
         _check(lib().gc_stream_fuse_stats(self.h, *[C.byref(x) for x in v]), "gc_stream_fuse_stats")
         return tuple(x.value for x in v)
 
+    def wait_stats(self):
+        """units that joined the group they conflict with and wait for units of it on the device (gc_stream_wait_stats)"""
+        v = C.c_uint64(0)
+        _check(lib().gc_stream_wait_stats(self.h, C.byref(v)), "gc_stream_wait_stats")
+        return v.value
+
     def garble_begin(self, gates, nwires, in_, out_):
         """gc_stream_garble_begin: queue one circuit, do not wait (up to 4 096 in flight; small independent circuits
         share a launch sequence)"""
@@ -862,6 +870,12 @@ class StreamEval:
         v = [C.c_uint64(0) for _ in range(4)]
         _check(lib().gc_stream_eval_fuse_stats(self.h, *[C.byref(x) for x in v]), "gc_stream_eval_fuse_stats")
         return tuple(x.value for x in v)
+
+    def wait_stats(self):
+        """the evaluator's counterpart of Stream.wait_stats (gc_stream_eval_wait_stats)"""
+        v = C.c_uint64(0)
+        _check(lib().gc_stream_eval_wait_stats(self.h, C.byref(v)), "gc_stream_eval_wait_stats")
+        return v.value
 
     def close(self):
         if self.h:

@@ -527,7 +527,7 @@ def eval_program_blocks(ctx, key, steps, prim, g, stream, sizes, piece=32 << 20,
         wire = g.get(o)
         assert lab in ((int(wire["l0"]["d0"]), int(wire["l0"]["d1"])), (int(wire["l1"]["d0"]), int(wire["l1"]["d1"]))), o
     st = ev.stats()
-    fz = ev.fuse_stats() + ev.dev_stats()
+    fz = ev.fuse_stats() + ev.dev_stats() + (ev.wait_stats(),)
     ev.close()
     if hold is not None:
         hold.close()
@@ -564,6 +564,7 @@ def run_program(name, key=bytes(range(32)), ctx=None, window=64, evaluate=True, 
         else:
             res["first_pass_s"] = first
         res["fuse"] = g.fuse_stats()
+        res["waiting_units"] = g.wait_stats()
         want = golden_sha(name, key) if not view else None
         if want is not None and want != sha:
             raise AssertionError("%s: stream SHA-256 %s != oracle's %s" % (name, sha, want))
@@ -694,6 +695,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
     r = run_program("ed25519like", key, ctx, window=WINDOWS["ed25519like"], view=True)
     out["ed25519like"]["garble_view_gates_per_s"] = r["garble_gates_per_s"]
     out["ed25519like"]["fuse"] = dict(zip(("fused_units", "fused_steps", "plans_asked", "unfit"), r.get("fuse", ())))
+    out["ed25519like"]["fuse"]["waiting_units"] = r.get("waiting_units")
     # the same programs with a C host in place of this interpreter (what a cgo caller gets)
     native = {}
     for name, win in (("big130", 2), ("ed25519like", WINDOWS["ed25519like"]), ("uniform512", 64), ("uniform4096", 64), ("mixed", 64),

@@ -687,11 +687,15 @@ def test_stream_big_steps_in_flight_while_their_circuits_are_evicted(monkeypatch
     gg.close(); ge.close(); ctx.close()
 
 
-def test_stream_mixed_program_matches_oracle():
-    """the mixed program of scripts/bench_stream.py (64-bit adders, 64 x 64 multipliers — 13 740 gates, still one
+@pytest.mark.parametrize("deps", [False, True])
+def test_stream_mixed_program_matches_oracle(deps, monkeypatch):
+    """(deps: with GC_STREAM_DEPS=1, the experiment of units that wait inside a launch — include/gcengine.h:
+    gc_stream_wait_stats)  The mixed program of scripts/bench_stream.py (64-bit adders, 64 x 64 multipliers — 13 740 gates, still one
     workgroup each — and 131 072-gate steps, operands mostly from the last few steps, variables overwritten) at a size
     the oracle restates in a second: every step's bytes and, on the evaluator's side, every label equal the oracle's"""
     from scripts.bench_stream import program_mixed
+    if deps:
+        monkeypatch.setenv("GC_STREAM_DEPS", "1")
     ctx = engine.Context(0)
     steps, prim = program_mixed(160, seed=9, big_every=53)
     key = drbg("mixkey", 32)
@@ -724,12 +728,15 @@ def test_stream_mixed_program_matches_oracle():
     gg.close(); ge.close(); ctx.close()
 
 
-def test_stream_instruction_mix_matches_oracle():
-    """the 23-circuit instruction mix of scripts/bench_stream.py (ssa23: adders to 512 bits, array multipliers to 256 bits —
+@pytest.mark.parametrize("deps", [False, True])
+def test_stream_instruction_mix_matches_oracle(deps, monkeypatch):
+    """(deps: with GC_STREAM_DEPS=1, as above)  The 23-circuit instruction mix of scripts/bench_stream.py (ssa23: adders to 512 bits, array multipliers to 256 bits —
     those of 128 and 256 bits run on the planner's late schedule —, a comparator with OR gates, table-free blocks, mux /
     shift / hash-like blocks) at a size the oracle restates in seconds, every one of the 23 circuits at least once: every
     step's bytes and the evaluated labels equal the oracle's, evaluated on random input bits"""
     from scripts.bench_stream import program_ssa, ssa_circuits
+    if deps:
+        monkeypatch.setenv("GC_STREAM_DEPS", "1")
     ctx = engine.Context(0)
     steps, prim = program_ssa(220, seed=3)
     seen = {id(c) for c, _, _ in steps}

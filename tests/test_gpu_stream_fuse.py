@@ -89,7 +89,7 @@ def _chain_program(base, bits=32):
     return steps, prim
 
 
-def _run(ctx, steps, prim, key, rnd, window, by_handle=True):
+def _run(ctx, steps, prim, key, rnd, window, by_handle=True, waits=None):
     og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
     first = {w: gg.get(w)["l0"] for w in prim}
     want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
@@ -122,6 +122,8 @@ def _run(ctx, steps, prim, key, rnd, window, by_handle=True):
     for o in wires:
         assert ge.get(o) == oe.get(o), "evaluated label of wire %d" % o
     st = (gg.stats(), gg.fuse_stats(), ge.fuse_stats())
+    if waits is not None:
+        waits.append((gg.wait_stats(), ge.wait_stats()))
     gg.close()
     ge.close()
     return st
@@ -150,6 +152,74 @@ def test_fused_chains_match_oracle(base, keylen, window, by_handle):
         _run(ctx, steps, prim, key, rnd, window, by_handle)
         _, gf3, ef3 = _run(ctx, steps, prim, key, rnd, window, by_handle)
         assert gf3[0] == gf[0] and gf3[2] == 0 and ef3[2] == 0, (gf3, ef3)
+    ctx.close()
+
+
+def _dag_program(base, bits=32):
+    """steps that conflict with SEVERAL queued steps at once (no chain to be fused into): diamonds, a multiplier behind two
+    chains, a wide block behind ten units, a value three units read and a fourth overwrites, the same wires written by three
+    steps in a row — and chains that go on behind such steps"""
+    mul, add, sub = multiplier(bits), adder(bits), subtractor(bits)
+    xorb = bitwise(bits, 0)
+    wide = synthetic_levelised(3, 64, 0.4, seed=91, ninputs=bits * 10, inv_frac=0.05)
+    nxt = [base + 2]
+    prim = [base, base + 1]
+
+    def fresh(n=bits):
+        w = list(range(nxt[0], nxt[0] + n))
+        nxt[0] += n
+        return w
+
+    vals = []
+    for _ in range(12):
+        v = fresh()
+        prim.extend(v)
+        vals.append(v)
+    steps = []
+
+    def op(c, a, b, out=None):
+        out = fresh(c.num_outputs) if out is None else out
+        steps.append((c, a + b, out))
+        return out
+
+    for rnd in range(3):
+        a = [op(add, vals[i], vals[i + 1]) for i in range(10)]          # ten independent units
+        b = [op(sub, a[i], a[i + 1]) for i in range(9)]                 # each behind two of them
+        c = op(mul, b[0], b[1])                                         # a large step behind two units
+        d = op(add, op(add, c[:bits], vals[0]), vals[1])                # a chain that goes on behind it
+        steps.append((wide, sum(a, []), fresh(wide.num_outputs)))       # behind ten units: more than a step may name
+        w = steps[-1][2]
+        r = [op(xorb, vals[2], b[i]) for i in range(3)]                 # three units read vals[2] ...
+        op(add, d, w[:bits], vals[2])                                   # ... and this one overwrites it
+        t = fresh()
+        op(add, r[0], r[1], t)                                          # the same wires written three times in a row,
+        op(sub, r[1], r[2], t)                                          # by steps that do not read one another
+        op(add, vals[2], r[2], t)
+        e = op(add, t, vals[3])
+        vals[4 + rnd] = op(mul, e, b[8])[:bits]                          # feeds the next round
+        vals[0] = op(add, e, a[9], vals[0])                             # in place: vals[0] is read by queued steps
+    return steps, prim
+
+
+@pytest.mark.parametrize("base,keylen,window", [(0, 32, 400), (0x30000, 16, 400), (0, 24, 7), (0x30000, 32, 1)])
+def test_units_that_wait_inside_a_launch_match_oracle(base, keylen, window, monkeypatch):
+    """GC_STREAM_DEPS=1 (an experiment, off by default; gc_stream_wait_stats): steps that conflict with several units of an open
+    group join it and wait on the device; bytes, wires and evaluated labels are the serial loop's (stream_garble.go:131-157,
+    161-192), whatever the window cuts"""
+    monkeypatch.setenv("GC_STREAM_DEPS", "1")
+    ctx = engine.Context(0)
+    steps, prim = _dag_program(base)
+    key = drbg("wkey", keylen)
+    rnd = drbg("wait%d" % base, 16 * (len(prim) + 1))
+    waits = []
+    for rep in range(2):
+        (groups, grouped, bigs), gf, ef = _run(ctx, steps, prim, key, rnd, window, waits=waits)
+        assert grouped == len(steps) and bigs == 0
+    if window >= 400 and not os.environ.get("GC_STREAM_NO_FUSE"):
+        assert waits[0][0] >= 30 and waits[0][1] >= 30, waits
+        assert groups <= 6, groups  # (level by level the program is some forty groups deep)
+    if window == 1:
+        assert waits[0][0] == 0
     ctx.close()
 
 
