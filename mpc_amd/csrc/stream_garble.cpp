@@ -94,14 +94,14 @@ inline void ensure(gc_stream *s, uint32_t max) {  // ensureWires, 64 Ki-wire pag
 }
 
 // the oldest open group leaves the window and is launched
-int launch_oldest(gc_stream *s) {
+int launch_oldest(gc_stream *s, bool one_stream = false) {
     if (s->win.open.empty()) return GC_OK;
     const uint32_t seq = s->win.first_seq, slot = s->win.pop();
     Slot &g = *s->slots[slot];
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
     s->prof.lap(StageProf::kOther);
-    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse);
+    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse, one_stream);
     s->prof.lap(StageProf::kLaunch);
     s->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) s->ctxq.pushed(slot, g.launch_no);
@@ -838,7 +838,8 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
     const StepRef ref = s->queue.front();
     Slot &g = *s->slots[ref.slot];
     while (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in an open group: launch up to that one
-        int rc = launch_oldest(s);
+        // (the only step queued, in the only open group: the caller garbles one instruction at a time — launch_group)
+        int rc = launch_oldest(s, s->queue.size() == 1 && s->win.open.size() == 1);
         if (rc != GC_OK && g.error == GC_OK && g.launched) g.error = rc;
         if (s->win.open.empty()) break;
     }

@@ -200,10 +200,14 @@ __global__ __launch_bounds__(256) void k_rows_gather(const RowGather *rg) {
 // writes again is dropped), the garbler's serialiser finding step k's rows in the chain's table array at row_base[k].  A chain
 // without a merged plan (not met often enough yet, or none fits a workgroup) still is ONE workgroup: it runs its steps' own
 // jobs one after the other, through the wire store (fused_flat_kernels.hip: k_*_flat_jobs).
+// one_stream (garbler): the caller waits for exactly this group and nothing else is queued (the unchanged caller: one
+// Streaming.Garble at a time) — serialiser and bytes follow the kernel on ITS stream: nothing to run beside, and the hand-over
+// to the copy stream (an event between two hardware queues) is latency the caller would sit through.
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats) {
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream) {
     const bool on_lane = g.deep_id != 0;
     hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : ctx->stream;
+    if (one_stream && !on_lane && !eval) copy_stream = st;
     const uint32_t n = (uint32_t)g.jobs.size(), nwg = (uint32_t)g.wgs.size();
     // ---- the merged plans of the chains (before the ctx lock: a chain met for the first time is planned here)
     std::vector<const FusedPlan *> plans(nwg, nullptr);
@@ -448,7 +452,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     }
     if (e == hipSuccess && !eval) {
         // serialiser and bytes on the copy stream: the next group's garbling need not wait for either
-        e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (copy_stream != st) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
         if (e == hipSuccess && on_lane && n == 1 && g.jobs[0].ngates > 4 * kSerGates) {
             // a deep step of many gates: the serialiser of the big steps, spread over the chip (one workgroup would write
             // megabytes byte by byte: 1 - 2 ms on the copy stream, more than the step's pass)
@@ -464,7 +468,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
                 e = hipGetLastError();
             }
         } else if (e == hipSuccess) {
-            ser_group((const FinJob *)(g.d_up + off_fin), n, copy_stream);
+            uint32_t max_gates = 0;
+            for (const JobRec &j : g.jobs) max_gates = std::max(max_gates, j.ngates);
+            ser_group((const FinJob *)(g.d_up + off_fin), n, max_gates, copy_stream);
             e = hipGetLastError();
         }
         if (e == hipSuccess)

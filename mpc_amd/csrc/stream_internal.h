@@ -884,7 +884,7 @@ struct SerArgs {
     uint32_t ngates, first_tmp, first_out;
 };
 
-// ---- the serialiser of a step group (garbler): workgroup j = job j ------------------------------------------------
+// ---- the serialiser of a step group (garbler): workgroup (p, j) = piece p of job j ------------------------------------
 // The job's gates in the wire format (stream_garble.go:391-446), gate order, into the job's byte slot; the byte count
 // into *size_out.  Runs on the copy stream behind the group's garbling kernel, beside the NEXT group's garbling (the
 // output labels went back into the wire store in the garbling kernel's own epilogue).
@@ -900,8 +900,9 @@ struct FinJob {
 // byte offset (T: the table rows, lt their layout)
 void ser_sizes_scan(const SerArgs &a, uint64_t *boff, uint32_t nblocks, uint32_t *total_out, hipStream_t s);
 void ser_write(const SerArgs &a, const uint64_t *boff, uint32_t nblocks, const uint4 *T, const Layout &lt, uint8_t *buf, hipStream_t s);
-// a step group: workgroup j serialises job j into its byte slot (d_jobs: device array of n records)
-void ser_group(const FinJob *d_jobs, uint32_t n, hipStream_t s);
+// a step group: job j into its byte slot, in pieces of 512 gates — one workgroup each (d_jobs: device array of n records;
+// max_gates: the gate count of the largest job)
+void ser_group(const FinJob *d_jobs, uint32_t n, uint32_t max_gates, hipStream_t s);
 
 template <typename T>
 hipError_t grow(T **p, size_t *cap, size_t need) {
@@ -1038,6 +1039,6 @@ bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream);
 Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big = false);
 void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng);
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats);
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream = false);
 
 }  // namespace gcs

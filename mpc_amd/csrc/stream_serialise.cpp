@@ -103,10 +103,27 @@ __global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblo
         run += v;
     }
 }
+// Bytes go out through LDS: a gate is 5 - 61 bytes at an arbitrary byte offset, and byte stores to global memory — every lane of
+// a wave in another cache line — kept ONE workgroup busy for 30 us on a 4 000-gate step (the whole of a window-1 step's
+// serialiser; profiles/r05_w1_timeline.txt).  A workgroup builds its contiguous piece of the stream in LDS at the piece's own
+// alignment (LDS offset = byte offset mod 16) and writes it out as whole uint4 lines, bytes only at the two ragged ends.
+constexpr uint32_t kMaxGateBytes = 1 + 4 * 3 + 16 * 3;  // op, three u32 ids, three rows
+__device__ __forceinline__ void flush_piece(const uint8_t *stage, uint8_t *dst, uint32_t sh, uint32_t nbytes, uint32_t nthreads) {
+    // stage[sh ..]: the piece; dst: where its first byte goes (dst - sh is 16-byte aligned)
+    const uint32_t head = min(nbytes, (16u - sh) & 15u);
+    const uint32_t body = (nbytes - head) >> 4, tail = (nbytes - head) & 15u;
+    if (threadIdx.x < head) dst[threadIdx.x] = stage[sh + threadIdx.x];
+    const uint4 *src16 = (const uint4 *)(stage + sh + head);
+    uint4 *dst16 = (uint4 *)(dst + head);
+    for (uint32_t k = threadIdx.x; k < body; k += nthreads) dst16[k] = src16[k];
+    if (threadIdx.x < tail) dst[head + 16u * body + threadIdx.x] = stage[sh + head + 16u * body + threadIdx.x];
+}
+
 // every gate to its byte offset
 __global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint64_t *boff, const uint4 *T, Layout lt,
                                                            uint8_t *buf) {
     __shared__ uint32_t wsum[kSerThreads / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kSerGates * kMaxGateBytes + 16];
     SerGate g[kSerPer];
     uint32_t mine = 0;
     for (uint32_t k = 0; k < kSerPer; k++) {
@@ -124,46 +141,61 @@ __global__ __launch_bounds__(kSerThreads) void k_ser_write(SerArgs a, const uint
     }
     if (lane == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += wsum[w];
-    size_t pos = boff[blockIdx.x] + base + (incl - mine);
+    uint32_t base = 0, total = 0;
+    for (uint32_t w = 0; w < kSerThreads / 64; w++) {
+        if (w < (threadIdx.x >> 6)) base += wsum[w];
+        total += wsum[w];
+    }
+    const uint64_t b0 = boff[blockIdx.x];
+    const uint32_t sh = (uint32_t)b0 & 15u;
+    uint32_t pos = sh + base + (incl - mine);
     for (uint32_t k = 0; k < kSerPer; k++) {
         const uint32_t i = blockIdx.x * kSerGates + threadIdx.x * kSerPer + k;
         if (i >= a.ngates) break;
-        ser_put(buf + pos, g[k], a.row_of_gate[i], T, lt);
+        ser_put(stage + pos, g[k], a.row_of_gate[i], T, lt);
         pos += g[k].size;
     }
+    __syncthreads();
+    flush_piece(stage, buf + b0, sh, total, kSerThreads);
 }
 
-constexpr uint32_t kFinThreads = 1024;
-__global__ __launch_bounds__(kFinThreads) void k_stream_serialise(const FinJob *jobs) {
-    const FinJob j = jobs[blockIdx.x];
-    __shared__ uint32_t wsum[kFinThreads / 64];
-    const uint32_t per = (j.a.ngates + kFinThreads - 1) / kFinThreads;  // consecutive gates per thread: byte order = gate order
-    const uint32_t lo = min(threadIdx.x * per, j.a.ngates), hi = min(lo + per, j.a.ngates);
-    uint32_t mine = 0;
-    for (uint32_t i = lo; i < hi; i++) mine += ser_gate(j.a, i).size;
-    uint32_t incl = mine;
+// A step group: workgroup (p, j) = piece p of job j — gates [p * kFinGates, (p + 1) * kFinGates), one per thread.  The byte
+// offset of the piece is the size of everything before it, which the workgroup adds up for itself (a job of a group has at
+// most kSmallGates gates: 63 sizes per thread for the last piece of the largest); the last piece knows the job's byte count.
+constexpr uint32_t kFinGates = 512;
+__global__ __launch_bounds__(kFinGates) void k_stream_serialise(const FinJob *jobs) {
+    const FinJob j = jobs[blockIdx.y];
+    const uint32_t lo = blockIdx.x * kFinGates;
+    if (lo >= j.a.ngates && blockIdx.x != 0) return;  // (a job of fewer pieces than the largest of its group)
+    __shared__ uint32_t wsum[kFinGates / 64], wpre[kFinGates / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFinGates * kMaxGateBytes + 16];
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < lo; i += kFinGates) before += ser_gate(j.a, i).size;
+    const uint32_t i = lo + threadIdx.x;
+    SerGate q{};
+    if (i < j.a.ngates) q = ser_gate(j.a, i);
+    uint32_t incl = q.size;
     const uint32_t lane = threadIdx.x & 63;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(incl, o, 64);
         if (lane >= (uint32_t)o) incl += v;
     }
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o, 64);
     if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    if (lane == 0) wpre[threadIdx.x >> 6] = before;
     __syncthreads();
-    uint32_t base = 0, total = 0;
-    for (uint32_t w = 0; w < kFinThreads / 64; w++) {
+    uint32_t base = 0, total = 0, b0 = 0;
+    for (uint32_t w = 0; w < kFinGates / 64; w++) {
         if (w < (threadIdx.x >> 6)) base += wsum[w];
         total += wsum[w];
+        b0 += wpre[w];
     }
-    if (threadIdx.x == 0) *j.size_out = total;
-    size_t pos = base + (incl - mine);
+    if (threadIdx.x == 0 && lo + kFinGates >= j.a.ngates) *j.size_out = b0 + total;
+    const uint32_t sh = b0 & 15u;
     const Layout dense{0, 0, 1, 0};  // one instance: table row r is element r
-    for (uint32_t i = lo; i < hi; i++) {
-        const SerGate q = ser_gate(j.a, i);
-        ser_put(j.bytes + pos, q, j.a.row_of_gate[i], j.T, dense);
-        pos += q.size;
-    }
+    if (i < j.a.ngates) ser_put(stage + sh + base + (incl - q.size), q, j.a.row_of_gate[i], j.T, dense);
+    __syncthreads();
+    flush_piece(stage, j.bytes + b0, sh, total, kFinGates);
 }
 }  // namespace
 
@@ -174,8 +206,9 @@ void ser_sizes_scan(const SerArgs &a, uint64_t *boff, uint32_t nblocks, uint32_t
 void ser_write(const SerArgs &a, const uint64_t *boff, uint32_t nblocks, const uint4 *T, const Layout &lt, uint8_t *buf, hipStream_t s) {
     hipLaunchKernelGGL(k_ser_write, dim3(nblocks), dim3(kSerThreads), 0, s, a, boff, T, lt, buf);
 }
-void ser_group(const FinJob *d_jobs, uint32_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_stream_serialise, dim3(n), dim3(kFinThreads), 0, s, d_jobs);
+void ser_group(const FinJob *d_jobs, uint32_t n, uint32_t max_gates, hipStream_t s) {
+    const uint32_t pieces = std::max(1u, (max_gates + kFinGates - 1) / kFinGates);
+    hipLaunchKernelGGL(k_stream_serialise, dim3(pieces, n), dim3(kFinGates), 0, s, d_jobs);
 }
 
 }  // namespace gcs
