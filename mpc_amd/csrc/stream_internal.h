@@ -45,10 +45,11 @@ struct StageProf {
     }
 };
 
-// developer aid: GC_TRACE=1 prints the wall-clock laps of a streaming step to stderr
+// developer aid: GC_TRACE=2 prints the wall-clock laps of every streaming step to stderr (GC_TRACE=1: only the summaries — a
+// line per step distorts what the stage cycles above measure)
 struct StreamTrace {
     static bool enabled() {  // (asked once: two getenv walks per streamed step were measurable on 512-gate steps)
-        static const bool v = std::getenv("GC_TRACE") != nullptr;
+        static const bool v = std::getenv("GC_TRACE") != nullptr && std::atoi(std::getenv("GC_TRACE")) >= 2;
         return v;
     }
     bool on;
@@ -500,7 +501,14 @@ inline hipError_t grow_pin(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) {
 // gc_stream_garble_finish (ssa23, 64 in flight: 1.1e8 gates/s with 4 open groups, 0.7e8 with 16; the Ed25519 program, 1 024 in
 // flight: 0.9e8 with 4, 4.4e8 with 16).  in_flight / 16, between 4 and 16.  The evaluator has no caller waiting for
 // results: 16.
-constexpr uint32_t kOpenGroupsMin = 4, kOpenGroupsMax = 16;
+// Round 5: with chain fusion the links of such a chain are ONE launch unit of one group, the window no longer needs a group
+// per link — and sixteen open groups hold everything a caller with 1 024 in flight allows (~7 groups of ~137 steps), so groups
+// went to the GPU only when the caller asked for bytes, and caller and GPU took turns waiting (host stage cycles: 30 - 45 % of
+// the garbler's run in hipEventSynchronize with the GPU 28 % busy).  At most 6 open groups while fusion is on: the Ed25519-shaped
+// program, C host, bytes in place 0.94 - 1.02e9 -> 1.36 - 1.38e9 gates/s, copied by the copier threads 0.70 -> 0.89 - 1.01e9, the
+// evaluator block by block 3.4 -> 4.0 - 4.4e8 (5: the same; 7, 10, 12: as 16).
+constexpr uint32_t kOpenGroupsMin = 4, kOpenGroupsMax = 16, kOpenGroupsMaxFused = 6;
+bool fuse_enabled();
 inline uint32_t open_groups_env() {
     static const uint32_t v = [] {
         const char *e = std::getenv("GC_STREAM_OPEN_GROUPS");
@@ -511,7 +519,7 @@ inline uint32_t open_groups_env() {
 }
 inline uint32_t open_groups_limit(size_t in_flight) {
     if (open_groups_env()) return open_groups_env();
-    return (uint32_t)std::min<size_t>(std::max<size_t>(in_flight / 16, kOpenGroupsMin), kOpenGroupsMax);
+    return (uint32_t)std::min<size_t>(std::max<size_t>(in_flight / 16, kOpenGroupsMin), fuse_enabled() ? kOpenGroupsMaxFused : kOpenGroupsMax);
 }
 struct GroupWindow {
     std::deque<uint32_t> open;      // slots of the open groups, oldest first
@@ -662,7 +670,7 @@ struct StepRef {
 // kKeepQueued of them are.  The garbler looks at it when its caller is about to wait for bytes (gc_stream_garble_finish): the
 // open groups behind the one it waits for then go to the GPU too, so that the GPU has a group to run and one behind it while
 // the host is busy with the bytes; everything younger stays open and keeps gathering steps.
-constexpr size_t kKeepQueued = 2;
+constexpr size_t kKeepQueued = 2;  // (3 / 4 / 6 / 8 measured on the Ed25519-shaped program, round 5: inside the run-to-run spread)
 struct CtxQueue {
     struct E {
         uint32_t slot;

@@ -44,7 +44,7 @@ def main():
     gates = sum(c.NumGates for c, _, _ in steps)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "program.bin")
-        bs.write_program(path, bytes(range(32)), bs.stream_rnd(name, len(prim)), prim, steps, 2 if name.startswith("big") else 64)
+        bs.write_program(path, bytes(range(32)), bs.stream_rnd(name, len(prim)), prim, steps, 2 if name.startswith("big") else bs.WINDOWS.get(name, 64))
         for n in ns:
             print(json.dumps(run(name, n, path, gates)), flush=True)
 

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd $REPO
 python scripts/bench_stream.py ed25519like:1 > $OUT/plain.json 2> $OUT/plain.err
 cut -c1-400 $OUT/plain.json
-GC_TRACE=1 python scripts/bench_stream.py ed25519like:1 2> $OUT/trace.err > $OUT/trace.json
+GC_TRACE=2 python scripts/bench_stream.py ed25519like:1 2> $OUT/trace.err > $OUT/trace.json
 grep "host cycles" $OUT/trace.err | tail -4
 python scripts/agg_trace.py < $OUT/trace.err | head -12
 cd /tmp
