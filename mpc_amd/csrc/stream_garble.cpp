@@ -229,6 +229,7 @@ void gc_stream_free(gc_stream *s) {
     if (s->ctx) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
+        if (GroupTimeline::enabled()) group_timeline().print_and_clear();
     }
     s->deep.release();
     if (s->copy_stream) {
@@ -852,13 +853,19 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
         // groups behind this one now (up to kKeepQueued in flight) and runs them while the caller digests these bytes.
         // (Launching them any earlier — whenever the stream runs dry — was measured: the groups shrink to 3 - 4 steps and the
         // host's launch sequences become the bound: 1.5e8 against 4.7e8 gates/s on the Ed25519 program.)
-        while (!s->win.open.empty() && hipEventQuery(g.done) != hipSuccess && s->ctxq.hungry(s->slots)) {
+        // (Also when this group's bytes are there already: a group that the full window sent to the GPU early would otherwise
+        // leave the GPU with nothing behind it until the caller reaches the NEXT group — and sits through that one's whole
+        // kernel, serialiser and copy.)
+        while (!s->win.open.empty() && s->ctxq.hungry(s->slots)) {
             int rcq = launch_oldest(s);
             if (rcq != GC_OK) break;
         }
         (void)hipGetLastError();
         s->prof.lap(StageProf::kOther);
+        GroupTimeline::G *tl = GroupTimeline::enabled() && g.kind == Slot::kGroup ? group_timeline().find(g.launch_no) : nullptr;
+        if (tl) tl->h_w0 = group_timeline().now();
         hipError_t e = hipEventSynchronize(g.done);
+        if (tl) tl->h_w1 = group_timeline().now();
         s->prof.lap(StageProf::kWait);
         if (e != hipSuccess) {
             set_error("gc_stream_garble_finish", e);

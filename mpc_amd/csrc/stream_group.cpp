@@ -190,6 +190,28 @@ __global__ __launch_bounds__(256) void k_rows_gather(const RowGather *rg) {
 }
 }  // namespace
 
+GroupTimeline &group_timeline() {
+    static GroupTimeline t;
+    return t;
+}
+void GroupTimeline::print_and_clear() {
+    for (const G &g : groups) {
+        float a = 0, b = 0, c = 0;
+        if (g.d) (void)hipEventSynchronize(g.d);
+        if (ref && g.k0) (void)hipEventElapsedTime(&a, ref, g.k0);
+        if (ref && g.k1) (void)hipEventElapsedTime(&b, ref, g.k1);
+        if (ref && g.d) (void)hipEventElapsedTime(&c, ref, g.d);
+        std::fprintf(stderr, "[gc timeline] group %llu steps %u host launch %.1f %.1f wait %.1f %.1f gpu head %.1f kernel_end %.1f bytes %.1f\n",
+                     (unsigned long long)g.launch_no, g.steps, g.h_l0, g.h_l1, g.h_w0, g.h_w1, a * 1e3, b * 1e3, c * 1e3);
+        if (g.k0) (void)hipEventDestroy(g.k0);
+        if (g.k1) (void)hipEventDestroy(g.k1);
+        if (g.d) (void)hipEventDestroy(g.d);
+    }
+    groups.clear();
+    if (ref) (void)hipEventDestroy(ref);
+    ref = nullptr;
+}
+
 // Launch sequence of a group (see the head of stream_garble.cpp).  eval: the jobs' table rows are part of the upload region and
 // nothing comes back.  On return the slot is `launched`; a failure is kept in slot.error for the group's steps.
 // A deep step (g.deep_id != 0, one job) takes the same sequence on its lane, behind an event recorded on the ctx stream here
@@ -427,6 +449,23 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         }
         off[nwg] = nl;
     }
+    GroupTimeline::G *tl = nullptr;
+    if (GroupTimeline::enabled() && !eval && !on_lane) {
+        GroupTimeline &t = group_timeline();
+        if (!t.ref) {
+            (void)hipEventCreate(&t.ref);
+            (void)hipEventRecord(t.ref, st);
+            (void)hipEventSynchronize(t.ref);
+            t.t0 = std::chrono::steady_clock::now();
+        }
+        t.groups.emplace_back();
+        tl = &t.groups.back();
+        tl->launch_no = g.launch_no, tl->steps = n, tl->h_l0 = t.now();
+        (void)hipEventCreate(&tl->k0);
+        (void)hipEventCreate(&tl->k1);
+        (void)hipEventCreate(&tl->d);
+        (void)hipEventRecord(tl->k0, st);
+    }
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
     if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
     if (e == hipSuccess && ncp) {
@@ -444,6 +483,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     // "the group's kernel has run": kdone for the garbler (the serialiser and the bytes' way back follow on the copy stream),
     // done itself for the evaluator (nothing follows)
     g.kernel_ev = eval ? g.done : g.kdone;
+    if (tl) (void)hipEventRecord(tl->k1, st);
     if (e == hipSuccess) e = hipEventRecord(g.kernel_ev, st);
     if (e == hipSuccess && on_lane) {
         deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
@@ -476,7 +516,9 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         if (e == hipSuccess)
             e = hipMemcpyAsync(g.h_down, g.d_down, sizes_bytes + g.down_used, hipMemcpyDeviceToHost, copy_stream);
         if (e == hipSuccess) e = hipEventRecord(g.done, copy_stream);
+        if (tl) (void)hipEventRecord(tl->d, copy_stream);
     }
+    if (tl) tl->h_l1 = group_timeline().now();
     if (e != hipSuccess) return fail("launch_group", e);
     return GC_OK;
 }

@@ -65,6 +65,33 @@ struct StreamTrace {
     }
 };
 
+// developer aid: GC_TRACE=3 — a timeline of the garbler's step groups: per group the host's clock when its launch sequence was
+// issued and when the caller waited for its bytes, and the GPU's clock (timing events) at the head of the sequence, behind
+// the kernel and behind the copy of the bytes; printed when the stream is freed (scripts/group_timeline.py reads it)
+struct GroupTimeline {
+    static bool enabled() {
+        static const bool v = std::getenv("GC_TRACE") != nullptr && std::atoi(std::getenv("GC_TRACE")) == 3;
+        return v;
+    }
+    struct G {
+        uint64_t launch_no = 0;
+        uint32_t steps = 0;
+        double h_l0 = 0, h_l1 = 0, h_w0 = -1, h_w1 = -1;
+        hipEvent_t k0 = nullptr, k1 = nullptr, d = nullptr;
+    };
+    std::vector<G> groups;
+    hipEvent_t ref = nullptr;
+    std::chrono::steady_clock::time_point t0;
+    double now() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+    G *find(uint64_t launch_no) {
+        for (size_t i = groups.size(); i-- > 0 && groups.size() - i < 64;)
+            if (groups[i].launch_no == launch_no) return &groups[i];
+        return nullptr;
+    }
+    void print_and_clear();
+};
+GroupTimeline &group_timeline();
+
 // A cached device circuit with the gate list it was built from.  The key is a 64-bit non-cryptographic hash: a hit is
 // only taken after the gates compare equal (an accidental — or, on the evaluator side, peer-crafted — collision would
 // otherwise select a plan with other input / output counts: wrong results or out-of-bounds label arrays).
