@@ -1391,3 +1391,43 @@ def test_c_host_drives_both_sides_of_a_streamed_program():
     r = bench_stream.run_native("uniform512", bytes(range(32)), 64)
     assert r["sha256_ok"] is True and r["steps"] == 4000
     assert r["eval_blocks_matched"] > 3900 and r["eval_blocks_gates_per_s"] and r["eval_blocks_chunk"] == 1 << 20
+
+
+@pytest.mark.parametrize("window", [1, 8])
+def test_stream_serialiser_pieces_and_lone_steps(window):
+    """the group serialiser writes a job in pieces of 512 gates, each built in LDS at the piece's own alignment: jobs of 40 to
+    3 600 gates (one to eight pieces, ragged last pieces, OR / INV / XNOR rows) side by side in one group, global ids on both
+    sides of 0xffff (16- and 32-bit id forms inside one job, so the pieces' byte offsets are not multiples of anything);
+    window 1: every step alone — kernel, serialiser and copy on one stream (the unchanged caller's path)"""
+    from mpc_amd.circuit import synthetic_levelised
+    ctx = engine.Context(0)
+    shapes = [(2, 20, 0.3, 0.0, 0.0, 0.0), (5, 100, 0.4, 0.1, 0.1, 0.1), (6, 170, 0.5, 0.05, 0.2, 0.0), (12, 300, 0.3, 0.1, 0.1, 0.2),
+              (9, 57, 0.9, 0.0, 0.0, 0.0), (4, 128, 0.0, 0.0, 0.5, 0.2)]
+    steps, prim, nxt = [], [], 0xfe80
+    for i, (lv, w, fa, fo, fi, fx) in enumerate(shapes * 2):
+        c = synthetic_levelised(lv, w, fa, seed=900 + i, ninputs=24, or_frac=fo, inv_frac=fi, xnor_frac=fx)
+        in_ = list(range(nxt, nxt + 24))
+        out_ = list(range(nxt + 24, nxt + 24 + c.num_outputs))
+        nxt += 24 + c.num_outputs + 3
+        prim += in_
+        steps.append((c, in_, out_))
+    assert max(c.NumGates for c, _, _ in steps) > 3000 and steps[-1][2][-1] > 0x10000 > steps[0][1][0]
+    key = drbg("serkey", 32)
+    rnd = drbg("ser", 16 * (len(prim) + 1))
+    og, gg = oracle.Stream(key, rnd, prim), engine.Stream(ctx, key, rnd, prim)
+    want = [og.garble(c.Gates, c.NumWires, in_, out_) for c, in_, out_ in steps]
+    got, issued = [], 0
+    for k in range(len(steps)):
+        while issued < len(steps) and issued < k + window:
+            c, in_, out_ = steps[issued]
+            gg.garble_begin(c.Gates, c.NumWires, in_, out_)
+            issued += 1
+        got.append(gg.garble_finish())
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert g == w, "step %d of %d (%d gates)" % (k, len(steps), steps[k][0].NumGates)
+    groups, grouped, bigs = gg.stats()
+    assert grouped == len(steps) and (groups == len(steps) if window == 1 else groups < len(steps))
+    for c, in_, out_ in steps:
+        for o in out_:
+            assert gg.get(o) == og.get(o)
+    gg.close(); ctx.close()
