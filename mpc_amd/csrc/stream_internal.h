@@ -527,7 +527,7 @@ inline hipError_t grow_pin(gc_ctx *ctx, uint8_t **p, size_t *cap, size_t need) {
 // fours, sixteen open groups would hold everything the caller allows and the ctx stream would run dry between two calls of
 // gc_stream_garble_finish (ssa23, 64 in flight: 1.1e8 gates/s with 4 open groups, 0.7e8 with 16; the Ed25519 program, 1 024 in
 // flight: 0.9e8 with 4, 4.4e8 with 16).  in_flight / 16, between 4 and 16.  The evaluator has no caller waiting for
-// results: 16.
+// results: the upper bound.
 // Round 5: with chain fusion the links of such a chain are ONE launch unit of one group, the window no longer needs a group
 // per link — and sixteen open groups hold everything a caller with 1 024 in flight allows (~7 groups of ~137 steps), so groups
 // went to the GPU only when the caller asked for bytes, and caller and GPU took turns waiting (host stage cycles: 30 - 45 % of
