@@ -105,7 +105,7 @@ __global__ __launch_bounds__(1024) void k_ser_scan(uint64_t *boff, uint32_t nblo
 }
 // Bytes go out through LDS: a gate is 5 - 61 bytes at an arbitrary byte offset, and byte stores to global memory — every lane of
 // a wave in another cache line — kept ONE workgroup busy for 30 us on a 4 000-gate step (the whole of a window-1 step's
-// serialiser; profiles/r05_w1_timeline.txt).  A workgroup builds its contiguous piece of the stream in LDS at the piece's own
+// serialiser; profiles/r05b_w1_timeline.txt).  A workgroup builds its contiguous piece of the stream in LDS at the piece's own
 // alignment (LDS offset = byte offset mod 16) and writes it out as whole uint4 lines, bytes only at the two ragged ends.
 constexpr uint32_t kMaxGateBytes = 1 + 4 * 3 + 16 * 3;  // op, three u32 ids, three rows
 __device__ __forceinline__ void flush_piece(const uint8_t *stage, uint8_t *dst, uint32_t sh, uint32_t nbytes, uint32_t nthreads) {
