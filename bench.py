@@ -567,12 +567,22 @@ def run(stage):
             d.close()
     if rank == 0 and world == 1:
         aes = args.circuit.endswith("aes_128.gcf")
+        # how long each group of side rows took (the timed region of `value` is ms_per_step x steps; the rest of the run is these)
+        side_wall = {}
+        t_side = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            side_wall[name] = round(now - t_side[0], 2)
+            t_side[0] = now
         if not args.no_synthetic and aes:
             # SURVEY §8d / north star: synthetic levelised circuits as absolute numbers and as fractions of the rooflines
             res["synthetic"] = sweep_rows_for_line(batch, key, ctx)
+            lap("synthetic")
         if not args.no_extra_rows and aes:
             res.update(reference_bench_rows(batch, circ, ctx))
             res["level_launch"] = level_launch_row(batch, circ, key, ctx)
+            lap("key16 + and_chain + level_launch")
         if not args.no_iknp:
             # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):
             # device-resident API, 4 Mi OTs
@@ -580,23 +590,28 @@ def run(stage):
             ot = ot_run(1 << 22, 5, ctx=ctx)
             res["iknp"] = ot.pop("iknp")
             res["ot"] = ot
+            lap("ot")
         if not args.no_host_api and aes:
             # the literal drop-in calls with HOST buffers (PCIe-inclusive; never `value`), see DESIGN.md §7
             from scripts.bench_host_api import run as host_api_run
             res["host_api"] = host_api_run(batch, 8, key)
+            lap("host_api")
         if not args.no_stream and aes:
             # config 5 shape: ONE instance through gc_stream_* (garbler pipelined, evaluator over the produced bytes);
             # bounded samples of scripts/bench_stream.py, SHA-256 of the byte streams checked against the oracle-made
             # goldens (tests/golden/stream_bench_golden.json) inside
             from scripts.bench_stream import run_for_line as stream_run
             res["stream"] = stream_run(key=key, ctx=ctx)
+            lap("stream")
         if not args.no_config3 and aes:
             # config 3: sha256xor x 256, the evaluator's labels through the 65 536-OT IKNP extension + COT pads, all on the
             # device; every digest checked against hashlib inside (scripts/bench_config3.py)
             from scripts.bench_config3 import run as config3_run
             res["config3"] = config3_run(256, 10, key)
+            lap("config3")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(circ, key)
+            lap("cpu_baseline")
         # "probe `go version` first" — with a Go toolchain on the box the baseline would be the reference itself
         import shutil
         go = shutil.which("go")
@@ -608,6 +623,7 @@ def run(stage):
             except Exception as e:  # noqa: BLE001
                 go_ver = "go found, `go version` failed: %s" % e
         res.setdefault("cpu_baseline", {})["go_on_box"] = go_ver or False
+        res["side_rows_wall_s"] = side_wall
     stage[0] = "shutdown"
     if comm is not None:
         comm.barrier()

@@ -666,6 +666,12 @@ def run_for_line(key=bytes(range(32)), ctx=None):
     1.3e8 gates, 2.4 GB of stream: about 2 s for both sides and both hosts), the two uniform small-step programs and the
     mixed program and the 23-circuit instruction mix (ssa23); every SHA-256 checked against the oracle's"""
     out = {}
+    wall, t_last = {}, [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        wall[name] = round(now - t_last[0], 2)
+        t_last[0] = now
     b = run_program("big130", key, ctx, window=4)  # (an interpreter's jitter between the calls: 2 in flight are enough for a C host)
     out.update({"program": "big130", "steps": b["steps"], "gates": b["gates"], "window": b["window"], "steady_ms_per_step": b["garble_us_per_step"] / 1e3,
                 "steady_gates_per_s": b["garble_gates_per_s"],
@@ -676,6 +682,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                 "eval_first_blocks_s": b.get("eval_first_blocks_s"), "eval_blocks_parsed": b["eval_blocks_parsed"],
                 "first_pass_s": b["first_pass_s"], "sha256": b["sha256"], "sha256_ok": b["sha256_ok"]})
     out["shape"] = SHAPES["big130"]
+    lap("big130")
     for name in ("ed25519like", "ssa23", "mixed", "uniform512", "uniform4096"):
         r = run_program(name, key, ctx, window=WINDOWS.get(name, 64))
         out[name] = {k: r[k] for k in ("steps", "gates", "and", "window", "garble_gates_per_s", "garble_us_per_step", "eval_gates_per_s",
@@ -683,6 +690,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                                        "eval_blocks_piece", "eval_fuse", "launch_groups", "grouped_steps", "big_steps",
                                        "deep_steps", "lanes", "sha256", "sha256_ok") if k in r}
         out[name]["shape"] = SHAPES[name]
+        lap(name)
     # The UNCHANGED caller: compiler/ssa/streamer.go:694 calls Streaming.Garble one instruction at a time —
     # begin + finish per step, nothing queued ahead (window 1).  Every row above queues 64 - 1 024 instructions ahead, which
     # needs the three-edit patch of the streamer (go/ssa/stream_window_hip.go).
@@ -690,6 +698,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
     out["ed25519like_window1"] = {k: r[k] for k in ("steps", "gates", "window", "garble_gates_per_s", "garble_us_per_step", "launch_groups",
                                                     "sha256", "sha256_ok") if k in r}
     out["ed25519like_window1"]["caller"] = "unchanged: Streaming.Garble per instruction (gc_stream_garble_begin + _finish, nothing in flight)"
+    lap("ed25519like_window1")
     # ... and the engine's rate when the bytes are consumed IN PLACE (gc_stream_garble_finish_view, as go/circuit/stream_hip.go
     # does: a pointer into the engine's pinned staging, no copy into a second buffer)
     r = run_program("ed25519like", key, ctx, window=WINDOWS["ed25519like"], view=True)
@@ -708,6 +717,8 @@ def run_for_line(key=bytes(range(32)), ctx=None):
             native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_view_gates_per_s", "garble_async_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_pinned_gates_per_s",
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
                                                       "window", "sha256_ok", "error")}
+    lap("ed25519like view + native_host")
+    out["wall_s"] = wall
     if native:
         out["native_host"] = native
     out["published_reference"] = "1.4e7 gates/s, Go, i5-8257U (benchmarks.md:677-704: Ed25519 sign.mpcl streamed)"
