@@ -100,6 +100,44 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
     std::map<std::vector<uint32_t>, uint32_t> sums;  // block of terms -> the producer that stands for its sum
     const bool two_level = std::getenv("GC_PLAN_NO_TWO_LEVEL") == nullptr;  // (developer switch: the chain of rounds)
     std::vector<uint32_t> t0, t1, tmp;
+    // The FULL expansion of an XOR value of a chunk — down to what exists when the chunk begins (and to the chunk's block sums) —
+    // with its parity, kept once it has been asked for: the two-level form below needs it for every long list, and working it
+    // out by substituting list into list again for every gate made an XOR-only circuit of 128 levels take ten minutes to plan
+    // (the synthetic f = 0 row of the bench line: 300 of the default run's 410 s).  Same sets, same plan.
+    std::vector<std::vector<uint32_t>> fx(ngates);
+    std::vector<uint8_t> fdone(ngates, 0), fp(ngates, 0);
+    std::vector<uint32_t> fstack, facc, fnxt, fsingles;
+    auto full_of = [&](uint32_t top) {  // top: the producer id of an XOR gate
+        const uint32_t nreal = ninputs + ngates;
+        fstack.assign(1, top);
+        while (!fstack.empty()) {
+            const uint32_t cur = fstack.back(), cg = cur - ninputs, ca = A[cur];
+            if (fdone[cg]) {
+                fstack.pop_back();
+                continue;
+            }
+            auto own_c = [&](uint32_t t) { return t < nreal && is_free[t] && A[t] == ca; };
+            bool ready = true;
+            for (uint32_t t : ex[cg])
+                if (own_c(t) && !fdone[t - ninputs]) fstack.push_back(t), ready = false;
+            if (!ready) continue;
+            fsingles.clear();
+            for (uint32_t t : ex[cg])
+                if (!own_c(t)) fsingles.push_back(t);  // (ex[] is sorted: so are these)
+            facc.swap(fsingles);
+            uint8_t par = rpar[cg];
+            for (uint32_t t : ex[cg])
+                if (own_c(t)) {
+                    symdiff(facc, fx[t - ninputs], &fnxt);
+                    facc.swap(fnxt);
+                    par ^= fp[t - ninputs];
+                }
+            fx[cg] = facc;
+            fp[cg] = par;
+            fdone[cg] = 1;
+            fstack.pop_back();
+        }
+    };
     for (uint32_t g = 0; g < ngates; g++) {
         const uint32_t pid = ninputs + g, s0 = src0[g], s1 = src1[g];
         const uint32_t a = std::max(A[s0], A[s1]);
@@ -132,24 +170,17 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
             // in ONE chunk) then takes 2 rounds, not n / 16.
             const uint32_t nreal = ninputs + ngates;
             auto own = [&](uint32_t t) { return t < nreal && is_free[t] && A[t] == a; };  // an XOR value of this chunk
-            std::vector<uint32_t> full = tmp, acc, nxt;
+            std::vector<uint32_t> full, nxt;
             uint8_t fpar = par;
-            for (bool again = true; again;) {
-                again = false;
-                acc.clear();
-                for (uint32_t t : full) {
-                    if (own(t)) {
-                        symdiff(acc, ex[t - ninputs], &nxt);
-                        fpar ^= rpar[t - ninputs];
-                        again = true;
-                    } else {
-                        t0.assign(1, t);
-                        symdiff(acc, t0, &nxt);
-                    }
-                    acc.swap(nxt);
+            for (uint32_t t : tmp)
+                if (!own(t)) full.push_back(t);  // (tmp is sorted: so is this)
+            for (uint32_t t : tmp)
+                if (own(t)) {
+                    full_of(t);
+                    symdiff(full, fx[t - ninputs], &nxt);
+                    full.swap(nxt);
+                    fpar ^= fp[t - ninputs];
                 }
-                full.swap(acc);
-            }
             std::vector<uint32_t> raw, rest;
             for (uint32_t t : full) ((t >= nreal && A[t] == a) ? rest : raw).push_back(t);  // rest: this chunk's block sums
             const size_t nblocks = (raw.size() + kFlatMaxTerms - 1) / kFlatMaxTerms;
@@ -174,6 +205,13 @@ static void build_flat(const OpView gates, uint32_t ngates, uint32_t nwires, uin
                     rest.push_back(it->second);
                 }
                 std::sort(rest.begin(), rest.end());
+                // (a block of raw terms may add up to a block sum the list holds already — shared by content —: x ^ x = 0)
+                size_t keep = 0;
+                for (size_t i = 0; i < rest.size(); i++) {
+                    if (i + 1 < rest.size() && rest[i] == rest[i + 1]) i++;
+                    else rest[keep++] = rest[i];
+                }
+                rest.resize(keep);
                 tmp.swap(rest);
                 par = fpar;
                 r = 2;
