@@ -98,16 +98,22 @@ def cpu_baseline(circ, key, seconds=12.0):
     return out
 
 
-def kernel_build_hash():
-    """SHA-256 over the sources the garble / eval kernels are compiled from: profiles/latest_pmc.json carries the hash of
-    the build its counters were measured on, and `roofline.traffic` goes null when the kernels have changed since."""
+def kernel_build_hash(circuit_path=None):
+    """What the PMC counters of profiles/latest_pmc.json are tied to: a SHA-256 over (i) the DEVICE sources the garble / eval
+    kernels are compiled from and (ii) the fingerprint of the benchmarked circuit's plan (gc_plan_fingerprint: the device
+    program the planner emits for it).  A change to the host side of the planner that leaves this circuit's program alone
+    keeps the counters valid (round 5 hashed plan.cpp's text, and a late planner commit for OTHER circuits nulled
+    `roofline.traffic` in the driver's line); a change to the kernels or to this circuit's schedule drops them."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "mpc_amd", "csrc")
-    for name in ("aes_device.h", "kernels.h", "plan.h", "plan.cpp", "fused_flat_kernels.hip", "fused_lds_kernels.hip",
+    for name in ("aes_device.h", "kernels.h", "plan.h", "level_gate.h", "fused_flat_kernels.hip", "fused_lds_kernels.hip",
                  "fused_kernels.hip", "gc_kernels.hip"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
+    from mpc_amd import engine, parse_file
+    c = parse_file(circuit_path or os.path.join(ROOT, "tests", "golden", "aes_128.gcf"))
+    h.update(b"plan\0" + engine.Plan(c.Gates, c.NumWires, c.num_inputs, c.num_outputs).fingerprint().encode())
     return h.hexdigest()[:16]
 
 
@@ -436,7 +442,7 @@ def run(stage):
     # scripts/profile.sh measured with rocprofv3 --pmc for this batch / schedule / key size AND this build of the
     # kernels (profiles/latest_pmc.json carries the hash of the kernel sources) — null otherwise.
     traffic, traffic_src = None, None
-    build_hash = kernel_build_hash()
+    build_hash = kernel_build_hash(args.circuit)
     pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
     if os.path.exists(pmc):
         try:

@@ -112,6 +112,9 @@ int gc_plan_get_info(const gc_plan *, gc_plan_info *out);
 int gc_plan_simulate(const gc_plan *, const uint8_t *in_bits, uint8_t *out_bits);
 int gc_plan_describe(const gc_plan *, uint32_t *level_of_gate, uint32_t *tweak_of_gate,
                      uint32_t *row_of_gate, uint32_t *slot_of_gate);
+/* 64-bit fingerprint of the device program of the plan (level steps, hash-phase schedule, flattened unit program and LDS
+ * slots): equal fingerprints = the same work launched for this circuit.  bench.py ties PMC counters to it (round 6). */
+int gc_plan_fingerprint(const gc_plan *, uint64_t *fp);
 
 /* ------------------------------------------------------------------------------------------
  * Device context + circuit

@@ -900,6 +900,32 @@ int gc_plan_simulate(const gc_plan *pl, const uint8_t *in_bits, uint8_t *out_bit
     return gc::on_exception();
 }
 
+// A 64-bit fingerprint (FNV-1a) of everything the kernels execute for this circuit: level steps and descriptors, the
+// hash-phase schedule, the flattened unit program with its LDS slots.  Two builds of the planner that give the same
+// fingerprint launch the same device work for the circuit — what bench.py ties measured counters to (scripts/profile.sh),
+// instead of the text of plan.cpp.
+int gc_plan_fingerprint(const gc_plan *pl, uint64_t *fp) try {
+    if (!pl || !fp) return GC_E_ARG;
+    const gc::Plan &p = pl->p;
+    uint64_t h = 14695981039346656037ull;
+    auto mix = [&h](const void *data, size_t n) {
+        const uint8_t *b = (const uint8_t *)data;
+        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+        h = (h ^ (uint64_t)n) * 1099511628211ull;
+    };
+    auto vec = [&mix](const auto &v) { mix(v.data(), v.size() * sizeof(v[0])); };
+    vec(p.descs), vec(p.levels), vec(p.out_slots);
+    vec(p.fdescs), vec(p.fgslot), vec(p.fsteps), vec(p.fchunks), vec(p.in_lds);
+    vec(p.fl_prog), vec(p.fl_units), vec(p.fl_hgslot), vec(p.fl_ogslot), vec(p.fl_in_lds);
+    const uint32_t tail[8] = {p.n_flat_slots, p.n_flat_outs, p.n_flat_terms, p.n_flat_steps, p.flat_late ? 1u : 0u,
+                              p.fl_unit_stride, p.fl_max_parts, p.n_lds_slots};
+    mix(tail, sizeof tail);
+    *fp = h;
+    return GC_OK;
+} catch (...) {
+    return gc::on_exception();
+}
+
 int gc_plan_describe(const gc_plan *pl, uint32_t *level_of_gate, uint32_t *tweak_of_gate, uint32_t *row_of_gate,
                      uint32_t *slot_of_gate) try {
     if (!pl) return GC_E_ARG;

@@ -105,6 +105,13 @@ static gcs_fuse_cache *cache_of(gc_ctx *ctx) {  // under ctx->fuse_mu
 uint32_t fuse_register(gc_ctx *ctx, bool eval_form, uint64_t hash, const std::vector<CircKey> &gates, uint32_t nwires, uint32_t nin,
                        uint32_t nout) {
     if (!fuse_enabled() || gates.empty() || gates.size() > kSmallGates) return 0;
+    // A caller's gate list may write one of its own INPUT wires (gc_stream_intern takes any list).  Step by step that only
+    // changes the step's local wire; in a merged plan the input IS an earlier member's output wire and the write would land
+    // there.  Such a circuit gets no identity: it never joins a chain (the evaluator's form names operands by the gate that
+    // wrote them, so the case cannot arise there).
+    if (!eval_form)
+        for (const CircKey &g : gates)
+            if (g.out < nin) return 0;
     std::lock_guard<std::mutex> lk(ctx->fuse_mu);
     gcs_fuse_cache *f = cache_of(ctx);
     if (!f) return 0;

@@ -832,10 +832,17 @@ static int stream_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *written
     StreamTrace tr;
     if (s->view_slot != 0xffffffffu) {  // the slot whose bytes the last view pointed into
         Slot &v = *s->slots[s->view_slot];
-        if (v.deep_id) s->deep.retire(v.lane, v.deep_id);
-        v.reset();
+        // (earlier steps of the same group may have been handed out by finish_async: their copies read v.h_down until the
+        // copier threads are through — such a slot is given back by retire_slots, never reset under them)
+        if (v.copies.load(std::memory_order_acquire) != 0) {
+            v.retire = true;
+        } else {
+            if (v.deep_id) s->deep.retire(v.lane, v.deep_id);
+            v.reset();
+        }
         s->view_slot = 0xffffffffu;
     }
+    retire_slots(s);  // (every kind of finish: a slot marked `retire` is not kept until the next copies_wait)
     const StepRef ref = s->queue.front();
     Slot &g = *s->slots[ref.slot];
     while (g.kind == Slot::kGroup && !g.launched) {  // the oldest step sits in an open group: launch up to that one
@@ -937,8 +944,7 @@ int gc_stream_garble_finish(gc_stream *s, uint8_t *buf, size_t cap, size_t *writ
 }
 
 int gc_stream_garble_finish_async(gc_stream *s, uint8_t *buf, size_t cap, size_t *written) try {
-    if (!buf) return GC_E_ARG;
-    retire_slots(s);
+    if (!s || !buf) return GC_E_ARG;
     return stream_finish(s, buf, cap, written, nullptr, true);
 } catch (...) {
     return gc::on_exception();

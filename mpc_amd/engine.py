@@ -75,6 +75,7 @@ def lib():
         "gc_plan_get_info": (i32, [vp, C.POINTER(PlanInfo)]),
         "gc_plan_simulate": (i32, [vp, vp, vp]),
         "gc_plan_describe": (i32, [vp, vp, vp, vp, vp]),
+        "gc_plan_fingerprint": (i32, [vp, vp]),
         "gc_device_count": (i32, []),
         "gc_ctx_create": (vp, [i32, ip]),
         "gc_ctx_destroy": (None, [vp]),
@@ -316,6 +317,12 @@ class Plan:
         self._describe(int(ng.sum()))
         self.gate_base = np.concatenate([[0], np.cumsum(ng)]).astype(np.uint32)
         return self
+
+    def fingerprint(self):
+        """64-bit fingerprint of the device program of this plan (gc_plan_fingerprint), as 16 hex digits"""
+        fp = C.c_uint64(0)
+        _check(lib().gc_plan_fingerprint(self.h, C.byref(fp)), "gc_plan_fingerprint")
+        return "%016x" % fp.value
 
     def simulate(self, in_bits):
         """plaintext walk of the flattened unit program (gc_plan_simulate): output bits"""

@@ -636,7 +636,9 @@ def run_native(name, key=bytes(range(32)), window=64):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "program.bin")
         write_program(path, key, rnd, prim, steps, window)
-        run = subprocess.run([NATIVE, path], check=True, capture_output=True, text=True, timeout=600)
+        run = subprocess.run([NATIVE, path], capture_output=True, text=True, timeout=600)
+        if run.returncode != 0:  # keep what the child said: the exit status alone explains nothing (BENCH_r05 native_host.big130)
+            raise RuntimeError("tools/stream_driver exit %d: %s" % (run.returncode, (run.stderr or run.stdout).strip()[-600:]))
         out = run.stdout
         if os.environ.get("GC_TRACE"):  # the engine's wall-clock laps (developer aid): pass them on
             sys.stderr.write(run.stderr)
@@ -712,7 +714,7 @@ def run_for_line(key=bytes(range(32)), ctx=None):
         try:
             r = run_native(name, key, win)
         except Exception as e:  # a side measurement: reported, never fatal for the bench line
-            r = {"error": str(e)[:200]}
+            r = {"error": str(e)[:800]}
         if r is not None:
             native[name] = {k: r[k] for k in r if k in ("garble_gates_per_s", "garble_view_gates_per_s", "garble_async_gates_per_s", "garble_us_per_step", "eval_gates_per_s", "eval_blocks_gates_per_s", "eval_blocks_pinned_gates_per_s",
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
