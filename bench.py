@@ -132,6 +132,56 @@ def sweep_rows_for_line(batch, key, ctx):
     return [{k: r[k] for k in SWEEP_KEEP if k in r} for r in rows]
 
 
+def per_gpu_share_row(batch, circ, key, ctx, steps=20):
+    """config 4's per-GPU share on ONE GPU (aes_128 x 8 192 instances, the production schedule, the step in a hipGraph): the
+    same-run N = 1 baseline of a scaling curve whose N > 1 points run 8 192 instances per rank."""
+    import numpy as np
+
+    from mpc_amd import engine
+    dc = engine.DeviceCircuit(ctx, circ)
+    info = dc.info
+    gb, ev = engine.Batch(dc, batch), engine.Batch(dc, batch)
+    for b in (gb, ev):
+        b.set_graph(True)
+        b.set_schedule(1)
+    d_rnd = ctx.random_u8((batch, circ.num_inputs + 1, 16), 256, seed=91)
+    d_bits = ctx.random_u8((batch, circ.num_inputs), 2, seed=92)
+    d_out = ctx.zeros((batch, circ.num_outputs))
+    d_mis = ctx.zeros(1, np.int32)
+
+    def step():
+        gb.garble(key, d_rnd)
+        ev.select_inputs(gb, d_bits)
+        ev.eval(key, gb)
+        gb.decode(ev, d_out, d_mis)
+
+    step()
+    ctx.sync()
+    try:
+        graph = ctx.capture(step)
+        launch = graph.launch
+    except Exception:  # (capture is an optimisation)
+        ctx.sync()
+        launch = step
+    for _ in range(12):
+        launch()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        launch()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    row = {"workload": "%s x %d instances (BASELINE config 4's share of one GPU), %d-byte key" % (circ.name, batch, len(key)),
+           "steps": steps, "ms_per_step": dt / steps * 1e3, "and_gates_per_s": info.n_and * batch * steps / dt,
+           "graph": launch is not step, "outputs_ok": int(d_mis.numpy()[0]) == 0}
+    gb.close()
+    ev.close()
+    dc.close()
+    for d in (d_rnd, d_bits, d_out, d_mis):
+        d.close()
+    return row
+
+
 def level_launch_row(batch, circ, key, ctx):
     """The north star's literal schedule beside the production one (SURVEY §7 hard part 4): schedule 0 —
     one data-parallel launch per dependency level (308 garbling + 308 evaluating launches for aes_128, thread = (gate,
@@ -565,12 +615,34 @@ def run(stage):
                                % (os.path.basename(os.environ["GC_RCCL_PATH"]), K),
             "gathered_outputs_ok": ok,
         }
+    if comm is not None:
+        # every rank's own time over the same K steps (the job's is the slowest rank's) -> per-rank AND/s, min / max over ranks
+        mine = np.array([getattr(loop, "local_elapsed", elapsed)], np.float64)
+        times = np.frombuffer(np.ascontiguousarray(comm.allgather_host(mine.view(np.uint8))).tobytes(), np.float64)
+        vals = [n_and * batch * args.steps / t for t in times]
+        res["per_rank"] = {"elapsed_s": [float(t) for t in times], "value": vals, "min": min(vals), "max": max(vals),
+                           "unit": "AND-gates/s per GPU over the timed steps (the job's value is all ranks' units over the slowest rank's time)"}
     gb.close()
     ev.close()
     dc.close()
     for d in (d_rnd, d_bits, d_acc, d_mis, d_all):
         if d is not None:
             d.close()
+    if (world > 1 and comm is not None and not args.no_synthetic and args.circuit.endswith("aes_128.gcf")
+            and not os.environ.get("GC_BENCH_ENGINE")):
+        # north star: "AND-gates/sec on synthetic levelised circuits reported at 1/2/4/8 GPUs": every rank runs the five rows
+        # of the N = 1 line on its own GPU (independent instances, 1 024 per GPU as there), the job's figure is the sum
+        stage[0] = "synthetic rows"
+        rows = sweep_rows_for_line(1024, key, ctx)
+        mine = np.array([[r.get("and_gates_per_s") or 0.0, r.get("gates_per_s") or 0.0] for r in rows], np.float64)
+        allv = np.frombuffer(np.ascontiguousarray(comm.allgather_host(mine.reshape(-1).view(np.uint8))).tobytes(),
+                             np.float64).reshape(world, len(rows), 2)
+        for i, r in enumerate(rows):
+            r["and_gates_per_s_job"] = float(allv[:, i, 0].sum())
+            r["gates_per_s_job"] = float(allv[:, i, 1].sum())
+            r["and_gates_per_s_per_rank"] = [float(v) for v in allv[:, i, 0]]
+            r["instances_per_gpu"] = 1024
+        res["synthetic"] = rows
     if rank == 0 and world == 1:
         aes = args.circuit.endswith("aes_128.gcf")
         # how long each group of side rows took (the timed region of `value` is ms_per_step x steps; the rest of the run is these)
@@ -588,6 +660,7 @@ def run(stage):
         if not args.no_extra_rows and aes:
             res.update(reference_bench_rows(batch, circ, ctx))
             res["level_launch"] = level_launch_row(batch, circ, key, ctx)
+            res["n1_batch8192"] = per_gpu_share_row(8192, circ, key, ctx)
             lap("key16 + and_chain + level_launch")
         if not args.no_iknp:
             # second kernel pair of the path (ot/iknp.go) and its callers (COT pads over MITCCRH, KOS check, bit-COT):

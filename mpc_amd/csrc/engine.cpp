@@ -219,9 +219,15 @@ int gc_ctx_coop_check(gc_ctx *c) {
     const uint32_t what = *c->h_coop_err;
     c->coop_state = -1;
     if (what >= 2) {  // (the word stays up: the ctx's results cannot be trusted any more)
-        std::snprintf(gc::tls_error, sizeof gc::tls_error,
-                      what == 3 ? "a unit of a step group waited ~2 s for a unit of the same launch and ran without it"
-                                : "a cooperative one-instance pass lost a workgroup and could not be repeated on the device");
+        if (what == 3)
+            std::snprintf(gc::tls_error, sizeof gc::tls_error, "a unit of a step group waited ~2 s for a unit of the same launch and ran without it");
+        else
+            std::snprintf(gc::tls_error, sizeof gc::tls_error,
+                          "a cooperative one-instance pass lost a workgroup and could not be repeated on the device "
+                          "(stand-by of pass %u: device has ended %u passes, host launched %u; arrivals %u, leavers %u, error flag %u, "
+                          "waited %u Ki ticks, %u levels)",
+                          c->h_coop_err[1], c->h_coop_err[2], c->coop_launched, c->h_coop_err[3], c->h_coop_err[4], c->h_coop_err[5],
+                          c->h_coop_err[6], c->h_coop_err[7]);
         return GC_E_HIP;
     }
     *c->h_coop_err = 0;

@@ -1110,7 +1110,18 @@ __device__ __noinline__ void coop_standby(CoopCtl *ctl, uint32_t seq, const Gate
             }
         }
         if (!ok)
-            if (uint32_t *host_err = ctl->host_err) __hip_atomic_store(host_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (uint32_t *host_err = ctl->host_err) {
+                // what the stand-by saw when it gave up (words 1.. of the pinned block: gc_ctx_coop_check puts them into the
+                // error text): its pass number, the device's count of ended passes, arrivals, leavers, the error flag, ticks waited
+                host_err[1] = seq;
+                host_err[2] = __hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host_err[3] = __hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host_err[4] = __hip_atomic_load(&ctl->left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host_err[5] = __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host_err[6] = (uint32_t)((__builtin_amdgcn_s_memtime() - t0) >> 10);
+                host_err[7] = nsteps;
+                __hip_atomic_store(host_err, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         ended = ok;
     }
     __syncthreads();

@@ -260,6 +260,7 @@ def run_timed(loop, fence, steps, warmup, allreduce_max=None, clock=time.perf_co
     loop.flush()
     fence()
     elapsed = clock() - t0
+    loop.local_elapsed = elapsed  # (this rank's own time; bench.py reports per-rank values beside the job's)
     if allreduce_max is not None:
         elapsed = allreduce_max(elapsed)
     return elapsed

@@ -82,6 +82,60 @@ static double now_s(void) {
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 #define DIE(...) (fprintf(stderr, __VA_ARGS__), fprintf(stderr, " [%s]\n", gc_last_error()), exit(1))
+static void *xmalloc(size_t n, const char *what) {
+    void *p = malloc(n ? n : 1);
+    if (!p) DIE("stream_driver: out of memory (%zu bytes for %s)", n, what);
+    return p;
+}
+static void *xcalloc(size_t n, size_t sz, const char *what) {
+    void *p = calloc(n ? n : 1, sz);
+    if (!p) DIE("stream_driver: out of memory (%zu x %zu bytes for %s)", n, sz, what);
+    return p;
+}
+/* A running 64-bit checksum of a byte stream that does not depend on how the stream is cut into pieces (8-byte words, a
+ * carry buffer across pieces): the passes that hand the same bytes out another way (deferred copies, views) are checked
+ * against the copying pass through it, a few GB/s, instead of against a second kept copy of a 2.4 GB stream. */
+typedef struct {
+    uint64_t h, len;
+    uint8_t buf[8];
+    size_t fill;
+} sum64_t;
+static void sum_init(sum64_t *s) { s->h = 0x9e3779b97f4a7c15ull, s->len = 0, s->fill = 0; }
+static inline void sum_word(sum64_t *s, uint64_t w) {
+    s->h = (s->h ^ w) * 0xff51afd7ed558ccdull;
+    s->h ^= s->h >> 29;
+}
+static void sum_update(sum64_t *s, const uint8_t *p, size_t n) {
+    s->len += n;
+    if (s->fill) {
+        const size_t take = n < 8 - s->fill ? n : 8 - s->fill;
+        memcpy(s->buf + s->fill, p, take);
+        s->fill += take, p += take, n -= take;
+        if (s->fill < 8) return;
+        uint64_t w;
+        memcpy(&w, s->buf, 8);
+        sum_word(s, w), s->fill = 0;
+    }
+    for (; n >= 8; p += 8, n -= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        sum_word(s, w);
+    }
+    if (n) memcpy(s->buf, p, n), s->fill = n;
+}
+static uint64_t sum_final(sum64_t *s) {
+    uint64_t w = 0;
+    memcpy(&w, s->buf, s->fill);
+    sum_word(s, w);
+    sum_word(s, s->len);
+    return s->h;
+}
+static uint64_t sum_of(const uint8_t *p, size_t n) {
+    sum64_t s;
+    sum_init(&s);
+    sum_update(&s, p, n);
+    return sum_final(&s);
+}
 static void rd(FILE *f, void *p, size_t n) {
     if (fread(p, 1, n, f) != n) DIE("stream_driver: short program file");
 }
@@ -113,26 +167,26 @@ int main(int argc, char **argv) {
     rd(f, key, keylen);
     uint64_t rndlen;
     rd(f, &rndlen, 8);
-    uint8_t *rnd = malloc(rndlen);
+    uint8_t *rnd = xmalloc(rndlen, "the random stream");
     rd(f, rnd, rndlen);
     const uint32_t nprim = rd32(f);
-    uint32_t *prim = malloc(4 * (size_t)nprim + 4);
+    uint32_t *prim = xmalloc(4 * (size_t)nprim + 4, "primary inputs");
     rd(f, prim, 4 * (size_t)nprim);
     const uint32_t ncirc = rd32(f);
-    circ_t *circ = calloc(ncirc, sizeof *circ);
+    circ_t *circ = xcalloc(ncirc, sizeof *circ, "circuits");
     for (uint32_t c = 0; c < ncirc; c++) {
         circ[c].ngates = rd32(f), circ[c].nwires = rd32(f), circ[c].nin = rd32(f), circ[c].nout = rd32(f);
-        circ[c].gates = malloc(sizeof(gc_gate) * (size_t)circ[c].ngates);
+        circ[c].gates = xmalloc(sizeof(gc_gate) * (size_t)circ[c].ngates, "a circuit's gates");
         rd(f, circ[c].gates, sizeof(gc_gate) * (size_t)circ[c].ngates);
     }
     const uint32_t nsteps = rd32(f);
-    step_t *step = calloc(nsteps, sizeof *step);
+    step_t *step = xcalloc(nsteps, sizeof *step, "steps");
     size_t cap = 64;
     uint32_t max_wire = 0;
     for (uint32_t k = 0; k < nsteps; k++) {
         const uint32_t c = step[k].circ = rd32(f);
         if (c >= ncirc) DIE("stream_driver: bad circuit index");
-        step[k].in = malloc(4 * (size_t)circ[c].nin + 4), step[k].out = malloc(4 * (size_t)circ[c].nout + 4);
+        step[k].in = xmalloc(4 * (size_t)circ[c].nin + 4, "a step's inputs"), step[k].out = xmalloc(4 * (size_t)circ[c].nout + 4, "a step's outputs");
         rd(f, step[k].in, 4 * (size_t)circ[c].nin);
         rd(f, step[k].out, 4 * (size_t)circ[c].nout);
         cap += (size_t)circ[c].ngates * 61;
@@ -148,14 +202,16 @@ int main(int argc, char **argv) {
     int st = 0;
     gc_ctx *ctx = gc_ctx_create(0, &st);
     if (!ctx) DIE("gc_ctx_create: %d", st);
-    uint8_t *bytes = malloc(cap);
-    size_t *sizes = malloc(sizeof(size_t) * (size_t)nsteps);
+    /* (cap is the format's upper bound, 61 bytes per gate; only the ~17 bytes per gate that are written get pages) */
+    uint8_t *bytes = xmalloc(cap, "the byte stream");
+    size_t *sizes = xmalloc(sizeof(size_t) * (size_t)nsteps, "step sizes");
     double garble_s = 0, eval_s = 0, eval_steady_s = 0;
     double g_t0 = 0, g_t1 = 0, e_t0 = 0, e_t1 = 0; /* CLOCK_MONOTONIC: the same clock in every process of the box */
     uint32_t eval_steady_steps = 0;
     char hex[65] = "";
-    gc_label *in0 = malloc(sizeof(gc_label) * ((size_t)nprim + 1));
+    gc_label *in0 = xmalloc(sizeof(gc_label) * ((size_t)nprim + 1), "input labels");
     size_t total = 0;
+    gc_wire last_w = {{0, 0}, {0, 0}}; /* the garbler's two labels of the program's last output: the evaluator must end on one of them */
     for (int pass = 0; pass < 2; pass++) { /* the first pass loads the circuits and sizes the engine's buffers */
         gc_stream *g = gc_stream_create(ctx, key, keylen, rnd, rndlen, prim, nprim, &st);
         if (!g) DIE("gc_stream_create: %d", st);
@@ -183,10 +239,20 @@ int main(int argc, char **argv) {
         garble_s = now_s() - t0;
         g_t0 = t0, g_t1 = t0 + garble_s;
         total = off;
+        if (gc_stream_get_wire(g, step[nsteps - 1].out[0], &last_w)) DIE("gc_stream_get_wire(last output)");
         gc_stream_free(g);
     }
+    /* what the copying pass produced, as a checksum and as SHA-256 (the golden the caller compares): the passes below hand the
+     * same bytes out another way and are checked against the checksum — no second copy of the stream is kept */
+    const uint64_t want_sum = sum_of(bytes, total);
+    uint64_t *step_sum = xmalloc(sizeof(uint64_t) * (size_t)nsteps, "step checksums"); /* (to name the step when a pass differs) */
+    for (size_t k = 0, o = 0; k < nsteps; o += sizes[k], k++) step_sum[k] = sum_of(bytes + o, sizes[k]);
+    sha256_t sh;
+    sha_init(&sh);
+    sha_update(&sh, bytes, total);
+    sha_final(&sh, hex);
     /* the same with the copies DEFERRED to the stream's copier threads (gc_stream_garble_finish_async + one wait at the end):
-     * the bytes land in the same buffer, this thread only queues and hands out */
+     * the bytes land in the same buffer (emptied first), this thread only queues and hands out */
     double garble_async_s = 0;
     {
         gc_stream *g = gc_stream_create(ctx, key, keylen, rnd, rndlen, prim, nprim, &st);
@@ -194,8 +260,7 @@ int main(int argc, char **argv) {
         for (uint32_t c = 0; c < ncirc; c++)
             if ((st = gc_stream_intern(g, circ[c].gates, circ[c].ngates, circ[c].nwires, circ[c].nin, circ[c].nout, &circ[c].handle)))
                 DIE("gc_stream_intern: %d", st);
-        uint8_t *copy = malloc(total ? total : 1);
-        memset(copy, 0, total); /* (its pages exist before the clock starts, like those of the buffer of the copying pass) */
+        memset(bytes, 0, total); /* (its pages stay: like those of the buffer of the copying pass) */
         size_t off = 0;
         uint32_t issued = 0;
         const double t0 = now_s();
@@ -205,19 +270,27 @@ int main(int argc, char **argv) {
                 if ((st = gc_stream_garble_begin_h(g, circ[step[issued].circ].handle, step[issued].in, step[issued].out)))
                     DIE("gc_stream_garble_begin_h(step %u): %d", issued, st);
             size_t n = 0;
-            if ((st = gc_stream_garble_finish_async(g, copy + off, total - off, &n))) DIE("gc_stream_garble_finish_async(step %u): %d", k, st);
+            if ((st = gc_stream_garble_finish_async(g, bytes + off, total - off, &n))) DIE("gc_stream_garble_finish_async(step %u): %d", k, st);
+            if (n != sizes[k]) DIE("gc_stream_garble_finish_async(step %u): %zu bytes, %zu when copied", k, n, sizes[k]);
             off += n;
         }
         if ((st = gc_stream_garble_copies_wait(g))) DIE("gc_stream_garble_copies_wait: %d", st);
         garble_async_s = now_s() - t0;
-        if (off != total || memcmp(copy, bytes, total)) DIE("deferred copies: other bytes than the copying finish");
-        free(copy);
+        if (off != total) DIE("deferred copies: %zu bytes of %zu", off, total);
+        if (sum_of(bytes, total) != want_sum) {
+            size_t o = 0;
+            uint32_t k = 0;
+            while (k < nsteps && sum_of(bytes + o, sizes[k]) == step_sum[k]) o += sizes[k], k++;
+            DIE("deferred copies: other bytes than the copying finish, first in step %u of %u (%zu bytes at offset %zu)", k, nsteps,
+                k < nsteps ? sizes[k] : 0, o);
+        }
         gc_stream_free(g);
     }
     /* the same program with the bytes consumed IN PLACE (gc_stream_garble_finish_view: a pointer into the engine's pinned staging,
-     * valid until the next finish — what go/circuit/stream_hip.go does: the copy into conn.WriteBuf is the transport's) */
+     * valid until the next finish — what go/circuit/stream_hip.go does: the copy into conn.WriteBuf is the transport's).  Twice:
+     * timed without touching the bytes (a transport would DMA them), then once more reading every view into the checksum. */
     double garble_view_s = 0;
-    {
+    for (int pass = 0; pass < 2; pass++) {
         gc_stream *g = gc_stream_create(ctx, key, keylen, rnd, rndlen, prim, nprim, &st);
         if (!g) DIE("gc_stream_create: %d", st);
         for (uint32_t c = 0; c < ncirc; c++)
@@ -225,6 +298,8 @@ int main(int argc, char **argv) {
                 DIE("gc_stream_intern: %d", st);
         uint32_t issued = 0;
         size_t seen = 0;
+        sum64_t vs;
+        sum_init(&vs);
         const double t0 = now_s();
         for (uint32_t k = 0; k < nsteps; k++) {
             const uint32_t lim = k + window < nsteps ? k + window : nsteps;
@@ -235,16 +310,17 @@ int main(int argc, char **argv) {
             size_t n = 0;
             if ((st = gc_stream_garble_finish_view(g, &view, &n))) DIE("gc_stream_garble_finish_view(step %u): %d", k, st);
             if (n != sizes[k]) DIE("gc_stream_garble_finish_view(step %u): %zu bytes, %zu when copied", k, n, sizes[k]);
+            if (pass == 1) {
+                if (sum_of(view, n) != step_sum[k]) DIE("view pass: step %u of %u: other bytes than the copying finish (%zu bytes)", k, nsteps, n);
+                sum_update(&vs, view, n);
+            }
             seen += n;
         }
-        garble_view_s = now_s() - t0;
+        if (pass == 0) garble_view_s = now_s() - t0;
         if (seen != total) DIE("view pass: %zu bytes of %zu", seen, total);
+        if (pass == 1 && sum_final(&vs) != want_sum) DIE("view pass: other bytes than the copying finish (checksum of %zu bytes)", total);
         gc_stream_free(g);
     }
-    sha256_t sh;
-    sha_init(&sh);
-    sha_update(&sh, bytes, total);
-    sha_final(&sh, hex);
     uint64_t parsed = 0, matched = 0;
     gc_label probe = {0, 0};
     for (int pass = 0; pass < 2; pass++) {
@@ -274,6 +350,9 @@ int main(int argc, char **argv) {
         }
         if (gc_stream_eval_get_wire(e, step[nsteps - 1].out[0], &probe)) DIE("gc_stream_eval_get_wire"); /* waits for everything */
         eval_s = now_s() - t0;
+        if (!((probe.d0 == last_w.l0.d0 && probe.d1 == last_w.l0.d1) || (probe.d0 == last_w.l1.d0 && probe.d1 == last_w.l1.d1)))
+            DIE("evaluator: the last output's label %016llx%016llx is neither of the garbler's two", (unsigned long long)probe.d0,
+                (unsigned long long)probe.d1);
         e_t0 = t0, e_t1 = t0 + eval_s;
         eval_steady_s = now_s() - t_known;
         gc_stream_eval_stats(e, &parsed, &matched);
@@ -290,7 +369,7 @@ int main(int argc, char **argv) {
     if (chunk < 64) chunk = 64;
     {
         const size_t ftotal = total + 20 * (size_t)nsteps;
-        uint8_t *framed = malloc(ftotal ? ftotal : 1);
+        uint8_t *framed = xmalloc(ftotal, "the framed stream");
         size_t fo = 0, off = 0;
         for (uint32_t k = 0; k < nsteps; k++) {
             const circ_t *c = &circ[step[k].circ];
@@ -302,6 +381,7 @@ int main(int argc, char **argv) {
             memcpy(framed + fo, bytes + off, sizes[k]);
             fo += sizes[k], off += sizes[k];
         }
+        free(bytes), bytes = NULL; /* (from here on the stream exists once: framed — then once more, pinned, with `framed` given back) */
         for (int pass = 0; pass < 2; pass++) {
             gc_stream_eval *e = gc_stream_eval_create(ctx, key, keylen, &st);
             if (!e) DIE("gc_stream_eval_create: %d", st);
@@ -334,10 +414,14 @@ int main(int argc, char **argv) {
         /* ... and from a PINNED read buffer (gc_host_alloc: the DMA reads it in place) in pieces of 32 MiB: whole read buffers go
          * to the GPU, which recognises the blocks itself (mpc_amd/csrc/stream_eval_dev.cpp) */
         uint8_t *pin = (uint8_t *)gc_host_alloc(ftotal ? ftotal : 1);
+        if (!pin) fprintf(stderr, "stream_driver: gc_host_alloc(%zu) refused [%s]: the pinned read-buffer pass is skipped\n", ftotal, gc_last_error());
         if (pin) {
             memcpy(pin, framed, ftotal);
+            free(framed), framed = NULL;
             const size_t big = (size_t)32 << 20;
-            for (int pass = 0; pass < 2; pass++) {
+            /* (GC_DRIVER_PINNED_PASSES: a stress knob — how often the pass over the pinned read buffers is repeated) */
+            const int npin = getenv("GC_DRIVER_PINNED_PASSES") ? atoi(getenv("GC_DRIVER_PINNED_PASSES")) : 2;
+            for (int pass = 0; pass < npin; pass++) {
                 gc_stream_eval *e = gc_stream_eval_create(ctx, key, keylen, &st);
                 if (!e) DIE("gc_stream_eval_create: %d", st);
                 for (uint32_t i = 0; i < nprim; i++)
@@ -370,13 +454,18 @@ int main(int argc, char **argv) {
         }
         free(framed);
     }
+    int coop_state = 0;
+    uint64_t coop_timeouts = 0;
+    (void)gc_ctx_coop_stats(ctx, &coop_state, &coop_timeouts); /* 1: big steps ran as cooperative launches; -1: level launches */
     printf("{\"native\": true, \"steps\": %u, \"window\": %u, \"garble_s\": %.6f, \"garble_view_s\": %.6f, \"garble_async_s\": %.6f, \"eval_s\": %.6f, \"eval_steady_s\": %.6f, "
            "\"eval_blocks_s\": %.6f, \"eval_blocks_pinned_s\": %.6f, \"eval_blocks_chunk\": %zu, "
            "\"eval_steady_steps\": %u, \"bytes\": %zu, \"sha256\": \"%s\", "
            "\"eval_blocks_parsed\": %llu, \"eval_blocks_matched\": %llu, \"last_out_d0\": \"%016llx\", "
-           "\"garble_t0\": %.6f, \"garble_t1\": %.6f, \"eval_t0\": %.6f, \"eval_t1\": %.6f}\n",
+           "\"garble_t0\": %.6f, \"garble_t1\": %.6f, \"eval_t0\": %.6f, \"eval_t1\": %.6f, "
+           "\"coop_state\": %d, \"coop_timeouts\": %llu, \"passes\": \"copying x2, deferred copies, views x2, eval per block x2, "
+           "eval_blocks 1 MiB x2, eval_blocks pinned 32 MiB x2\"}\n",
            nsteps, window, garble_s, garble_view_s, garble_async_s, eval_s, eval_steady_s, eval_blocks_s, eval_blocks_pinned_s, chunk, eval_steady_steps, total, hex, (unsigned long long)parsed, (unsigned long long)matched,
-           (unsigned long long)probe.d0, g_t0, g_t1, e_t0, e_t1);
+           (unsigned long long)probe.d0, g_t0, g_t1, e_t0, e_t1, coop_state, (unsigned long long)coop_timeouts);
     gc_ctx_destroy(ctx);
     return 0;
 }
