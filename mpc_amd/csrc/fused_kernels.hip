@@ -1031,10 +1031,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_eval_level1(const GateDesc *_
 // its store is acknowledged (the vector L1 writes through), the counter lives in that L2, and the readers fetch labels
 // past their L1; no write-back or invalidate of L2, which an agent-scope release / acquire would cost at every level.
 // The placement is checked, not assumed: gc_ctx runs k_coop_selftest once (XCC_ID of every group, values handed round
-// through the barrier) and keeps the level launches if it fails; every wait is bounded (kCoopTimeout), a workgroup that
+// through the barrier) and keeps the level launches if it fails; every wait is bounded (kCoopPolls), a workgroup that
 // gives up raises ctl->error and the pass is reported as failed.
 constexpr uint32_t kCoopThreads = 256;
-constexpr uint64_t kCoopTimeout = 40u * 1000u * 1000u;  // s_memtime ticks (~1.1 GHz): ~36 ms
+// The bound of a wait is a number of POLLS, not a span of time (until round 6: 40 M s_memtime ticks, ~36 ms): a queue that the
+// hardware scheduler takes off the GPU for a while — a second process with a context on the same GPU is enough: BENCH_r05's C
+// host failed so once in ~10 runs at config 5's size, "lost a workgroup and could not be repeated" — stops every workgroup of
+// the pass together, the clock runs on, and a time bound then fires in ALL of them (and in the stand-by, whose ~2 s backstop was
+// what made the failure fatal).  Polls only happen while the wave runs.  One poll is a load past the L1 (0.3 - 0.8 us): 2^16
+// polls are 20 - 50 ms of RUNNING time, what a workgroup that is really missing costs once.
+constexpr uint32_t kCoopPolls = 1u << 16;
+// the stand-by's backstop, in sleeps of 100 x 64 clocks (3 - 6 us each): 2^21 of them are ~10 s of running time
+constexpr uint32_t kCoopStandbySleeps = 1u << 21;
 
 // barrier number `gen` (1, 2, ... within one launch): one atomic add, then a plain load past the L1 until every group has
 // added.  Measured on one XCD: an atomic add takes 0.7 us to come back whatever its scope; 32 workgroups that poll the
@@ -1050,12 +1058,11 @@ __device__ __forceinline__ void coop_arrive(CoopCtl *ctl) {
 __device__ __forceinline__ void coop_wait(CoopCtl *ctl, uint32_t gen) {
     if (threadIdx.x == 0) {
         const uint32_t target = gen * kCoopGroups;
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
         uint32_t spins = 0;
         while (__hip_atomic_load(&ctl->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if ((++spins & 63u) == 0) {
                 if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (__builtin_amdgcn_s_memtime() - t0 > kCoopTimeout) {
+                if (spins > kCoopPolls) {
                     // (the host hears of it from the stand-by: 1 once the pass has been done again, 2 if that was not possible)
                     __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -1098,13 +1105,13 @@ __device__ __noinline__ void coop_standby(CoopCtl *ctl, uint32_t seq, const Gate
     __shared__ uint32_t ended;
     if (threadIdx.x == 0) {
         // the last workgroup to leave counts the pass (ctl->passes becomes seq + 1); every wait inside the pass is bounded, so
-        // this one ends.  The bound here is a backstop (~2 s): a pass that has NOT ended by then — or a count the host and the
-        // device do not agree on — cannot be repaired from here: the host is told that the results are not to be used (2).
+        // this one ends.  The bound here is a backstop (~10 s of running time): a pass that has NOT ended by then — or a count the
+        // host and the device do not agree on — cannot be repaired from here: the host is told that the results are not to be used (2).
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        uint32_t ok = 1;
+        uint32_t ok = 1, sleeps = 0;
         while ((int32_t)(__hip_atomic_load(&ctl->passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) <= 0) {
             __builtin_amdgcn_s_sleep(100);
-            if (__builtin_amdgcn_s_memtime() - t0 > 50u * kCoopTimeout) {
+            if (++sleeps > kCoopStandbySleeps) {  // (counted, not timed: see kCoopPolls)
                 ok = 0;
                 break;
             }

@@ -18,8 +18,10 @@ for i in range(n):
     r = bs.run_program("ed25519like", key, ctx, window=bs.WINDOWS["ed25519like"], view=True)
     t1 = time.time()
     try:
-        nat = bs.run_native("big130", key, 2)
-        out = {"i": i, "ok": True, "garble": nat["garble_gates_per_s"], "sha256_ok": nat["sha256_ok"]}
+        steps, prim = bs.PROGRAMS["big130"]()
+        nat = bs.run_native_steps(steps, prim, bs.stream_rnd("big130", len(prim)), key, 2)
+        out = {"i": i, "ok": nat["sha256"] == bs.golden_sha("big130", key), "garble_s": nat["garble_s"], "eval_blocks_pinned_s": nat["eval_blocks_pinned_s"],
+               "coop_state": nat["coop_state"], "coop_timeouts": nat["coop_timeouts"]}
     except Exception as e:
         out = {"i": i, "ok": False, "error": str(e)[:1500]}
     out["parent_s"] = round(t1 - t0, 2)
