@@ -5,6 +5,8 @@
 // coalesced transaction, the gate descriptor is wave-uniform (scalar loads, no divergence)
 // and the AES round keys live in SGPRs.  The four T-tables sit in LDS (4 KiB per block).
 // Arithmetic restated from circuit/garble.go:311-482 (garbleInto) and circuit/eval.go:28-112.
+#include <cstdlib>
+
 #include "aes_device.h"
 #include "kernels.h"
 #include "level_gate.h"
@@ -109,6 +111,159 @@ __global__ __launch_bounds__(256) void k_eval_level(const GateDesc *__restrict__
     eval_one<NR>(d, tp.inst, bstride, W, T, W + (size_t)(out_slot0 + tp.gate) * bstride + tp.inst, rk, te);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same level with the hashes of a gate SPREAD OVER WAVES (round 6).  In the kernels above a thread garbles a whole AND:
+// four interleaved AES blocks, ~2 800 instructions of ONE wave per level — measured 6 us of an 8 us graph node on aes_128 x
+// 1 024 (a dependent EMPTY node costs 1.6 us, one that moves the level's 6.5 MB 2.0 us: profiles/r06_graph_node_ubench.txt),
+// i.e. a level was its busiest wave's instruction stream, not a launch.  Here a workgroup owns ONE table-producing gate and 64
+// instances (the evaluator: 128) and wave q computes hash q of the gate for them — garbler AND: H(a0), H(a1), H(b0), H(b1);
+// INV: two; OR: its four encryptions — the lanes still run along the instance axis (every label access one coalesced 1 KiB
+// read), the hashes meet in 3 KiB of LDS and wave 0 does the Half-Gates combine exactly as garble_one / eval_one (level_gate.h)
+// do.  The free gates of the level stay thread = (gate, instance), in the workgroups behind the hash workgroups of the SAME
+// launch: still one data-parallel launch per dependency level.
+// ------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(256) void k_garble_level_split(const GateDesc *__restrict__ descs, uint32_t count, uint32_t nonfree,
+                                                            uint32_t out_slot0, uint32_t batch, uint32_t bstride, uint32_t lg,
+                                                            uint4 *__restrict__ W, const uint4 *__restrict__ Rv,
+                                                            uint4 *__restrict__ T, const uint32_t *__restrict__ rk,
+                                                            const uint32_t *__restrict__ g_te0, uint32_t chunks, uint32_t nb_hash,
+                                                            uint32_t gx_free) {
+    __shared__ uint32_t te[kTeWords];
+    __shared__ uint4 xh[3][64];
+    if (blockIdx.x >= nb_hash) {  // the level's free gates: thread = (gate, instance)
+        const uint32_t b = blockIdx.x - nb_hash, bx = b % gx_free, by = b / gx_free;
+        const uint32_t gate = nonfree + bx * (256u >> lg) + (threadIdx.x >> lg);
+        const uint32_t inst = by * 256u + (threadIdx.x & ((1u << lg) - 1u));
+        if (gate >= count || inst >= batch) return;
+        const GateDesc d = descs[gate];
+        garble_one<NR>(d, inst, bstride, W, Rv[inst], T, W + (size_t)(out_slot0 + gate) * bstride + inst, rk, te);
+        return;
+    }
+    const uint32_t gate = blockIdx.x / chunks, chunk = blockIdx.x - gate * chunks;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t inst = chunk * 64u + lane;
+    const bool live = inst < batch;
+    const size_t i = live ? inst : batch - 1;
+    load_te_tables(te, g_te0);
+    __syncthreads();
+    const GateDesc d = descs[gate];
+    const uint32_t op = d.row_op >> kOpShift;
+    const uint4 R = Rv[i];
+    const uint4 a0 = W[(size_t)d.in0 * bstride + i];
+    const uint4 b0 = op == GC_INV ? a0 : W[(size_t)d.in1 * bstride + i];
+    uint4 h[1] = {make_uint4(0, 0, 0, 0)};
+    if (op != GC_INV || q < 2) {
+        uint32_t k[1][4];
+        if (op == GC_OR) {  // e[2u + v] = enc(a_u, b_v, 0, id): wave q = 2u + v
+            make_k(lxor(a0, land(R, (q & 2) ? ~0u : 0u)), lxor(b0, land(R, (q & 1) ? ~0u : 0u)), d.tweak, k[0]);
+        } else {  // AND: H(a0), H(a1) under the gate's tweak, H(b0), H(b1) under tweak + 1; INV: H(a0), H(a1)
+            const uint4 x = lxor((op == GC_AND && (q & 2)) ? b0 : a0, land(R, (q & 1) ? ~0u : 0u));
+            make_k_half(x, d.tweak + (op == GC_AND ? (q >> 1) : 0u), k[0]);
+        }
+        hash_n<NR, 1>(k, h, rk, te);
+    }
+    if (q > 0) xh[q - 1][lane] = h[0];
+    __syncthreads();
+    if (q != 0 || !live) return;
+    const uint4 h0 = h[0], h1 = xh[0][lane], h2 = xh[1][lane], h3 = xh[2][lane];
+    uint4 *out = W + (size_t)(out_slot0 + gate) * bstride + inst;
+    uint4 *row = T + (size_t)(d.row_op & kRowMask) * bstride + inst;
+    if (op == GC_AND) {  // garble.go:353-395
+        const uint32_t pa = smask(a0), pb = smask(b0);
+        const uint4 tg = lxor(lxor(h0, h1), land(R, pb));
+        const uint4 wg0 = lxor(h0, land(tg, pa));
+        const uint4 te_ = lxor(lxor(h2, h3), a0);
+        const uint4 we0 = lxor(h2, land(lxor(te_, a0), pb));
+        *out = lxor(wg0, we0);
+        row[0] = tg;
+        row[bstride] = te_;
+    } else if (op == GC_INV) {  // garble.go:446-474
+        *out = lbit_s(a0) ? h1 : lxor(h0, R);
+        row[0] = lxor(lxor(h0, h1), R);
+    } else {  // GC_OR: garble.go:412-444 (as garble_one)
+        const uint4 e[4] = {h0, h1, h2, h3};
+        const uint32_t pa = lbit_s(a0) ? 1u : 0u, pb = lbit_s(b0) ? 1u : 0u;
+        const uint32_t l0 = 2u * pa + pb;
+        const uint32_t m0 = l0 == 0 ? ~0u : 0u, m1 = l0 == 1 ? ~0u : 0u, m2 = l0 == 2 ? ~0u : 0u, m3 = l0 == 3 ? ~0u : 0u;
+        auto pick = [&](uint32_t ma, uint32_t mb, uint32_t mc, uint32_t md) {
+            return lxor(lxor(land(e[0], ma), land(e[1], mb)), lxor(land(e[2], mc), land(e[3], md)));
+        };
+        const uint4 t0 = pick(m0, m1, m2, m3), t1 = pick(m1, m0, m3, m2), t2 = pick(m2, m3, m0, m1), t3 = pick(m3, m2, m1, m0);
+        const uint4 c0 = lxor(t0, land(R, ~m0)), c1 = lxor(t0, land(R, m0));
+        row[0] = lxor(t1, lxor(land(c0, m1), land(c1, ~m1)));
+        row[bstride] = lxor(t2, lxor(land(c0, m2), land(c1, ~m2)));
+        row[2 * (size_t)bstride] = lxor(t3, lxor(land(c0, m3), land(c1, ~m3)));
+        *out = c0;
+    }
+}
+
+// the evaluator: an AND has two hashes (eval.go:53-78), INV and OR one: a workgroup owns one gate and 128 instances — waves 0 / 1
+// the first 64 (hashes of a and b), waves 2 / 3 the second
+template <int NR>
+__global__ __launch_bounds__(256) void k_eval_level_split(const GateDesc *__restrict__ descs, uint32_t count, uint32_t nonfree,
+                                                          uint32_t out_slot0, uint32_t batch, uint32_t bstride, uint32_t lg,
+                                                          uint4 *__restrict__ W, const uint4 *__restrict__ T,
+                                                          const uint32_t *__restrict__ rk, const uint32_t *__restrict__ g_te0,
+                                                          uint32_t chunks, uint32_t nb_hash, uint32_t gx_free) {
+    __shared__ uint32_t te[kTeWords];
+    __shared__ uint4 xh[2][64];
+    if (blockIdx.x >= nb_hash) {
+        const uint32_t b = blockIdx.x - nb_hash, bx = b % gx_free, by = b / gx_free;
+        const uint32_t gate = nonfree + bx * (256u >> lg) + (threadIdx.x >> lg);
+        const uint32_t inst = by * 256u + (threadIdx.x & ((1u << lg) - 1u));
+        if (gate >= count || inst >= batch) return;
+        const GateDesc d = descs[gate];
+        eval_one<NR>(d, inst, bstride, W, T, W + (size_t)(out_slot0 + gate) * bstride + inst, rk, te);
+        return;
+    }
+    const uint32_t gate = blockIdx.x / chunks, chunk = blockIdx.x - gate * chunks;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = w >> 1, q = w & 1u, lane = threadIdx.x & 63u;
+    const uint32_t inst = chunk * 128u + sub * 64u + lane;
+    const bool live = inst < batch;
+    const size_t i = live ? inst : batch - 1;
+    load_te_tables(te, g_te0);
+    __syncthreads();
+    const GateDesc d = descs[gate];
+    const uint32_t op = d.row_op >> kOpShift;
+    const uint4 a = W[(size_t)d.in0 * bstride + i];
+    const uint4 b = op == GC_INV ? a : W[(size_t)d.in1 * bstride + i];
+    const uint4 *row = T + (size_t)(d.row_op & kRowMask) * bstride + i;
+    uint4 h[1] = {make_uint4(0, 0, 0, 0)};
+    if (op == GC_AND || q == 0) {
+        uint32_t k[1][4];
+        if (op == GC_OR) make_k(a, b, d.tweak, k[0]);
+        else make_k_half(q ? b : a, d.tweak + q, k[0]);
+        hash_n<NR, 1>(k, h, rk, te);
+    }
+    if (q) xh[sub][lane] = h[0];
+    __syncthreads();
+    if (q != 0 || !live) return;
+    uint4 *out = W + (size_t)(out_slot0 + gate) * bstride + inst;
+    if (op == GC_AND) {  // eval.go:53-78
+        const uint4 tg = row[0], te_ = row[bstride];
+        const uint4 wg = lxor(h[0], land(tg, smask(a)));
+        const uint4 we = lxor(xh[sub][lane], land(lxor(te_, a), smask(b)));
+        *out = lxor(wg, we);
+    } else if (op == GC_INV) {  // eval.go:96-109
+        *out = lxor(h[0], land(row[0], smask(a)));
+    } else {  // GC_OR: eval.go:80-94
+        const uint32_t index = (lbit_s(a) ? 2u : 0u) | (lbit_s(b) ? 1u : 0u);
+        uint4 c = make_uint4(0, 0, 0, 0);
+        if (index > 0) c = row[(size_t)(index - 1) * bstride];
+        *out = lxor(h[0], c);
+    }
+}
+
+// GC_LEVEL_WHOLE_GATES=1: the kernels above (a thread garbles / evaluates a whole gate) — the form until round 6, kept for comparison
+static bool level_whole_gates() {
+    static const bool v = [] {
+        const char *e = std::getenv("GC_LEVEL_WHOLE_GATES");
+        return e && *e && *e != '0';
+    }();
+    return v;
+}
+
 #define GC_DISPATCH_LEVEL(KERNEL, ...)                                                                     \
     do {                                                                                                   \
         dim3 grid((a.count + (256u >> g.lg) - 1) / (256u >> g.lg), g.yblocks), block(256);                 \
@@ -129,14 +284,37 @@ __global__ __launch_bounds__(256) void k_eval_level(const GateDesc *__restrict__
         }                                                                                                  \
     } while (0)
 
+#define GC_DISPATCH_SPLIT(KERNEL, PER, ...)                                                                \
+    do {                                                                                                   \
+        const uint32_t chunks = (g.batch + (PER) - 1) / (PER), nb_hash = a.nonfree * chunks;               \
+        const uint32_t nfree = a.count - a.nonfree, per_blk = 256u >> g.lg;                                \
+        const uint32_t gx_free = nfree ? (nfree + per_blk - 1) / per_blk : 1u;                             \
+        const dim3 grid(nb_hash + (nfree ? gx_free * g.yblocks : 0u)), block(256);                         \
+        switch (a.rounds) {                                                                                \
+        case 10: hipLaunchKernelGGL((KERNEL<10>), grid, block, 0, s, __VA_ARGS__, chunks, nb_hash, gx_free); break; \
+        case 12: hipLaunchKernelGGL((KERNEL<12>), grid, block, 0, s, __VA_ARGS__, chunks, nb_hash, gx_free); break; \
+        default: hipLaunchKernelGGL((KERNEL<14>), grid, block, 0, s, __VA_ARGS__, chunks, nb_hash, gx_free); break; \
+        }                                                                                                  \
+    } while (0)
+
 void launch_garble_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.count == 0) return;
+    if (a.nonfree && !level_whole_gates()) {
+        GC_DISPATCH_SPLIT(k_garble_level_split, 64u, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W, a.R,
+                          a.T, a.rk, a.te0);
+        return;
+    }
     GC_DISPATCH_LEVEL(k_garble_level, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W, a.R,
                       a.T, a.rk, a.te0);
 }
 
 void launch_eval_level(const LevelArgs &a, const BatchGeom &g, hipStream_t s) {
     if (a.count == 0) return;
+    if (a.nonfree && !level_whole_gates()) {
+        GC_DISPATCH_SPLIT(k_eval_level_split, 128u, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W,
+                          (const uint4 *)a.T, a.rk, a.te0);
+        return;
+    }
     GC_DISPATCH_LEVEL(k_eval_level, a.descs, a.count, a.nonfree, a.out_slot0, g.batch, g.bstride, g.lg, a.W,
                       (const uint4 *)a.T, a.rk, a.te0);
 }
