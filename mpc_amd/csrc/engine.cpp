@@ -95,17 +95,19 @@ static bool coop_ready(gc_ctx *c) {
     c->coop_state = -1;
     if (std::getenv("GC_NO_COOP")) return false;
     if (hipMalloc((void **)&c->d_coop, sizeof(CoopCtl)) != hipSuccess) return false;
-    if (!c->h_coop_err && hipHostMalloc((void **)&c->h_coop_err, 256, hipHostMallocPortable) != hipSuccess) return false;
-    CoopCtl *h = (CoopCtl *)c->h_coop_err;  // the head of the control block after the self-test
-    std::memset(h, 0xff, 256);
+    // the ctx's error word (gc_ctx_err_word: kernels of step groups in flight may raise it — it is never written from here) and,
+    // apart from it, a read-back buffer of its own for the head of the control block after the self-test
+    if (!gc_ctx_err_word(c)) return false;
+    uint32_t head[4];
+    std::memset(head, 0xff, sizeof head);
     launch_coop_selftest(c->d_coop, c->stream);
-    if (hipMemcpyAsync(h, c->d_coop, 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+    if (hipMemcpyAsync(head, c->d_coop, sizeof head, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    const CoopCtl *h = (const CoopCtl *)head;  // count, error, bad, ticks: the first four words
     const bool ok = h->error == 0 && h->bad == 0 && h->count == 128u * kCoopGroups;
     if (std::getenv("GC_TRACE"))
         std::fprintf(stderr, "[gc trace] coop self-test: %s, error %u bad %u, 128 barriers in %u ticks\n", ok ? "passed" : "FAILED",
                      h->error, h->bad, h->ticks);
-    *c->h_coop_err = 0;
     // the passes find the counters at zero and leave them so
     CoopCtl zero{};
     if (const char *f = std::getenv("GC_COOP_FORCE_TIMEOUT")) zero.drop_at = (uint32_t)std::max(0, std::atoi(f));  // (testing)

@@ -682,16 +682,18 @@ __device__ __forceinline__ uint32_t unit_enter(uint32_t *sync) {
         if (host_err) __hip_atomic_fetch_max(host_err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
-    // what those units stored is what this one loads: store_get / store_put.  (sync[1] bit 31 — GC_STREAM_DEP_FENCES, a
-    // cross-check — has both sides write back / invalidate their L2 as a release / acquire at agent scope would.)
-    if (d1 != d0 && (nun_raw & 0x80000000u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // what those units stored is what this one loads (store_get / store_put, themselves agent-scope accesses past the L1): the
+    // flags were read relaxed inside the poll loop; ONE acquire fence at agent scope behind it orders every later load after them
+    // (round 6, ADVICE r5: until then the order rested on gfx9's in-order acknowledgement of stores alone)
+    (void)nun_raw;
+    if (d1 != d0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return unit;
 }
 __device__ __forceinline__ void unit_leave(uint32_t *sync, uint32_t unit) {
-    if (__builtin_amdgcn_readfirstlane(sync[1]) & 0x80000000u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread's stores into the wire store have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(sync + kSyncHead + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the done-flag is a RELEASE at agent scope: everything this workgroup stored happens-before what a unit that sees the flag loads
+    if (threadIdx.x == 0) __hip_atomic_store(sync + kSyncHead + unit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int NR, bool HAS_OR, bool CHAIN>

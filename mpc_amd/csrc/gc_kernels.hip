@@ -145,13 +145,14 @@ __global__ __launch_bounds__(256) void k_garble_level_split(const GateDesc *__re
     const uint32_t inst = chunk * 64u + lane;
     const bool live = inst < batch;
     const size_t i = live ? inst : batch - 1;
-    load_te_tables(te, g_te0);
-    __syncthreads();
+    // the operands' loads go out first: their round trip to HBM runs under the table load and its barrier
     const GateDesc d = descs[gate];
     const uint32_t op = d.row_op >> kOpShift;
     const uint4 R = Rv[i];
     const uint4 a0 = W[(size_t)d.in0 * bstride + i];
     const uint4 b0 = op == GC_INV ? a0 : W[(size_t)d.in1 * bstride + i];
+    load_te_tables(te, g_te0);
+    __syncthreads();
     uint4 h[1] = {make_uint4(0, 0, 0, 0)};
     if (op != GC_INV || q < 2) {
         uint32_t k[1][4];
@@ -222,13 +223,24 @@ __global__ __launch_bounds__(256) void k_eval_level_split(const GateDesc *__rest
     const uint32_t inst = chunk * 128u + sub * 64u + lane;
     const bool live = inst < batch;
     const size_t i = live ? inst : batch - 1;
-    load_te_tables(te, g_te0);
-    __syncthreads();
+    // operands and (the combining wave) table rows first: their round trip runs under the table load and the AES
     const GateDesc d = descs[gate];
     const uint32_t op = d.row_op >> kOpShift;
     const uint4 a = W[(size_t)d.in0 * bstride + i];
     const uint4 b = op == GC_INV ? a : W[(size_t)d.in1 * bstride + i];
     const uint4 *row = T + (size_t)(d.row_op & kRowMask) * bstride + i;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
+    if (q == 0) {
+        if (op == GC_OR) {
+            const uint32_t index = (lbit_s(a) ? 2u : 0u) | (lbit_s(b) ? 1u : 0u);
+            if (index > 0) r0 = row[(size_t)(index - 1) * bstride];
+        } else {
+            r0 = row[0];
+            if (op == GC_AND) r1 = row[bstride];
+        }
+    }
+    load_te_tables(te, g_te0);
+    __syncthreads();
     uint4 h[1] = {make_uint4(0, 0, 0, 0)};
     if (op == GC_AND || q == 0) {
         uint32_t k[1][4];
@@ -240,18 +252,14 @@ __global__ __launch_bounds__(256) void k_eval_level_split(const GateDesc *__rest
     __syncthreads();
     if (q != 0 || !live) return;
     uint4 *out = W + (size_t)(out_slot0 + gate) * bstride + inst;
-    if (op == GC_AND) {  // eval.go:53-78
-        const uint4 tg = row[0], te_ = row[bstride];
-        const uint4 wg = lxor(h[0], land(tg, smask(a)));
-        const uint4 we = lxor(xh[sub][lane], land(lxor(te_, a), smask(b)));
+    if (op == GC_AND) {  // eval.go:53-78 (r0 = TG, r1 = TE)
+        const uint4 wg = lxor(h[0], land(r0, smask(a)));
+        const uint4 we = lxor(xh[sub][lane], land(lxor(r1, a), smask(b)));
         *out = lxor(wg, we);
     } else if (op == GC_INV) {  // eval.go:96-109
-        *out = lxor(h[0], land(row[0], smask(a)));
-    } else {  // GC_OR: eval.go:80-94
-        const uint32_t index = (lbit_s(a) ? 2u : 0u) | (lbit_s(b) ? 1u : 0u);
-        uint4 c = make_uint4(0, 0, 0, 0);
-        if (index > 0) c = row[(size_t)(index - 1) * bstride];
-        *out = lxor(h[0], c);
+        *out = lxor(h[0], land(r0, smask(a)));
+    } else {  // GC_OR: eval.go:80-94 (r0 = the row its index names, 0 for index 0)
+        *out = lxor(h[0], r0);
     }
 }
 

@@ -425,11 +425,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (g.has_waits) {
         uint32_t *sy = (uint32_t *)(g.h_up + off_sync);
         std::memset(sy, 0, (kSyncHead + (size_t)nwg) * sizeof(uint32_t));
-        static const bool fences = [] {
-            const char *v = std::getenv("GC_STREAM_DEP_FENCES");
-            return v && *v && std::strcmp(v, "0") != 0;
-        }();
-        sy[1] = nwg | (fences ? 0x80000000u : 0u);
+        sy[1] = nwg;
         uint32_t *d_err = gc_ctx_err_word(ctx);
         std::memcpy(sy + 2, &d_err, sizeof d_err);
         static_assert(sizeof(uint32_t *) == 2 * sizeof(uint32_t) && kSyncHead == 4, "layout of the sync block's head");
