@@ -3,7 +3,10 @@ the oracle, batches from 1 to 16 500 instances (tiles of 1 to 64 instances per w
 Run on a GPU box: python tests/ext_fuzz.py [N]"""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")  # every chain of the streamed cases on its merged plan (as tests/conftest.py)
+if os.environ.get("GC_FUZZ_DEFAULT_PLANNER"):  # the product's default instead: plans in the background, unplanned chains step by step (ADVICE r5)
+    os.environ.pop("GC_STREAM_FUSE_EAGER", None)
+else:
+    os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")  # every chain of the streamed cases on its merged plan (as tests/conftest.py)
 import oracle
 from mpc_amd import engine
 from tests.test_gpu_fuzz import random_circuit, xor_tree, KEY

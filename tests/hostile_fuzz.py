@@ -29,7 +29,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 import numpy as np
 
-os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")  # every chain on its merged plan, at first sight (as tests/conftest.py)
+if os.environ.get("GC_FUZZ_DEFAULT_PLANNER"):  # the product's default instead: plans in the background, unplanned chains step by step
+    os.environ.pop("GC_STREAM_FUSE_EAGER", None)
+else:
+    os.environ.setdefault("GC_STREAM_FUSE_EAGER", "1")  # every chain on its merged plan, at first sight (as tests/conftest.py)
 
 import oracle
 from mpc_amd import engine
