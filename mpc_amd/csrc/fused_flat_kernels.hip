@@ -432,6 +432,18 @@ __device__ __forceinline__ void store_put(uint4 *p, const uint4 &v) {
     __hip_atomic_store(q + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr uint32_t kDepSpins = 1u << 22;  // bound of a wait for another unit (~2 s), in polls
+// Dataflow across launches (kernels.h: DfBlock): wait until the word at p has reached `want` (wrap-safe), bounded by polls
+__device__ __forceinline__ void df_wait_reached(const uint32_t *p, uint32_t want, uint32_t *host_err) {
+    for (uint32_t spins = 0; (int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kDepSpins) {
+            if (host_err) __hip_atomic_fetch_max(host_err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
 // MULTI (job launches): `a` is this workgroup's own record, its tile is 0 and the input labels come from the wire store
 #define GC_FL_PROLOGUE(LOAD_R)                                                                               \
     const uint32_t tile = MULTI ? 0u : blockIdx.x;                                                           \
@@ -483,9 +495,16 @@ __device__ __forceinline__ void store_put(uint4 *p, const uint4 &v) {
         for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                \
             const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                               \
             if constexpr (MULTI) { /* Get through in[] (stream_garble.go:131-141) on the device */           \
-                const uint4 v = store_get(a.store + a.in_idx[w]);                                            \
+                const uint32_t sidx = a.in_idx[w];                                                           \
+                const DfBlock *dfb = LOAD_R ? (const DfBlock *)a.prof : nullptr; /* garbler, dataflow across launches: the wire's version first */ \
+                if (dfb) df_wait_reached(dfb->ver + sidx, ((const uint32_t *)(dfb + 1))[w], dfb->host_err);  \
+                const uint4 v = store_get(a.store + sidx);                                                   \
                 Wt[i] = v;                                                                                   \
                 if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = v;                                      \
+                if (dfb) { /* ... and the read is counted once the label is here (whoever overwrites the wire waits for it) */ \
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+                    __hip_atomic_fetch_add(dfb->rd + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
+                }                                                                                            \
             } else if (ls != 0xffffu) {                                                                      \
                 wl[(ls << ti_log2) + (i & tim)] = Wt[i];                                                     \
             }                                                                                                \
@@ -622,9 +641,22 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
         // Set through out[] (stream_garble.go:143-157): the job's output labels go back into the wire store.  They were
         // written to W by other waves of this workgroup: the barrier (with its vmcnt(0)) makes them visible.
         __syncthreads();
+        const DfBlock *dfb = (const DfBlock *)a.prof;
         for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
             const uint32_t idx = a.out_idx[k];
-            if (idx != 0xffffffffu) store_put(a.store + idx, Wt[a.out_slots[k]]);
+            if (idx == 0xffffffffu) continue;
+            if (dfb) {
+                // dataflow across launches: the wire must have reached the version this write follows and every read of
+                // that version must have happened; the new version goes up behind the label (its store acknowledged first)
+                const uint32_t *req = (const uint32_t *)(dfb + 1) + dfb->nin + 3 * k;
+                df_wait_reached(dfb->ver + idx, req[0], dfb->host_err);
+                df_wait_reached(dfb->rd + idx, req[1], dfb->host_err);
+                store_put(a.store + idx, Wt[a.out_slots[k]]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(dfb->ver + idx, req[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                store_put(a.store + idx, Wt[a.out_slots[k]]);
+            }
         }
     }
 }
@@ -656,7 +688,6 @@ __global__ __launch_bounds__(TF) void k_garble_flat(FlArgs a) {
 // Units that depend on one another inside ONE launch (kernels.h: d_sync).  unit_enter: this workgroup's unit = the next ticket;
 // then every thread polls one of the done-flags the unit waits for (a bounded wait: ~2 s, then the pinned error word goes up
 // and the unit runs anyway — garbage, reported by gc_ctx_coop_check, rather than a hung queue).
-constexpr uint32_t kDepSpins = 1u << 22;
 __device__ __forceinline__ uint32_t unit_enter(uint32_t *sync) {
     extern __shared__ uint4 smem[];
     uint32_t *scratch = (uint32_t *)smem;  // (the AES table's place: loaded after the barriers below)

@@ -180,7 +180,7 @@ struct FlatJob {
     uint4 *T;
     const uint32_t *rk;
     const uint32_t *te0;
-    uint64_t *prof;
+    uint64_t *prof;    // debug profile of the batch kernels; JOB launches (never profiled): the unit's DfBlock, or nullptr
     const uint4 *rnd;  // garbler only: the caller's random stream (nullptr: R / input labels are already in place)
     uint4 *Rout;       // garbler only: R of every instance, for the later passes of the pipeline
     uint32_t batch;
@@ -203,6 +203,20 @@ struct FlatJob {
 // ticket as its unit number (so every unit it may wait for has started: no wait can starve, whatever order the hardware
 // dispatches workgroups in), waits for the done-flags of its list, runs its records, raises its own flag.
 constexpr uint32_t kSyncHead = 4;
+// Dataflow between the launch units of a stream ACROSS launches (round 6, GC_STREAM_DATAFLOW, garbler): the wire store carries,
+// beside every label, how often the wire has been WRITTEN (ver) and READ (rd) by launch units so far; the host keeps the same
+// counts in launch order (= program order for every pair of units that share a wire) and tells each unit, per input, the version
+// it must find before it loads the label, and per output the version and the number of reads the wire must have reached before
+// it may be overwritten, and the version the write makes.  Launches then need no order between one another: a unit starts when
+// ITS operands exist.  FlatJob::prof of a job record points at this block (device memory): the header, then ver_in[nin], then
+// {prev, reads, next}[nout].  Every wait is bounded by polls; a wait that runs out raises *host_err to 3 and goes on.
+struct DfBlock {
+    uint32_t *ver, *rd;    // per global wire (as the store)
+    uint32_t *host_err;    // pinned word of the ctx (gc_ctx_err_word), device address
+    uint32_t nin, nout;
+    uint32_t pad_[2];
+};
+static_assert(sizeof(DfBlock) == 40 || sizeof(DfBlock) == 48, "DfBlock layout");
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
                                   size_t lds_bytes, hipStream_t s, uint32_t *d_sync = nullptr);
 

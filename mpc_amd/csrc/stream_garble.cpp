@@ -72,6 +72,7 @@ struct gc_stream {
     CopyPool copier;              // gc_stream_garble_finish_async: the copies into the caller's buffer, off this thread
     FuseStats fuse;               // chain fusion: launch units of several steps, merged plans built
     bool use_deps = deps_wanted();  // units that wait inside a launch (stream_internal.h: kUnitDeps)
+    Dataflow df;                    // units ordered by the versions of their wires, across launches (GC_STREAM_DATAFLOW)
     StageProf prof;
     uint64_t n_steps_total = 0;
     // gc_stream_garble_finish_view: the slot whose pinned bytes the caller is still reading (given back by the next finish),
@@ -101,7 +102,8 @@ int launch_oldest(gc_stream *s, bool one_stream = false) {
     s->n_groups++;
     s->n_group_steps += g.jobs.size();
     s->prof.lap(StageProf::kOther);
-    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse, one_stream);
+    const int rc = launch_group(s->ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse, one_stream,
+                                &s->df);
     s->prof.lap(StageProf::kLaunch);
     s->win.note(seq, slot, g.launch_no);
     if (rc == GC_OK) s->ctxq.pushed(slot, g.launch_no);
@@ -206,6 +208,11 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_R, sizeof(uint4));
         if (e == hipSuccess) e = hipMemcpy(s->d_rk, k.w, sizeof k.w, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s->d_R, &s->r, sizeof(gc_label), hipMemcpyHostToDevice);
+        if (e == hipSuccess && dataflow_wanted() && fuse_enabled()) {  // (experiment: off unless GC_STREAM_DATAFLOW=1)
+            e = s->df.setup();
+            s->df.on = e == hipSuccess;
+            s->use_deps = false;  // (units ordered by their wires' versions: no done-flags inside a launch as well)
+        }
         if (e != hipSuccess) {
             set_error("gc_stream_create", e);
             rc = GC_E_HIP;
@@ -232,6 +239,7 @@ void gc_stream_free(gc_stream *s) {
         if (GroupTimeline::enabled()) group_timeline().print_and_clear();
     }
     s->deep.release();
+    s->df.release();
     if (s->copy_stream) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
@@ -349,6 +357,7 @@ int gc_stream_get_wire(gc_stream *s, uint32_t w, gc_wire *out) try {  // Streami
     int rc = close_group(s);  // a queued step may be the one that sets the wire
     if (rc != GC_OK) return rc;
     if (s->deep.n_inflight) s->deep.drain();  // ... or a deep step on its lane
+    if (s->df.on) s->df.drain();              // ... or a group on one of the rotating streams (Dataflow)
     gc_label l0;
     rc = s->store.get(s->ctx, w, &l0);
     if (rc != GC_OK) return rc;
@@ -488,6 +497,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         // and before the step is put anywhere: a failure here leaves nothing half-queued
         if (!s->store.dirty.empty()) {
             std::lock_guard<std::mutex> lk(ctx->mu);
+            if (s->df.on) GC_HIP(s->df.join(ctx->stream));  // (the upload overwrites store entries: behind every group launched so far)
             int rcs = s->store.flush(ctx);
             if (rcs != GC_OK) return rcs;
         }
@@ -647,7 +657,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             if (s->deep.n_inflight) g.deps.merge(s->deep.conflicts(in, nin, s->skip_scratch.data(), nout));
         }
         if (is_deep) {  // launched at once, on its lane
-            int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse);
+            int rcl = launch_group(ctx, g, false, s->store, s->d_rk, s->d_R, s->rounds, s->copy_stream, s->deep, &s->fuse, false, &s->df);
             if (rcl != GC_OK) {
                 (void)hipStreamSynchronize(s->deep.lanes[(size_t)g.lane]);
                 s->deep.retire(g.lane, g.deep_id);
@@ -674,6 +684,10 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
             s->deep.poll();
             std::lock_guard<std::mutex> lk(ctx->mu);
             GC_HIP(s->deep.wait_all(st));
+        }
+        if (s->df.on) {  // ... and behind every group on the rotating streams (Dataflow)
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            GC_HIP(s->df.join(st));
         }
         if (ngates) {  // ... and later deep steps must see what it reads and writes
             s->win.ensure(s->store.host.size());
@@ -766,6 +780,18 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
     int rc = gc_pass_dev(circ, false, s->key.data(), s->key.size(), &s->r, s->store.d, b.d_io, b.d_io + nin + nout, nullptr, 0, &bt,
                          (const gc::StoreXchg *)(b.d_io + x_off));
     if (rc != GC_OK) return rc;
+    if (s->df.on) {
+        // dataflow across launches: the pass has read in[] and written the stored outputs — the wires' counts follow, on the device
+        // behind the pass and in the host's mirrors, and every later group launch waits for this point of the ctx stream
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        GC_HIP(s->df.ensure(s->store.cap));
+        launch_df_bump(s->df.d_ver, s->df.d_rd, b.d_io, nin, b.d_io + nin + nout, nout, st);
+        GC_HIP(hipGetLastError());
+        for (uint32_t i = 0; i < nin; i++) s->df.vr[in[i]].rd++;
+        for (uint32_t j = 0; j < nout; j++)
+            if (s->skip_scratch[j] != 0xffffffffu) s->df.vr[out[j]].ver++;
+        GC_HIP(s->df.fence_from(st));
+    }
     for (uint32_t j = 0; j < nout; j++)
         if (first_out + j >= first_tmp) s->store.on_dev[out[j]] = 1;
     // (3) byte size of this call's serialisation (depends on in[] / out[]: ids above 0xffff take the long form), then the

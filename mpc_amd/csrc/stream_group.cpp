@@ -166,6 +166,18 @@ struct RowCopy {
     uint4 *dst;
     uint32_t n, pad_;
 };
+// dataflow across launches: a pass that is no group launch (a big step on the ctx stream) has read / written these wires
+__global__ __launch_bounds__(256) void k_df_bump(uint32_t *ver, uint32_t *rd, const uint32_t *in_idx, uint32_t nin, const uint32_t *out_idx,
+                                                 uint32_t nout) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nin) {
+        __hip_atomic_fetch_add(rd + in_idx[i], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (i < nin + nout) {
+        const uint32_t w = out_idx[i - nin];
+        if (w != 0xffffffffu) __hip_atomic_fetch_add(ver + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rows_copy(const RowCopy *rc) {
     const RowCopy c = rc[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
@@ -225,10 +237,29 @@ void GroupTimeline::print_and_clear() {
 // one_stream (garbler): the caller waits for exactly this group and nothing else is queued (the unchanged caller: one
 // Streaming.Garble at a time) — serialiser and bytes follow the kernel on ITS stream: nothing to run beside, and the hand-over
 // to the copy stream (an event between two hardware queues) is latency the caller would sit through.
+// (GC_STREAM_DATAFLOW=2: the lanes of the deep steps keep their events towards the groups — for comparison)
+static bool df_free_lanes() {
+    static const bool v = [] {
+        const char *e = std::getenv("GC_STREAM_DATAFLOW");
+        return !(e && e[0] == '2');
+    }();
+    return v;
+}
+
+void launch_df_bump(uint32_t *d_ver, uint32_t *d_rd, const uint32_t *d_in_idx, uint32_t nin, const uint32_t *d_out_idx, uint32_t nout,
+                    hipStream_t st) {
+    if (nin + nout == 0) return;
+    hipLaunchKernelGGL(k_df_bump, dim3((nin + nout + 255) / 256), dim3(256), 0, st, d_ver, d_rd, d_in_idx, nin, d_out_idx, nout);
+}
+
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream) {
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream, Dataflow *df) {
     const bool on_lane = g.deep_id != 0;
-    hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : ctx->stream;
+    if (df && (!df->on || eval)) df = nullptr;
+    // dataflow across launches (stream_internal.h: Dataflow): the group goes to the next of the rotating streams — nothing orders
+    // it against the groups before it but the versions of the wires its units read and write
+    uint32_t df_k = 0;
+    hipStream_t st = on_lane ? deep.lanes[(size_t)g.lane] : df ? df->next(&df_k) : ctx->stream;
     if (one_stream && !on_lane && !eval) copy_stream = st;
     const uint32_t n = (uint32_t)g.jobs.size(), nwg = (uint32_t)g.wgs.size();
     // ---- the merged plans of the chains (before the ctx lock: a chain met for the first time is planned here)
@@ -282,9 +313,35 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     };
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail("launch_group", e);
+    // (dataflow: an upload of host-set labels overwrites store entries on the ctx stream — behind every group launched so far)
+    if (df && !store.dirty.empty() && (e = df->join(ctx->stream)) != hipSuccess) return fail("launch_group (dataflow join)", e);
     int rcs = store.flush(ctx);  // host-set labels go up first; the store may move (its pointer is taken below)
     if (rcs != GC_OK) return g.error = rcs;
-    if (on_lane) {
+    if (df) {
+        if ((e = df->ensure(store.cap)) != hipSuccess) return fail("launch_group (dataflow counts)", e);
+        // what the ctx stream did to the store outside group launches (uploads, big steps) comes first
+        if (!on_lane && store.up_ev) e = hipStreamWaitEvent(st, store.up_ev, 0);
+        if (e == hipSuccess && df->ctx_ev_set) e = hipStreamWaitEvent(st, df->ctx_ev, 0);
+        if (e != hipSuccess) return fail("launch_group (dataflow order)", e);
+        // bounded: every unit launched must be able to become resident while it waits for another
+        while (!df->inflight.empty()) {
+            const Dataflow::InFlight &f = df->inflight.front();
+            const bool gone = !f.slot->launched || f.slot->launch_no != f.launch_no;
+            if (!gone && !df->fits(nwg)) {
+                (void)hipEventSynchronize(f.slot->kernel_ev);
+                df->n_cap_waits++;
+            } else if (!gone && hipEventQuery(f.slot->kernel_ev) != hipSuccess) {
+                break;
+            }
+            df->account(f.units, false);
+            df->inflight.pop_front();
+        }
+        (void)hipGetLastError();  // hipErrorNotReady
+    }
+    if (df && df_free_lanes()) {
+        // dataflow: the versions of the wires order lanes and groups against one another as well — no events between them
+        if (on_lane && store.up_ev) e = hipStreamWaitEvent(st, store.up_ev, 0);
+    } else if (on_lane) {
         if (store.up_ev) e = hipStreamWaitEvent(st, store.up_ev, 0);  // host-set labels it may read (long done, as a rule)
         if (e == hipSuccess && g.after_tail) {
             if (!g.dep) e = hipEventCreateWithFlags(&g.dep, hipEventDisableTiming);
@@ -313,7 +370,12 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         for (uint32_t u = 0; u < nwg; u++) sync_words += g.wgs[u].dep_n == kDepsAllEarlier ? u : g.wgs[u].dep_n;
     }
     const size_t off_sync = off_first + up16((size_t)nwg * sizeof(uint32_t));
-    const size_t total_up = off_sync + up16(sync_words * sizeof(uint32_t));
+    // [the units' dataflow blocks: header, version per input, {prev, reads, next} per output] (an upper bound: every step a record)
+    const size_t off_df = off_sync + up16(sync_words * sizeof(uint32_t));
+    size_t df_bytes = 0;
+    if (df)
+        for (const JobRec &j : g.jobs) df_bytes += up16(sizeof(DfBlock) + ((size_t)j.nin + 3 * (size_t)j.nout) * sizeof(uint32_t));
+    const size_t total_up = off_df + df_bytes;
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
     const size_t arena_chain = up256(g.arena_used);
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
@@ -365,6 +427,12 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     };
     size_t maps = off_maps, arena = arena_chain;
     uint32_t ncp = 0;
+    struct DfRec {  // a record's wire maps in the upload region (host side), for its dataflow block
+        uint32_t rec, nin, nout;
+        size_t off_in, off_out;
+    };
+    std::vector<DfRec> dfrecs;
+    if (df) dfrecs.reserve(nrec);
     std::vector<uint32_t> out_base;  // (chains: where each step's outputs start in the merged list; indexed by step)
     if (!g.kills.empty()) out_base.assign(n, 0xffffffffu);
     for (uint32_t u = 0; u < nwg; u++) {
@@ -377,6 +445,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
                 FlatJob f = step_job(j);
                 f.pad_ = r == 0 ? w.n - 1 : 0;
                 f.pad2_ = r;
+                if (df) dfrecs.push_back(DfRec{rec, j.nin, j.nout, j.off_io, j.off_io + ((size_t)j.nin + j.nout) * sizeof(uint32_t)});
                 fj[rec++] = f;
                 if (eval && j.d_block && j.nrows) rgp[ngt++] = RowGather{j.d_block, j.d_row_off, f.T, j.nrows, 0};
                 step_fin(j, (uint32_t)k, f.T, j.ent->circ->d_row_of_gate);
@@ -401,6 +470,7 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         f.out_idx = d_in + fp.n_ext;
         f.nout = fp.n_out;
         f.pad_ = f.pad2_ = 0;
+        if (df) dfrecs.push_back(DfRec{rec, fp.n_ext, fp.n_out, (size_t)((uint8_t *)h_in - g.h_up), (size_t)((uint8_t *)h_out - g.h_up)});
         fj[rec++] = f;
         uint32_t ni = 0, no = 0, m = 0;
         for (int32_t k = (int32_t)w.head; k >= 0; k = g.jobs[(size_t)k].next, m++) {
@@ -422,6 +492,39 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     }
     for (const auto &kl : g.kills)  // an output a later step of the same chain writes again
         if (kl.first < n && out_base[kl.first] != 0xffffffffu) ((uint32_t *)g.h_up)[out_base[kl.first] + kl.second] = 0xffffffffu;
+    if (df) {
+        // The dataflow blocks, in record order — the order in which the host's counts advance IS the order of the launches, which
+        // is program order for every two units that share a wire.  A record's reads first (it gathers before it stores); a killed
+        // output (0xffffffff) is no store.
+        size_t o = off_df;
+        uint32_t *d_err = gc_ctx_err_word(ctx);
+        for (const DfRec &r : dfrecs) {
+            DfBlock *b = (DfBlock *)(g.h_up + o);
+            uint32_t *vin = (uint32_t *)(b + 1), *req = vin + r.nin;
+            const uint32_t *in_idx = (const uint32_t *)(g.h_up + r.off_in), *out_idx = (const uint32_t *)(g.h_up + r.off_out);
+            *b = DfBlock{df->d_ver, df->d_rd, d_err, r.nin, r.nout, {0, 0}};
+            for (uint32_t i = 0; i < r.nin; i += 4) __builtin_prefetch(&df->vr[in_idx[i]]);  // (consecutive ids share lines)
+            for (uint32_t k = 0; k < r.nout; k += 4)
+                if (out_idx[k] != 0xffffffffu) __builtin_prefetch(&df->vr[out_idx[k]]);
+            for (uint32_t i = 0; i < r.nin; i++) {
+                Dataflow::VR &c = df->vr[in_idx[i]];
+                vin[i] = c.ver;
+                c.rd++;
+            }
+            for (uint32_t k = 0; k < r.nout; k++) {
+                const uint32_t w = out_idx[k];
+                if (w == 0xffffffffu) {
+                    req[3 * k] = req[3 * k + 1] = req[3 * k + 2] = 0;
+                    continue;
+                }
+                Dataflow::VR &c = df->vr[w];
+                req[3 * k] = c.ver, req[3 * k + 1] = c.rd, req[3 * k + 2] = ++c.ver;
+            }
+            fj[r.rec].prof = (uint64_t *)(g.d_up + o);
+            o += up16(sizeof(DfBlock) + ((size_t)r.nin + 3 * (size_t)r.nout) * sizeof(uint32_t));
+        }
+        if (o > total_up) return fail("launch_group (dataflow blocks)", hipErrorInvalidValue);
+    }
     if (g.has_waits) {
         uint32_t *sy = (uint32_t *)(g.h_up + off_sync);
         std::memset(sy, 0, (kSyncHead + (size_t)nwg) * sizeof(uint32_t));
@@ -481,6 +584,15 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     g.kernel_ev = eval ? g.done : g.kdone;
     if (tl) (void)hipEventRecord(tl->k1, st);
     if (e == hipSuccess) e = hipEventRecord(g.kernel_ev, st);
+    if (e == hipSuccess && df) {
+        if (!on_lane) {
+            e = hipEventRecord(df->tail[df_k], st);
+            df->used[df_k] = 1;
+        }
+        df->inflight.push_back(Dataflow::InFlight{&g, g.launch_no, nwg});
+        df->account(nwg, true);
+        df->n_launches++;
+    }
     if (e == hipSuccess && on_lane) {
         deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
         deep.n_inflight++;

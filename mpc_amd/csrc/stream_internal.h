@@ -548,6 +548,135 @@ inline uint32_t open_groups_limit(size_t in_flight) {
     if (open_groups_env()) return open_groups_env();
     return (uint32_t)std::min<size_t>(std::max<size_t>(in_flight / 16, kOpenGroupsMin), fuse_enabled() ? kOpenGroupsMaxFused : kOpenGroupsMax);
 }
+// ---- dataflow between launch units ACROSS launches (round 6, GC_STREAM_DATAFLOW=1, the garbler; kernels.h: DfBlock) ------------
+// Today a group is a level: it ends with its slowest unit and the ctx stream runs the groups one after the other; the ideal
+// under the caller's window is twice what that reaches on the instruction mixes (scripts/stream_ideal_model.py).  Here the wire
+// store carries per wire how often launch units have WRITTEN (ver) and READ (rd) it; the host keeps the same counts in launch
+// order — which is program order for every two units that share a wire: that is the invariant the windows, lanes and events
+// already keep — and every unit is told what to wait for (launch_group builds its DfBlock).  The groups of the window are
+// formed exactly as before (chain fusion included) but launched on ROTATING streams with no order between them; what is not a
+// group launch (big steps, uploads of host-set labels, read-backs) joins all of them first and bumps the counts itself.
+inline uint32_t df_streams_wanted() {  // (GC_STREAM_DF_STREAMS: how many streams the group launches rotate over; default 4)
+    const char *e = std::getenv("GC_STREAM_DF_STREAMS");
+    const int n = e && *e ? std::atoi(e) : 4;
+    return (uint32_t)std::min(std::max(n, 1), 12);
+}
+// Launch units launched and not known to be done, at most PER XCD: a unit that waits holds its CU, so every unit launched must
+// be able to become resident beside the others — and workgroup i of EVERY launch goes to XCD i mod 8 (32 CUs each): a hundred
+// launches of one unit would all sit on XCD 0.
+constexpr uint32_t kDfUnitsPerXcd = 26;
+inline bool dataflow_wanted() {
+    const char *e = std::getenv("GC_STREAM_DATAFLOW");
+    return e && *e && std::strcmp(e, "0") != 0;
+}
+struct Slot;
+struct Dataflow {
+    bool on = false;
+    struct VR {
+        uint32_t ver, rd;
+    };
+    std::vector<VR> vr;             // host mirrors of the device counts, advanced at launch (side by side: one cache line per wire)
+    uint32_t *d_ver = nullptr, *d_rd = nullptr;
+    size_t cap = 0;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> tail;   // per stream: behind its latest launch
+    std::vector<uint8_t> used;      // ... if it has had one since the last join
+    uint32_t turn = 0;
+    hipEvent_t ctx_ev = nullptr;    // behind the latest pass of the ctx stream that touched the store outside a group launch
+    bool ctx_ev_set = false;
+    struct InFlight {
+        Slot *slot;
+        uint64_t launch_no;
+        uint32_t units;
+    };
+    std::deque<InFlight> inflight;
+    uint32_t xcd_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups in flight per XCD (workgroup i of a launch: XCD i mod 8)
+    uint64_t n_launches = 0, n_cap_waits = 0;
+    static uint32_t on_xcd(uint32_t units, uint32_t x) { return (units + 7u - x) / 8u; }
+    bool fits(uint32_t units) const {
+        for (uint32_t x = 0; x < 8; x++)
+            if (xcd_load[x] + on_xcd(units, x) > kDfUnitsPerXcd) return false;
+        return true;
+    }
+    void account(uint32_t units, bool add) {
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t n = on_xcd(units, x);
+            xcd_load[x] = add ? xcd_load[x] + n : xcd_load[x] - std::min(xcd_load[x], n);
+        }
+    }
+
+    hipError_t setup() {
+        if (!streams.empty()) return hipSuccess;
+        for (uint32_t k = 0, n = df_streams_wanted(); k < n; k++) {
+            hipStream_t st = nullptr;
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+            streams.push_back(st), tail.push_back(ev), used.push_back(0);
+        }
+        return hipEventCreateWithFlags(&ctx_ev, hipEventDisableTiming);
+    }
+    // the counts cover wires [0, n): a grown array starts at zero for the new wires (nothing may be in flight: the caller's
+    // store has just moved with a device-wide wait, or this is the first use)
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        const size_t ncap = std::max(n, cap * 2);
+        uint32_t *nv = nullptr, *nr = nullptr;
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMalloc((void **)&nv, ncap * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&nr, ncap * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(nv, 0, ncap * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(nr, 0, ncap * sizeof(uint32_t));
+        if (e == hipSuccess && cap) e = hipMemcpy(nv, d_ver, cap * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && cap) e = hipMemcpy(nr, d_rd, cap * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            if (nv) (void)hipFree(nv);
+            if (nr) (void)hipFree(nr);
+            return e;
+        }
+        if (d_ver) (void)hipFree(d_ver);
+        if (d_rd) (void)hipFree(d_rd);
+        d_ver = nv, d_rd = nr, cap = ncap;
+        vr.resize(ncap, VR{0, 0});
+        return hipSuccess;
+    }
+    hipStream_t next(uint32_t *k) {
+        *k = turn++ % (uint32_t)streams.size();
+        return streams[*k];
+    }
+    // `st` (the ctx stream, as a rule) waits for every group launched so far
+    hipError_t join(hipStream_t st) {
+        hipError_t e = hipSuccess;
+        for (size_t k = 0; k < streams.size() && e == hipSuccess; k++)
+            if (used[k]) e = hipStreamWaitEvent(st, tail[k], 0);
+        return e;
+    }
+    // ... and every later group launch for what `st` holds now
+    hipError_t fence_from(hipStream_t st) {
+        hipError_t e = hipEventRecord(ctx_ev, st);
+        ctx_ev_set = e == hipSuccess;
+        return e;
+    }
+    void drain() {
+        for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
+    }
+    void release() {
+        drain();
+        for (hipStream_t st : streams) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : tail) (void)hipEventDestroy(ev);
+        if (ctx_ev) (void)hipEventDestroy(ctx_ev);
+        if (d_ver) (void)hipFree(d_ver);
+        if (d_rd) (void)hipFree(d_rd);
+        streams.clear(), tail.clear(), used.clear();
+        d_ver = d_rd = nullptr, ctx_ev = nullptr, cap = 0;
+    }
+};
+// a pass of the ctx stream (a big step) has read in_idx[0, nin) and written out_idx[0, nout) (0xffffffff: not stored): the
+// device counts follow (stream_group.cpp); the caller advances the host mirrors
+void launch_df_bump(uint32_t *d_ver, uint32_t *d_rd, const uint32_t *d_in_idx, uint32_t nin, const uint32_t *d_out_idx, uint32_t nout,
+                    hipStream_t st);
+
 struct GroupWindow {
     std::deque<uint32_t> open;      // slots of the open groups, oldest first
     uint32_t first_seq = 1;         // sequence number of open.front()
@@ -1074,6 +1203,6 @@ bool entry_is_deep(CircEntry *e, uint32_t min_steps, bool in_stream);
 Slot *slot_new(gc_ctx *ctx, std::vector<std::unique_ptr<Slot>> &slots, uint32_t *index, bool big = false);
 void deep_after(const GroupWindow &win, const std::vector<std::unique_ptr<Slot>> &slots, uint32_t cs, Slot *ng);
 int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_t *d_rk, const uint4 *d_R, int rounds,
-                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream = false);
+                 hipStream_t copy_stream, DeepLanes &deep, FuseStats *fstats, bool one_stream = false, Dataflow *df = nullptr);
 
 }  // namespace gcs
