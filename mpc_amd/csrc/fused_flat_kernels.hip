@@ -748,6 +748,80 @@ __global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs, con
     }
 }
 
+// Out-of-order issue (kernels.h: PoolCtl): a workgroup claims the lowest published unit nobody has claimed, runs its records,
+// counts it done, and claims again; it leaves when nothing is published that is not claimed.  (HAS_OR always: a workgroup of an
+// earlier launch may claim a unit of a later one.)
+template <int NR>
+__global__ __launch_bounds__(TF) void k_garble_flat_pool(PoolCtl *ctl) {
+    for (;;) {
+        extern __shared__ uint4 smem[];
+        uint32_t *scratch = (uint32_t *)smem;  // (the AES table's place: a unit's first record loads the table behind the barriers below)
+        if (threadIdx.x == 0) {
+            uint32_t t = 0xffffffffu;
+            for (;;) {
+                uint32_t h = __hip_atomic_load(&ctl->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t tl = __hip_atomic_load(&ctl->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int32_t)(tl - h) <= 0) break;
+                if (__hip_atomic_compare_exchange_strong(&ctl->head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    t = h;
+                    break;
+                }
+            }
+            scratch[0] = t;
+        }
+        __syncthreads();
+        const uint32_t t = __builtin_amdgcn_readfirstlane(scratch[0]);
+        __syncthreads();
+        if (t == 0xffffffffu) return;
+        // The unit's records, wire maps and dataflow block came up by DMA after this workgroup's KERNEL began (that is the point:
+        // it runs units of later launches), into upload regions that earlier launches used too: this XCD's L2 — coherent with
+        // the others only at kernel boundaries — may still hold the old lines.  An acquire at agent scope drops them (every wave:
+        // its vector L1 and scalar cache as well).  (Found as faults on null / stale pointers once the workgroups looped.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const PoolEntry *e = ctl->ring + (t & (kPoolRing - 1u));
+        const uint64_t recp = __hip_atomic_load((const uint64_t *)&e->rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t mg = __hip_atomic_load((const uint64_t *)&e->more, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (readfirstlane returns a signed int: the low half must not sign-extend into the high one)
+        const FlArgs *rec = (const FlArgs *)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(recp >> 32)) << 32) |
+                                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)recp));
+        const uint32_t more = __builtin_amdgcn_readfirstlane((uint32_t)mg), group = __builtin_amdgcn_readfirstlane((uint32_t)(mg >> 32));
+        for (uint32_t j = 0; j <= more; j++) {
+            const FlArgs a = load_job(rec + j);
+            garble_flat_body<NR, false, true, true>(a);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (store_put / store_get: no cache to flush)
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctl->done + group, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&ctl->done_total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (__builtin_amdgcn_readfirstlane(ctl->pad_)) return;  // (developer aid, GC_DF_DEBUG=2: one unit per workgroup)
+    }
+}
+// the units [first_ticket, first_ticket + n) of a launch go into the ring; the tail moves behind them
+__global__ void k_pool_publish(PoolCtl *ctl, const PoolEntry *entries, uint32_t first_ticket, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const PoolEntry e = entries[i];
+        PoolEntry *d = ctl->ring + ((first_ticket + i) & (kPoolRing - 1u));
+        __hip_atomic_store((uint64_t *)&d->rec, (uint64_t)(uintptr_t)e.rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((uint64_t *)&d->more, (uint64_t)e.more | ((uint64_t)e.group << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&ctl->tail, first_ticket + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread waits until a counter has reached `want` (the units of a group / everything published so far are done): what stands
+// behind it on its stream — the group's serialiser, a big step's pass — sees their labels and table rows
+__global__ void k_pool_wait(const uint32_t *ctr, uint32_t want, uint32_t *host_err) {
+    for (uint32_t spins = 0; (int32_t)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 24)) {  // (~20 s: a unit may be a 2 ms multiplier behind thirty others)
+            if (host_err) __hip_atomic_fetch_max(host_err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
 template <int NR, bool PROF, bool HAS_OR, bool MULTI>
 __device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
     GC_FL_PROLOGUE(false)
@@ -922,6 +996,26 @@ static hipError_t launch_jobs(K kern, const FlatJob *jobs, const uint32_t *first
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nunits), dim3(TF), lds, s, jobs, first, sync);
     return hipGetLastError();
+}
+
+template <typename K>
+static hipError_t launch_pool(K kern, PoolCtl *ctl, uint32_t nworkers, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nworkers), dim3(TF), lds, s, ctl);
+    return hipGetLastError();
+}
+hipError_t launch_fused_flat_pool(int rounds, PoolCtl *ctl, uint32_t nworkers, size_t lds_bytes, hipStream_t s) {
+    if (nworkers == 0) return hipSuccess;
+    return rounds == 10 ? launch_pool(k_garble_flat_pool<10>, ctl, nworkers, lds_bytes, s)
+           : rounds == 12 ? launch_pool(k_garble_flat_pool<12>, ctl, nworkers, lds_bytes, s)
+                          : launch_pool(k_garble_flat_pool<14>, ctl, nworkers, lds_bytes, s);
+}
+void launch_pool_publish(PoolCtl *ctl, const PoolEntry *d_entries, uint32_t first_ticket, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(256), 0, s, ctl, d_entries, first_ticket, n);
+}
+void launch_pool_wait(const uint32_t *d_counter, uint32_t want, uint32_t *d_host_err, hipStream_t s) {
+    hipLaunchKernelGGL(k_pool_wait, dim3(1), dim3(1), 0, s, d_counter, want, d_host_err);
 }
 
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,

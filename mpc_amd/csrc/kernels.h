@@ -217,6 +217,28 @@ struct DfBlock {
     uint32_t pad_[2];
 };
 static_assert(sizeof(DfBlock) == 40 || sizeof(DfBlock) == 48, "DfBlock layout");
+// ... and out-of-order ISSUE on top of it (GC_STREAM_DATAFLOW=3): the units of every launch are PUBLISHED into a ring of the
+// stream, in program order, and the workgroups of ANY launch claim the lowest unclaimed one, run it, and claim again until
+// nothing is left — a unit whose own launch sits behind a waiting kernel in its in-order queue is run by a workgroup of another
+// launch.  Claims are in ticket order, so a unit only ever waits for units that are already running: no wait can starve, whatever
+// is resident.  A unit is `more + 1` job records in a row (a chain without a merged plan: stream_fuse.cpp); when it is done it
+// counts itself in done[group] (the serialiser of that group waits for the count: k_pool_wait) and in done_total (joins).
+constexpr uint32_t kPoolRing = 8192;    // > the steps a stream may have in flight (kMaxPending)
+constexpr uint32_t kPoolGroups = 8192;
+struct PoolEntry {
+    const FlatJob *rec;
+    uint32_t more, group;
+};
+struct PoolCtl {
+    uint32_t head, tail;      // tickets claimed / published
+    uint32_t done_total, pad_;
+    uint32_t *host_err;
+    uint32_t done[kPoolGroups];
+    PoolEntry ring[kPoolRing];
+};
+hipError_t launch_fused_flat_pool(int rounds, PoolCtl *ctl, uint32_t nworkers, size_t lds_bytes, hipStream_t s);
+void launch_pool_publish(PoolCtl *ctl, const PoolEntry *d_entries, uint32_t first_ticket, uint32_t n, hipStream_t s);
+void launch_pool_wait(const uint32_t *d_counter, uint32_t want, uint32_t *d_host_err, hipStream_t s);
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
                                   size_t lds_bytes, hipStream_t s, uint32_t *d_sync = nullptr);
 

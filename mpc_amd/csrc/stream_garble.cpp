@@ -211,7 +211,8 @@ gc_stream *gc_stream_create(gc_ctx *ctx, const uint8_t *key, size_t keylen, cons
         if (e == hipSuccess && dataflow_wanted() && fuse_enabled()) {  // (experiment: off unless GC_STREAM_DATAFLOW=1)
             e = s->df.setup();
             s->df.on = e == hipSuccess;
-            s->use_deps = false;  // (units ordered by their wires' versions: no done-flags inside a launch as well)
+            // (GC_STREAM_DEPS=1 on top: steps that conflict with several units of an open group join it — units that depend on
+            // one another inside a launch, in ticket order — instead of opening a later group)
         }
         if (e != hipSuccess) {
             set_error("gc_stream_create", e);

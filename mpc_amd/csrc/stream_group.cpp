@@ -324,7 +324,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         if (e == hipSuccess && df->ctx_ev_set) e = hipStreamWaitEvent(st, df->ctx_ev, 0);
         if (e != hipSuccess) return fail("launch_group (dataflow order)", e);
         // bounded: every unit launched must be able to become resident while it waits for another
-        while (!df->inflight.empty()) {
+        // (not under out-of-order issue: a unit is claimed by a workgroup that IS resident, in program order)
+        while (!df->pool && !df->inflight.empty()) {
             const Dataflow::InFlight &f = df->inflight.front();
             const bool gone = !f.slot->launched || f.slot->launch_no != f.launch_no;
             if (!gone && !df->fits(nwg)) {
@@ -375,7 +376,10 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     size_t df_bytes = 0;
     if (df)
         for (const JobRec &j : g.jobs) df_bytes += up16(sizeof(DfBlock) + ((size_t)j.nin + 3 * (size_t)j.nout) * sizeof(uint32_t));
-    const size_t total_up = off_df + df_bytes;
+    // [out-of-order issue: the units' ring entries]
+    const bool pool = df && df->pool;
+    const size_t off_pool = off_df + df_bytes;
+    const size_t total_up = off_pool + (pool ? up16((size_t)nwg * sizeof(PoolEntry)) : 0);
     const size_t sizes_bytes = up256((size_t)n * sizeof(uint32_t));
     const size_t arena_chain = up256(g.arena_used);
     if ((e = g.reserve_up(total_up - g.up_used)) != hipSuccess) return fail("launch_group (pinned)", e);
@@ -565,6 +569,73 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         (void)hipEventCreate(&tl->d);
         (void)hipEventRecord(tl->k0, st);
     }
+    if (pool) {
+        // Out-of-order issue: the records go up and the units are PUBLISHED on the upload stream, in launch order — behind what the
+        // ctx stream did to the store outside group launches, because a workgroup of ANY launch may claim them at once —, then this
+        // launch's workgroups join the pool on their own stream; the group's serialiser waits for the group's count of done units.
+        if (g.pool_id == 0xffffffffu) {
+            if (df->next_group >= kPoolGroups) return fail("launch_group (pool groups)", hipErrorOutOfMemory);
+            g.pool_id = df->next_group++;
+        }
+        PoolEntry *pe = (PoolEntry *)(g.h_up + off_pool);
+        for (uint32_t u = 0; u < nwg; u++) pe[u] = PoolEntry{(const FlatJob *)(g.d_up + off_fj) + first[u], fj[first[u]].pad_, g.pool_id};
+        hipStream_t us = df->up_stream;
+        if (store.up_ev) e = hipStreamWaitEvent(us, store.up_ev, 0);
+        if (e == hipSuccess && df->ctx_ev_set) e = hipStreamWaitEvent(us, df->ctx_ev, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, us);
+        if (e == hipSuccess && df->published == 0) {  // (once: where a wait that runs out is reported)
+            uint32_t *d_err = gc_ctx_err_word(ctx);
+            e = hipMemcpy(&df->d_pool->host_err, &d_err, sizeof d_err, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) {
+            launch_pool_publish(df->d_pool, (const PoolEntry *)(g.d_up + off_pool), df->published, nwg, us);
+            df->published += nwg;
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && std::getenv("GC_DF_DEBUG")) {  // developer aid: what the ring holds against what was meant
+            (void)hipStreamSynchronize(us);
+            uint32_t head[4];
+            (void)hipMemcpy(head, df->d_pool, sizeof head, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[df pool] published %u (+%u) head %u tail %u done_total %u; d_up %p off_fj %zu off_pool %zu total_up %zu\n",
+                         df->published, nwg, head[0], head[1], head[2], (void *)g.d_up, off_fj, off_pool, total_up);
+            {
+                const FlatJob &f0 = fj[first[0]];
+                std::fprintf(stderr, "[df pool]   record 0: prog %p units %p hgslot %p ogslot %p in_lds %p W %p R %p T %p rk %p te0 %p prof %p rnd %p Rout %p store %p in_idx %p out_slots %p out_idx %p nunits %u ninputs %u nout %u pad %u/%u\n",
+                             (const void *)f0.prog, (const void *)f0.units, (const void *)f0.hgslot, (const void *)f0.ogslot, (const void *)f0.in_lds,
+                             (void *)f0.W, (const void *)f0.R, (void *)f0.T, (const void *)f0.rk, (const void *)f0.te0, (void *)f0.prof, (const void *)f0.rnd,
+                             (void *)f0.Rout, (void *)f0.store, (const void *)f0.in_idx, (const void *)f0.out_slots, (const void *)f0.out_idx, f0.nunits,
+                             f0.ninputs, f0.nout, f0.pad_, f0.pad2_);
+                if (std::getenv("GC_DF_DEBUG")[0] == '2') {
+                    const uint32_t one = 1;
+                    (void)hipMemcpy(&df->d_pool->pad_, &one, 4, hipMemcpyHostToDevice);
+                }
+            }
+            for (uint32_t u = 0; u < std::min(nwg, 4u); u++) {
+                PoolEntry back{};
+                (void)hipMemcpy(&back, &df->d_pool->ring[(df->published - nwg + u) & (kPoolRing - 1u)], sizeof back, hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "[df pool]   unit %u: ring rec %p more %u group %u | meant rec %p more %u group %u\n", u, (const void *)back.rec,
+                             back.more, back.group, (const void *)pe[u].rec, pe[u].more, pe[u].group);
+            }
+        }
+        if (e == hipSuccess && !g.dep) e = hipEventCreateWithFlags(&g.dep, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(g.dep, us);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, g.dep, 0);
+        if (e == hipSuccess) e = launch_fused_flat_pool(rounds, df->d_pool, nwg, kFlatLdsBytes, st);
+        if (e == hipSuccess && copy_stream != st) e = hipStreamWaitEvent(copy_stream, g.dep, 0);  // (the wait below reads the counter of THIS launch's units)
+        g.pool_done += nwg;
+        if (e == hipSuccess) {
+            launch_pool_wait(df->d_pool->done + g.pool_id, g.pool_done, gc_ctx_err_word(ctx), copy_stream);
+            e = hipGetLastError();
+        }
+        g.kernel_ev = g.kdone;
+        if (e == hipSuccess) e = hipEventRecord(g.kdone, copy_stream);
+        df->n_launches++;
+        if (e == hipSuccess && on_lane) {
+            deep.inflight[(size_t)g.lane].push_back(DeepLanes::InFlight{g.deep_id, g.kernel_ev});
+            deep.n_inflight++;
+            deep.n_steps++;
+        }
+    } else {
     e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, st);  // pinned source: a true asynchronous copy
     if (e == hipSuccess && g.rows_ev) e = hipStreamWaitEvent(st, g.rows_ev, 0);
     if (e == hipSuccess && ncp) {
@@ -598,9 +669,10 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         deep.n_inflight++;
         deep.n_steps++;
     }
+    }  // (!pool)
     if (e == hipSuccess && !eval) {
         // serialiser and bytes on the copy stream: the next group's garbling need not wait for either
-        if (copy_stream != st) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
+        if (copy_stream != st && !pool) e = hipStreamWaitEvent(copy_stream, g.kdone, 0);
         if (e == hipSuccess && on_lane && n == 1 && g.jobs[0].ngates > 4 * kSerGates) {
             // a deep step of many gates: the serialiser of the big steps, spread over the chip (one workgroup would write
             // megabytes byte by byte: 1 - 2 ms on the copy stream, more than the step's pass)

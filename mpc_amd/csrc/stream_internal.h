@@ -409,6 +409,7 @@ struct Slot {
     // steps have all been handed out is only given back (retire) when they are done
     std::atomic<uint32_t> copies{0};
     bool retire = false;
+    uint32_t pool_id = 0xffffffffu, pool_done = 0;  // Dataflow (pool): the slot's counter in PoolCtl::done and what it has reached (kept across reset())
     hipEvent_t kdone = nullptr, done = nullptr;  // kernels of the group enqueued-and-done / bytes back in pinned memory
     hipEvent_t kernel_ev = nullptr;              // whichever of the two says "the group's kernel has run" (set at launch)
     std::vector<JobRec> jobs;
@@ -589,6 +590,13 @@ struct Dataflow {
         uint64_t launch_no;
         uint32_t units;
     };
+    // out-of-order issue on top (GC_STREAM_DATAFLOW=3; kernels.h: PoolCtl): the units of every launch are published into a ring
+    // by the upload stream, in launch order, and the workgroups of any launch claim the lowest unclaimed one
+    bool pool = false;
+    gc::PoolCtl *d_pool = nullptr;
+    hipStream_t up_stream = nullptr;
+    uint32_t published = 0;   // tickets published so far
+    uint32_t next_group = 0;  // ids handed to slots (Slot::pool_id: the slot's counter in PoolCtl::done)
     std::deque<InFlight> inflight;
     uint32_t xcd_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups in flight per XCD (workgroup i of a launch: XCD i mod 8)
     uint64_t n_launches = 0, n_cap_waits = 0;
@@ -615,7 +623,16 @@ struct Dataflow {
             if (e != hipSuccess) return e;
             streams.push_back(st), tail.push_back(ev), used.push_back(0);
         }
-        return hipEventCreateWithFlags(&ctx_ev, hipEventDisableTiming);
+        hipError_t e = hipEventCreateWithFlags(&ctx_ev, hipEventDisableTiming);
+        const char *m = std::getenv("GC_STREAM_DATAFLOW");
+        if (e == hipSuccess && m && m[0] == '3') {
+            e = hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_pool, sizeof(gc::PoolCtl));
+            if (e == hipSuccess) e = hipMemset(d_pool, 0, sizeof(gc::PoolCtl));
+            if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill runs on the null stream: the streams here do not wait for it)
+            pool = e == hipSuccess;
+        }
+        return e;
     }
     // the counts cover wires [0, n): a grown array starts at zero for the new wires (nothing may be in flight: the caller's
     // store has just moved with a device-wide wait, or this is the first use)
@@ -630,6 +647,7 @@ struct Dataflow {
         if (e == hipSuccess) e = hipMemset(nr, 0, ncap * sizeof(uint32_t));
         if (e == hipSuccess && cap) e = hipMemcpy(nv, d_ver, cap * sizeof(uint32_t), hipMemcpyDeviceToDevice);
         if (e == hipSuccess && cap) e = hipMemcpy(nr, d_rd, cap * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // (fills and copies of the null stream: the non-blocking streams do not wait for them)
         if (e != hipSuccess) {
             if (nv) (void)hipFree(nv);
             if (nr) (void)hipFree(nr);
@@ -648,6 +666,10 @@ struct Dataflow {
     // `st` (the ctx stream, as a rule) waits for every group launched so far
     hipError_t join(hipStream_t st) {
         hipError_t e = hipSuccess;
+        if (pool) {  // every unit published so far has counted itself done (whoever ran it)
+            if (published) gc::launch_pool_wait(&d_pool->done_total, published, nullptr, st);
+            return hipGetLastError();
+        }
         for (size_t k = 0; k < streams.size() && e == hipSuccess; k++)
             if (used[k]) e = hipStreamWaitEvent(st, tail[k], 0);
         return e;
@@ -659,6 +681,11 @@ struct Dataflow {
         return e;
     }
     void drain() {
+        if (pool && up_stream) {
+            (void)hipStreamSynchronize(up_stream);
+            if (published) gc::launch_pool_wait(&d_pool->done_total, published, nullptr, up_stream);
+            (void)hipStreamSynchronize(up_stream);
+        }
         for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
     }
     void release() {
@@ -668,6 +695,9 @@ struct Dataflow {
         if (ctx_ev) (void)hipEventDestroy(ctx_ev);
         if (d_ver) (void)hipFree(d_ver);
         if (d_rd) (void)hipFree(d_rd);
+        if (up_stream) (void)hipStreamDestroy(up_stream);
+        if (d_pool) (void)hipFree(d_pool);
+        up_stream = nullptr, d_pool = nullptr, pool = false;
         streams.clear(), tail.clear(), used.clear();
         d_ver = d_rd = nullptr, ctx_ev = nullptr, cap = 0;
     }

@@ -10,9 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _dataflow(monkeypatch):
-    monkeypatch.setenv("GC_STREAM_DATAFLOW", "1")
+@pytest.fixture(autouse=True, params=["1", "3"], ids=["versions", "versions+pool"])
+def _dataflow(monkeypatch, request):
+    """1: units wait for their wires' versions, one launch's workgroups run that launch's units; 3: out-of-order issue on top —
+    every unit is published into a ring and the workgroups of ANY launch claim the lowest unclaimed one (kernels.h: PoolCtl)"""
+    monkeypatch.setenv("GC_STREAM_DATAFLOW", request.param)
 
 
 def test_ed25519like_under_dataflow():
