@@ -42,6 +42,11 @@ def test_bench_two_ranks_runs_config4_shape(tmp_path):
     assert c4["gathers_in_timed_region"] == j["config"]["gathers"] == -(-5 // 8) + -(-19 // 8)
     assert j["value"] > 0 and abs(j["value"] - 6400 * 8192 * 2 * 19 / (j["ms_per_step"] * 19e-3)) < 1e-6 * j["value"]
     assert not [f for f in os.listdir(tmp_path) if f.startswith("gc_comm_id.")], "rank 0 removes the id file"
+    # round 6: every rank's own time and rate over the timed steps beside the job's (the slowest rank's time, all ranks' units)
+    pr = j["per_rank"]
+    assert len(pr["value"]) == len(pr["elapsed_s"]) == 2 and pr["min"] <= pr["max"] and min(pr["elapsed_s"]) > 0
+    assert abs(pr["min"] - 6400 * 8192 * 19 / max(pr["elapsed_s"])) < 1e-6 * pr["min"]
+    assert j["value"] <= sum(pr["value"]) * (1 + 1e-9)  # (the job's clock is the slowest rank's)
 
 
 def test_bench_explicit_batch_and_single_rank_default(tmp_path):
