@@ -433,6 +433,9 @@ __device__ __forceinline__ void store_put(uint4 *p, const uint4 &v) {
 }
 
 constexpr uint32_t kDepSpins = 1u << 22;  // bound of a wait for another unit (~2 s), in polls
+// a word of an upload region that came up by DMA while this kernel was already running (workgroups that serve units of later
+// launches: kernels.h: PoolCtl): past this XCD's L2, which is coherent with memory only at kernel boundaries
+__device__ __forceinline__ uint32_t fresh_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // Dataflow across launches (kernels.h: DfBlock): wait until the word at p has reached `want` (wrap-safe), bounded by polls
 __device__ __forceinline__ void df_wait_reached(const uint32_t *p, uint32_t want, uint32_t *host_err) {
     for (uint32_t spins = 0; (int32_t)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0;) {
@@ -495,9 +498,9 @@ __device__ __forceinline__ void df_wait_reached(const uint32_t *p, uint32_t want
         for (uint32_t i = threadIdx.x; i < (a.ninputs << ti_log2); i += TF) {                                \
             const uint32_t w = i >> ti_log2, ls = a.in_lds[w];                                               \
             if constexpr (MULTI) { /* Get through in[] (stream_garble.go:131-141) on the device */           \
-                const uint32_t sidx = a.in_idx[w];                                                           \
                 const DfBlock *dfb = LOAD_R ? (const DfBlock *)a.prof : nullptr; /* garbler, dataflow across launches: the wire's version first */ \
-                if (dfb) df_wait_reached(dfb->ver + sidx, ((const uint32_t *)(dfb + 1))[w], dfb->host_err);  \
+                const uint32_t sidx = dfb ? fresh_u32(a.in_idx + w) : a.in_idx[w];                           \
+                if (dfb) df_wait_reached(dfb->ver + sidx, fresh_u32((const uint32_t *)(dfb + 1) + w), dfb->host_err); \
                 const uint4 v = store_get(a.store + sidx);                                                   \
                 Wt[i] = v;                                                                                   \
                 if (ls != 0xffffu) wl[(ls << ti_log2) + (i & tim)] = v;                                      \
@@ -643,17 +646,17 @@ __device__ __forceinline__ void garble_flat_body(const FlArgs &a) {
         __syncthreads();
         const DfBlock *dfb = (const DfBlock *)a.prof;
         for (uint32_t k = threadIdx.x; k < a.nout; k += TF) {
-            const uint32_t idx = a.out_idx[k];
+            const uint32_t idx = dfb ? fresh_u32(a.out_idx + k) : a.out_idx[k];
             if (idx == 0xffffffffu) continue;
             if (dfb) {
                 // dataflow across launches: the wire must have reached the version this write follows and every read of
                 // that version must have happened; the new version goes up behind the label (its store acknowledged first)
-                const uint32_t *req = (const uint32_t *)(dfb + 1) + dfb->nin + 3 * k;
-                df_wait_reached(dfb->ver + idx, req[0], dfb->host_err);
-                df_wait_reached(dfb->rd + idx, req[1], dfb->host_err);
+                const uint32_t *req = (const uint32_t *)(dfb + 1) + fresh_u32(&dfb->nin) + 3 * k;
+                df_wait_reached(dfb->ver + idx, fresh_u32(req), dfb->host_err);
+                df_wait_reached(dfb->rd + idx, fresh_u32(req + 1), dfb->host_err);
                 store_put(a.store + idx, Wt[a.out_slots[k]]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(dfb->ver + idx, req[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dfb->ver + idx, fresh_u32(req + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 store_put(a.store + idx, Wt[a.out_slots[k]]);
             }
@@ -727,6 +730,18 @@ __device__ __forceinline__ void unit_leave(uint32_t *sync, uint32_t unit) {
     if (threadIdx.x == 0) __hip_atomic_store(sync + kSyncHead + unit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same for a record that came up while this kernel was running (the pool: fresh_u32)
+__device__ __forceinline__ FlArgs load_job_fresh(const FlArgs *job) {
+    constexpr int kWords = sizeof(FlArgs) / 4;
+    const uint32_t *p = (const uint32_t *)job;
+    uint32_t w[kWords];
+#pragma unroll
+    for (int i = 0; i < kWords; i++) w[i] = __builtin_amdgcn_readfirstlane(fresh_u32(p + i));
+    FlArgs a;
+    __builtin_memcpy(&a, w, sizeof a);
+    return a;
+}
+
 template <int NR, bool HAS_OR, bool CHAIN>
 __global__ __launch_bounds__(TF) void k_garble_flat_jobs(const FlArgs *jobs, const uint32_t *first, uint32_t *sync) {
     if constexpr (!CHAIN) {
@@ -758,14 +773,28 @@ __global__ __launch_bounds__(TF) void k_garble_flat_pool(PoolCtl *ctl) {
         uint32_t *scratch = (uint32_t *)smem;  // (the AES table's place: a unit's first record loads the table behind the barriers below)
         if (threadIdx.x == 0) {
             uint32_t t = 0xffffffffu;
-            for (;;) {
+            const uint32_t persist = __hip_atomic_load(&ctl->persist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool seen_stop = false;
+            for (uint32_t idle = 0;;) {
                 uint32_t h = __hip_atomic_load(&ctl->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t tl = __hip_atomic_load(&ctl->tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int32_t)(tl - h) <= 0) break;
-                if (__hip_atomic_compare_exchange_strong(&ctl->head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    t = h;
-                    break;
+                if ((int32_t)(tl - h) > 0) {
+                    if (__hip_atomic_compare_exchange_strong(&ctl->head, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        t = h;
+                        break;
+                    }
+                    continue;
                 }
+                if (!persist) break;
+                // persistent: nothing to claim now.  `stop` goes up BEHIND the host's last publication: once it is seen, one more
+                // look at the tail is final.  (Bounded all the same: ~20 s of idle polls.)
+                if (__hip_atomic_load(&ctl->stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (seen_stop) break;
+                    seen_stop = true;
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(32);
+                if (++idle > (1u << 24)) break;
             }
             scratch[0] = t;
         }
@@ -786,7 +815,7 @@ __global__ __launch_bounds__(TF) void k_garble_flat_pool(PoolCtl *ctl) {
                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)recp));
         const uint32_t more = __builtin_amdgcn_readfirstlane((uint32_t)mg), group = __builtin_amdgcn_readfirstlane((uint32_t)(mg >> 32));
         for (uint32_t j = 0; j <= more; j++) {
-            const FlArgs a = load_job(rec + j);
+            const FlArgs a = load_job_fresh(rec + j);
             garble_flat_body<NR, false, true, true>(a);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (store_put / store_get: no cache to flush)
             __syncthreads();
@@ -821,6 +850,8 @@ __global__ void k_pool_wait(const uint32_t *ctr, uint32_t want, uint32_t *host_e
         }
     }
 }
+
+__global__ void k_pool_stop(PoolCtl *ctl) { __hip_atomic_store(&ctl->stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int NR, bool PROF, bool HAS_OR, bool MULTI>
 __device__ __forceinline__ void eval_flat_body(const FlArgs &a) {
@@ -1014,6 +1045,7 @@ hipError_t launch_fused_flat_pool(int rounds, PoolCtl *ctl, uint32_t nworkers, s
 void launch_pool_publish(PoolCtl *ctl, const PoolEntry *d_entries, uint32_t first_ticket, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pool_publish, dim3(1), dim3(256), 0, s, ctl, d_entries, first_ticket, n);
 }
+void launch_pool_stop(PoolCtl *ctl, hipStream_t s) { hipLaunchKernelGGL(k_pool_stop, dim3(1), dim3(1), 0, s, ctl); }
 void launch_pool_wait(const uint32_t *d_counter, uint32_t want, uint32_t *d_host_err, hipStream_t s) {
     hipLaunchKernelGGL(k_pool_wait, dim3(1), dim3(1), 0, s, d_counter, want, d_host_err);
 }

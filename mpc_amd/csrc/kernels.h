@@ -233,12 +233,17 @@ struct PoolCtl {
     uint32_t head, tail;      // tickets claimed / published
     uint32_t done_total, pad_;
     uint32_t *host_err;
+    // GC_STREAM_DATAFLOW=4: the workgroups are PERSISTENT — launched once, they wait (sleeping polls) for units to be published
+    // instead of leaving when there is none, until the host raises `stop` behind its last publication (a join: big steps,
+    // read-backs, the stream's end); units then never wait for a workgroup of their own launch to reach the head of its queue
+    uint32_t persist, stop;
     uint32_t done[kPoolGroups];
     PoolEntry ring[kPoolRing];
 };
 hipError_t launch_fused_flat_pool(int rounds, PoolCtl *ctl, uint32_t nworkers, size_t lds_bytes, hipStream_t s);
 void launch_pool_publish(PoolCtl *ctl, const PoolEntry *d_entries, uint32_t first_ticket, uint32_t n, hipStream_t s);
 void launch_pool_wait(const uint32_t *d_counter, uint32_t want, uint32_t *d_host_err, hipStream_t s);
+void launch_pool_stop(PoolCtl *ctl, hipStream_t s);
 hipError_t launch_fused_flat_jobs(bool eval, int rounds, bool has_or, const FlatJob *d_jobs, const uint32_t *d_first, uint32_t nunits,
                                   size_t lds_bytes, hipStream_t s, uint32_t *d_sync = nullptr);
 

@@ -499,6 +499,7 @@ int stream_begin(gc_stream *s, const gc_gate *gates, uint32_t ngates, uint32_t n
         if (!s->store.dirty.empty()) {
             std::lock_guard<std::mutex> lk(ctx->mu);
             if (s->df.on) GC_HIP(s->df.join(ctx->stream));  // (the upload overwrites store entries: behind every group launched so far)
+            if (s->df.persist && s->store.host.size() > s->store.cap) s->df.drain();  // (a growing store moves behind a device-wide wait)
             int rcs = s->store.flush(ctx);
             if (rcs != GC_OK) return rcs;
         }

@@ -315,6 +315,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
     if (e != hipSuccess) return fail("launch_group", e);
     // (dataflow: an upload of host-set labels overwrites store entries on the ctx stream — behind every group launched so far)
     if (df && !store.dirty.empty() && (e = df->join(ctx->stream)) != hipSuccess) return fail("launch_group (dataflow join)", e);
+    // (persistent workgroups: a store that has to GROW moves behind a device-wide wait — they must have left before it)
+    if (df && df->persist && store.host.size() > store.cap) df->drain();
     int rcs = store.flush(ctx);  // host-set labels go up first; the store may move (its pointer is taken below)
     if (rcs != GC_OK) return g.error = rcs;
     if (df) {
@@ -580,8 +582,10 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         PoolEntry *pe = (PoolEntry *)(g.h_up + off_pool);
         for (uint32_t u = 0; u < nwg; u++) pe[u] = PoolEntry{(const FlatJob *)(g.d_up + off_fj) + first[u], fj[first[u]].pad_, g.pool_id};
         hipStream_t us = df->up_stream;
+        df->pool_rounds = rounds;
         if (store.up_ev) e = hipStreamWaitEvent(us, store.up_ev, 0);
         if (e == hipSuccess && df->ctx_ev_set) e = hipStreamWaitEvent(us, df->ctx_ev, 0);
+        if (e == hipSuccess) e = df->pool_start(kFlatLdsBytes);  // (persistent workgroups: behind a big step's pass, which wants its XCD)
         if (e == hipSuccess) e = hipMemcpyAsync(g.d_up, g.h_up, total_up, hipMemcpyHostToDevice, us);
         if (e == hipSuccess && df->published == 0) {  // (once: where a wait that runs out is reported)
             uint32_t *d_err = gc_ctx_err_word(ctx);
@@ -620,7 +624,8 @@ int launch_group(gc_ctx *ctx, Slot &g, bool eval, DevStore &store, const uint32_
         if (e == hipSuccess && !g.dep) e = hipEventCreateWithFlags(&g.dep, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(g.dep, us);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, g.dep, 0);
-        if (e == hipSuccess) e = launch_fused_flat_pool(rounds, df->d_pool, nwg, kFlatLdsBytes, st);
+        // (persistent workgroups serve every publication: no workgroups of this launch's own)
+        if (e == hipSuccess && !df->persist) e = launch_fused_flat_pool(rounds, df->d_pool, nwg, kFlatLdsBytes, st);
         if (e == hipSuccess && copy_stream != st) e = hipStreamWaitEvent(copy_stream, g.dep, 0);  // (the wait below reads the counter of THIS launch's units)
         g.pool_done += nwg;
         if (e == hipSuccess) {

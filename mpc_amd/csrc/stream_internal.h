@@ -566,6 +566,12 @@ inline uint32_t df_streams_wanted() {  // (GC_STREAM_DF_STREAMS: how many stream
 // be able to become resident beside the others — and workgroup i of EVERY launch goes to XCD i mod 8 (32 CUs each): a hundred
 // launches of one unit would all sit on XCD 0.
 constexpr uint32_t kDfUnitsPerXcd = 26;
+inline uint32_t pool_workers_wanted() {  // (GC_STREAM_DF_WORKERS: persistent workgroups of GC_STREAM_DATAFLOW=4; default 96 of 256 CUs)
+    const char *e = std::getenv("GC_STREAM_DF_WORKERS");
+    const int n = e && *e ? std::atoi(e) : 96;
+    return (uint32_t)std::min(std::max(n, 1), 224);
+}
+#define kPoolWorkers pool_workers_wanted()
 inline bool dataflow_wanted() {
     const char *e = std::getenv("GC_STREAM_DATAFLOW");
     return e && *e && std::strcmp(e, "0") != 0;
@@ -597,6 +603,13 @@ struct Dataflow {
     hipStream_t up_stream = nullptr;
     uint32_t published = 0;   // tickets published so far
     uint32_t next_group = 0;  // ids handed to slots (Slot::pool_id: the slot's counter in PoolCtl::done)
+    // =4: PERSISTENT workgroups (PoolCtl::persist): one launch of kPoolWorkers on a stream of its own serves every publication
+    // until the next join raises `stop`
+    bool persist = false, pool_running = false;
+    int pool_rounds = 14;
+    hipStream_t pool_stream = nullptr;
+    hipEvent_t pool_ev = nullptr, pool_go = nullptr;
+    uint64_t n_pool_starts = 0;
     std::deque<InFlight> inflight;
     uint32_t xcd_load[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // workgroups in flight per XCD (workgroup i of a launch: XCD i mod 8)
     uint64_t n_launches = 0, n_cap_waits = 0;
@@ -615,7 +628,10 @@ struct Dataflow {
 
     hipError_t setup() {
         if (!streams.empty()) return hipSuccess;
-        for (uint32_t k = 0, n = df_streams_wanted(); k < n; k++) {
+        const char *mode = std::getenv("GC_STREAM_DATAFLOW");
+        // (persistent workgroups: no launch has workgroups of its own — one stream for the order of its waits is enough, and every
+        // stream less is one less that may share a hardware queue with the kernel that never ends)
+        for (uint32_t k = 0, n = mode && mode[0] == '4' ? 1u : df_streams_wanted(); k < n; k++) {
             hipStream_t st = nullptr;
             hipEvent_t ev = nullptr;
             hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -625,10 +641,22 @@ struct Dataflow {
         }
         hipError_t e = hipEventCreateWithFlags(&ctx_ev, hipEventDisableTiming);
         const char *m = std::getenv("GC_STREAM_DATAFLOW");
-        if (e == hipSuccess && m && m[0] == '3') {
+        if (e == hipSuccess && m && (m[0] == '3' || m[0] == '4')) {
             e = hipStreamCreateWithFlags(&up_stream, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipMalloc((void **)&d_pool, sizeof(gc::PoolCtl));
             if (e == hipSuccess) e = hipMemset(d_pool, 0, sizeof(gc::PoolCtl));
+            // (persistent workgroups never leave their hardware queue: any stream of the process that SHARES that queue would wait for
+            // them for ever — publications included.  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES queues (4 by default);
+            // the host must have asked for at least 16, else the form with workgroups per launch, =3, is used)
+            const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+            if (e == hipSuccess && m[0] == '4' && q && std::atoi(q) >= 16) {
+                const uint32_t one = 1;
+                e = hipMemcpy(&d_pool->persist, &one, sizeof one, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&pool_stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pool_ev, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pool_go, hipEventDisableTiming);
+                persist = e == hipSuccess;
+            }
             if (e == hipSuccess) e = hipDeviceSynchronize();  // (the fill runs on the null stream: the streams here do not wait for it)
             pool = e == hipSuccess;
         }
@@ -664,11 +692,34 @@ struct Dataflow {
         return streams[*k];
     }
     // `st` (the ctx stream, as a rule) waits for every group launched so far
+    // persistent workgroups: make sure they run (behind a `stop` of zero), before a publication
+    hipError_t pool_start(size_t lds_bytes) {
+        if (!persist || pool_running) return hipSuccess;
+        hipError_t e = hipMemsetAsync(&d_pool->stop, 0, sizeof(uint32_t), up_stream);
+        if (e == hipSuccess) e = hipEventRecord(pool_go, up_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pool_stream, pool_go, 0);
+        if (e == hipSuccess) e = gc::launch_fused_flat_pool(pool_rounds, d_pool, kPoolWorkers, lds_bytes, pool_stream);
+        if (e == hipSuccess) e = hipEventRecord(pool_ev, pool_stream);
+        pool_running = e == hipSuccess;
+        n_pool_starts++;
+        return e;
+    }
+    // ... and have left (behind everything published so far) before `st` goes on
+    hipError_t pool_stop(hipStream_t st) {
+        if (!persist || !pool_running) return hipSuccess;
+        gc::launch_pool_stop(d_pool, up_stream);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && st) e = hipStreamWaitEvent(st, pool_ev, 0);
+        pool_running = false;
+        return e;
+    }
     hipError_t join(hipStream_t st) {
         hipError_t e = hipSuccess;
         if (pool) {  // every unit published so far has counted itself done (whoever ran it)
             if (published) gc::launch_pool_wait(&d_pool->done_total, published, nullptr, st);
-            return hipGetLastError();
+            e = hipGetLastError();
+            if (e == hipSuccess) e = pool_stop(st);  // (a big step's cooperative launch wants an XCD's CUs to itself)
+            return e;
         }
         for (size_t k = 0; k < streams.size() && e == hipSuccess; k++)
             if (used[k]) e = hipStreamWaitEvent(st, tail[k], 0);
@@ -684,7 +735,9 @@ struct Dataflow {
         if (pool && up_stream) {
             (void)hipStreamSynchronize(up_stream);
             if (published) gc::launch_pool_wait(&d_pool->done_total, published, nullptr, up_stream);
+            (void)pool_stop(nullptr);
             (void)hipStreamSynchronize(up_stream);
+            if (pool_stream) (void)hipStreamSynchronize(pool_stream);
         }
         for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
     }
@@ -696,8 +749,11 @@ struct Dataflow {
         if (d_ver) (void)hipFree(d_ver);
         if (d_rd) (void)hipFree(d_rd);
         if (up_stream) (void)hipStreamDestroy(up_stream);
+        if (pool_stream) (void)hipStreamDestroy(pool_stream);
+        if (pool_ev) (void)hipEventDestroy(pool_ev);
+        if (pool_go) (void)hipEventDestroy(pool_go);
         if (d_pool) (void)hipFree(d_pool);
-        up_stream = nullptr, d_pool = nullptr, pool = false;
+        up_stream = pool_stream = nullptr, pool_ev = pool_go = nullptr, d_pool = nullptr, pool = persist = pool_running = false;
         streams.clear(), tail.clear(), used.clear();
         d_ver = d_rd = nullptr, ctx_ev = nullptr, cap = 0;
     }

@@ -649,7 +649,7 @@ def run_native_steps(steps, prim, rnd, key=bytes(range(32)), window=64, env=None
     return r
 
 
-def run_native(name, key=bytes(range(32)), window=64):
+def run_native(name, key=bytes(range(32)), window=64, env=None):
     """the same program driven by tools/stream_driver (plain C over the C ABI: what a cgo host sees, no interpreter
     between the calls); the SHA-256 of its byte stream is checked against the oracle's like the Python-driven run's.
     None if the driver has not been built."""
@@ -658,7 +658,7 @@ def run_native(name, key=bytes(range(32)), window=64):
     steps, prim = PROGRAMS[name]()
     rnd = stream_rnd(name, len(prim))
     gates = sum(c.NumGates for c, _, _ in steps)
-    r = run_native_steps(steps, prim, rnd, key, window)
+    r = run_native_steps(steps, prim, rnd, key, window, env=env)
     want = golden_sha(name, key)
     if want is not None and want != r["sha256"]:
         raise AssertionError("%s (native driver): stream SHA-256 %s != oracle's %s" % (name, r["sha256"], want))
@@ -741,6 +741,22 @@ def run_for_line(key=bytes(range(32)), ctx=None):
                                                       "eval_us_per_step", "eval_steady_gates_per_s", "eval_steady_us_per_step",
                                                       "window", "sha256_ok", "error", "first_attempt_error")}
     lap("ed25519like view + native_host")
+    # The round-6 EXPERIMENT (off in every row above): launch units ordered by per-wire versions on the device and run by persistent
+    # workgroups that claim published units in program order (GC_STREAM_DATAFLOW=4; needs 16 hardware queues) — C host, its own process
+    exp = {}
+    for label, name, win, og in (("ssa23_window256", "ssa23", 256, None), ("ssa23_window64_eager", "ssa23", 64, "1")):
+        env = {"GC_STREAM_DATAFLOW": "4", "GPU_MAX_HW_QUEUES": "16"}
+        if og:
+            env["GC_STREAM_OPEN_GROUPS"] = og
+        try:
+            r = run_native(name, key, win, env=env)
+            exp[label] = {k: r[k] for k in ("window", "garble_gates_per_s", "garble_view_gates_per_s", "sha256_ok")}
+        except Exception as e:  # an experiment's side row: reported, never fatal
+            exp[label] = {"error": str(e)[:400]}
+    exp["note"] = ("EXPERIMENT, off by default (DESIGN.md §5, EXPERIMENTS.md round 6): ssa23 garbling under GC_STREAM_DATAFLOW=4; the rows "
+                   "above it are the product's default; it costs ed25519like 17 %")
+    out["dataflow_experiment"] = exp
+    lap("dataflow_experiment")
     out["wall_s"] = wall
     if native:
         out["native_host"] = native

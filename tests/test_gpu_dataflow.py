@@ -5,16 +5,22 @@ counts themselves.  The bytes on the wire and every wire label are the serial lo
 programs as the default path, against the oracle.
 
 Reference: circuit/stream_garble.go:131-157 (Get / Set through in[] / out[]), :161-192."""
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["1", "3"], ids=["versions", "versions+pool"])
+@pytest.fixture(autouse=True, params=["1", "3", "4"], ids=["versions", "versions+pool", "versions+persistent-pool"])
 def _dataflow(monkeypatch, request):
     """1: units wait for their wires' versions, one launch's workgroups run that launch's units; 3: out-of-order issue on top —
-    every unit is published into a ring and the workgroups of ANY launch claim the lowest unclaimed one (kernels.h: PoolCtl)"""
+    every unit is published into a ring and the workgroups of ANY launch claim the lowest unclaimed one (kernels.h: PoolCtl); 4: the
+    same with PERSISTENT workgroups that wait for publications"""
     monkeypatch.setenv("GC_STREAM_DATAFLOW", request.param)
+    if request.param == "4" and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 16:
+        pytest.skip("persistent workgroups need GPU_MAX_HW_QUEUES >= 16, set before the process's first HIP call "
+                    "(GPU_MAX_HW_QUEUES=16 python -m pytest tests/test_gpu_dataflow.py -m gpu)")
 
 
 def test_ed25519like_under_dataflow():
