@@ -19,6 +19,9 @@ bash scripts/profile_sq.sh > $OUT/profile_sq.log 2>&1; cp gpurun_out/prof_sq/sum
 cp $OUT/latest_pmc.json profiles/latest_pmc.json   # (this box's copy: the bench run below reads it)
 timeout 1800 python -m pytest tests -m gpu -x -q > $OUT/${TAG}_gpu_suite.log 2>&1; echo "gpu suite rc=$?" >> $OUT/${TAG}_gpu_suite.log
 tail -n 3 $OUT/${TAG}_gpu_suite.log
+# (the persistent-workgroup form of the dataflow experiment needs 16 hardware queues from the host: skipped in the suite above)
+GPU_MAX_HW_QUEUES=16 timeout 900 python -m pytest tests/test_gpu_dataflow.py -m gpu -q > $OUT/${TAG}_gpu_dataflow_hwq16.log 2>&1; echo "rc=$?" >> $OUT/${TAG}_gpu_dataflow_hwq16.log
+tail -n 2 $OUT/${TAG}_gpu_dataflow_hwq16.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_b1024.json 2> $OUT/bench.err
 tail -c 300 $OUT/bench.err
 python - "$OUT/${TAG}_bench_b1024.json" <<'PY'
@@ -32,6 +35,7 @@ for k in ("ed25519like", "ssa23", "mixed", "uniform512", "uniform4096"):
     print(k, "%.3g %.3g %s" % (s[k]["garble_gates_per_s"], s[k]["eval_gates_per_s"], s[k].get("eval_blocks_gates_per_s")), s[k]["sha256_ok"])
 print("big130 %.3g %.3g" % (s["steady_gates_per_s"], s["eval_steady_gates_per_s"]))
 print("window1 %.3g" % s["ed25519like_window1"]["garble_gates_per_s"], "view %.3g" % s["ed25519like"]["garble_view_gates_per_s"])
+print("dataflow_experiment", {k: v for k, v in s.get("dataflow_experiment", {}).items() if k != "note"})
 print({k: {a: ("%.3g" % b if isinstance(b, float) else b) for a, b in v.items()} for k, v in s["native_host"].items()})
 PY
 timeout 900 python scripts/r06_native_loop.py 10 > $OUT/${TAG}_native_host_loop.jsonl 2> $OUT/native_loop.err; echo "rc=$?" >> $OUT/${TAG}_native_host_loop.jsonl
