@@ -385,3 +385,19 @@ def test_every_environment_switch_of_the_library_is_documented():
     for hook in ("GC_COOP_FORCE_TIMEOUT", "GC_STREAM_FUSE_EAGER", "GC_RCCL_PATH"):
         line = [l for l in table.splitlines() if "`%s`" % hook in l][0]
         assert "TEST HOOK" in line, hook
+
+
+def test_integration_appendix_lists_every_entry_point():
+    """INTEGRATION.md's appendix (scripts/abi_index.py --write) is current: it names every function the header declares — the
+    same set the library exports — on the line the header declares it on"""
+    import importlib.util
+    root = os.path.join(os.path.dirname(engine.HEADER), "..")
+    spec = importlib.util.spec_from_file_location("abi_index", os.path.join(root, "scripts", "abi_index.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    md, total = mod.markdown()
+    assert sorted(mod.names()) == declared_functions() and total == len(declared_functions())
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert mod.BEGIN in doc and mod.END in doc
+    have = doc[doc.index(mod.BEGIN): doc.index(mod.END) + len(mod.END)]
+    assert have == md, "INTEGRATION.md's appendix is stale: run `python scripts/abi_index.py --write`"
